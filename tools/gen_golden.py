@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Generate golden vectors under tests/golden/ by IMPORTING the real reference.
+
+Runs only in the build container, where /root/reference exists (read-only).  The reference's
+.py files never travel: what is committed is this script plus small .npz files holding inputs
+and the reference's outputs for them.  Inputs come from numpy's default_rng so they can be
+re-created without torch's RNG; weights for the default-size net come from torch.manual_seed(1)
+in the reference's module-creation order (sha256 of the state_dict is stored so a test can tell
+whether the local torch reproduces it).
+
+    python tools/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import hashlib
+import io
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+sys.path.insert(0, REF)
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+from models.codec import DenseED, Decoder            # noqa: E402  (reference)
+from models import darcy as rdarcy                   # noqa: E402  (reference)
+from utils.image_gradient import SobelFilter         # noqa: E402  (reference)
+from utils.practices import OneCycleScheduler        # noqa: E402  (reference)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def sd_sha(sd):
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def ref_loss(K, y, sobel, wb, nonlinear=False, b1=0.0, b2=0.0):
+    if nonlinear:
+        lc = rdarcy.conv_constitutive_constraint_nonlinear(K, y, sobel, b1, b2)
+    else:
+        lc = rdarcy.conv_constitutive_constraint(K, y, sobel)
+    lt = rdarcy.conv_continuity_constraint(y, sobel)
+    ld, ln = rdarcy.conv_boundary_condition(y)
+    return lc + lt + (ld + ln) * wb, lc, lt, ld, ln
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    rng = np.random.default_rng(20190524)
+
+    # ---- G1: Sobel fields, 64x64 and a ragged-ish small 8x8 (edge formulas dominate)
+    g1 = {}
+    for n in (64, 8):
+        img = rng.standard_normal((2, 1, n, n)).astype(np.float32) * 3 + 1
+        sob = SobelFilter(n, correct=True)
+        sob_nc = SobelFilter(n, correct=False)
+        t = torch.from_numpy(img)
+        g1[f'img{n}'] = img
+        g1[f'gh{n}'] = sob.grad_h(t).numpy()
+        g1[f'gv{n}'] = sob.grad_v(t).numpy()
+        g1[f'gh{n}_nocorrect'] = sob_nc.grad_h(t).numpy()
+        g1[f'gv{n}_nocorrect'] = sob_nc.grad_v(t).numpy()
+    np.savez_compressed(os.path.join(OUT, 'G1_sobel.npz'), **g1)
+
+    # ---- G2: linear loss + dL/dy (autograd of the reference), wb=10; G3: nonlinear
+    K = np.exp(0.5 * rng.standard_normal((2, 1, 64, 64))).astype(np.float32)
+    y = rng.standard_normal((2, 3, 64, 64)).astype(np.float32)
+    sob = SobelFilter(64, correct=True)
+    out = {'K': K, 'y': y, 'weight_bound': np.float32(10)}
+    for tag, nl in (('lin', False), ('nl', True)):
+        yt = torch.from_numpy(y).clone().requires_grad_(True)
+        terms = ref_loss(torch.from_numpy(K), yt, sob, 10.0, nl, 0.1, 0.1)
+        terms[0].backward()
+        out[f'{tag}_terms'] = np.array([float(t) for t in terms], np.float64)
+        out[f'{tag}_grad'] = yt.grad.numpy()
+        # per-term gradients (the drop-in API differentiates each function separately)
+        for i, nm in enumerate(('const', 'cont', 'dir', 'neu'), 1):
+            yt2 = torch.from_numpy(y).clone().requires_grad_(True)
+            t2 = ref_loss(torch.from_numpy(K), yt2, sob, 10.0, nl, 0.1, 0.1)
+            t2[i].backward()
+            out[f'{tag}_grad_{nm}'] = yt2.grad.numpy()
+    out['beta'] = np.array([0.1, 0.1], np.float32)
+    np.savez_compressed(os.path.join(OUT, 'G2_G3_loss.npz'), **out)
+
+    # ---- G4: closed form u = 1 - j/W, sigma1 = K, sigma2 = 0
+    Kc = np.exp(0.5 * rng.standard_normal((1, 1, 64, 64))).astype(np.float32)
+    yc = np.zeros((1, 3, 64, 64), np.float32)
+    yc[0, 0] = 1.0 - np.arange(64, dtype=np.float32)[None, :] / 64
+    yc[0, 1] = Kc[0, 0]
+    terms = ref_loss(torch.from_numpy(Kc), torch.from_numpy(yc), sob, 10.0)
+    np.savez_compressed(os.path.join(OUT, 'G4_closed_form.npz'), K=Kc, y=yc,
+                        terms=np.array([float(t) for t in terms], np.float64))
+
+    # ---- G5: tiny DenseED, everything stored
+    torch.manual_seed(7)
+    cfg = dict(blocks=[1, 1, 1], growth_rate=4, init_features=8, imsize=16)
+    net = quiet(DenseED, 1, 3, cfg['imsize'], cfg['blocks'], cfg['growth_rate'], cfg['init_features'])
+    # make BN affine non-trivial so gamma/beta gradients are exercised
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if k.endswith('norm1.weight') or k.endswith('norm2.weight') or k.endswith('norm3.weight'):
+                v.copy_(1 + 0.2 * torch.randn_like(v))
+            if k.endswith('.bias'):
+                v.copy_(0.1 * torch.randn_like(v))
+    sd0 = {k: v.clone().numpy() for k, v in net.state_dict().items()}
+    x = np.exp(0.5 * rng.standard_normal((4, 1, 16, 16))).astype(np.float32)
+    sob16 = SobelFilter(16, correct=True)
+    net.train()
+    xt = torch.from_numpy(x)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob16, 10.0)
+    terms[0].backward()
+    g5 = {'x': x, 'y': yo.detach().numpy(), 'terms': np.array([float(t) for t in terms], np.float64)}
+    for k, v in sd0.items():
+        g5['sd0/' + k] = v
+    for k, p in net.named_parameters():
+        g5['grad/' + k] = p.grad.numpy()
+    for k, v in net.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            g5['sd1/' + k] = v.numpy()
+    net.eval()
+    with torch.no_grad():
+        g5['y_eval'] = net(xt).numpy()
+    np.savez_compressed(os.path.join(OUT, 'G5_densed_tiny.npz'), **g5)
+
+    # ---- G6: default DenseED (blocks [6,8,6], growth 16, init 48), weights from manual_seed(1)
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    sha = sd_sha(net.state_dict())
+    xb = np.exp(0.5 * rng.standard_normal((8, 1, 64, 64))).astype(np.float32)
+    net.train()
+    xt = torch.from_numpy(xb)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob, 10.0)
+    terms[0].backward()
+    names = [k for k, _ in net.named_parameters()]
+    g6 = {'x': xb, 'sha256': np.array(sha), 'y_slice': yo.detach().numpy()[:, :, ::8, ::8],
+          'y0': yo.detach().numpy()[0], 'terms': np.array([float(t) for t in terms], np.float64),
+          'param_names': np.array(names),
+          'grad_norms': np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()]),
+          'grad_In_conv': net.features.In_conv.weight.grad.numpy(),
+          'grad_last_conv3': net.features.LastTransUp.conv3.weight.grad.numpy(),
+          'grad_enc1_l1_bn_w': net.features.EncBlock1.denselayer1.norm1.weight.grad.numpy(),
+          'grad_enc1_l1_bn_b': net.features.EncBlock1.denselayer1.norm1.bias.grad.numpy(),
+          'n_params': np.array(net.model_size[0]), 'n_conv': np.array(net.model_size[1]),
+          'n_state': np.array(len(net.state_dict()))}
+    np.savez_compressed(os.path.join(OUT, 'G6_densed_default.npz'), **g6)
+
+    # ---- G7: 8-step trajectory, bs=8, reference loop body (Adam + one-cycle), explicit batches
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.0)
+    sched = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)
+    data = np.exp(0.5 * rng.standard_normal((16, 1, 64, 64))).astype(np.float32)
+    order = np.array([[0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11, 12, 13, 14, 15]] * 4)
+    total_steps, losses, lrs = 40, [], []
+    net.train()
+    for step, idx in enumerate(order, 1):
+        inp = torch.from_numpy(data[idx])
+        net.zero_grad()
+        outp = net(inp)
+        terms = ref_loss(inp, outp, sob, 10.0)
+        terms[0].backward()
+        lr = sched.step(step / total_steps)
+        for g in opt.param_groups:
+            g['lr'] = lr
+        opt.step()
+        losses.append(float(terms[0]))
+        lrs.append(lr)
+    np.savez_compressed(os.path.join(OUT, 'G7_trajectory.npz'), data=data, order=order,
+                        total_steps=np.array(total_steps), losses=np.array(losses), lrs=np.array(lrs),
+                        final_In_conv=net.features.In_conv.weight.detach().numpy(),
+                        final_running_mean=net.features.LastTransUp.norm3.running_mean.numpy())
+
+    # ---- G8: one-cycle LR values
+    pcts = np.linspace(0, 1, 11)
+    s = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)
+    s25 = OneCycleScheduler(lr_max=5e-4, div_factor=25.0, pct_start=0.3)
+    np.savez_compressed(os.path.join(OUT, 'G8_one_cycle.npz'), pcts=pcts,
+                        lr=np.array([s.step(p) for p in pcts]), lr25=np.array([s25.step(p) for p in pcts]))
+
+    # ---- G9: metrics as computed in test() (train_codec_mixed_residual.py:180-197, load.py:28-30)
+    tgt = rng.standard_normal((6, 3, 16, 16)).astype(np.float32)
+    prd = tgt + 0.1 * rng.standard_normal((6, 3, 16, 16)).astype(np.float32)
+    yvar = ((tgt - tgt.mean(0, keepdims=True)) ** 2).sum(axis=(0, 2, 3))
+    o, t = torch.from_numpy(prd), torch.from_numpy(tgt)
+    err2 = torch.sum((o - t) ** 2, [-1, -2])
+    rel = torch.sqrt(err2 / (t ** 2).sum([-1, -2])).mean(0).numpy()
+    r2 = 1 - err2.sum(0).numpy() / yvar
+    np.savez_compressed(os.path.join(OUT, 'G9_metrics.npz'), target=tgt, pred=prd, y_variation=yvar,
+                        nrmse=rel, r2=r2)
+
+    # ---- G10: Decoder (config 5) -- shapes, one closure value (nonlinear), grads norms
+    torch.manual_seed(3)
+    dec = Decoder(1, 3, [8, 6])
+    sha_dec = sd_sha(dec.state_dict())
+    z = (0.5 * rng.standard_normal((1, 1, 16, 16))).astype(np.float32)
+    K1 = np.exp(0.5 * rng.standard_normal((1, 1, 64, 64))).astype(np.float32)
+    dec.train()
+    yo = dec(torch.from_numpy(z))
+    terms = ref_loss(torch.from_numpy(K1), yo, sob, 10.0, True, 0.1, 0.1)
+    terms[0].backward()
+    np.savez_compressed(os.path.join(OUT, 'G10_decoder.npz'), z=z, K=K1, y=yo.detach().numpy(),
+                        sha256=np.array(sha_dec), terms=np.array([float(t) for t in terms], np.float64),
+                        param_names=np.array([k for k, _ in dec.named_parameters()]),
+                        grad_norms=np.array([float(p.grad.double().norm()) for _, p in dec.named_parameters()]),
+                        n_params=np.array(dec.model_size[0]), n_conv=np.array(dec.model_size[1]))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == '__main__':
+    main()
