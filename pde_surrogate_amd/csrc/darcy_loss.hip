@@ -1,0 +1,494 @@
+// Fused Sobel + Darcy mixed-residual loss (+ boundary loss), forward and analytic backward,
+// one launch, for CDNA4 / gfx950.
+//
+// Replaces, on the GPU, the ~294 aten ops the reference issues per loss evaluation:
+//   utils/image_gradient.py:50-92   SobelFilter.grad_h / grad_v (replicate pad, 3x3 conv, `modifier`)
+//   models/darcy.py:162-176         conv_constitutive_constraint
+//   models/darcy.py:179-191         conv_constitutive_constraint_nonlinear
+//   models/darcy.py:210-224         conv_continuity_constraint (use_tb=True)
+//   models/darcy.py:226-233         conv_boundary_condition
+//   train_codec_mixed_residual.py:228-233  loss combination and its autograd backward wrt `output`
+//
+// Math.  grad_h(U) = n * S U A, grad_v(U) = n * A^T U S with S the replicate-edge
+// [1,2,1]/4 smoother and A the clamped central difference times the reference's `modifier`
+// (2nd-order one-sided differences in the first/last column).  Adjoints: n * S G A^T, n * A G S.
+//
+// Layout / mapping.  Fields are fp32 NCHW.  ONE workgroup (512 threads at n = 64) owns ONE n x n
+// image: the three planes u, sigma1, sigma2 are staged in LDS (3 * n*n * 4 B = 48 KiB at n = 64;
+// the kernel is register-capped at 128 VGPRs so 2 workgroups = 16 waves share a CU), K stays in
+// registers.  A thread owns 1x4-pixel strips (one float4 = one 16-B global access; a wave covers
+// 4 full image rows = 1 KiB contiguous).  Horizontal neighbours come from the
+// adjacent lane by DPP row shifts (an image row is 16 / 8 / 4 lanes, never crossing a 16-lane DPP
+// row); vertical neighbours are conflict-free ds_read_b128 of whole rows.  The same three LDS
+// planes are then overwritten with the adjoint sources (w*K*r1, w*K*r2, w*c) for the backward
+// stencils, so HBM traffic is exactly the algorithmic 7 planes (4 read, 3 written) per sample.
+// Loss sums: fp32 per strip -> wave shuffle -> per-image partials; a second tiny kernel reduces
+// the per-image partials in fp64 in a fixed order (deterministic, no float atomics).
+#include "pdes_common.h"
+
+namespace pdes {
+
+struct LossParams {
+  float a_const;   // w_const * 2 / (B n n)
+  float a_cont;    // w_cont  * 2 / (B n n)
+  float b_dir;     // w_dir   * 2 / (B n)
+  float b_neu;     // w_neu   * 2 / (2 B n)
+  float beta1, beta2;
+};
+
+struct F4 {
+  float v[4];
+  __device__ __forceinline__ F4() {}
+  __device__ __forceinline__ F4(const float4& a) { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+  __device__ __forceinline__ float4 f4() const { return make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+// o = a*x + b*y + c*z + d*w elementwise
+__device__ __forceinline__ F4 comb4(float a, const F4& x, float b, const F4& y, float c, const F4& z,
+                                    float d, const F4& w) {
+  F4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o.v[i] = a * x.v[i] + b * y.v[i] + c * z.v[i] + d * w.v[i];
+  return o;
+}
+__device__ __forceinline__ F4 vsmooth3(const F4& up, const F4& own, const F4& dn) {
+  F4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o.v[i] = 0.25f * up.v[i] + 0.5f * own.v[i] + 0.25f * dn.v[i];
+  return o;
+}
+
+// left/right neighbours of a strip with replicate clamping at the image edge.
+__device__ __forceinline__ void halo(const F4& x, bool first, bool last, float& l, float& r) {
+  float ll = dpp_row_shr1(x.v[3]);
+  float rr = dpp_row_shl1(x.v[0]);
+  l = first ? x.v[0] : ll;
+  r = last ? x.v[3] : rr;
+}
+
+// [1,2,1]/4 along the row, replicate edges
+__device__ __forceinline__ F4 hsmooth(const F4& x, bool first, bool last, float scale) {
+  float l, r;
+  halo(x, first, last, l, r);
+  F4 o;
+  o.v[0] = scale * (0.25f * l + 0.5f * x.v[0] + 0.25f * x.v[1]);
+  o.v[1] = scale * (0.25f * x.v[0] + 0.5f * x.v[1] + 0.25f * x.v[2]);
+  o.v[2] = scale * (0.25f * x.v[1] + 0.5f * x.v[2] + 0.25f * x.v[3]);
+  o.v[3] = scale * (0.25f * x.v[2] + 0.5f * x.v[3] + 0.25f * r);
+  return o;
+}
+
+// (x A) along the row: clamped central difference, one-sided 2nd order in the first/last column
+// when `correct` (reference `modifier`, image_gradient.py:43-46).
+__device__ __forceinline__ F4 hdiff(const F4& x, bool first, bool last, bool correct, float scale) {
+  float l, r;
+  halo(x, first, last, l, r);
+  F4 o;
+  o.v[0] = 0.5f * (x.v[1] - l);
+  o.v[1] = 0.5f * (x.v[2] - x.v[0]);
+  o.v[2] = 0.5f * (x.v[3] - x.v[1]);
+  o.v[3] = 0.5f * (r - x.v[2]);
+  if (correct) {
+    if (first) o.v[0] = 0.5f * (-3.f * x.v[0] + 4.f * x.v[1] - x.v[2]);
+    if (last) o.v[3] = 0.5f * (3.f * x.v[3] - 4.f * x.v[2] + x.v[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o.v[i] *= scale;
+  return o;
+}
+
+// (g A^T) along the row: adjoint of hdiff(correct=true)
+__device__ __forceinline__ F4 hdiff_adj(const F4& g, bool first, bool last, float scale) {
+  // neighbours WITHOUT clamping: outside the image the adjoint has no contribution
+  float l = dpp_row_shr1(g.v[3]);
+  float r = dpp_row_shl1(g.v[0]);
+  F4 o;
+  o.v[0] = 0.5f * (l - g.v[1]);
+  o.v[1] = 0.5f * (g.v[0] - g.v[2]);
+  o.v[2] = 0.5f * (g.v[1] - g.v[3]);
+  o.v[3] = 0.5f * (g.v[2] - r);
+  if (first) {
+    o.v[0] = -1.5f * g.v[0] - 0.5f * g.v[1];
+    o.v[1] = 2.f * g.v[0] - 0.5f * g.v[2];
+    o.v[2] = 0.5f * g.v[1] - 0.5f * g.v[3] - 0.5f * g.v[0];
+  }
+  if (last) {
+    o.v[1] = 0.5f * g.v[0] - 0.5f * g.v[2] + 0.5f * g.v[3];
+    o.v[2] = 0.5f * g.v[1] - 2.f * g.v[3];
+    o.v[3] = 0.5f * g.v[2] + 1.5f * g.v[3];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o.v[i] *= scale;
+  return o;
+}
+
+// Row geometry of one strip: clamped smoothing neighbours and the coefficient sets of the
+// vertical difference (A^T applied to rows) and of its adjoint (A applied to rows).
+struct RowGeom {
+  int up, dn, farF, farA;
+  float f_own, f_up, f_dn, f_far;   // forward vertical difference
+  float a_own, a_up, a_dn, a_far;   // adjoint vertical difference
+};
+
+template <int N>
+__device__ __forceinline__ RowGeom row_geom(int r, bool correct) {
+  RowGeom g;
+  g.up = r > 0 ? r - 1 : 0;
+  g.dn = r < N - 1 ? r + 1 : N - 1;
+  g.farF = r;
+  g.farA = r;
+  g.f_own = 0.f; g.f_up = -0.5f; g.f_dn = 0.5f; g.f_far = 0.f;
+  g.a_own = 0.f; g.a_up = 0.5f; g.a_dn = -0.5f; g.a_far = 0.f;
+  if (r == 0) {
+    if (correct) { g.f_own = -1.5f; g.f_up = 0.f; g.f_dn = 2.f; g.f_far = -0.5f; g.farF = 2; }
+    else         { g.f_own = -0.5f; g.f_up = 0.f; g.f_dn = 0.5f; }
+    g.a_own = -1.5f; g.a_up = 0.f; g.a_dn = -0.5f;
+  } else if (r == N - 1) {
+    if (correct) { g.f_own = 1.5f; g.f_up = -2.f; g.f_dn = 0.f; g.f_far = 0.5f; g.farF = N - 3; }
+    else         { g.f_own = 0.5f; g.f_up = -0.5f; g.f_dn = 0.f; }
+    g.a_own = 1.5f; g.a_up = 0.5f; g.a_dn = 0.f;
+  } else if (r == 1) {
+    g.a_up = 2.f;
+  } else if (r == N - 2) {
+    g.a_dn = -2.f;
+  }
+  if (r == 2) { g.a_far = -0.5f; g.farA = 0; }
+  if (r == N - 3) { g.a_far = 0.5f; g.farA = N - 1; }
+  return g;
+}
+
+#ifndef PDES_LOSS_NTMAX
+#define PDES_LOSS_NTMAX 512
+#endif
+#ifndef PDES_LOSS_WPS
+#define PDES_LOSS_WPS 4   // waves per SIMD the n=64 loss kernel is register-capped for
+#endif
+template <int N>
+struct Geo {
+  static constexpr int SPR = N / 4;                       // strips per image row
+  static constexpr int NSTRIP = N * N / 4;                // strips (float4) per plane
+  static constexpr int NT = NSTRIP < PDES_LOSS_NTMAX ? NSTRIP : PDES_LOSS_NTMAX;  // threads per workgroup
+  static constexpr int SPT = NSTRIP / NT;                 // strips per thread
+  static constexpr int NW = NT / 64;
+};
+
+// ------------------------------------------------------------------------------------------
+template <int N, bool BWD, bool NONLIN>
+__global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS) : 1)) void darcy_loss_kernel(const float* __restrict__ Kp,
+                                                                const float* __restrict__ yp,
+                                                                float* __restrict__ gyp,
+                                                                float* __restrict__ partials,
+                                                                LossParams p) {
+  using G = Geo<N>;
+  constexpr int SPR = G::SPR, NSTRIP = G::NSTRIP, NT = G::NT, SPT = G::SPT, NW = G::NW;
+  __shared__ float4 lds[3 * NSTRIP + NW];   // 3 planes + NW x 4 floats of reduction scratch
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float fn = (float)N;
+
+  const float4* K4 = reinterpret_cast<const float4*>(Kp + (size_t)b * N * N);
+  const float4* y4 = reinterpret_cast<const float4*>(yp + (size_t)b * 3 * N * N);
+
+  F4 kk[SPT];
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = tid + NT * k;
+    kk[k] = F4(K4[s]);
+    lds[s] = y4[s];
+    lds[NSTRIP + s] = y4[NSTRIP + s];
+    lds[2 * NSTRIP + s] = y4[2 * NSTRIP + s];
+  }
+  __syncthreads();
+
+  float sum_const = 0.f, sum_cont = 0.f, sum_dir = 0.f, sum_neu = 0.f;
+  F4 R1[SPT], R2[SPT], P1[SPT], P2[SPT], CC[SPT];
+  float dub[SPT];
+
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = tid + NT * k;
+    const int r = s / SPR, cs = s % SPR;
+    const bool first = cs == 0, last = cs == SPR - 1;
+    const RowGeom g = row_geom<N>(r, true);
+    const F4 u_own(lds[s]), s1_own(lds[NSTRIP + s]), s2_own(lds[2 * NSTRIP + s]);
+    const F4 u_up(lds[g.up * SPR + cs]), u_dn(lds[g.dn * SPR + cs]), u_far(lds[g.farF * SPR + cs]);
+    const F4 a_up(lds[NSTRIP + g.up * SPR + cs]), a_dn(lds[NSTRIP + g.dn * SPR + cs]);
+    const F4 b_up(lds[2 * NSTRIP + g.up * SPR + cs]), b_dn(lds[2 * NSTRIP + g.dn * SPR + cs]),
+        b_far(lds[2 * NSTRIP + g.farF * SPR + cs]);
+
+    const F4 ghu = hdiff(vsmooth3(u_up, u_own, u_dn), first, last, true, fn);
+    const F4 gvu = hsmooth(comb4(g.f_own, u_own, g.f_up, u_up, g.f_dn, u_dn, g.f_far, u_far), first, last, fn);
+    const F4 gh1 = hdiff(vsmooth3(a_up, s1_own, a_dn), first, last, true, fn);
+    const F4 gv2 = hsmooth(comb4(g.f_own, s2_own, g.f_up, b_up, g.f_dn, b_dn, g.f_far, b_far), first, last, fn);
+
+    const bool tb = (r == 0) || (r == N - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float K = kk[k].v[i];
+      float r1 = s1_own.v[i] + K * ghu.v[i];
+      float r2 = s2_own.v[i] + K * gvu.v[i];
+      float q1 = 1.f, q2 = 1.f;
+      if (NONLIN) {
+        const float sq = sqrtf(K), x1 = s1_own.v[i], x2 = s2_own.v[i];
+        r1 += p.beta1 * sq * x1 * x1 + p.beta2 * K * x1 * x1 * x1;
+        r2 += p.beta1 * sq * x2 * x2 + p.beta2 * K * x2 * x2 * x2;
+        q1 += 2.f * p.beta1 * sq * x1 + 3.f * p.beta2 * K * x1 * x1;
+        q2 += 2.f * p.beta1 * sq * x2 + 3.f * p.beta2 * K * x2 * x2;
+      }
+      const float c = gh1.v[i] + gv2.v[i];
+      sum_const += r1 * r1 + r2 * r2;
+      sum_cont += c * c;
+      if (tb) sum_neu += s2_own.v[i] * s2_own.v[i];
+      if (BWD) {
+        R1[k].v[i] = p.a_const * r1 * q1;
+        R2[k].v[i] = p.a_const * r2 * q2 + (tb ? p.b_neu * s2_own.v[i] : 0.f);
+        P1[k].v[i] = p.a_const * K * r1;
+        P2[k].v[i] = p.a_const * K * r2;
+        CC[k].v[i] = p.a_cont * c;
+      }
+    }
+    float db = 0.f;
+    if (first) { const float e = u_own.v[0] - 1.f; sum_dir += e * e; db = p.b_dir * e; }
+    if (last) { const float e = u_own.v[3]; sum_dir += e * e; db = p.b_dir * e; }
+    dub[k] = db;
+  }
+
+  // per-image partial sums -> partials[b][4]
+  float* red = reinterpret_cast<float*>(&lds[3 * NSTRIP]);
+  {
+    const float t0 = wave_sum(sum_const), t1 = wave_sum(sum_cont), t2 = wave_sum(sum_dir),
+                t3 = wave_sum(sum_neu);
+    if ((tid & 63) == 0) {
+      const int w = tid >> 6;
+      red[w * 4 + 0] = t0; red[w * 4 + 1] = t1; red[w * 4 + 2] = t2; red[w * 4 + 3] = t3;
+    }
+  }
+  __syncthreads();   // also: every read of the input planes is done
+  if (tid < 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w * 4 + tid];
+    partials[(size_t)b * 4 + tid] = t;
+  }
+  if (!BWD) return;
+
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = tid + NT * k;
+    lds[s] = P1[k].f4();
+    lds[NSTRIP + s] = P2[k].f4();
+    lds[2 * NSTRIP + s] = CC[k].f4();
+  }
+  __syncthreads();
+
+  float4* g4 = reinterpret_cast<float4*>(gyp + (size_t)b * 3 * N * N);
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = tid + NT * k;
+    const int r = s / SPR, cs = s % SPR;
+    const bool first = cs == 0, last = cs == SPR - 1;
+    const RowGeom g = row_geom<N>(r, true);
+    const F4 p1_own(lds[s]), p2_own(lds[NSTRIP + s]), c_own(lds[2 * NSTRIP + s]);
+    const F4 p1_up(lds[g.up * SPR + cs]), p1_dn(lds[g.dn * SPR + cs]);
+    const F4 p2_up(lds[NSTRIP + g.up * SPR + cs]), p2_dn(lds[NSTRIP + g.dn * SPR + cs]),
+        p2_far(lds[NSTRIP + g.farA * SPR + cs]);
+    const F4 c_up(lds[2 * NSTRIP + g.up * SPR + cs]), c_dn(lds[2 * NSTRIP + g.dn * SPR + cs]),
+        c_far(lds[2 * NSTRIP + g.farA * SPR + cs]);
+
+    const F4 ghT_c = hdiff_adj(vsmooth3(c_up, c_own, c_dn), first, last, fn);
+    const F4 gvT_c = hsmooth(comb4(g.a_own, c_own, g.a_up, c_up, g.a_dn, c_dn, g.a_far, c_far), first, last, fn);
+    const F4 ghT_p1 = hdiff_adj(vsmooth3(p1_up, p1_own, p1_dn), first, last, fn);
+    const F4 gvT_p2 = hsmooth(comb4(g.a_own, p2_own, g.a_up, p2_up, g.a_dn, p2_dn, g.a_far, p2_far), first, last, fn);
+
+    F4 du, d1, d2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      du.v[i] = ghT_p1.v[i] + gvT_p2.v[i];
+      d1.v[i] = R1[k].v[i] + ghT_c.v[i];
+      d2.v[i] = R2[k].v[i] + gvT_c.v[i];
+    }
+    if (first) du.v[0] += dub[k];
+    if (last) du.v[3] += dub[k];
+    g4[s] = du.f4();
+    g4[NSTRIP + s] = d1.f4();
+    g4[2 * NSTRIP + s] = d2.f4();
+  }
+}
+
+// The adjoint of hsmooth is hsmooth (S is symmetric) and the adjoint of vsmooth3 is vsmooth3,
+// so the backward above reuses them; only the difference operators have distinct adjoints.
+
+// Fixed-order fp64 reduction of the per-image partials -> out[5] = {total, const, cont, dir, neu}.
+__global__ __launch_bounds__(256) void darcy_loss_finalize(const float* __restrict__ partials, int B,
+                                                           float* __restrict__ out, double inv_n,
+                                                           double inv_dir, double inv_neu, float w0,
+                                                           float w1, float w2, float w3) {
+  __shared__ double sh[4][4];
+  double acc[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float4 v = reinterpret_cast<const float4*>(partials)[b];
+    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sh[threadIdx.x >> 6][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
+    const double lc = t[0] * inv_n, lt = t[1] * inv_n, ld = t[2] * inv_dir, ln = t[3] * inv_neu;
+    out[0] = (float)(w0 * lc + w1 * lt + w2 * ld + w3 * ln);
+    out[1] = (float)lc; out[2] = (float)lt; out[3] = (float)ld; out[4] = (float)ln;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stand-alone Sobel gradients of single-channel images (SobelFilter.grad_h / grad_v) and the
+// adjoint used by their autograd backward.  One workgroup per image, plane staged in LDS.
+template <int N>
+__global__ __launch_bounds__(Geo<N>::NT) void sobel_grad_kernel(const float* __restrict__ img,
+                                                                float* __restrict__ gh,
+                                                                float* __restrict__ gv, int correct) {
+  using G = Geo<N>;
+  constexpr int SPR = G::SPR, NSTRIP = G::NSTRIP, NT = G::NT, SPT = G::SPT;
+  __shared__ float4 lds[NSTRIP];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float fn = (float)N;
+  const float4* i4 = reinterpret_cast<const float4*>(img + (size_t)b * N * N);
+  F4 x[SPT];
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) { x[k] = F4(i4[tid + NT * k]); lds[tid + NT * k] = x[k].f4(); }
+  __syncthreads();
+  const bool corr = correct != 0;
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = tid + NT * k;
+    const int r = s / SPR, cs = s % SPR;
+    const bool first = cs == 0, last = cs == SPR - 1;
+    const RowGeom g = row_geom<N>(r, corr);
+    const F4 up(lds[g.up * SPR + cs]), dn(lds[g.dn * SPR + cs]), far(lds[g.farF * SPR + cs]);
+    if (gh) {
+      const F4 o = hdiff(vsmooth3(up, x[k], dn), first, last, corr, fn);
+      reinterpret_cast<float4*>(gh + (size_t)b * N * N)[s] = o.f4();
+    }
+    if (gv) {
+      const F4 o = hsmooth(comb4(g.f_own, x[k], g.f_up, up, g.f_dn, dn, g.f_far, far), first, last, fn);
+      reinterpret_cast<float4*>(gv + (size_t)b * N * N)[s] = o.f4();
+    }
+  }
+}
+
+// img_bar = grad_h^T(gh_bar) + grad_v^T(gv_bar)   (either input may be null)
+template <int N>
+__global__ __launch_bounds__(Geo<N>::NT) void sobel_adjoint_kernel(const float* __restrict__ ghb,
+                                                                   const float* __restrict__ gvb,
+                                                                   float* __restrict__ out) {
+  using G = Geo<N>;
+  constexpr int SPR = G::SPR, NSTRIP = G::NSTRIP, NT = G::NT, SPT = G::SPT;
+  __shared__ float4 lds[2 * NSTRIP];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float fn = (float)N;
+  F4 a[SPT], c[SPT];
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = tid + NT * k;
+    a[k] = ghb ? F4(reinterpret_cast<const float4*>(ghb + (size_t)b * N * N)[s]) : F4(make_float4(0, 0, 0, 0));
+    c[k] = gvb ? F4(reinterpret_cast<const float4*>(gvb + (size_t)b * N * N)[s]) : F4(make_float4(0, 0, 0, 0));
+    lds[s] = a[k].f4();
+    lds[NSTRIP + s] = c[k].f4();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = tid + NT * k;
+    const int r = s / SPR, cs = s % SPR;
+    const bool first = cs == 0, last = cs == SPR - 1;
+    const RowGeom g = row_geom<N>(r, true);
+    const F4 a_up(lds[g.up * SPR + cs]), a_dn(lds[g.dn * SPR + cs]);
+    const F4 c_up(lds[NSTRIP + g.up * SPR + cs]), c_dn(lds[NSTRIP + g.dn * SPR + cs]),
+        c_far(lds[NSTRIP + g.farA * SPR + cs]);
+    const F4 t1 = hdiff_adj(vsmooth3(a_up, a[k], a_dn), first, last, fn);
+    const F4 t2 = hsmooth(comb4(g.a_own, c[k], g.a_up, c_up, g.a_dn, c_dn, g.a_far, c_far), first, last, fn);
+    F4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.v[i] = t1.v[i] + t2.v[i];
+    reinterpret_cast<float4*>(out + (size_t)b * N * N)[s] = o.f4();
+  }
+}
+
+template <int N>
+static int launch_loss(const float* K, const float* y, float* gy, float* partials, int B, LossParams p,
+                       int nonlinear, hipStream_t st) {
+  dim3 grid(B), block(Geo<N>::NT);
+  if (gy) {
+    if (nonlinear) hipLaunchKernelGGL((darcy_loss_kernel<N, true, true>), grid, block, 0, st, K, y, gy, partials, p);
+    else hipLaunchKernelGGL((darcy_loss_kernel<N, true, false>), grid, block, 0, st, K, y, gy, partials, p);
+  } else {
+    if (nonlinear) hipLaunchKernelGGL((darcy_loss_kernel<N, false, true>), grid, block, 0, st, K, y, gy, partials, p);
+    else hipLaunchKernelGGL((darcy_loss_kernel<N, false, false>), grid, block, 0, st, K, y, gy, partials, p);
+  }
+  return 0;
+}
+
+}  // namespace pdes
+
+using namespace pdes;
+
+extern "C" int pdes_darcy_loss(const float* K, const float* y, float* grad_y, float* partials,
+                               float* loss_out, int B, int H, int W, float w_const, float w_cont,
+                               float w_dir, float w_neu, int nonlinear, float beta1, float beta2,
+                               void* stream) {
+  if (!K || !y || !partials || B <= 0) return PDES_EINVAL;
+  if (H != W || !(H == 16 || H == 32 || H == 64)) return PDES_ENOSUP;
+  if (!aligned16(K) || !aligned16(y) || !aligned16(partials) || (grad_y && !aligned16(grad_y))) return PDES_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double ntot = (double)B * H * W;
+  LossParams p;
+  p.a_const = (float)(2.0 * w_const / ntot);
+  p.a_cont = (float)(2.0 * w_cont / ntot);
+  p.b_dir = (float)(2.0 * w_dir / ((double)B * H));
+  p.b_neu = (float)(2.0 * w_neu / (2.0 * B * W));
+  p.beta1 = beta1;
+  p.beta2 = beta2;
+  if (H == 64) launch_loss<64>(K, y, grad_y, partials, B, p, nonlinear, st);
+  else if (H == 32) launch_loss<32>(K, y, grad_y, partials, B, p, nonlinear, st);
+  else launch_loss<16>(K, y, grad_y, partials, B, p, nonlinear, st);
+  PDES_LAUNCH_CHECK();
+  if (loss_out) {
+    hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partials, B, loss_out, 1.0 / ntot,
+                       1.0 / ((double)B * H), 1.0 / (2.0 * B * W), w_const, w_cont, w_dir, w_neu);
+    PDES_LAUNCH_CHECK();
+  }
+  return PDES_OK;
+}
+
+extern "C" int pdes_sobel_grad(const float* img, float* gh, float* gv, int nimg, int H, int W,
+                               int correct, void* stream) {
+  if (!img || (!gh && !gv) || nimg <= 0) return PDES_EINVAL;
+  if (H != W || !(H == 16 || H == 32 || H == 64)) return PDES_ENOSUP;
+  if (!aligned16(img) || (gh && !aligned16(gh)) || (gv && !aligned16(gv))) return PDES_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (H == 64) hipLaunchKernelGGL(sobel_grad_kernel<64>, dim3(nimg), dim3(Geo<64>::NT), 0, st, img, gh, gv, correct);
+  else if (H == 32) hipLaunchKernelGGL(sobel_grad_kernel<32>, dim3(nimg), dim3(Geo<32>::NT), 0, st, img, gh, gv, correct);
+  else hipLaunchKernelGGL(sobel_grad_kernel<16>, dim3(nimg), dim3(Geo<16>::NT), 0, st, img, gh, gv, correct);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg,
+                                       int H, int W, void* stream) {
+  if ((!gh_bar && !gv_bar) || !img_bar || nimg <= 0) return PDES_EINVAL;
+  if (H != W || !(H == 16 || H == 32 || H == 64)) return PDES_ENOSUP;
+  if ((gh_bar && !aligned16(gh_bar)) || (gv_bar && !aligned16(gv_bar)) || !aligned16(img_bar)) return PDES_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (H == 64) hipLaunchKernelGGL(sobel_adjoint_kernel<64>, dim3(nimg), dim3(Geo<64>::NT), 0, st, gh_bar, gv_bar, img_bar);
+  else if (H == 32) hipLaunchKernelGGL(sobel_adjoint_kernel<32>, dim3(nimg), dim3(Geo<32>::NT), 0, st, gh_bar, gv_bar, img_bar);
+  else hipLaunchKernelGGL(sobel_adjoint_kernel<16>, dim3(nimg), dim3(Geo<16>::NT), 0, st, gh_bar, gv_bar, img_bar);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_abi_version(void) { return 1; }

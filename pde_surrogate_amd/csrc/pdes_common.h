@@ -1,0 +1,44 @@
+// Shared device/host helpers for the pde-surrogate MI355X (gfx950) kernels.
+// Everything here is written for CDNA4 only: 64-lane wavefronts, DPP row shifts, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PDES_OK 0
+#define PDES_EINVAL (-1)      // bad argument (null pointer, size <= 0)
+#define PDES_ENOSUP (-2)      // shape/option the kernels do not implement
+#define PDES_EALIGN (-3)      // pointer not 16-byte aligned
+
+// enqueue-only launches: report the launch error code (>0 = hipError_t), never synchronise
+#define PDES_LAUNCH_CHECK()                          \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+namespace pdes {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float dpp_row_shr1(float v) {   // lane i <- lane i-1 (within 16-lane row)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_row_shl1(float v) {   // lane i <- lane i+1 (within 16-lane row)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace pdes

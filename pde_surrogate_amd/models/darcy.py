@@ -1,0 +1,134 @@
+"""Darcy-flow physics losses for ConvNet surrogates on MI355X -- drop-in for the ConvNet half of
+the reference's models/darcy.py (:147-233), backed by ONE fused HIP kernel
+(csrc/darcy_loss.hip, C ABI `pdes_darcy_loss`).
+
+Same names, argument meaning and return values as the reference:
+    conv_constitutive_constraint(input, output, sobel_filter)                  darcy.py:162-176
+    conv_constitutive_constraint_nonlinear(input, output, sobel_filter, b1, b2) darcy.py:179-191
+    conv_continuity_constraint(output, sobel_filter, use_tb=True)               darcy.py:210-224
+    conv_boundary_condition(output) -> (loss_dirichlet, loss_neumann)           darcy.py:226-233
+All results are 0-dim tensors differentiable wrt `output` (callers just do loss.backward()).
+
+`darcy_mixed_residual_loss` is the additional fused fast path: the whole loss of
+train_codec_mixed_residual.py:228-232 and its gradient wrt `output` in a single launch.
+
+There is no CPU path: tensors must live on the GPU and the HIP library must be built.
+"""
+import torch
+
+from .. import _lib
+
+
+def _check_fields(input, output):
+    _lib.require_cuda(input, output)
+    if output.dim() != 4 or output.shape[1] != 3:
+        raise ValueError(f'output must be (B, 3, H, W): u, sigma1, sigma2; got {tuple(output.shape)}')
+    B, _, H, W = output.shape
+    if input is not None and tuple(input.shape) != (B, 1, H, W):
+        raise ValueError(f'input must be (B, 1, H, W) = {(B, 1, H, W)}; got {tuple(input.shape)}')
+    if input is not None and input.dtype != torch.float32 or output.dtype != torch.float32:
+        raise RuntimeError('the HIP loss kernel computes in fp32: pass fp32 tensors')
+    return B, H, W
+
+
+def _check_sobel(sobel_filter, H):
+    if sobel_filter is None:
+        return
+    if not getattr(sobel_filter, 'correct', True):
+        raise NotImplementedError('fused Darcy loss implements SobelFilter(correct=True) only '
+                                  '(every reference caller constructs it that way)')
+    n = getattr(sobel_filter, 'imsize', H)
+    if n != H:
+        raise ValueError(f'sobel_filter was built for imsize {n}, fields are {H}')
+
+
+def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta2=0.0):
+    """Raw launch: returns (terms[5] = {total, const, cont, dir, neu} device tensor, grad_y or None)."""
+    B, H, W = _check_fields(K, y)
+    if K is None:
+        K = torch.zeros((B, 1, H, W), device=y.device, dtype=torch.float32)
+    K = K.detach().contiguous()
+    y = y.detach().contiguous()
+    partials = torch.empty((B, 4), device=y.device, dtype=torch.float32)
+    terms = torch.empty(5, device=y.device, dtype=torch.float32)
+    grad = torch.empty_like(y) if want_grad else None
+    w = [float(v) for v in weights]
+    rc = _lib.lib().pdes_darcy_loss(_lib.ptr(K), _lib.ptr(y), _lib.ptr(grad), _lib.ptr(partials),
+                                    _lib.ptr(terms), B, H, W, w[0], w[1], w[2], w[3],
+                                    1 if nonlinear else 0, float(beta1), float(beta2), _lib.stream_ptr())
+    _lib.check(rc, 'pdes_darcy_loss')
+    return terms, grad
+
+
+class _MixedResidual(torch.autograd.Function):
+    """loss and dL/dy in one launch; backward is a scale by the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, K, y, weight_bound, nonlinear, beta1, beta2):
+        need = y.requires_grad
+        terms, grad = darcy_loss_launch(K, y, (1.0, 1.0, weight_bound, weight_bound), need,
+                                        nonlinear, beta1, beta2)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(terms)
+        return terms[0].clone(), terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        (grad,) = ctx.saved_tensors
+        return None, grad * g_loss, None, None, None, None
+
+
+def darcy_mixed_residual_loss(input, output, weight_bound=10.0, nonlinear=False, beta1=0.0, beta2=0.0):
+    """Fused loss of train_codec_mixed_residual.py:228-232.
+
+    Returns (loss, loss_pde, loss_dirichlet, loss_neumann): `loss` is differentiable wrt `output`,
+    the other three are detached 0-dim tensors for logging."""
+    loss, terms = _MixedResidual.apply(input, output, float(weight_bound), bool(nonlinear),
+                                       float(beta1), float(beta2))
+    return loss, terms[1] + terms[2], terms[3], terms[4]
+
+
+class _Terms(torch.autograd.Function):
+    """All four loss terms from one forward-only launch; backward = one launch whose per-term
+    weights are the upstream gradients (exactly autograd's linear combination)."""
+
+    @staticmethod
+    def forward(ctx, K, y, nonlinear, beta1, beta2):
+        terms, _ = darcy_loss_launch(K, y, (1.0, 1.0, 1.0, 1.0), False, nonlinear, beta1, beta2)
+        ctx.save_for_backward(K, y)
+        ctx.cfg = (nonlinear, beta1, beta2)
+        return terms[1:5].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        K, y = ctx.saved_tensors
+        w = g.detach().float().cpu().tolist()
+        _, grad = darcy_loss_launch(K, y, w, True, *ctx.cfg)
+        return None, grad, None, None, None
+
+
+def conv_constitutive_constraint(input, output, sobel_filter):
+    """sigma = -K grad(u): mean[(sigma1 + K u_x)^2 + (sigma2 + K u_y)^2]   (darcy.py:162-176)"""
+    _check_sobel(sobel_filter, output.shape[-1])
+    return _Terms.apply(input, output, False, 0.0, 0.0)[0]
+
+
+def conv_constitutive_constraint_nonlinear(input, output, sobel_filter, beta1, beta2):
+    """-K grad(u) = sigma + beta1 sqrt(K) sigma^2 + beta2 K sigma^3          (darcy.py:179-191)"""
+    _check_sobel(sobel_filter, output.shape[-1])
+    return _Terms.apply(input, output, True, float(beta1), float(beta2))[0]
+
+
+def conv_continuity_constraint(output, sobel_filter, use_tb=True):
+    """div(sigma) = 0: mean[(d sigma1/dx + d sigma2/dy)^2]                    (darcy.py:210-224)"""
+    if not use_tb:
+        raise NotImplementedError('use_tb=False (drop rows 0, H-1) is not used by any reference '
+                                  'script and is not implemented by the HIP kernel')
+    _check_sobel(sobel_filter, output.shape[-1])
+    return _Terms.apply(None, output, False, 0.0, 0.0)[1]
+
+
+def conv_boundary_condition(output):
+    """(loss_dirichlet, loss_neumann): u=1 left, u=0 right, sigma2=0 top/bottom (darcy.py:226-233)"""
+    t = _Terms.apply(None, output, False, 0.0, 0.0)
+    return t[2], t[3]

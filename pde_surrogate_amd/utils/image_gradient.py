@@ -1,0 +1,75 @@
+"""SobelFilter on MI355X -- drop-in for the reference's utils/image_gradient.py:24-92.
+
+grad_h / grad_v are HIP kernels (csrc/darcy_loss.hip: `pdes_sobel_grad`, and
+`pdes_sobel_grad_adjoint` for autograd) instead of pad + conv2d + matmul.  3x3 filter only
+(no reference caller passes filter_size); correct=False is forward-only.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _launch_grad(image, want_h, want_v, correct):
+    _lib.require_cuda(image)
+    if image.dim() != 4 or image.shape[1] != 1:
+        raise ValueError(f'image must be (B, 1, H, W); got {tuple(image.shape)}')
+    if image.dtype != torch.float32:
+        raise RuntimeError('the HIP Sobel kernel computes in fp32')
+    B, _, H, W = image.shape
+    x = image.detach().contiguous()
+    gh = torch.empty_like(x) if want_h else None
+    gv = torch.empty_like(x) if want_v else None
+    rc = _lib.lib().pdes_sobel_grad(_lib.ptr(x), _lib.ptr(gh), _lib.ptr(gv), B, H, W,
+                                    1 if correct else 0, _lib.stream_ptr())
+    _lib.check(rc, 'pdes_sobel_grad')
+    return gh, gv
+
+
+class _Grad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, horizontal, correct):
+        ctx.horizontal, ctx.correct = horizontal, correct
+        gh, gv = _launch_grad(image, horizontal, not horizontal, correct)
+        return gh if horizontal else gv
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.correct:
+            raise NotImplementedError('backward of SobelFilter(correct=False) is not implemented')
+        g = g.contiguous()
+        B, _, H, W = g.shape
+        out = torch.empty_like(g)
+        a, b = (g, None) if ctx.horizontal else (None, g)
+        rc = _lib.lib().pdes_sobel_grad_adjoint(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), B, H, W,
+                                                _lib.stream_ptr())
+        _lib.check(rc, 'pdes_sobel_grad_adjoint')
+        return out, None, None
+
+
+class SobelFilter(object):
+    """Same constructor and methods as the reference (image_gradient.py:24-92)."""
+
+    def __init__(self, imsize, correct=True, device='cpu'):
+        self.imsize = imsize
+        self.correct = correct
+        self.device = device
+        # kept for attribute compatibility with reference users (image_gradient.py:43-46)
+        modifier = np.eye(imsize)
+        modifier[0:2, 0] = np.array([4, -1])
+        modifier[-2:, -1] = np.array([-1, 4])
+        self.modifier = torch.tensor(modifier, dtype=torch.float32, device=device)
+
+    def _check(self, filter_size):
+        if filter_size != 3:
+            raise NotImplementedError('only the 3x3 Sobel filter is implemented (no reference '
+                                      'caller selects filter_size=5)')
+
+    def grad_h(self, image, filter_size=3):
+        """image gradient along the horizontal direction (x axis), (B,1,H,W) -> (B,1,H,W)"""
+        self._check(filter_size)
+        return _Grad.apply(image, True, self.correct)
+
+    def grad_v(self, image, filter_size=3):
+        self._check(filter_size)
+        return _Grad.apply(image, False, self.correct)

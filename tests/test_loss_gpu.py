@@ -1,0 +1,203 @@
+"""GPU parity tests (run with -m gpu on an MI355X): fused Sobel + Darcy loss HIP kernels, called
+through the C ABI, against (1) golden vectors produced by the real reference and (2) the CPU
+oracle on seeded inputs.  Tolerances (fp32): Sobel fields atol 1e-4 / rtol 1e-5, loss scalars
+rel 1e-5 (north_star), dL/dy rel-L2 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+GRAD_RL2 = 1e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def _fields(B, n, seed, dev):
+    rng = np.random.default_rng(seed)
+    K = np.exp(0.5 * rng.standard_normal((B, 1, n, n))).astype(np.float32)
+    y = rng.standard_normal((B, 3, n, n)).astype(np.float32)
+    return K, y, torch.from_numpy(K).to(dev), torch.from_numpy(y).to(dev)
+
+
+def test_g1_sobel_fixture(dev):
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    g = golden('G1_sobel.npz')
+    img = torch.from_numpy(g['img64']).to(dev)
+    for correct, sfx in ((True, ''), (False, '_nocorrect')):
+        sob = SobelFilter(64, correct=correct, device=dev)
+        np.testing.assert_allclose(sob.grad_h(img).cpu().numpy(), g['gh64' + sfx], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(sob.grad_v(img).cpu().numpy(), g['gv64' + sfx], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('n', [16, 32, 64])
+@pytest.mark.parametrize('B', [1, 5])
+def test_sobel_vs_oracle_and_adjoint(dev, n, B):
+    from oracle import darcy as od
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    rng = np.random.default_rng(n * 10 + B)
+    img = (rng.standard_normal((B, 1, n, n)) * 2 + 0.5).astype(np.float32)
+    t = torch.from_numpy(img).to(dev).requires_grad_(True)
+    sob = SobelFilter(n, device=dev)
+    gh, gv = sob.grad_h(t), sob.grad_v(t)
+    ref_h = od.sobel_grad_h(torch.from_numpy(img).double()).numpy()
+    ref_v = od.sobel_grad_v(torch.from_numpy(img).double()).numpy()
+    np.testing.assert_allclose(gh.detach().cpu().numpy(), ref_h, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(gv.detach().cpu().numpy(), ref_v, rtol=1e-5, atol=1e-4)
+    # autograd through the HIP adjoint kernel == autograd through the oracle
+    wh = rng.standard_normal(gh.shape).astype(np.float32)
+    wv = rng.standard_normal(gv.shape).astype(np.float32)
+    ((gh * torch.from_numpy(wh).to(dev)).sum() + (gv * torch.from_numpy(wv).to(dev)).sum()).backward()
+    to = torch.from_numpy(img).double().requires_grad_(True)
+    ((od.sobel_grad_h(to) * torch.from_numpy(wh).double()).sum()
+     + (od.sobel_grad_v(to) * torch.from_numpy(wv).double()).sum()).backward()
+    assert rel_l2(t.grad.cpu().numpy(), to.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('tag,nl', [('lin', False), ('nl', True)])
+def test_g2_g3_fused_loss_fixture(dev, tag, nl):
+    from pde_surrogate_amd.models import darcy
+    g = golden('G2_G3_loss.npz')
+    K = torch.from_numpy(g['K']).to(dev)
+    y = torch.from_numpy(g['y']).to(dev).requires_grad_(True)
+    b1, b2 = (float(v) for v in g['beta'])
+    loss, l_pde, l_dir, l_neu = darcy.darcy_mixed_residual_loss(K, y, 10.0, nl, b1, b2)
+    loss.backward()
+    ref = g[f'{tag}_terms']
+    np.testing.assert_allclose(float(loss), ref[0], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(float(l_pde), ref[1] + ref[2], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(float(l_dir), ref[3], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(float(l_neu), ref[4], rtol=LOSS_RTOL)
+    assert rel_l2(y.grad.cpu().numpy(), g[f'{tag}_grad']) < GRAD_RL2
+
+
+@pytest.mark.parametrize('tag,nl', [('lin', False), ('nl', True)])
+def test_g2_g3_dropin_functions_fixture(dev, tag, nl):
+    """the reference's call pattern (train_codec_mixed_residual.py:228-233) on the drop-in API"""
+    from pde_surrogate_amd.models import darcy
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    g = golden('G2_G3_loss.npz')
+    K = torch.from_numpy(g['K']).to(dev)
+    sob = SobelFilter(64, correct=True, device=dev)
+    b1, b2 = (float(v) for v in g['beta'])
+    ref = g[f'{tag}_terms']
+
+    def terms(y):
+        lc = (darcy.conv_constitutive_constraint_nonlinear(K, y, sob, b1, b2) if nl
+              else darcy.conv_constitutive_constraint(K, y, sob))
+        lt = darcy.conv_continuity_constraint(y, sob)
+        ld, ln = darcy.conv_boundary_condition(y)
+        return lc, lt, ld, ln
+
+    y = torch.from_numpy(g['y']).to(dev).requires_grad_(True)
+    lc, lt, ld, ln = terms(y)
+    loss = lc + lt + (ld + ln) * 10.0
+    loss.backward()
+    np.testing.assert_allclose([float(loss), float(lc), float(lt), float(ld), float(ln)], ref, rtol=LOSS_RTOL)
+    assert rel_l2(y.grad.cpu().numpy(), g[f'{tag}_grad']) < GRAD_RL2
+    for i, nm in enumerate(('const', 'cont', 'dir', 'neu')):
+        y = torch.from_numpy(g['y']).to(dev).requires_grad_(True)
+        terms(y)[i].backward()
+        assert rel_l2(y.grad.cpu().numpy(), g[f'{tag}_grad_{nm}']) < GRAD_RL2, nm
+
+
+def test_g4_closed_form(dev):
+    from pde_surrogate_amd.models import darcy
+    g = golden('G4_closed_form.npz')
+    K, y = torch.from_numpy(g['K']).to(dev), torch.from_numpy(g['y']).to(dev)
+    terms, _ = darcy.darcy_loss_launch(K, y, (1, 1, 10, 10), False)
+    t = terms.cpu().numpy()
+    assert abs(t[1]) < 1e-9 and t[4] == 0.0
+    assert abs(t[3] - (1 / 64) ** 2) < 1e-9
+    np.testing.assert_allclose(t[2], g['terms'][2], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize('n', [16, 32, 64])
+@pytest.mark.parametrize('B', [1, 3, 32])
+@pytest.mark.parametrize('nl', [False, True])
+def test_fused_loss_vs_oracle(dev, n, B, nl):
+    from oracle import darcy as od
+    from pde_surrogate_amd.models import darcy
+    K, y, Kd, yd = _fields(B, n, 1000 + n + B, dev)
+    wb = 7.5
+    terms, grad = darcy.darcy_loss_launch(Kd, yd, (1, 1, wb, wb), True, nl, 0.3, 0.2)
+    ref_terms, ref_grad = od.loss_and_grad_autograd(torch.from_numpy(K).double(), torch.from_numpy(y).double(),
+                                                    wb, 0.3, 0.2, nl)
+    np.testing.assert_allclose(terms.cpu().numpy(), [float(v) for v in ref_terms], rtol=LOSS_RTOL)
+    assert rel_l2(grad.cpu().numpy(), ref_grad.numpy()) < GRAD_RL2
+    # forward-only launch (eval path) gives the same scalars
+    terms2, g2 = darcy.darcy_loss_launch(Kd, yd, (1, 1, wb, wb), False, nl, 0.3, 0.2)
+    assert g2 is None
+    np.testing.assert_array_equal(terms.cpu().numpy(), terms2.cpu().numpy())
+
+
+def test_edge_pixels_sharp_interface(dev):
+    """channelized-like inputs (config 4): two-valued K, step fields -- exercises every edge formula"""
+    from oracle import darcy as od
+    from pde_surrogate_amd.models import darcy
+    rng = np.random.default_rng(5)
+    K = np.where(rng.random((4, 1, 64, 64)) > 0.5, 10.0, 1.0).astype(np.float32)
+    y = np.sign(rng.standard_normal((4, 3, 64, 64))).astype(np.float32)
+    y[:, :, :3, :] *= 5
+    y[:, :, -3:, :] *= -4
+    y[:, :, :, :3] *= 3
+    y[:, :, :, -3:] *= -2
+    terms, grad = darcy.darcy_loss_launch(torch.from_numpy(K).to(dev), torch.from_numpy(y).to(dev),
+                                          (1, 1, 10, 10), True)
+    rt, rg = od.loss_and_grad_analytic(K, y, 10.0)
+    np.testing.assert_allclose(terms.cpu().numpy(), rt, rtol=LOSS_RTOL)
+    assert rel_l2(grad.cpu().numpy(), rg) < GRAD_RL2
+    # edge rows/cols individually (a wrong boundary stencil hides in a global norm)
+    gg = grad.cpu().numpy()
+    for sl in (np.s_[:, :, :3, :], np.s_[:, :, -3:, :], np.s_[:, :, :, :3], np.s_[:, :, :, -3:]):
+        assert rel_l2(gg[sl], rg[sl]) < 1e-5
+
+
+def test_full_size_properties(dev):
+    """B = 4096 (ntrain of config 2): size-independent properties instead of a CPU re-computation:
+    (a) loss == mean over chunks of the chunk losses; (b) gradient of the big batch == chunk
+    gradients scaled by chunk/B; (c) sample permutation permutes gradients; (d) oracle on a slice."""
+    from oracle import darcy as od
+    from pde_surrogate_amd.models import darcy
+    B, n, C = 4096, 64, 512
+    gen = torch.Generator(device='cpu').manual_seed(11)
+    K = torch.exp(0.5 * torch.randn((B, 1, n, n), generator=gen)).to(dev)
+    y = torch.randn((B, 3, n, n), generator=gen).to(dev)
+    w = (1, 1, 10, 10)
+    terms, grad = darcy.darcy_loss_launch(K, y, w, True)
+    chunk_terms = []
+    for i in range(0, B, C):
+        t, g = darcy.darcy_loss_launch(K[i:i + C].contiguous(), y[i:i + C].contiguous(), w, True)
+        chunk_terms.append(t.double().cpu().numpy())
+        assert rel_l2(grad[i:i + C].cpu().numpy(), g.cpu().numpy() * (C / B)) < 2e-6
+    np.testing.assert_allclose(terms.cpu().numpy(), np.mean(chunk_terms, 0), rtol=LOSS_RTOL)
+    perm = torch.randperm(B, generator=gen).to(dev)
+    t2, g2 = darcy.darcy_loss_launch(K[perm].contiguous(), y[perm].contiguous(), w, True)
+    np.testing.assert_allclose(t2.cpu().numpy(), terms.cpu().numpy(), rtol=LOSS_RTOL)
+    assert torch.equal(g2, grad[perm])
+    rt, rg = od.loss_and_grad_analytic(K[:4].cpu().numpy(), y[:4].cpu().numpy(), 10.0)
+    assert rel_l2(grad[:4].cpu().numpy() * (B / 4), rg) < GRAD_RL2
+
+
+def test_rejects_bad_arguments(dev):
+    from pde_surrogate_amd.models import darcy
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    K, y, Kd, yd = _fields(2, 64, 3, dev)
+    with pytest.raises(RuntimeError):      # CPU tensors: no fallback
+        darcy.darcy_mixed_residual_loss(torch.from_numpy(K), torch.from_numpy(y))
+    with pytest.raises(RuntimeError):      # 48x48 is not implemented by the kernel
+        darcy.darcy_loss_launch(Kd[:, :, :48, :48].contiguous(), yd[:, :, :48, :48].contiguous(), (1, 1, 1, 1), True)
+    with pytest.raises(NotImplementedError):
+        darcy.conv_continuity_constraint(yd, SobelFilter(64, device=dev), use_tb=False)
+    with pytest.raises(NotImplementedError):
+        darcy.conv_constitutive_constraint(Kd, yd, SobelFilter(64, correct=False, device=dev))
+    with pytest.raises(NotImplementedError):
+        SobelFilter(64, device=dev).grad_h(Kd, filter_size=5)
