@@ -61,6 +61,102 @@ int pdes_sobel_grad(const float* img, float* gh, float* gv, int nimg, int H, int
 int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg, int H,
                             int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * DenseED / Decoder building blocks (models/codec.py).  One descriptor per convolution; the
+ * BatchNorm + ReLU (+ nearest x2 upsampling) that PRECEDES the convolution in the reference
+ * (codec.py:66-69 dense layer, :103-150 transition, :163-188 last decoding) is fused into the
+ * convolution's operand load, and the batch statistics of the convolution's OUTPUT (needed by the
+ * BatchNorms that consume it) are accumulated in its epilogue.  The `torch.cat` of dense blocks
+ * (codec.py:73-75) disappears: a block owns one (B, Ctot, H, W) buffer and each layer writes its
+ * `growth_rate` channels at `out_coff`.
+ *
+ * Backward uses one accumulator tensor T per activation buffer (same shape as the buffer):
+ *   T_c = sum over consumer BNs j of gamma_jc * dz_jc * 1[BN_j(x)_c > 0]
+ * and then dL/dx_c = invstd_c * (T_c - mean(T_c) - xhat_c * mean(T_c xhat_c)) (pdes_bn_backward_finalize),
+ * which is exactly the sum of the BatchNorm backward formulas of all consumers (shared batch stats).
+ */
+typedef struct pdes_conv_desc {
+  /* geometry */
+  int B, Cin, Cout, Hin, Win, Hout, Wout;
+  int ksize, stride, pad, upsample; /* upsample=1: nearest x2 between BN-ReLU and the conv */
+  /* input activation (raw, pre-BN) */
+  const float* x;        /* (B, x_ctot, Hin, Win); channels [0, Cin) are read */
+  int x_ctot;
+  int has_bn;            /* 0: first convolution, input used as is (no BN, no ReLU) */
+  int eval_mode;         /* 1: BN uses run_mean/run_var instead of batch statistics */
+  float eps;
+  const float* gamma;    /* (Cin) BN weight */
+  const float* beta;     /* (Cin) BN bias */
+  const double* x_stats; /* (x_ctot, 2) {sum x, sum x^2} over (B,Hin,Win), train mode */
+  const float* run_mean; /* (Cin) eval mode */
+  const float* run_var;  /* (Cin) eval mode */
+  /* weights: reference layout and the two packed copies made by pdes_pack_weights */
+  const float* w;        /* (Cout, Cin, k, k) */
+  const float* w_fwd;    /* (Cin, k*k, cout_pad) */
+  const float* w_bwd;    /* (Cout, k*k, cin_pad) */
+  int cout_pad, cin_pad; /* multiples of 16 */
+  /* output */
+  float* out;            /* (B, out_ctot, Hout, Wout); channels [out_coff, out_coff+Cout) written */
+  int out_ctot, out_coff;
+  double* out_stats;     /* (out_ctot, 2) accumulated for the written channels; NULL: none */
+  /* backward */
+  const float* g;        /* dL/d(out): (B, g_ctot, Hout, Wout), channels [g_coff, g_coff+Cout) */
+  int g_ctot, g_coff;
+  float* t_in;           /* T accumulator of the input buffer (B, x_ctot, Hin, Win) */
+  int t_accumulate;      /* 0: T = ..., 1: T += ... */
+  int final_c0, final_c1;/* input channels whose T is complete after this call: their
+                            {sum T, sum T*xhat} are accumulated into t_stats */
+  double* t_stats;       /* (x_ctot, 2) */
+  double* bn_grad;       /* (Cin, 2) {dgamma, dbeta} accumulators (fp64) */
+  float* dw;             /* (Cout, Cin, k, k) weight gradient, ACCUMULATED (zero it first) */
+} pdes_conv_desc;
+
+/* `descs` is a HOST array; one kernel launch per descriptor, in order.
+ * out = conv(relu(bn(x))) for `n` descriptors in order; accumulates out_stats.
+ * Replaces nn.BatchNorm2d + nn.ReLU + [UpsamplingNearest2d] + nn.Conv2d + torch.cat
+ * (models/codec.py:43-75, :89-160, :163-188, :242-243). */
+int pdes_conv_forward(const pdes_conv_desc* descs, int n, void* stream);
+/* dw += sum_{b,p} g * relu(bn(x)) (autograd of F.conv2d wrt weight). */
+int pdes_conv_backward_weight(const pdes_conv_desc* descs, int n, void* stream);
+/* T_in (+)= gamma * (conv^T(g)) * 1[bn(x) > 0]; also dgamma/dbeta and the finished channels'
+ * {sum T, sum T xhat} (autograd of conv2d wrt input, ReLU, BatchNorm wrt gamma/beta). */
+int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void* stream);
+/* In place T -> dL/dx for channels [c0, c1) of a (B, ctot, H, W) buffer (BatchNorm backward wrt
+ * its input, summed over every consumer BN). */
+int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
+                              int B, int ctot, int c0, int c1, int HW, float eps, void* stream);
+
+/* Table-driven helpers: one launch for the whole network. */
+typedef struct pdes_pack_item {  /* one convolution's weights */
+  const float* w; float* w_fwd; float* w_bwd;
+  int Cout, Cin, kk, cout_pad, cin_pad;
+} pdes_pack_item;
+/* items: DEVICE array of n entries; total = max elements over items (grid sizing). */
+int pdes_pack_weights(const pdes_pack_item* items, int n, int max_elems, void* stream);
+
+typedef struct pdes_bn_item {    /* one BatchNorm layer */
+  const double* x_stats;  /* (>=C, 2) batch sums of its input channels */
+  const double* bn_grad;  /* (C, 2) {dgamma, dbeta} */
+  float* run_mean; float* run_var; /* (C) updated in place */
+  float* dgamma; float* dbeta;     /* (C) fp32 gradients, ACCUMULATED */
+  long long* num_batches_tracked;  /* scalar, incremented */
+  int C; int count;                /* count = B*H*W */
+} pdes_bn_item;
+/* running_mean/var <- momentum update with batch mean / unbiased var (nn.BatchNorm2d train mode). */
+int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_c, float momentum, void* stream);
+/* dgamma/dbeta (fp32) += fp64 accumulators. */
+int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, void* stream);
+
+/* Adam step on flat fp32 buffers, torch.optim.Adam semantics (L2 weight decay added to the
+ * gradient, bias correction, eps outside the sqrt).  lr and step live in DEVICE memory so a
+ * captured hipGraph can replay with a new learning rate: hyper = {lr, beta1, beta2, eps,
+ * weight_decay, 1-beta1^step, sqrt(1-beta2^step)} (7 floats, bias corrections computed by the
+ * host in double like torch).  grad_scale multiplies the gradient first
+ * (1/world_size after a SUM all-reduce).
+ * Replaces optimizer.step() of train_codec_mixed_residual.py:239 (torch.optim.Adam, :151-152). */
+int pdes_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   const float* hyper, float grad_scale, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

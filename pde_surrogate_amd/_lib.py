@@ -17,6 +17,14 @@ SIGNATURES = {
     'pdes_darcy_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_p],
     'pdes_sobel_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
     'pdes_sobel_grad_adjoint': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
+    'pdes_conv_forward': [_c_p, _c_i, _c_p],
+    'pdes_conv_backward_weight': [_c_p, _c_i, _c_p],
+    'pdes_conv_backward_data': [_c_p, _c_i, _c_p],
+    'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p],
+    'pdes_pack_weights': [_c_p, _c_i, _c_i, _c_p],
+    'pdes_bn_update_running': [_c_p, _c_i, _c_i, _c_f, _c_p],
+    'pdes_bn_param_grads': [_c_p, _c_i, _c_i, _c_p],
+    'pdes_adam_step': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, ctypes.c_longlong, _c_p],
 }
 
 _ERR = {-1: 'PDES_EINVAL (null pointer / non-positive size)',

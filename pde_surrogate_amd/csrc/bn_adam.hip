@@ -1,0 +1,149 @@
+// Small table-driven kernels around the convolutions: BatchNorm backward finalisation, running
+// statistics, fp64->fp32 parameter gradients, weight packing, and the flat Adam step.
+// References: nn.BatchNorm2d semantics as used by models/codec.py (train: batch stats, biased var
+// for normalisation, unbiased var into running_var, momentum 0.1, eps 1e-5);
+// torch.optim.Adam as called in train_codec_mixed_residual.py:151-152,239.
+#include "pdes_common.h"
+#include "../../include/pdes_hip.h"
+
+namespace pdes {
+
+// T -> dL/dx in place: g = invstd * (T - mean(T) - xhat * mean(T*xhat))
+// grid: (ceil(HW/256)?, c1-c0, B) -> use flat: x = HW tiles, y = channel, z = sample
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ t, const float* __restrict__ x,
+                                                              const double* __restrict__ x_stats,
+                                                              const double* __restrict__ t_stats, int B, int ctot,
+                                                              int c0, int HW, float eps) {
+  const int c = c0 + blockIdx.y, b = blockIdx.z;
+  const double n = (double)B * HW;
+  const double m = x_stats[2 * c] / n;
+  double var = x_stats[2 * c + 1] / n - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  const float mean = (float)m;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float m1 = (float)(t_stats[2 * c] / n), m2 = (float)(t_stats[2 * c + 1] / n);
+  const size_t base = ((size_t)b * ctot + c) * HW;
+  // HW is a multiple of 4 for every supported feature map (>= 8x8); vectorise when aligned
+  if ((HW & 3) == 0) {
+    float4* t4 = reinterpret_cast<float4*>(t + base);
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
+      float4 tv = t4[i];
+      const float4 xv = x4[i];
+      tv.x = invstd * (tv.x - m1 - (xv.x - mean) * invstd * m2);
+      tv.y = invstd * (tv.y - m1 - (xv.y - mean) * invstd * m2);
+      tv.z = invstd * (tv.z - m1 - (xv.z - mean) * invstd * m2);
+      tv.w = invstd * (tv.w - m1 - (xv.w - mean) * invstd * m2);
+      t4[i] = tv;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256)
+      t[base + i] = invstd * (t[base + i] - m1 - (x[base + i] - mean) * invstd * m2);
+  }
+}
+
+// (Cout,Cin,kk) -> w_fwd (Cin,kk,cout_pad) and w_bwd (Cout,kk,cin_pad); pads are pre-zeroed once.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const pdes_pack_item* __restrict__ items) {
+  const pdes_pack_item it = items[blockIdx.y];
+  const int total = it.Cout * it.Cin * it.kk;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int t = i % it.kk, ci = (i / it.kk) % it.Cin, co = i / (it.kk * it.Cin);
+    const float v = it.w[i];
+    it.w_fwd[((size_t)ci * it.kk + t) * it.cout_pad + co] = v;
+    it.w_bwd[((size_t)co * it.kk + t) * it.cin_pad + ci] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_update_running_kernel(const pdes_bn_item* __restrict__ items, float momentum) {
+  const pdes_bn_item it = items[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && it.num_batches_tracked) *it.num_batches_tracked += 1;
+  if (c >= it.C) return;
+  const double n = (double)it.count;
+  const double m = it.x_stats[2 * c] / n;
+  double var = it.x_stats[2 * c + 1] / n - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  const double unbiased = it.count > 1 ? var * n / (n - 1.0) : var;
+  it.run_mean[c] = (float)((1.0 - momentum) * it.run_mean[c] + momentum * m);
+  it.run_var[c] = (float)((1.0 - momentum) * it.run_var[c] + momentum * unbiased);
+}
+
+__global__ __launch_bounds__(256) void bn_param_grads_kernel(const pdes_bn_item* __restrict__ items) {
+  const pdes_bn_item it = items[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= it.C) return;
+  it.dgamma[c] += (float)it.bn_grad[2 * c];
+  it.dbeta[c] += (float)it.bn_grad[2 * c + 1];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ hyper, float gscale, long long n) {
+  // torch.optim.Adam (non-amsgrad, non-maximize); the host computes the bias corrections in
+  // double exactly as torch does: bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step)
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float bc1 = hyper[5], bc2_sqrt = hyper[6];
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);          // lerp, as torch does
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+}  // namespace pdes
+
+using namespace pdes;
+
+extern "C" int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
+                                         int B, int ctot, int c0, int c1, int HW, float eps, void* stream) {
+  if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0) return PDES_EINVAL;
+  if (!aligned16(t) || !aligned16(x)) return PDES_EALIGN;
+  dim3 grid(cdiv(cdiv(HW, 4), 256), c1 - c0, B), block(256);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, static_cast<hipStream_t>(stream), t, x, x_stats, t_stats,
+                     B, ctot, c0, HW, eps);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_pack_weights(const pdes_pack_item* items, int n, int max_elems, void* stream) {
+  if (!items || n <= 0 || max_elems <= 0) return PDES_EINVAL;
+  int gx = cdiv(max_elems, 256);
+  gx = gx > 64 ? 64 : gx;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, n), dim3(256), 0, static_cast<hipStream_t>(stream), items);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_c, float momentum, void* stream) {
+  if (!items || n <= 0 || max_c <= 0) return PDES_EINVAL;
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3(cdiv(max_c, 256), n), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, momentum);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, void* stream) {
+  if (!items || n <= 0 || max_c <= 0) return PDES_EINVAL;
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(max_c, 256), n), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* hyper,
+                              float grad_scale, long long n, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return PDES_EINVAL;
+  long long gx = (n + 255) / 256;
+  gx = gx > 2048 ? 2048 : gx;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad,
+                     exp_avg, exp_avg_sq, hyper, grad_scale, n);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}

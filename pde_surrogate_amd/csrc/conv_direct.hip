@@ -1,0 +1,359 @@
+// Generic direct convolutions with fused BatchNorm+ReLU(+nearest x2) operand transform for
+// DenseED / Decoder (reference models/codec.py:43-188), gfx950 VALU path.
+//
+// These kernels cover EVERY convolution shape of the network (k = 1,3,5,7; stride 1,2; fused
+// nearest upsampling; any Cin/Cout) and are the reference HIP path the MFMA kernels
+// (conv_mfma.hip) are tested against on the GPU; the dispatcher in conv_dispatch.hip prefers the
+// MFMA kernels where they apply.
+//
+// Mapping: one thread = one output pixel x COT output channels kept in registers.  Weights are
+// read through the scalar cache (s_load_dwordx16 from the packed (Cin, k*k, cout_pad) copy: the
+// address is wave-uniform), so the inner loop is 1 vector load + COT v_fmac per (ci, tap).
+// Activations stay NCHW; lanes of a wave are consecutive pixels of one channel plane -> coalesced.
+// BatchNorm coefficients (mean, gamma*invstd, beta) are derived per workgroup from the fp64
+// {sum, sum^2} the producer accumulated, so no separate BN kernel or normalised copy exists.
+#include "pdes_common.h"
+#include "../../include/pdes_hip.h"
+
+namespace pdes {
+
+typedef const float __attribute__((address_space(4)))* kfloatp;   // scalar-cache (constant) loads
+
+// BN coefficients of channel c of the input buffer.
+struct BnC { float mean, invstd, gamma, beta; };
+
+__device__ __forceinline__ BnC bn_coef(const pdes_conv_desc& d, int c) {
+  BnC o;
+  if (!d.has_bn) { o.mean = 0.f; o.invstd = 1.f; o.gamma = 1.f; o.beta = 0.f; return o; }
+  if (d.eval_mode) {
+    o.mean = d.run_mean[c];
+    o.invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
+  } else {
+    const double n = (double)d.B * d.Hin * d.Win;
+    const double m = d.x_stats[2 * c] / n;
+    double var = d.x_stats[2 * c + 1] / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    o.mean = (float)m;
+    o.invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+  }
+  o.gamma = d.gamma[c];
+  o.beta = d.beta[c];
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------ fwd
+// grid: (ceil(Hout*Wout/256), ceil(Cout/COT), B), block 256.  dyn LDS: 3*Cin floats + 4*COT*2 doubles
+template <int COT>
+__global__ __launch_bounds__(256) void conv_fwd_direct(pdes_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* red = reinterpret_cast<double*>(smem_raw);                 // [4 waves][COT][2]
+  float* cf = reinterpret_cast<float*>(smem_raw + 4 * COT * 2 * sizeof(double));  // [Cin][3]
+  const int tid = threadIdx.x;
+  for (int c = tid; c < d.Cin; c += 256) {
+    const BnC k = bn_coef(d, c);
+    cf[3 * c + 0] = k.mean;
+    cf[3 * c + 1] = k.gamma * k.invstd;
+    cf[3 * c + 2] = k.beta;
+  }
+  __syncthreads();
+
+  const int HWo = d.Hout * d.Wout, HWi = d.Hin * d.Win;
+  const int p = blockIdx.x * 256 + tid;
+  const int co0 = blockIdx.y * COT;
+  const int b = blockIdx.z;
+  const bool active = p < HWo;
+  const int oy = active ? p / d.Wout : 0, ox = active ? p % d.Wout : 0;
+  const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;
+  const int k = d.ksize, KK = k * k;
+  const float* xb = d.x + (size_t)b * d.x_ctot * HWi;
+  float acc[COT];
+#pragma unroll
+  for (int j = 0; j < COT; ++j) acc[j] = 0.f;
+
+  for (int ci = 0; ci < d.Cin; ++ci) {
+    const float mean = cf[3 * ci], scale = cf[3 * ci + 1], beta = cf[3 * ci + 2];
+    const float* xc = xb + (size_t)ci * HWi;
+    const kfloatp wrow = (kfloatp)(d.w_fwd + (size_t)ci * KK * d.cout_pad + co0);
+    for (int ky = 0; ky < k; ++ky) {
+      const int cy = oy * d.stride + ky - d.pad;
+      const bool vy = active && cy >= 0 && cy < Hc;
+      const int sy = d.upsample ? (cy >> 1) : cy;
+      for (int kx = 0; kx < k; ++kx) {
+        const int cx = ox * d.stride + kx - d.pad;
+        const bool v = vy && cx >= 0 && cx < Wc;
+        const int sx = d.upsample ? (cx >> 1) : cx;
+        float z = 0.f;
+        if (v) {
+          const float x = xc[sy * d.Win + sx];
+          z = d.has_bn ? fmaxf(0.f, (x - mean) * scale + beta) : x;
+        }
+        const kfloatp wp = wrow + (ky * k + kx) * d.cout_pad;
+#pragma unroll
+        for (int j = 0; j < COT; ++j) acc[j] += z * wp[j];
+      }
+    }
+  }
+  float* ob = d.out + ((size_t)b * d.out_ctot + d.out_coff + co0) * HWo;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+      if (co0 + j < d.Cout) ob[(size_t)j * HWo + p] = acc[j];
+  }
+  if (d.out_stats) {
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+      const float v = active ? acc[j] : 0.f;
+      const float s = wave_sum(v), q = wave_sum(v * v);
+      if (lane == 0) { red[(wave * COT + j) * 2] = (double)s; red[(wave * COT + j) * 2 + 1] = (double)q; }
+    }
+    __syncthreads();
+    if (tid < COT * 2) {
+      const int j = tid >> 1, w = tid & 1;
+      if (co0 + j < d.Cout) {
+        double t = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) t += red[(wv * COT + j) * 2 + w];
+        atomicAdd(&d.out_stats[2 * (d.out_coff + co0 + j) + w], t);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ bwd data
+// one thread = one INPUT pixel (low-res pixel when upsample) x CIT input channels.
+// grid: (ceil(Hin*Win/256), ceil(Cin/CIT), B).  dyn LDS: 4 waves*CIT*4 doubles + 4*Cin floats
+template <int CIT>
+__global__ __launch_bounds__(256) void conv_bwd_data_direct(pdes_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* red = reinterpret_cast<double*>(smem_raw);                 // [4][CIT][4]
+  float* cf = reinterpret_cast<float*>(smem_raw + 4 * CIT * 4 * sizeof(double));  // [Cin][4]
+  const int tid = threadIdx.x;
+  const int ci0 = blockIdx.y * CIT;
+  for (int c = tid; c < CIT; c += 256) {
+    if (ci0 + c < d.Cin) {
+      const BnC k = bn_coef(d, ci0 + c);
+      cf[4 * c + 0] = k.mean; cf[4 * c + 1] = k.invstd; cf[4 * c + 2] = k.gamma; cf[4 * c + 3] = k.beta;
+    }
+  }
+  __syncthreads();
+
+  const int HWo = d.Hout * d.Wout, HWi = d.Hin * d.Win;
+  const int p = blockIdx.x * 256 + tid;
+  const int b = blockIdx.z;
+  const bool active = p < HWi;
+  const int iy = active ? p / d.Win : 0, ix = active ? p % d.Win : 0;
+  const int k = d.ksize, KK = k * k;
+  const int nsub = d.upsample ? 2 : 1;
+  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HWo;
+  float acc[CIT];
+#pragma unroll
+  for (int j = 0; j < CIT; ++j) acc[j] = 0.f;
+
+  for (int co = 0; co < d.Cout; ++co) {
+    const float* gc = gb + (size_t)co * HWo;
+    const kfloatp wrow = (kfloatp)(d.w_bwd + (size_t)co * KK * d.cin_pad + ci0);
+    for (int dy = 0; dy < nsub; ++dy) {
+      const int cy = d.upsample ? 2 * iy + dy : iy;          // conv-input coordinate
+      for (int ky = 0; ky < k; ++ky) {
+        const int ty = cy + d.pad - ky;
+        if (ty < 0) continue;                                 // wave-divergent but cheap
+        const int oy = ty / d.stride;
+        const bool vy = active && (ty - oy * d.stride == 0) && oy < d.Hout;
+        for (int dx = 0; dx < nsub; ++dx) {
+          const int cx = d.upsample ? 2 * ix + dx : ix;
+          for (int kx = 0; kx < k; ++kx) {
+            const int tx = cx + d.pad - kx;
+            const int ox = tx / d.stride;
+            const bool v = vy && tx >= 0 && (tx - ox * d.stride == 0) && ox < d.Wout;
+            const float g = v ? gc[oy * d.Wout + ox] : 0.f;
+            const kfloatp wp = wrow + (ky * k + kx) * d.cin_pad;
+#pragma unroll
+            for (int j = 0; j < CIT; ++j) acc[j] += g * wp[j];
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: ReLU mask, gamma, T (+)=, dgamma/dbeta, finished-channel sums
+  const float* xb = d.x + (size_t)b * d.x_ctot * HWi;
+  float* tb = d.t_in + (size_t)b * d.x_ctot * HWi;
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int j = 0; j < CIT; ++j) {
+    const int ci = ci0 + j;
+    float dg = 0.f, db = 0.f, st = 0.f, sx = 0.f;
+    if (ci < d.Cin && active) {
+      const float mean = cf[4 * j], invstd = cf[4 * j + 1], gamma = cf[4 * j + 2], beta = cf[4 * j + 3];
+      const size_t idx = (size_t)ci * HWi + p;
+      const float x = xb[idx];
+      const float y = (x - mean) * (gamma * invstd) + beta;     // same expression as the forward
+      const float xh = (x - mean) * invstd;
+      const float dyv = (y > 0.f) ? acc[j] : 0.f;
+      db = dyv;
+      dg = dyv * xh;
+      float t = gamma * dyv;
+      if (d.t_accumulate) t += tb[idx];
+      tb[idx] = t;
+      if (ci >= d.final_c0 && ci < d.final_c1) { st = t; sx = t * xh; }
+    }
+    const float r0 = wave_sum(dg), r1 = wave_sum(db), r2 = wave_sum(st), r3 = wave_sum(sx);
+    if (lane == 0) {
+      double* r = &red[(wave * CIT + j) * 4];
+      r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+    }
+  }
+  __syncthreads();
+  if (tid < CIT * 4) {
+    const int j = tid >> 2, q = tid & 3, ci = ci0 + j;
+    if (ci < d.Cin) {
+      double t = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) t += red[(wv * CIT + j) * 4 + q];
+      if (q < 2) atomicAdd(&d.bn_grad[2 * ci + q], t);
+      else if (ci >= d.final_c0 && ci < d.final_c1) atomicAdd(&d.t_stats[2 * ci + (q - 2)], t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- bwd weight
+// one workgroup = one input channel x COT output channels x a slice of the batch; every thread
+// accumulates its pixels' COT x KS*KS products, then wave/LDS reduce and fp32 atomicAdd into dw.
+// grid: (Cin, ceil(Cout/COT), nsplit), block 256.
+template <int KS, int COT>
+__global__ __launch_bounds__(256) void conv_bwd_weight_direct(pdes_conv_desc d, int nsplit) {
+  constexpr int KK = KS * KS;
+  __shared__ float red[4][COT * KK];
+  const int tid = threadIdx.x;
+  const int ci = blockIdx.x, co0 = blockIdx.y * COT;
+  const int b0 = (int)(((long long)d.B * blockIdx.z) / nsplit), b1 = (int)(((long long)d.B * (blockIdx.z + 1)) / nsplit);
+  const BnC bc = bn_coef(d, ci);
+  const float mean = bc.mean, scale = bc.gamma * bc.invstd, beta = bc.beta;
+  const int HWo = d.Hout * d.Wout, HWi = d.Hin * d.Win;
+  const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;
+  float acc[COT][KK];
+#pragma unroll
+  for (int j = 0; j < COT; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.f;
+
+  for (int b = b0; b < b1; ++b) {
+    const float* xc = d.x + ((size_t)b * d.x_ctot + ci) * HWi;
+    const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
+    for (int p = tid; p < HWo; p += 256) {
+      const int oy = p / d.Wout, ox = p % d.Wout;
+      float z[KK];
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int cy = oy * d.stride + ky - d.pad;
+        const bool vy = cy >= 0 && cy < Hc;
+        const int sy = d.upsample ? (cy >> 1) : cy;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int cx = ox * d.stride + kx - d.pad;
+          const bool v = vy && cx >= 0 && cx < Wc;
+          const int sx = d.upsample ? (cx >> 1) : cx;
+          float zz = 0.f;
+          if (v) {
+            const float x = xc[sy * d.Win + sx];
+            zz = d.has_bn ? fmaxf(0.f, (x - mean) * scale + beta) : x;
+          }
+          z[ky * KS + kx] = zz;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < COT; ++j) {
+        const float g = (co0 + j < d.Cout) ? gb[(size_t)j * HWo + p] : 0.f;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc[j][t] += g * z[t];
+      }
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int j = 0; j < COT; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const float s = wave_sum(acc[j][t]);
+      if (lane == 0) red[wave][j * KK + t] = s;
+    }
+  __syncthreads();
+  for (int i = tid; i < COT * KK; i += 256) {
+    const int j = i / KK, t = i % KK;
+    if (co0 + j < d.Cout) {
+      const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+      atomicAdd(&d.dw[((size_t)(co0 + j) * d.Cin + ci) * KK + t], s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- host dispatch
+static int validate(const pdes_conv_desc& d, int mode) {
+  if (d.B <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return PDES_EINVAL;
+  if (!d.x) return PDES_EINVAL;
+  if (!(d.ksize == 1 || d.ksize == 3 || d.ksize == 5 || d.ksize == 7)) return PDES_ENOSUP;
+  if (d.stride < 1 || d.stride > 2 || (d.upsample && d.stride != 1)) return PDES_ENOSUP;
+  if (d.has_bn && (!d.gamma || !d.beta || (d.eval_mode ? (!d.run_mean || !d.run_var) : !d.x_stats))) return PDES_EINVAL;
+  const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;
+  if ((Hc + 2 * d.pad - d.ksize) / d.stride + 1 != d.Hout || (Wc + 2 * d.pad - d.ksize) / d.stride + 1 != d.Wout) return PDES_EINVAL;
+  if (d.cout_pad % 16 || d.cin_pad % 16 || d.cout_pad < d.Cout || d.cin_pad < d.Cin) return PDES_EINVAL;
+  if (mode == 0 && (!d.out || !d.w_fwd)) return PDES_EINVAL;
+  if (mode == 1 && (!d.g || !d.dw)) return PDES_EINVAL;
+  if (mode == 2 && (!d.g || !d.w_bwd || !d.t_in || !d.bn_grad || !d.t_stats || !d.has_bn || d.eval_mode)) return PDES_EINVAL;
+  return PDES_OK;
+}
+
+int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st) {
+  const int rc = validate(d, 0);
+  if (rc) return rc;
+  const int HWo = d.Hout * d.Wout;
+  // fewer channels per thread when that is needed to fill the chip (>= 2 waves per SIMD)
+  const long long px_blocks = (long long)cdiv(HWo, 256) * d.B;
+  int cot = 16;
+  if (d.Cout <= 4) cot = 4;
+  else if (px_blocks * cdiv(d.Cout, 16) < 512 && d.Cout >= 8) cot = 8;
+  dim3 grid(cdiv(HWo, 256), cdiv(d.Cout, cot), d.B), block(256);
+  const size_t lds = 4 * cot * 2 * sizeof(double) + (size_t)3 * d.Cin * sizeof(float);
+  if (cot == 16) hipLaunchKernelGGL(conv_fwd_direct<16>, grid, block, lds, st, d);
+  else if (cot == 8) hipLaunchKernelGGL(conv_fwd_direct<8>, grid, block, lds, st, d);
+  else hipLaunchKernelGGL(conv_fwd_direct<4>, grid, block, lds, st, d);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st) {
+  const int rc = validate(d, 2);
+  if (rc) return rc;
+  const int HWi = d.Hin * d.Win;
+  const long long px_blocks = (long long)cdiv(HWi, 256) * d.B;
+  int cit = 16;
+  if (px_blocks * cdiv(d.Cin, 16) < 512) cit = 8;
+  dim3 grid(cdiv(HWi, 256), cdiv(d.Cin, cit), d.B), block(256);
+  const size_t lds = 4 * cit * 4 * sizeof(double) + (size_t)4 * cit * sizeof(float);
+  if (cit == 16) hipLaunchKernelGGL(conv_bwd_data_direct<16>, grid, block, lds, st, d);
+  else hipLaunchKernelGGL(conv_bwd_data_direct<8>, grid, block, lds, st, d);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st) {
+  const int rc = validate(d, 1);
+  if (rc) return rc;
+  int cot;
+  switch (d.ksize) { case 1: cot = 16; break; case 3: cot = 8; break; case 5: cot = 4; break; default: cot = 2; }
+  const int ncog = cdiv(d.Cout, cot);
+  int nsplit = cdiv(1024, d.Cin * ncog);
+  nsplit = nsplit < 1 ? 1 : (nsplit > d.B ? d.B : nsplit);
+  dim3 grid(d.Cin, ncog, nsplit), block(256);
+  switch (d.ksize) {
+    case 1: hipLaunchKernelGGL((conv_bwd_weight_direct<1, 16>), grid, block, 0, st, d, nsplit); break;
+    case 3: hipLaunchKernelGGL((conv_bwd_weight_direct<3, 8>), grid, block, 0, st, d, nsplit); break;
+    case 5: hipLaunchKernelGGL((conv_bwd_weight_direct<5, 4>), grid, block, 0, st, d, nsplit); break;
+    default: hipLaunchKernelGGL((conv_bwd_weight_direct<7, 2>), grid, block, 0, st, d, nsplit); break;
+  }
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+}  // namespace pdes

@@ -1,0 +1,518 @@
+"""DenseED / Decoder on MI355X -- drop-in for the reference's models/codec.py (:210-370).
+
+Same constructor arguments, ``forward`` contract, ``model_size`` / ``forward_test`` and the same
+``state_dict`` keys (checkpoints interchange with the reference), but ``forward``/``backward`` run
+hand-written HIP kernels through the C ABI (include/pdes_hip.h) instead of aten ops:
+
+  * every parameter lives in ONE flat fp32 buffer (one RCCL all-reduce, one Adam launch);
+  * a dense block owns one (B, Ctot, H, W) buffer, layers write their 16 channels in place
+    (no ``torch.cat``), BatchNorm+ReLU(+nearest x2) are applied on the fly when a convolution
+    loads its operand, batch statistics are accumulated by the producing convolution;
+  * backward keeps one accumulator T per activation buffer (see include/pdes_hip.h) so the 27
+    BatchNorm backward passes cost no extra pass over the activations.
+
+There is no CPU implementation: inputs must be CUDA (ROCm) tensors.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of `pdes_conv_desc` (include/pdes_hip.h) -- field order and types must match"""
+    _fields_ = [
+        ('B', _I), ('Cin', _I), ('Cout', _I), ('Hin', _I), ('Win', _I), ('Hout', _I), ('Wout', _I),
+        ('ksize', _I), ('stride', _I), ('pad', _I), ('upsample', _I),
+        ('x', _P), ('x_ctot', _I), ('has_bn', _I), ('eval_mode', _I), ('eps', _F),
+        ('gamma', _P), ('beta', _P), ('x_stats', _P), ('run_mean', _P), ('run_var', _P),
+        ('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('cout_pad', _I), ('cin_pad', _I),
+        ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P),
+        ('g', _P), ('g_ctot', _I), ('g_coff', _I),
+        ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
+        ('t_stats', _P), ('bn_grad', _P), ('dw', _P),
+    ]
+
+
+class PackItem(ctypes.Structure):
+    _fields_ = [('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('Cout', _I), ('Cin', _I), ('kk', _I),
+                ('cout_pad', _I), ('cin_pad', _I)]
+
+
+class BnItem(ctypes.Structure):
+    _fields_ = [('x_stats', _P), ('bn_grad', _P), ('run_mean', _P), ('run_var', _P), ('dgamma', _P),
+                ('dbeta', _P), ('num_batches_tracked', _P), ('C', _I), ('count', _I)]
+
+
+def module_size(module):
+    """(n_params, n_conv_layers): counts parameter names containing 'conv' (codec.py:14-21)"""
+    assert isinstance(module, torch.nn.Module)
+    n_params, n_conv_layers = 0, 0
+    for name, param in module.named_parameters():
+        if 'conv' in name:
+            n_conv_layers += 1
+        n_params += param.numel()
+    return n_params, n_conv_layers
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+# ------------------------------------------------------------------------------------------------
+# network description: a list of convolution specs in forward order
+class _ConvSpec:
+    __slots__ = ('conv', 'norm', 'cin', 'cout', 'k', 'stride', 'pad', 'up', 'src', 'dst', 'dst_coff', 'scale')
+
+    def __init__(self, conv, norm, cin, cout, k, stride, pad, up, src, dst, dst_coff, scale):
+        self.conv, self.norm = conv, norm          # module paths under `features`
+        self.cin, self.cout, self.k, self.stride, self.pad, self.up = cin, cout, k, stride, pad, up
+        self.src, self.dst, self.dst_coff = src, dst, dst_coff   # activation buffer ids
+        self.scale = scale                          # (num, den): input-buffer size = imsize*num/den
+
+
+def _plan_block(specs, bufs, name, c, n_layers, growth, src, scale):
+    """dense block: buffer `src` has room for all channels; layer j reads [0,c) writes [c,c+g)"""
+    for j in range(1, n_layers + 1):
+        p = f'{name}.denselayer{j}'
+        specs.append(_ConvSpec(p + '.conv1', p + '.norm1', c, growth, 3, 1, 1, 0, src, src, c, scale))
+        c += growth
+    return c
+
+
+def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsize):
+    """stage order and channel bookkeeping of DenseED (reference codec.py:229-293)"""
+    if len(blocks) > 1 and len(blocks) % 2 == 0:
+        raise ValueError('length of blocks must be an odd number, but got {}'.format(len(blocks)))
+    enc, dec = blocks[:len(blocks) // 2], blocks[len(blocks) // 2:]
+    specs, bufs = [], {}          # bufs: id -> [channels, (num, den)]
+    pad = 3 if imsize % 2 == 0 else 2
+    res = (1, 2)                  # feature-map size relative to the image, as a fraction
+    bufs['in'] = [in_channels, (1, 1)]
+    cur, c = 'b0', init_features
+    bufs[cur] = [c + (enc[0] if enc else dec[0]) * growth, res]
+    specs.append(_ConvSpec('In_conv', None, in_channels, init_features, 7, 2, pad, 0, 'in', cur, 0, (1, 1)))
+    nb = 1
+    for i, n in enumerate(enc, 1):
+        c = _plan_block(specs, bufs, f'EncBlock{i}', c, n, growth, cur, res)
+        t = f'TransDown{i}'
+        mid, nxt = f'b{nb}', f'b{nb + 1}'
+        nb += 2
+        bufs[mid] = [c // 2, res]
+        specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
+        nres = (res[0], res[1] * 2)
+        following = enc[i] if i < len(enc) else dec[0]
+        bufs[nxt] = [c // 2 + following * growth, nres]
+        specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 2, 3, 2, 1, 0, mid, nxt, 0, res))
+        cur, c, res = nxt, c // 2, nres
+    for i, n in enumerate(dec, 1):
+        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res)
+        if i < len(dec):
+            t = f'TransUp{i}'
+            mid, nxt = f'b{nb}', f'b{nb + 1}'
+            nb += 2
+            bufs[mid] = [c // 2, res]
+            specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
+            nres = (res[0] * 2, res[1])
+            bufs[nxt] = [c // 2 + dec[i] * growth, nres]
+            specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 2, 3, 1, 1, 1, mid, nxt, 0, res))
+            cur, c, res = nxt, c // 2, nres
+    _plan_last(specs, bufs, cur, c, res, out_channels, nb)
+    return specs, bufs
+
+
+def _plan_last(specs, bufs, cur, c, res, out_channels, nb):
+    """last decoding (reference codec.py:163-188)"""
+    t = 'LastTransUp'
+    m1, m2 = f'b{nb}', f'b{nb + 1}'
+    bufs[m1] = [c // 2, res]
+    specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 3, 1, 1, 0, cur, m1, 0, res))
+    nres = (res[0] * 2, res[1])
+    bufs[m2] = [c // 4, nres]
+    specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 4, 3, 1, 1, 1, m1, m2, 0, res))
+    bufs['out'] = [out_channels, nres]
+    specs.append(_ConvSpec(t + '.conv3', t + '.norm3', c // 4, out_channels, 5, 1, 2, 0, m2, 'out', 0, nres))
+
+
+def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels):
+    """Decoder (reference codec.py:326-354); sizes are relative to the latent map (16x16 -> 64x64)"""
+    specs, bufs = [], {}
+    res = (1, 1)
+    bufs['in'] = [dim_latent, res]
+    cur, c, nb = 'b0', init_features, 1
+    bufs[cur] = [c + blocks[0] * growth, res]
+    specs.append(_ConvSpec('conv0', None, dim_latent, init_features, 3, 1, 1, 0, 'in', cur, 0, res))
+    for i, n in enumerate(blocks, 1):
+        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res)
+        if i < len(blocks):
+            t = f'TransUp{i}'
+            mid, nxt = f'b{nb}', f'b{nb + 1}'
+            nb += 2
+            bufs[mid] = [c // 2, res]
+            specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
+            nres = (res[0] * 2, res[1])
+            bufs[nxt] = [c // 2 + blocks[i] * growth, nres]
+            specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 2, 3, 1, 1, 1, mid, nxt, 0, res))
+            cur, c, res = nxt, c // 2, nres
+    _plan_last(specs, bufs, cur, c, res, out_channels, nb)
+    return specs, bufs
+
+
+def _add_path(root, path, module):
+    parts = path.split('.')
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, nn.Sequential())
+        m = m._modules[p]
+    m.add_module(parts[-1], module)
+
+
+def _build_modules(features, specs):
+    """parameter containers in the reference's creation order (same RNG stream, same state_dict keys).
+    nn.Conv2d / nn.BatchNorm2d are used for their parameters and default init only -- their forward
+    is never called."""
+    for s in specs:
+        if s.norm is not None:
+            _add_path(features, s.norm, nn.BatchNorm2d(s.cin))
+            # the reference inserts ReLU (and upsample) modules here; they hold no state
+        _add_path(features, s.conv, nn.Conv2d(s.cin, s.cout, s.k, s.stride, s.pad, bias=False))
+
+
+def _get(root, path):
+    m = root
+    for p in path.split('.'):
+        m = m._modules[p]
+    return m
+
+
+# ------------------------------------------------------------------------------------------------
+class _Engine:
+    """Activation/accumulator buffers + kernel descriptors for one (batch, size, device)."""
+
+    def __init__(self, net, B, hin, win):
+        self.net, self.B = net, B
+        dev = net._flat.device
+        self.dev = dev
+        specs, bufs = net._specs, net._bufs
+
+        def size_of(scale, base):
+            v = base * scale[0]
+            if v % scale[1]:
+                raise ValueError(f'input size {base} is not divisible by {scale[1]}')
+            return v // scale[1]
+
+        self.buf_hw = {k: (size_of(sc, hin), size_of(sc, win)) for k, (c, sc) in bufs.items()}
+        self.X, self.T = {}, {}
+        n_stat = 0
+        self.stat_off = {}
+        for k, (c, sc) in bufs.items():
+            h, w = self.buf_hw[k]
+            if k != 'in':
+                self.X[k] = torch.empty((B, c, h, w), device=dev, dtype=torch.float32)
+            if k not in ('in', 'out'):
+                self.T[k] = torch.empty((B, c, h, w), device=dev, dtype=torch.float32)
+            self.stat_off[k] = n_stat
+            n_stat += 2 * c
+        # fp64 arena: per buffer {sum x, sum x^2}, then per buffer {sum T, sum T xhat}, then per BN {dgamma, dbeta}
+        self.n_xstat = n_stat
+        bn_off, n_bn = {}, 0
+        for s in specs:
+            if s.norm is not None:
+                bn_off[s.norm] = n_bn
+                n_bn += 2 * s.cin
+        self.arena = torch.zeros(2 * n_stat + n_bn, device=dev, dtype=torch.float64)
+        a0 = self.arena.data_ptr()
+        xs = lambda k: a0 + 8 * self.stat_off[k]
+        ts = lambda k: a0 + 8 * (n_stat + self.stat_off[k])
+        bg = lambda nm: a0 + 8 * (2 * n_stat + bn_off[nm])
+
+        n = len(specs)
+        self.descs = (ConvDesc * n)()
+        last_reader = {}
+        for i, s in enumerate(specs):
+            last_reader[s.src] = i
+        consumed = {}
+        pk = net._packed
+        for i, s in enumerate(specs):
+            d = self.descs[i]
+            hi, wi = self.buf_hw[s.src]
+            ho, wo = self.buf_hw[s.dst]
+            d.B, d.Cin, d.Cout, d.Hin, d.Win, d.Hout, d.Wout = B, s.cin, s.cout, hi, wi, ho, wo
+            d.ksize, d.stride, d.pad, d.upsample = s.k, s.stride, s.pad, s.up
+            d.x = self.X[s.src].data_ptr() if s.src != 'in' else None
+            d.x_ctot = bufs[s.src][0]
+            d.has_bn = 1 if s.norm is not None else 0
+            d.eval_mode = 0
+            d.eps = 1e-5
+            conv = _get(net.features, s.conv)
+            d.w = conv.weight.data_ptr()
+            d.w_fwd, d.w_bwd = pk[s.conv][0].data_ptr(), pk[s.conv][1].data_ptr()
+            d.cout_pad, d.cin_pad = _pad16(s.cout), _pad16(s.cin)
+            d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
+            if s.norm is not None:
+                bn = _get(net.features, s.norm)
+                d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                d.run_mean, d.run_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                d.x_stats = xs(s.src)
+                d.t_in = self.T[s.src].data_ptr()
+                d.t_stats = ts(s.src)
+                d.bn_grad = bg(s.norm)
+                d.t_accumulate = 0 if last_reader[s.src] == i else 1
+                d.final_c0 = consumed.get(s.src, 0)
+                d.final_c1 = s.cin
+                consumed[s.src] = max(consumed.get(s.src, 0), s.cin)
+            d.out = self.X[s.dst].data_ptr()
+            d.out_ctot, d.out_coff = bufs[s.dst][0], s.dst_coff
+            if s.dst != 'out':
+                d.out_stats = xs(s.dst)
+                d.g = self.T[s.dst].data_ptr()      # finalised in place before use
+                d.g_ctot, d.g_coff = bufs[s.dst][0], s.dst_coff
+            else:
+                d.out_stats = None
+                d.g, d.g_ctot, d.g_coff = None, bufs[s.dst][0], 0
+        self._out_stats = [d.out_stats for d in self.descs]
+        # BatchNorm table (device) for running statistics and fp32 gamma/beta gradients
+        items = []
+        for s in specs:
+            if s.norm is None:
+                continue
+            bn = _get(net.features, s.norm)
+            hi, wi = self.buf_hw[s.src]
+            it = BnItem()
+            it.x_stats, it.bn_grad = xs(s.src), bg(s.norm)
+            it.run_mean, it.run_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            it.dgamma = net._grad_view[s.norm + '.weight'].data_ptr()
+            it.dbeta = net._grad_view[s.norm + '.bias'].data_ptr()
+            it.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+            it.C, it.count = s.cin, B * hi * wi
+            items.append(it)
+        self.n_bn = len(items)
+        self.max_c = max(it.C for it in items)
+        arr = (BnItem * len(items))(*items)
+        self.bn_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+    # -- launches -------------------------------------------------------------------------------
+    def forward(self, x, training):
+        L, st = _lib.lib(), _lib.stream_ptr()
+        net = self.net
+        self.descs[0].x = x.data_ptr()
+        ev = 0 if training else 1
+        for d, os_ in zip(self.descs, self._out_stats):
+            d.eval_mode = ev
+            d.out_stats = os_ if training else None     # eval: running statistics, nothing accumulated
+        if training:
+            self.arena.zero_()
+        net._pack_weights()
+        _lib.check(L.pdes_conv_forward(self.descs, len(self.descs), st), 'pdes_conv_forward')
+        if training:
+            _lib.check(L.pdes_bn_update_running(self.bn_table.data_ptr(), self.n_bn, self.max_c,
+                                                ctypes.c_float(0.1), st), 'pdes_bn_update_running')
+        return self.X['out']
+
+    def backward(self, grad_y, need_input_grad=False):
+        """parameter gradients are ACCUMULATED into net._gflat (zero it first for plain gradients)"""
+        L, st = _lib.lib(), _lib.stream_ptr()
+        n = len(self.descs)
+        self.descs[n - 1].g = grad_y.data_ptr()
+        specs, bufs = self.net._specs, self.net._bufs
+        one = ConvDesc * 1
+        for i in range(n - 1, -1, -1):
+            s, d = specs[i], self.descs[i]
+            if s.dst != 'out':
+                h, w = self.buf_hw[s.dst]
+                os_ = self._out_stats[i]
+                rc = L.pdes_bn_backward_finalize(self.T[s.dst].data_ptr(), self.X[s.dst].data_ptr(),
+                                                 os_, os_ + 8 * self.n_xstat,
+                                                 self.B, bufs[s.dst][0], s.dst_coff, s.dst_coff + s.cout, h * w,
+                                                 ctypes.c_float(1e-5), st)
+                _lib.check(rc, 'pdes_bn_backward_finalize')
+            ref = ctypes.byref(d)
+            _lib.check(L.pdes_conv_backward_weight(ref, 1, st), 'pdes_conv_backward_weight')
+            if s.norm is not None:
+                _lib.check(L.pdes_conv_backward_data(ref, 1, st), 'pdes_conv_backward_data')
+        _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, st), 'pdes_bn_param_grads')
+
+
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        eng = net._engine(x)
+        ctx.net, ctx.eng = net, eng
+        ctx.n_params = len(params)
+        y = eng.forward(x, net.training)
+        ctx.trained = net.training
+        return y.clone()      # engine buffers are reused by the next call
+
+    @staticmethod
+    def backward(ctx, gy):
+        net, eng = ctx.net, ctx.eng
+        if not ctx.trained:
+            raise RuntimeError('backward through an eval-mode forward is not implemented (BatchNorm in eval mode '
+                               'is only used under torch.no_grad() by the reference)')
+        net._gscratch.zero_()
+        eng.backward(gy.contiguous())
+        # hand autograd views of ONE fresh copy (it may keep them as .grad; the scratch is reused)
+        fresh = net._gscratch.clone()
+        grads, off = [], 0
+        for p in net._params:
+            grads.append(fresh[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return (None, None) + tuple(grads)
+
+
+class _HipNet(nn.Module):
+    """shared machinery of DenseED and Decoder"""
+
+    def _finish_init(self, specs, bufs, drop_rate, upsample, out_activation):
+        if drop_rate and drop_rate > 0:
+            raise NotImplementedError('drop_rate > 0 (Dropout2d) is not implemented by the HIP path '
+                                      '(the reference default and every published setup use 0)')
+        if upsample != 'nearest':
+            raise NotImplementedError("only upsample='nearest' (the reference default) is implemented in HIP")
+        if out_activation is not None:
+            raise NotImplementedError('out_activation is not implemented (the mixed-residual scripts pass None)')
+        self._specs, self._bufs = specs, bufs
+        self.features = nn.Sequential()
+        _build_modules(self.features, specs)
+        self._flat = None
+        self._engines = {}
+
+    # -- flat parameter / gradient storage -------------------------------------------------------
+    def _flatten(self, device):
+        """move every parameter into one flat fp32 buffer on `device` and re-point .data at views"""
+        named = list(self.named_parameters())
+        total = sum(p.numel() for _, p in named)
+        flat = torch.empty(total, device=device, dtype=torch.float32)
+        gflat = torch.zeros(total, device=device, dtype=torch.float32)
+        self._grad_view = {}
+        views, off = [], 0
+        for name, p in named:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            key = name[len('features.'):]
+            self._grad_view[key] = gflat[off:off + n].view(p.shape)
+            views.append(self._grad_view[key])
+            off += n
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.data = m.running_mean.data.to(device).contiguous()
+                m.running_var.data = m.running_var.data.to(device).contiguous()
+                m.num_batches_tracked.data = m.num_batches_tracked.data.to(device)
+        self._flat, self._gscratch, self._gscratch_views = flat, gflat, views
+        self._params = [p for _, p in named]
+        # packed weight copies (zero padded once; the pack kernel rewrites the live part every forward)
+        self._packed, items, mx = {}, [], 0
+        for s in self._specs:
+            kk = s.k * s.k
+            wf = torch.zeros(s.cin * kk * _pad16(s.cout), device=device)
+            wb = torch.zeros(s.cout * kk * _pad16(s.cin), device=device)
+            self._packed[s.conv] = (wf, wb)
+            it = PackItem()
+            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.w_fwd, it.w_bwd = wf.data_ptr(), wb.data_ptr()
+            it.Cout, it.Cin, it.kk, it.cout_pad, it.cin_pad = s.cout, s.cin, kk, _pad16(s.cout), _pad16(s.cin)
+            items.append(it)
+            mx = max(mx, s.cout * s.cin * kk)
+        arr = (PackItem * len(items))(*items)
+        self._pack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self._pack_n, self._pack_max = len(items), mx
+        self._engines = {}
+
+    def _pack_weights(self):
+        rc = _lib.lib().pdes_pack_weights(self._pack_table.data_ptr(), self._pack_n, self._pack_max, _lib.stream_ptr())
+        _lib.check(rc, 'pdes_pack_weights')
+
+    def _is_flat(self, device):
+        if self._flat is None or self._flat.device != device:
+            return False
+        off = 0
+        base = self._flat.data_ptr()
+        for p in self._params:
+            if p.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def _engine(self, x):
+        if not self._is_flat(x.device):
+            self._flatten(x.device)
+        key = (x.shape[0], x.shape[2], x.shape[3])
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _Engine(self, *key)
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, x):
+        _lib.require_cuda(x)
+        if x.dim() != 4 or x.shape[1] != self._bufs['in'][0]:
+            raise ValueError(f'expected input (B, {self._bufs["in"][0]}, H, W); got {tuple(x.shape)}')
+        if x.dtype != torch.float32:
+            raise RuntimeError('the HIP kernels compute in fp32: pass an fp32 input')
+        x = x.contiguous()
+        self._engine(x)   # flattens parameters before autograd sees them
+        return _NetFn.apply(x, self, *self._params)
+
+    def forward_test(self, x):
+        print('input: {}'.format(x.data.size()))
+        y = self.forward(x)
+        eng = self._engine(x)
+        seen = []
+        for s in self._specs:
+            stage = s.conv.split('.')[0]
+            if stage not in seen:
+                seen.append(stage)
+        for stage in seen:
+            last = [s for s in self._specs if s.conv.split('.')[0] == stage][-1]
+            c = last.dst_coff + last.cout
+            h, w = eng.buf_hw[last.dst]
+            print('{}: {}'.format(stage, torch.Size((x.shape[0], c, h, w))))
+        return y
+
+    @property
+    def model_size(self):
+        return module_size(self)
+
+    def reset_parameters(self, verbose=False):
+        for module in self.modules():
+            if isinstance(module, (nn.Conv2d, nn.BatchNorm2d)):
+                module.reset_parameters()
+                if verbose:
+                    print('Reset parameters in {}'.format(module))
+
+
+class DenseED(_HipNet):
+    def __init__(self, in_channels, out_channels, imsize, blocks, growth_rate=16,
+                 init_features=48, drop_rate=0, bn_size=8, bottleneck=False,
+                 out_activation=None, upsample='nearest'):
+        """Dense Convolutional Encoder-Decoder Network (reference codec.py:210-293).
+
+        Args are the reference's.  `bn_size` is unused there too; `bottleneck=True` for dense
+        layers, dropout, bilinear upsampling and output activations are not implemented in HIP.
+        """
+        super(DenseED, self).__init__()
+        if bottleneck:
+            raise NotImplementedError('bottleneck dense layers are not implemented (reference default False)')
+        blocks = [int(b) for b in blocks]
+        specs, bufs = _plan_densed(blocks, growth_rate, init_features, in_channels, out_channels, imsize)
+        self._finish_init(specs, bufs, drop_rate, upsample, out_activation)
+        print('# params {}, # conv layers {}'.format(*self.model_size))
+
+
+class Decoder(_HipNet):
+    """Decoder to solve one PDE instance (reference codec.py:321-370)."""
+
+    def __init__(self, dim_latent, out_channels, blocks, growth_rate=16, init_features=48,
+                 drop_rate=0., upsample='nearest', out_activation=None):
+        super(Decoder, self).__init__()
+        blocks = [int(b) for b in blocks]
+        specs, bufs = _plan_decoder(blocks, growth_rate, init_features, dim_latent, out_channels)
+        self._finish_init(specs, bufs, drop_rate, upsample, out_activation)
