@@ -38,6 +38,9 @@ def lib():
     """Load the library once.  Raises RuntimeError (never falls back) when it is absent."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64: load it FIRST so this library binds to the same HIP
+        # runtime (two runtimes in one process lose the device: hipErrorNoDevice)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f'{LIB_PATH} not found: build it with `python -m pde_surrogate_amd.build` '
