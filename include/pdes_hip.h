@@ -95,6 +95,8 @@ typedef struct pdes_conv_desc {
   const float* w_fwd;    /* (Cin, k*k, cout_pad) */
   const float* w_bwd;    /* (Cout, k*k, cin_pad) */
   int cout_pad, cin_pad; /* multiples of 16 */
+  const float* wm_fwd;   /* MFMA image of w for the forward, or NULL (pdes_pack_weights_mfma) */
+  const float* wm_bwd;   /* MFMA image of w for the data gradient, or NULL */
   /* output */
   float* out;            /* (B, out_ctot, Hout, Wout); channels [out_coff, out_coff+Cout) written */
   int out_ctot, out_coff;
@@ -133,6 +135,15 @@ typedef struct pdes_pack_item {  /* one convolution's weights */
 } pdes_pack_item;
 /* items: DEVICE array of n entries; total = max elements over items (grid sizing). */
 int pdes_pack_weights(const pdes_pack_item* items, int n, int max_elems, void* stream);
+
+typedef struct pdes_mfma_pack_item { /* one convolution's matrix-core weight images */
+  const float* w;        /* (Cout, Cin, kk) */
+  float* wm_fwd;         /* (ceil(Cin/16)*4, kk, ceil(Cout/16), 64) */
+  float* wm_bwd;         /* (ceil(Cout/16)*4, kk, ceil(Cin/16), 64), or NULL */
+  int Cout, Cin, kk;
+} pdes_mfma_pack_item;
+/* items: DEVICE array; rebuilds both images from the live weights (zero padded). */
+int pdes_pack_weights_mfma(const pdes_mfma_pack_item* items, int n, int max_elems, void* stream);
 
 typedef struct pdes_bn_item {    /* one BatchNorm layer */
   const double* x_stats;  /* (>=C, 2) batch sums of its input channels */

@@ -22,6 +22,7 @@ SIGNATURES = {
     'pdes_conv_backward_data': [_c_p, _c_i, _c_p],
     'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p],
     'pdes_pack_weights': [_c_p, _c_i, _c_i, _c_p],
+    'pdes_pack_weights_mfma': [_c_p, _c_i, _c_i, _c_p],
     'pdes_bn_update_running': [_c_p, _c_i, _c_i, _c_f, _c_p],
     'pdes_bn_param_grads': [_c_p, _c_i, _c_i, _c_p],
     'pdes_adam_step': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, ctypes.c_longlong, _c_p],

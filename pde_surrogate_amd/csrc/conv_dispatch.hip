@@ -1,6 +1,7 @@
 // C-ABI entry points for the convolution family: walk a host array of descriptors and enqueue
 // one kernel per descriptor on the caller's stream.  Kernel selection lives here so the Python
 // side never needs to know which implementation (MFMA or VALU) serves a shape.
+#include <stdlib.h>
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
 
@@ -8,6 +9,15 @@ namespace pdes {
 int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st);
+int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st);        // PDES_ENOSUP: shape not covered
+int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st);
+
+// PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
+// the matrix-core kernels against them); anything else = automatic selection.
+static bool force_direct() {
+  const char* e = getenv("PDES_CONV_IMPL");
+  return e && e[0] == 'd';
+}
 }  // namespace pdes
 
 using namespace pdes;
@@ -16,7 +26,8 @@ extern "C" int pdes_conv_forward(const pdes_conv_desc* descs, int n, void* strea
   if (!descs || n <= 0) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
-    const int rc = conv_forward_direct(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_forward_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP) rc = conv_forward_direct(descs[i], st);
     if (rc) return rc;
   }
   return PDES_OK;
@@ -36,7 +47,8 @@ extern "C" int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void*
   if (!descs || n <= 0) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
-    const int rc = conv_backward_data_direct(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP) rc = conv_backward_data_direct(descs[i], st);
     if (rc) return rc;
   }
   return PDES_OK;

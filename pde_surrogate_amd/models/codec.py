@@ -33,6 +33,7 @@ class ConvDesc(ctypes.Structure):
         ('x', _P), ('x_ctot', _I), ('has_bn', _I), ('eval_mode', _I), ('eps', _F),
         ('gamma', _P), ('beta', _P), ('x_stats', _P), ('run_mean', _P), ('run_var', _P),
         ('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('cout_pad', _I), ('cin_pad', _I),
+        ('wm_fwd', _P), ('wm_bwd', _P),
         ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P),
         ('g', _P), ('g_ctot', _I), ('g_coff', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
@@ -43,6 +44,10 @@ class ConvDesc(ctypes.Structure):
 class PackItem(ctypes.Structure):
     _fields_ = [('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('Cout', _I), ('Cin', _I), ('kk', _I),
                 ('cout_pad', _I), ('cin_pad', _I)]
+
+
+class MfmaPackItem(ctypes.Structure):
+    _fields_ = [('w', _P), ('wm_fwd', _P), ('wm_bwd', _P), ('Cout', _I), ('Cin', _I), ('kk', _I)]
 
 
 class BnItem(ctypes.Structure):
@@ -255,6 +260,9 @@ class _Engine:
             d.w = conv.weight.data_ptr()
             d.w_fwd, d.w_bwd = pk[s.conv][0].data_ptr(), pk[s.conv][1].data_ptr()
             d.cout_pad, d.cin_pad = _pad16(s.cout), _pad16(s.cin)
+            mf = net._packed_mfma.get(s.conv)
+            d.wm_fwd = mf[0].data_ptr() if mf else None
+            d.wm_bwd = mf[1].data_ptr() if mf and mf[1] is not None else None
             d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
             if s.norm is not None:
                 bn = _get(net.features, s.norm)
@@ -424,11 +432,35 @@ class _HipNet(nn.Module):
         arr = (PackItem * len(items))(*items)
         self._pack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._pack_n, self._pack_max = len(items), mx
+        # matrix-core weight images for the 1x1 / 3x3 stride-1 convolutions with >= 16 input channels
+        self._packed_mfma, mitems, mmx = {}, [], 0
+        for s in self._specs:
+            if s.k not in (1, 3) or s.stride != 1 or s.norm is None:
+                continue
+            kk = s.k * s.k
+            nf = _pad16(s.cin) * kk * _pad16(s.cout)          # = ksteps*kk*ntiles*64
+            wf = torch.zeros(nf, device=device)
+            wb = torch.zeros(nf, device=device)
+            self._packed_mfma[s.conv] = (wf, wb)
+            it = MfmaPackItem()
+            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.wm_fwd, it.wm_bwd = wf.data_ptr(), wb.data_ptr()
+            it.Cout, it.Cin, it.kk = s.cout, s.cin, kk
+            mitems.append(it)
+            mmx = max(mmx, nf)
+        self._mpack_n, self._mpack_max = len(mitems), mmx
+        if mitems:
+            arr = (MfmaPackItem * len(mitems))(*mitems)
+            self._mpack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._engines = {}
 
     def _pack_weights(self):
         rc = _lib.lib().pdes_pack_weights(self._pack_table.data_ptr(), self._pack_n, self._pack_max, _lib.stream_ptr())
         _lib.check(rc, 'pdes_pack_weights')
+        if self._mpack_n:
+            rc = _lib.lib().pdes_pack_weights_mfma(self._mpack_table.data_ptr(), self._mpack_n, self._mpack_max,
+                                                   _lib.stream_ptr())
+            _lib.check(rc, 'pdes_pack_weights_mfma')
 
     def _is_flat(self, device):
         if self._flat is None or self._flat.device != device:

@@ -148,3 +148,39 @@ def test_rejects_unsupported_options(dev):
     net = DenseED(1, 3, 64, [1, 1, 1], growth_rate=4, init_features=8)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         net(torch.zeros(1, 1, 64, 64))
+
+
+def _run_default(dev, B=4, seed=5):
+    """forward + loss + backward of the default net; returns output, loss terms and the gradients"""
+    import contextlib
+    import io
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DenseED(1, 3, 64, [6, 8, 6])
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if 'norm' in k and k.endswith('.weight'):
+                v.copy_(1 + 0.2 * torch.randn_like(v))
+            if 'norm' in k and k.endswith('.bias'):
+                v.copy_(0.1 * torch.randn_like(v))
+    net = net.to(dev).train()
+    x = torch.exp(0.5 * torch.randn(B, 1, 64, 64)).to(dev)
+    y = net(x)
+    loss, *_ = darcy_mixed_residual_loss(x, y, 10.0)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    return y.detach().clone(), float(loss.detach()), grads
+
+
+def test_mfma_kernels_match_direct_kernels(dev, monkeypatch):
+    """matrix-core implicit-GEMM convolutions vs the VALU reference kernels, same weights/inputs"""
+    monkeypatch.setenv('PDES_CONV_IMPL', 'direct')
+    y0, l0, g0 = _run_default(dev)
+    monkeypatch.setenv('PDES_CONV_IMPL', 'auto')
+    y1, l1, g1 = _run_default(dev)
+    assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-6
+    assert abs(l1 - l0) < 1e-5 * abs(l0)
+    for k in g0:
+        assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-4, k
