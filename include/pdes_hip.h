@@ -111,6 +111,8 @@ typedef struct pdes_conv_desc {
   double* t_stats;       /* (x_ctot, 2) */
   double* bn_grad;       /* (Cin, 2) {dgamma, dbeta} accumulators (fp64) */
   float* dw;             /* (Cout, Cin, k, k) weight gradient, ACCUMULATED (zero it first) */
+  float* ws;             /* scratch for split-K partial weight gradients (may be NULL) */
+  long long ws_bytes;
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.

@@ -22,12 +22,15 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def headers():
+    return glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(os.path.dirname(HERE), 'include', '*.h'))
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h'))
-    return any(os.path.getmtime(p) > t for p in deps)
+    return any(os.path.getmtime(p) > t for p in sources() + headers())
 
 
 def build(force=False, verbose=True):
@@ -41,7 +44,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                [os.path.getmtime(src)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))]):
+                [os.path.getmtime(src)] + [os.path.getmtime(h) for h in headers()]):
             cmd = [hipcc] + [f for f in FLAGS if f != '-shared'] + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)

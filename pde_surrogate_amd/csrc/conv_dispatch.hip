@@ -11,6 +11,7 @@ int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st);        // PDES_ENOSUP: shape not covered
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st);
+int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st);
 
 // PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
 // the matrix-core kernels against them); anything else = automatic selection.
@@ -37,7 +38,8 @@ extern "C" int pdes_conv_backward_weight(const pdes_conv_desc* descs, int n, voi
   if (!descs || n <= 0) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
-    const int rc = conv_backward_weight_direct(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_backward_weight_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP) rc = conv_backward_weight_direct(descs[i], st);
     if (rc) return rc;
   }
   return PDES_OK;

@@ -1,0 +1,240 @@
+// Weight gradient of the 1x1 / 3x3 stride-1 convolutions on the f32 matrix cores (gfx950):
+//     dW[co][ci][tap] = sum_{b, pixel} g[b][co][pixel] * z[b][ci][pixel + tap],  z = relu(bn(x)) (+ nearest x2)
+// (autograd of F.conv2d wrt its weight for reference models/codec.py:66-69, :103-150, :163-188).
+//
+// GEMM roles per v_mfma_f32_16x16x4_f32: M = 16 input channels (A = z, one ds_read_b32 per lane),
+// N = 16 output channels (B = g), K = 4 consecutive pixels of an image row.  The K dimension
+// (B*H*W pixels) is what has to be split for parallelism: a workgroup owns ONE 16-channel M-tile,
+// NTW N-tiles and a run of pixel tiles of one sample; its 4 waves take different rows of each
+// pixel tile and are summed through LDS at the end.  Partial results of the pixel splits go to a
+// scratch buffer and are reduced in a fixed order by a second kernel (deterministic, no float
+// atomics).  LDS images are [channel][pixel] with a channel stride == 2 (mod 32) dwords so that
+// the 16 channels x 2 pixels of a ds_read_b32 lane group hit 32 distinct banks.
+#include "pdes_common.h"
+#include "../../include/pdes_hip.h"
+
+namespace pdes {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int KS, int TWG>
+struct WGeo {
+  static constexpr int TH = 8 / TWG, TW = 16 * TWG;
+  static constexpr int ROWS = TH + KS - 1, COLS = TW + KS - 1;
+  // row pitch chosen so that ROWS*LDW == 2 (mod 32)
+  static constexpr int LDW = (KS == 3) ? (TWG == 2 ? 43 : 29) : (TWG == 2 ? 40 : 20);
+  static constexpr int CS = ROWS * LDW + ((KS == 1) ? 2 : 0);
+  static constexpr int GS = TH * TW + 2;                       // g image channel stride (130)
+  static constexpr int NZ = 16 * ROWS * COLS;                  // z elements per tile
+  static constexpr int NPZ = (NZ + 255) / 256;
+  static_assert(CS % 32 == 2 && GS % 32 == 2, "LDS channel strides must be 2 mod 32 dwords");
+  static_assert(LDW >= COLS, "row pitch");
+};
+
+template <int KS, int TWG, int NTW>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
+                                                             int n_ngroups) {
+  using G = WGeo<KS, TWG>;
+  constexpr int KK = KS * KS, PADL = (KS - 1) / 2;
+  constexpr int NG = 16 * NTW * G::TH * G::TW;                 // g elements per tile
+  constexpr int NPG = NG / 256;
+  constexpr int KSTEPS = G::TH * G::TW / 4 / 4;                // k-steps per wave per tile (8)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* zt = smem;                                            // [16][CS]
+  float* gt = smem + 16 * G::CS;                               // [16*NTW][GS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;   // == Hout, Wout
+  const int tiles_x = Wc / G::TW, tps = tiles_x * (Hc / G::TH);
+  const int groups = tps / tpw;
+  const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
+  const int mtile = blockIdx.y / n_ngroups, ng = blockIdx.y % n_ngroups;
+  const int ci0 = mtile * 16, co0 = ng * 16 * NTW;
+  const int HWi = d.Hin * d.Win, HWo = d.Hout * d.Wout;
+
+  // BN coefficients of this thread's staging channels are per element; keep the 16 channels' in LDS-free regs:
+  // every thread needs (mean, scale, beta) of channel ch(e) for its NPZ elements -> recompute from a tiny table
+  __shared__ float cf[16][3];
+  if (tid < 16) {
+    const int c = ci0 + tid;
+    float m = 0.f, s = 0.f, bt = 0.f;
+    if (c < d.Cin) {
+      double mean, invstd;
+      if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
+      else {
+        const double n = (double)d.B * HWi;
+        mean = d.x_stats[2 * c] / n;
+        double var = d.x_stats[2 * c + 1] / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        invstd = 1.0 / sqrt(var + (double)d.eps);
+      }
+      m = (float)mean; s = d.gamma[c] * (float)invstd; bt = d.beta[c];
+    }
+    cf[tid][0] = m; cf[tid][1] = s; cf[tid][2] = bt;
+  }
+
+  const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWi;
+  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
+  const int crem = d.Cin - ci0, corem = d.Cout - co0;
+
+  float pz[G::NPZ], pg[NPG];
+  auto issue = [&](int tile) {
+    const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
+#pragma unroll
+    for (int i = 0; i < G::NPZ; ++i) {
+      const int e = tid + 256 * i;
+      const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
+      const int r = rem / G::COLS, c = rem % G::COLS;
+      const int cy = oy0 - PADL + r, cx = ox0 - PADL + c;
+      const bool v = e < G::NZ && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+      const int sy = d.upsample ? (cy >> 1) : cy, sx = d.upsample ? (cx >> 1) : cx;
+      // NaN marks "outside": the BN transform must map it to 0, not relu(beta - mean*scale)
+      pz[i] = v ? xb[(size_t)ch * HWi + sy * d.Win + sx] : __int_as_float(0x7fc00000);
+    }
+#pragma unroll
+    for (int i = 0; i < NPG; ++i) {
+      const int e = tid + 256 * i;
+      const int ch = e / (G::TH * G::TW), p = e % (G::TH * G::TW);
+      const int oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
+      pg[i] = ch < corem ? gb[(size_t)ch * HWo + oy * d.Wout + ox] : 0.f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::NPZ; ++i) {
+      const int e = tid + 256 * i;
+      if (e < G::NZ) {
+        const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
+        const int r = rem / G::COLS, c = rem % G::COLS;
+        const float x = pz[i];
+        const float z = (x != x) ? 0.f : fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]);
+        zt[ch * G::CS + r * G::LDW + c] = z;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPG; ++i) {
+      const int e = tid + 256 * i;
+      const int ch = e / (G::TH * G::TW), p = e % (G::TH * G::TW);
+      gt[ch * G::GS + p] = pg[i];
+    }
+  };
+
+  v4f acc[KK][NTW];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  // wave w owns rows [w*TH/4, (w+1)*TH/4) of each pixel tile
+  constexpr int RPW = (G::TH >= 4) ? G::TH / 4 : 1;
+  const int a_lane = (lane & 15) * G::CS + (lane >> 4);       // A: i = ci, k = pixel offset
+  const int b_lane = (lane & 15) * G::GS + (lane >> 4);       // B: j = co, k = pixel offset
+
+  const int tile0 = tg * tpw;
+  issue(tile0);
+  __syncthreads();                 // cf visible
+  for (int tt = 0; tt < tpw; ++tt) {
+    commit();
+    __syncthreads();
+    if (tt + 1 < tpw) issue(tile0 + tt + 1);
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = wave * RPW + rr;
+#pragma unroll
+      for (int ks = 0; ks < G::TW / 4; ++ks) {
+        float bv[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bv[nt] = gt[b_lane + nt * 16 * G::GS + row * G::TW + 4 * ks];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const float a = zt[a_lane + (row + ky) * G::LDW + 4 * ks + kx];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+              acc[ky * KS + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[ky * KS + kx][nt], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();               // every wave is done with the LDS images before the next commit
+  }
+
+  // ---- sum the 4 waves through LDS, then write this pixel split's partial dW
+  float* red = smem;               // [4][KK*NTW*4][64]
+  constexpr int NR = KK * NTW * 4;
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * NR + (t * NTW + nt) * 4 + r) * 64 + lane] = acc[t][nt][r];
+  __syncthreads();
+  float* pout = part + (size_t)blockIdx.x * d.Cout * d.Cin * KK;
+  for (int q = wave; q < NR; q += 4) {
+    const float s = red[(0 * NR + q) * 64 + lane] + red[(1 * NR + q) * 64 + lane] +
+                    red[(2 * NR + q) * 64 + lane] + red[(3 * NR + q) * 64 + lane];
+    const int r = q & 3, nt = (q >> 2) % NTW, t = (q >> 2) / NTW;
+    const int co = co0 + nt * 16 + (lane & 15), ci = ci0 + (lane >> 4) * 4 + r;
+    if (co < d.Cout && ci < d.Cin) pout[((size_t)co * d.Cin + ci) * KK + t] = s;
+  }
+}
+
+// dw[i] += sum_s part[s][i], fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int n, int nsplit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+  dw[i] += s;
+}
+
+template <int KS>
+static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
+  const int Hc = d.Hout, Wc = d.Wout;
+  const int twg = Wc >= 32 ? 2 : 1;
+  const int tps = (Wc / (16 * twg)) * (Hc / (8 / twg));
+  const int mtiles = (d.Cin + 15) / 16, ntiles = (d.Cout + 15) / 16;
+  const int ntw = ntiles >= 2 ? 2 : 1;
+  const int ngroups = (ntiles + ntw - 1) / ntw;
+  const int gy = mtiles * ngroups;
+  const long long per = (long long)d.Cout * d.Cin * KS * KS;
+  // pixel tiles per workgroup: as few as possible while (a) >= ~512 workgroups are not needed any more and
+  // (b) the partial buffer fits the scratch
+  int tpw = tps;
+  for (int cand = 1; cand <= tps; cand *= 2) {
+    if (tps % cand) continue;
+    const long long nsplit = (long long)d.B * (tps / cand);
+    if (nsplit * per * 4 > d.ws_bytes) continue;
+    if (nsplit * gy <= 1024 || cand == tps) { tpw = cand; break; }
+  }
+  const int nsplit = d.B * (tps / tpw);
+  if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
+  dim3 grid(nsplit, gy), block(256);
+#define PDES_WG_LAUNCH(TWG_, NTW_)                                                                          \
+  do {                                                                                                        \
+    using G = WGeo<KS, TWG_>;                                                                                 \
+    size_t lds = (size_t)(16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                                    \
+    const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
+    if (red > lds) lds = red;                                                                                 \
+    hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+  } while (0)
+  if (twg == 2) { if (ntw == 2) PDES_WG_LAUNCH(2, 2); else PDES_WG_LAUNCH(2, 1); }
+  else { if (ntw == 2) PDES_WG_LAUNCH(1, 2); else PDES_WG_LAUNCH(1, 1); }
+#undef PDES_WG_LAUNCH
+  PDES_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)per, 256)), dim3(256), 0, st, d.ws, d.dw, (int)per, nsplit);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
+  if (!d.ws || !d.has_bn || !(d.ksize == 3 || d.ksize == 1) || d.stride != 1 || d.pad != (d.ksize - 1) / 2)
+    return PDES_ENOSUP;
+  if (d.Cin < 16) return PDES_ENOSUP;
+  const int W = d.Wout, H = d.Hout;
+  if (W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8))) return PDES_ENOSUP;
+  return d.ksize == 3 ? launch_wgrad<3>(d, st) : launch_wgrad<1>(d, st);
+}
+
+}  // namespace pdes

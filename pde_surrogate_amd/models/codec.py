@@ -37,7 +37,7 @@ class ConvDesc(ctypes.Structure):
         ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P),
         ('g', _P), ('g_ctot', _I), ('g_coff', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
-        ('t_stats', _P), ('bn_grad', _P), ('dw', _P),
+        ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
     ]
 
 
@@ -264,6 +264,7 @@ class _Engine:
             d.wm_fwd = mf[0].data_ptr() if mf else None
             d.wm_bwd = mf[1].data_ptr() if mf and mf[1] is not None else None
             d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
+            d.ws, d.ws_bytes = net._ws.data_ptr(), net._ws.numel() * 4
             if s.norm is not None:
                 bn = _get(net.features, s.norm)
                 d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
@@ -449,6 +450,7 @@ class _HipNet(nn.Module):
             mitems.append(it)
             mmx = max(mmx, nf)
         self._mpack_n, self._mpack_max = len(mitems), mmx
+        self._ws = torch.empty(8 << 20, device=device)       # 32 MiB split-K scratch (weight gradients)
         if mitems:
             arr = (MfmaPackItem * len(mitems))(*mitems)
             self._mpack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
