@@ -53,7 +53,8 @@ template <int KS, int TWG>
 struct TileGeo {
   static constexpr int TH = 8 / TWG, TW = 16 * TWG;          // output tile (pixels)
   static constexpr int ROWS = TH + KS - 1, COLS = TW + KS - 1;
-  static constexpr int LDW = (KS == 3) ? (TWG == 2 ? 40 : 24) : (TWG == 2 ? 36 : 18);
+  static constexpr int LDW = (KS == 5) ? (TWG == 2 ? 38 : 20)
+                             : (KS == 3) ? (TWG == 2 ? 40 : 24) : (TWG == 2 ? 36 : 18);
   static constexpr int CS = ROWS * LDW;                       // channel stride in LDS (dwords)
   static constexpr int KC = 16;                               // input channels per chunk
   static constexpr int NELEM = KC * ROWS * COLS;
@@ -176,20 +177,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   const int a_lane = (lane >> 4) * G::CS + (lane & 15);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int buf = chunk & 1;
-    if (chunk + 1 < nchunk) issue(chunk + 1);
-    const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
+    // B operand of this chunk, packed image [(kstep*KK + tap)*nt_total + nt][64].  These loads are
+    // issued BEFORE the next chunk's activation prefetch: vmcnt retires loads in order, so the
+    // MFMAs (which wait for B) would otherwise also wait for the whole prefetch.
+    float bw[KSW][KK][NT_W];
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
-      // B operand of this k-step: packed image [(kstep*KK + tap)*nt_total + nt][64]
       const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-      float bw[KK][NT_W];
 #pragma unroll
       for (int t = 0; t < KK; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT_W; ++nt) {
           const int ntg = nt_base + nt;
-          bw[t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
+          bw[s][t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
         }
+    }
+    if (chunk + 1 < nchunk) issue(chunk + 1);
+    const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
+#pragma unroll
+    for (int s = 0; s < KSW; ++s) {
+      const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
+      if (kstep * 4 >= kv.C) continue;          // wave-uniform: k-step entirely in the zero padding
       const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky)
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
             const float a = tk[((mt / TWG) + ky) * G::LDW + (mt % TWG) * 16 + kx];
 #pragma unroll
             for (int nt = 0; nt < NT_W; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
           }
         }
     }
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const pdes_mfma_pack_ite
 
 // ------------------------------------------------------------------------------- host dispatch
 static bool mfma_shape_ok(const pdes_conv_desc& d, bool bwd) {
-  if (!(d.ksize == 3 || d.ksize == 1) || d.stride != 1 || d.pad != (d.ksize - 1) / 2) return false;
+  if (!(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.stride != 1 || d.pad != (d.ksize - 1) / 2) return false;
   if (!d.has_bn) return false;
   const int W = bwd ? (d.upsample ? 2 * d.Win : d.Win) : d.Wout;
   const int H = bwd ? (d.upsample ? 2 * d.Hin : d.Hin) : d.Hout;
@@ -405,12 +413,14 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, hipStream_t st)
 // returns PDES_ENOSUP when the shape is not covered (caller falls back to the direct kernels)
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st) {
   if (!d.wm_fwd || !mfma_shape_ok(d, false) || d.Cin < 16) return PDES_ENOSUP;
+  if (d.ksize == 5) return d.upsample ? PDES_ENOSUP : launch_mfma<5, MODE_FWD>(d, d.wm_fwd, st);
   return d.ksize == 3 ? launch_mfma<3, MODE_FWD>(d, d.wm_fwd, st) : launch_mfma<1, MODE_FWD>(d, d.wm_fwd, st);
 }
 
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st) {
   if (!d.wm_bwd || !mfma_shape_ok(d, true) || d.eval_mode) return PDES_ENOSUP;
   if (d.upsample && d.ksize != 3) return PDES_ENOSUP;
+  if (d.ksize == 5) return launch_mfma<5, MODE_BWD>(d, d.wm_bwd, st);
   return d.ksize == 3 ? launch_mfma<3, MODE_BWD>(d, d.wm_bwd, st) : launch_mfma<1, MODE_BWD>(d, d.wm_bwd, st);
 }
 

@@ -21,9 +21,8 @@ template <int KS, int TWG>
 struct WGeo {
   static constexpr int TH = 8 / TWG, TW = 16 * TWG;
   static constexpr int ROWS = TH + KS - 1, COLS = TW + KS - 1;
-  // row pitch chosen so that ROWS*LDW == 2 (mod 32)
-  static constexpr int LDW = (KS == 3) ? (TWG == 2 ? 43 : 29) : (TWG == 2 ? 40 : 20);
-  static constexpr int CS = ROWS * LDW + ((KS == 1) ? 2 : 0);
+  static constexpr int LDW = COLS + (COLS & 1);               // even row pitch
+  static constexpr int CS = ((ROWS * LDW + 29) / 32) * 32 + 2;  // channel stride rounded up to 2 (mod 32)
   static constexpr int GS = TH * TW + 2;                       // g image channel stride (130)
   static constexpr int NZ = 16 * ROWS * COLS;                  // z elements per tile
   static constexpr int NPZ = (NZ + 255) / 256;
@@ -180,13 +179,20 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
 }
 
 // dw[i] += sum_s part[s][i], fixed order
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+__global__ __launch_bounds__(64) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            int n, int nsplit) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
-  dw[i] += s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= nsplit; k += 4) {
+    s0 += part[(size_t)k * n + i];
+    s1 += part[(size_t)(k + 1) * n + i];
+    s2 += part[(size_t)(k + 2) * n + i];
+    s3 += part[(size_t)(k + 3) * n + i];
+  }
+  for (; k < nsplit; ++k) s0 += part[(size_t)k * n + i];
+  dw[i] += (s0 + s1) + (s2 + s3);
 }
 
 template <int KS>
@@ -206,7 +212,7 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     if (tps % cand) continue;
     const long long nsplit = (long long)d.B * (tps / cand);
     if (nsplit * per * 4 > d.ws_bytes) continue;
-    if (nsplit * gy <= 1024 || cand == tps) { tpw = cand; break; }
+    if (nsplit * gy <= 768 || cand == tps) { tpw = cand; break; }
   }
   const int nsplit = d.B * (tps / tpw);
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
@@ -223,17 +229,19 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   else { if (ntw == 2) PDES_WG_LAUNCH(1, 2); else PDES_WG_LAUNCH(1, 1); }
 #undef PDES_WG_LAUNCH
   PDES_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)per, 256)), dim3(256), 0, st, d.ws, d.dw, (int)per, nsplit);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)per, nsplit);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
 
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
-  if (!d.ws || !d.has_bn || !(d.ksize == 3 || d.ksize == 1) || d.stride != 1 || d.pad != (d.ksize - 1) / 2)
+  if (!d.ws || !d.has_bn || !(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.stride != 1 ||
+      d.pad != (d.ksize - 1) / 2)
     return PDES_ENOSUP;
   if (d.Cin < 16) return PDES_ENOSUP;
   const int W = d.Wout, H = d.Hout;
   if (W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8))) return PDES_ENOSUP;
+  if (d.ksize == 5) return launch_wgrad<5>(d, st);
   return d.ksize == 3 ? launch_wgrad<3>(d, st) : launch_wgrad<1>(d, st);
 }
 

@@ -180,10 +180,10 @@ def test_mfma_kernels_match_direct_kernels(dev, monkeypatch):
     y0, l0, g0 = _run_default(dev)
     monkeypatch.setenv('PDES_CONV_IMPL', 'auto')
     y1, l1, g1 = _run_default(dev)
-    assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-6
+    assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
     assert abs(l1 - l0) < 1e-5 * abs(l0)
     # parameter gradients: fp32 rounding flips individual ReLU masks, so two correct fp32
     # implementations differ by up to ~3e-3 here (each is 1e-3-class vs the fp64 oracle, measured
     # with tools/debug_layers.py); a wrong stencil / layout would be O(1)
-    for k in g0:
-        assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-2, k
+    errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
+    assert errs[0][0] < 1e-2, errs[:8]
