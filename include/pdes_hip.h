@@ -113,6 +113,10 @@ typedef struct pdes_conv_desc {
   float* dw;             /* (Cout, Cin, k, k) weight gradient, ACCUMULATED (zero it first) */
   float* ws;             /* scratch for split-K partial weight gradients (may be NULL) */
   long long ws_bytes;
+  /* the fp64 accumulators (x_stats, out_stats, t_stats, bn_grad) exist in `nrep` replicas,
+     `rep_stride` doubles apart, to spread same-address atomics; readers sum the replicas */
+  int nrep;
+  long long rep_stride;
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.
@@ -128,7 +132,8 @@ int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void* stream);
 /* In place T -> dL/dx for channels [c0, c1) of a (B, ctot, H, W) buffer (BatchNorm backward wrt
  * its input, summed over every consumer BN). */
 int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
-                              int B, int ctot, int c0, int c1, int HW, float eps, void* stream);
+                              int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
+                              long long rep_stride, void* stream);
 
 /* Table-driven helpers: one launch for the whole network. */
 typedef struct pdes_pack_item {  /* one convolution's weights */
@@ -156,9 +161,11 @@ typedef struct pdes_bn_item {    /* one BatchNorm layer */
   int C; int count;                /* count = B*H*W */
 } pdes_bn_item;
 /* running_mean/var <- momentum update with batch mean / unbiased var (nn.BatchNorm2d train mode). */
-int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_c, float momentum, void* stream);
+int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_c, float momentum, int nrep,
+                           long long rep_stride, void* stream);
 /* dgamma/dbeta (fp32) += fp64 accumulators. */
-int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, void* stream);
+int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, int nrep, long long rep_stride,
+                        void* stream);
 
 /* Adam step on flat fp32 buffers, torch.optim.Adam semantics (L2 weight decay added to the
  * gradient, bias correction, eps outside the sqrt).  lr and step live in DEVICE memory so a

@@ -13,15 +13,15 @@ namespace pdes {
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ t, const float* __restrict__ x,
                                                               const double* __restrict__ x_stats,
                                                               const double* __restrict__ t_stats, int B, int ctot,
-                                                              int c0, int HW, float eps) {
+                                                              int c0, int HW, float eps, int nrep, long long rs) {
   const int c = c0 + blockIdx.y, b = blockIdx.z;
   const double n = (double)B * HW;
-  const double m = x_stats[2 * c] / n;
-  double var = x_stats[2 * c + 1] / n - m * m;
+  const double m = rep_sum(x_stats, 2 * c, nrep, rs) / n;
+  double var = rep_sum(x_stats, 2 * c + 1, nrep, rs) / n - m * m;
   var = var < 0.0 ? 0.0 : var;
   const float mean = (float)m;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float m1 = (float)(t_stats[2 * c] / n), m2 = (float)(t_stats[2 * c + 1] / n);
+  const float m1 = (float)(rep_sum(t_stats, 2 * c, nrep, rs) / n), m2 = (float)(rep_sum(t_stats, 2 * c + 1, nrep, rs) / n);
   const size_t base = ((size_t)b * ctot + c) * HW;
   // HW is a multiple of 4 for every supported feature map (>= 8x8); vectorise when aligned
   if ((HW & 3) == 0) {
@@ -54,26 +54,27 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const pdes_pack_item*
   }
 }
 
-__global__ __launch_bounds__(256) void bn_update_running_kernel(const pdes_bn_item* __restrict__ items, float momentum) {
+__global__ __launch_bounds__(256) void bn_update_running_kernel(const pdes_bn_item* __restrict__ items, float momentum,
+                                                                int nrep, long long rs) {
   const pdes_bn_item it = items[blockIdx.y];
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c == 0 && it.num_batches_tracked) *it.num_batches_tracked += 1;
   if (c >= it.C) return;
   const double n = (double)it.count;
-  const double m = it.x_stats[2 * c] / n;
-  double var = it.x_stats[2 * c + 1] / n - m * m;
+  const double m = rep_sum(it.x_stats, 2 * c, nrep, rs) / n;
+  double var = rep_sum(it.x_stats, 2 * c + 1, nrep, rs) / n - m * m;
   var = var < 0.0 ? 0.0 : var;
   const double unbiased = it.count > 1 ? var * n / (n - 1.0) : var;
   it.run_mean[c] = (float)((1.0 - momentum) * it.run_mean[c] + momentum * m);
   it.run_var[c] = (float)((1.0 - momentum) * it.run_var[c] + momentum * unbiased);
 }
 
-__global__ __launch_bounds__(256) void bn_param_grads_kernel(const pdes_bn_item* __restrict__ items) {
+__global__ __launch_bounds__(256) void bn_param_grads_kernel(const pdes_bn_item* __restrict__ items, int nrep, long long rs) {
   const pdes_bn_item it = items[blockIdx.y];
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= it.C) return;
-  it.dgamma[c] += (float)it.bn_grad[2 * c];
-  it.dbeta[c] += (float)it.bn_grad[2 * c + 1];
+  it.dgamma[c] += (float)rep_sum(it.bn_grad, 2 * c, nrep, rs);
+  it.dbeta[c] += (float)rep_sum(it.bn_grad, 2 * c + 1, nrep, rs);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -102,12 +103,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 using namespace pdes;
 
 extern "C" int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
-                                         int B, int ctot, int c0, int c1, int HW, float eps, void* stream) {
-  if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0) return PDES_EINVAL;
+                                         int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
+                                         long long rep_stride, void* stream) {
+  if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0 || nrep < 1) return PDES_EINVAL;
   if (!aligned16(t) || !aligned16(x)) return PDES_EALIGN;
   dim3 grid(cdiv(cdiv(HW, 4), 256), c1 - c0, B), block(256);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, static_cast<hipStream_t>(stream), t, x, x_stats, t_stats,
-                     B, ctot, c0, HW, eps);
+                     B, ctot, c0, HW, eps, nrep, rep_stride);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
@@ -121,18 +123,20 @@ extern "C" int pdes_pack_weights(const pdes_pack_item* items, int n, int max_ele
   return PDES_OK;
 }
 
-extern "C" int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_c, float momentum, void* stream) {
-  if (!items || n <= 0 || max_c <= 0) return PDES_EINVAL;
+extern "C" int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_c, float momentum, int nrep,
+                                      long long rep_stride, void* stream) {
+  if (!items || n <= 0 || max_c <= 0 || nrep < 1) return PDES_EINVAL;
   hipLaunchKernelGGL(bn_update_running_kernel, dim3(cdiv(max_c, 256), n), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), items, momentum);
+                     static_cast<hipStream_t>(stream), items, momentum, nrep, rep_stride);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
 
-extern "C" int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, void* stream) {
-  if (!items || n <= 0 || max_c <= 0) return PDES_EINVAL;
+extern "C" int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, int nrep, long long rep_stride,
+                                   void* stream) {
+  if (!items || n <= 0 || max_c <= 0 || nrep < 1) return PDES_EINVAL;
   hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(max_c, 256), n), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), items);
+                     static_cast<hipStream_t>(stream), items, nrep, rep_stride);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

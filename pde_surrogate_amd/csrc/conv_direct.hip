@@ -30,8 +30,8 @@ __device__ __forceinline__ BnC bn_coef(const pdes_conv_desc& d, int c) {
     o.invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
   } else {
     const double n = (double)d.B * d.Hin * d.Win;
-    const double m = d.x_stats[2 * c] / n;
-    double var = d.x_stats[2 * c + 1] / n - m * m;
+    const double m = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
+    double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - m * m;
     var = var < 0.0 ? 0.0 : var;
     o.mean = (float)m;
     o.invstd = (float)(1.0 / sqrt(var + (double)d.eps));
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_fwd_direct(pdes_conv_desc d) {
         double t = 0.0;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) t += red[(wv * COT + j) * 2 + w];
-        atomicAdd(&d.out_stats[2 * (d.out_coff + co0 + j) + w], t);
+        atomicAdd(&d.out_stats[(long long)rep_of_block(d.nrep) * d.rep_stride + 2 * (d.out_coff + co0 + j) + w], t);
       }
     }
   }
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void conv_bwd_data_direct(pdes_conv_desc d) {
       double t = 0.0;
 #pragma unroll
       for (int wv = 0; wv < 4; ++wv) t += red[(wv * CIT + j) * 4 + q];
-      if (q < 2) atomicAdd(&d.bn_grad[2 * ci + q], t);
-      else if (ci >= d.final_c0 && ci < d.final_c1) atomicAdd(&d.t_stats[2 * ci + (q - 2)], t);
+      if (q < 2) atomicAdd(&d.bn_grad[(long long)rep_of_block(d.nrep) * d.rep_stride + 2 * ci + q], t);
+      else if (ci >= d.final_c0 && ci < d.final_c1) atomicAdd(&d.t_stats[(long long)rep_of_block(d.nrep) * d.rep_stride + 2 * ci + (q - 2)], t);
     }
   }
 }
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct(pdes_conv_desc d, 
 
 // ------------------------------------------------------------------------------- host dispatch
 static int validate(const pdes_conv_desc& d, int mode) {
+  if (d.nrep < 1) return PDES_EINVAL;
   if (d.B <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return PDES_EINVAL;
   if (!d.x) return PDES_EINVAL;
   if (!(d.ksize == 1 || d.ksize == 3 || d.ksize == 5 || d.ksize == 7)) return PDES_ENOSUP;

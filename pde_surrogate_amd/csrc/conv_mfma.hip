@@ -38,8 +38,8 @@ __device__ __forceinline__ BnC bn_coef_m(const pdes_conv_desc& d, int c) {
     o.invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
   } else {
     const double n = (double)d.B * d.Hin * d.Win;
-    const double m = d.x_stats[2 * c] / n;
-    double var = d.x_stats[2 * c + 1] / n - m * m;
+    const double m = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
+    double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - m * m;
     var = var < 0.0 ? 0.0 : var;
     o.mean = (float)m;
     o.invstd = (float)(1.0 / sqrt(var + (double)d.eps));
@@ -259,9 +259,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       if (d.out_stats) {
         s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-        if (lane < 16 && co < d.Cout) {
-          atomicAdd(&d.out_stats[2 * (d.out_coff + co)], (double)s);
-          atomicAdd(&d.out_stats[2 * (d.out_coff + co) + 1], (double)q);
+        double* os = d.out_stats + (long long)rep_of_block(d.nrep) * d.rep_stride;
+        if (WAVES_K == 4) {
+          // the four waves hold partial sums of the SAME 16 channels: combine through LDS -> one
+          // pair of atomics per channel per workgroup
+          float* sred = tile + 8192;                 // past the accumulator exchange area
+          if (lane < 16) { sred[(wave * 16 + lane) * 2] = s; sred[(wave * 16 + lane) * 2 + 1] = q; }
+          __syncthreads();
+          if (wave == 0 && lane < 32) {
+            const int c = lane >> 1, w = lane & 1;
+            const float t = (sred[(0 * 16 + c) * 2 + w] + sred[(1 * 16 + c) * 2 + w]) +
+                            (sred[(2 * 16 + c) * 2 + w] + sred[(3 * 16 + c) * 2 + w]);
+            const int cc = nt_base * 16 + c;
+            if (cc < d.Cout) atomicAdd(&os[2 * (d.out_coff + cc) + w], (double)t);
+          }
+        } else if (lane < 16 && co < d.Cout) {
+          atomicAdd(&os[2 * (d.out_coff + co)], (double)s);
+          atomicAdd(&os[2 * (d.out_coff + co) + 1], (double)q);
         }
       }
     }
@@ -333,11 +347,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       st += __shfl_xor(st, 16, 64); st += __shfl_xor(st, 32, 64);
       sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
       if (lane < 16 && ci < d.Cin) {
-        atomicAdd(&d.bn_grad[2 * ci], (double)dg);
-        atomicAdd(&d.bn_grad[2 * ci + 1], (double)db);
+        const long long ro = (long long)rep_of_block(d.nrep) * d.rep_stride;
+        atomicAdd(&d.bn_grad[ro + 2 * ci], (double)dg);
+        atomicAdd(&d.bn_grad[ro + 2 * ci + 1], (double)db);
         if (ci >= d.final_c0 && ci < d.final_c1) {
-          atomicAdd(&d.t_stats[2 * ci], (double)st);
-          atomicAdd(&d.t_stats[2 * ci + 1], (double)sx);
+          atomicAdd(&d.t_stats[ro + 2 * ci], (double)st);
+          atomicAdd(&d.t_stats[ro + 2 * ci + 1], (double)sx);
         }
       }
     }
@@ -390,7 +405,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, hipStream_t st)
   dim3 grid(tiles, d.B), block(256);
   const int cs = twg == 2 ? TileGeo<KS, 2>::CS : TileGeo<KS, 1>::CS;
   size_t lds_f = (size_t)(bwd ? 0 : 3 * kpad) + (size_t)2 * 16 * cs;
-  const size_t red_f = (size_t)(bwd ? 0 : 3 * kpad) + 8192;
+  const size_t red_f = (size_t)(bwd ? 0 : 3 * kpad) + 8192 + 128;
 #define PDES_MFMA_LAUNCH(TWG_, WK_, NTW_)                                                                    \
   hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, WK_, NTW_, MODE>), grid, block,                              \
                      ((WK_) == 4 && red_f > lds_f ? red_f : lds_f) * sizeof(float), st, d, wm, nt_total)
@@ -412,6 +427,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, hipStream_t st)
 
 // returns PDES_ENOSUP when the shape is not covered (caller falls back to the direct kernels)
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st) {
+  if (d.nrep < 1) return PDES_EINVAL;
   if (!d.wm_fwd || !mfma_shape_ok(d, false) || d.Cin < 16) return PDES_ENOSUP;
   if (d.ksize == 5) return d.upsample ? PDES_ENOSUP : launch_mfma<5, MODE_FWD>(d, d.wm_fwd, st);
   return d.ksize == 3 ? launch_mfma<3, MODE_FWD>(d, d.wm_fwd, st) : launch_mfma<1, MODE_FWD>(d, d.wm_fwd, st);

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
       else {
         const double n = (double)d.B * HWi;
-        mean = d.x_stats[2 * c] / n;
-        double var = d.x_stats[2 * c + 1] / n - mean * mean;
+        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
+        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         invstd = 1.0 / sqrt(var + (double)d.eps);
       }

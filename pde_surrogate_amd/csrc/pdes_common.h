@@ -38,6 +38,17 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// fp64 statistics are accumulated into one of `nrep` replicas of the arena (replica stride in
+// doubles) to keep same-address atomic contention low; readers sum the replicas.
+__device__ __forceinline__ double rep_sum(const double* p, int idx, int nrep, long long stride) {
+  double s = 0.0;
+  for (int r = 0; r < nrep; ++r) s += p[(long long)r * stride + idx];
+  return s;
+}
+__device__ __forceinline__ int rep_of_block(int nrep) {
+  return (int)((blockIdx.x + 7u * blockIdx.y + 3u * blockIdx.z) % (unsigned)nrep);
+}
+
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -38,6 +38,7 @@ class ConvDesc(ctypes.Structure):
         ('g', _P), ('g_ctot', _I), ('g_coff', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
         ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
+        ('nrep', _I), ('rep_stride', ctypes.c_longlong),
     ]
 
 
@@ -232,7 +233,9 @@ class _Engine:
             if s.norm is not None:
                 bn_off[s.norm] = n_bn
                 n_bn += 2 * s.cin
-        self.arena = torch.zeros(2 * n_stat + n_bn, device=dev, dtype=torch.float64)
+        # NREP replicas of the whole arena spread same-address fp64 atomics (readers sum them)
+        self.nrep, self.rep_stride = 16, 2 * n_stat + n_bn
+        self.arena = torch.zeros(self.nrep * self.rep_stride, device=dev, dtype=torch.float64)
         a0 = self.arena.data_ptr()
         xs = lambda k: a0 + 8 * self.stat_off[k]
         ts = lambda k: a0 + 8 * (n_stat + self.stat_off[k])
@@ -265,6 +268,7 @@ class _Engine:
             d.wm_bwd = mf[1].data_ptr() if mf and mf[1] is not None else None
             d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
             d.ws, d.ws_bytes = net._ws.data_ptr(), net._ws.numel() * 4
+            d.nrep, d.rep_stride = self.nrep, self.rep_stride
             if s.norm is not None:
                 bn = _get(net.features, s.norm)
                 d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
@@ -322,7 +326,8 @@ class _Engine:
         _lib.check(L.pdes_conv_forward(self.descs, len(self.descs), st), 'pdes_conv_forward')
         if training:
             _lib.check(L.pdes_bn_update_running(self.bn_table.data_ptr(), self.n_bn, self.max_c,
-                                                ctypes.c_float(0.1), st), 'pdes_bn_update_running')
+                                                ctypes.c_float(0.1), self.nrep, self.rep_stride, st),
+                       'pdes_bn_update_running')
         return self.X['out']
 
     def backward(self, grad_y, need_input_grad=False):
@@ -340,13 +345,14 @@ class _Engine:
                 rc = L.pdes_bn_backward_finalize(self.T[s.dst].data_ptr(), self.X[s.dst].data_ptr(),
                                                  os_, os_ + 8 * self.n_xstat,
                                                  self.B, bufs[s.dst][0], s.dst_coff, s.dst_coff + s.cout, h * w,
-                                                 ctypes.c_float(1e-5), st)
+                                                 ctypes.c_float(1e-5), self.nrep, self.rep_stride, st)
                 _lib.check(rc, 'pdes_bn_backward_finalize')
             ref = ctypes.byref(d)
             _lib.check(L.pdes_conv_backward_weight(ref, 1, st), 'pdes_conv_backward_weight')
             if s.norm is not None:
                 _lib.check(L.pdes_conv_backward_data(ref, 1, st), 'pdes_conv_backward_data')
-        _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, st), 'pdes_bn_param_grads')
+        _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, self.nrep, self.rep_stride,
+                                         st), 'pdes_bn_param_grads')
 
 
 class _NetFn(torch.autograd.Function):
