@@ -29,6 +29,8 @@ extern "C" {
 
 /* ABI version of this header; bumped on any signature change. */
 int pdes_abi_version(void);
+/* number of replicas of the fp64 accumulator arena the kernels are compiled for (see pdes_conv_desc.nrep) */
+int pdes_stat_replicas(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused Sobel + Darcy mixed-residual loss, forward and (optionally) backward, ONE kernel.

@@ -14,6 +14,7 @@ _c_p = ctypes.c_void_p
 # name -> argtypes; mirrors include/pdes_hip.h one to one (tests check every symbol is exported)
 SIGNATURES = {
     'pdes_abi_version': [],
+    'pdes_stat_replicas': [],
     'pdes_darcy_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_p],
     'pdes_sobel_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
     'pdes_sobel_grad_adjoint': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],

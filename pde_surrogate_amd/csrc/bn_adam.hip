@@ -15,13 +15,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
                                                               const double* __restrict__ t_stats, int B, int ctot,
                                                               int c0, int HW, float eps, int nrep, long long rs) {
   const int c = c0 + blockIdx.y, b = blockIdx.z;
-  const double n = (double)B * HW;
-  const double m = rep_sum(x_stats, 2 * c, nrep, rs) / n;
-  double var = rep_sum(x_stats, 2 * c + 1, nrep, rs) / n - m * m;
-  var = var < 0.0 ? 0.0 : var;
-  const float mean = (float)m;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float m1 = (float)(rep_sum(t_stats, 2 * c, nrep, rs) / n), m2 = (float)(rep_sum(t_stats, 2 * c + 1, nrep, rs) / n);
+  __shared__ float sc[4];
+  if (threadIdx.x == 0) {
+    const double n = (double)B * HW;
+    const double m = rep_sum(x_stats, 2 * c, nrep, rs) / n;
+    double var = rep_sum(x_stats, 2 * c + 1, nrep, rs) / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    sc[0] = (float)m;
+    sc[1] = (float)(1.0 / sqrt(var + (double)eps));
+    sc[2] = (float)(rep_sum(t_stats, 2 * c, nrep, rs) / n);
+    sc[3] = (float)(rep_sum(t_stats, 2 * c + 1, nrep, rs) / n);
+  }
+  __syncthreads();
+  const float mean = sc[0], invstd = sc[1], m1 = sc[2], m2 = sc[3];
   const size_t base = ((size_t)b * ctot + c) * HW;
   // HW is a multiple of 4 for every supported feature map (>= 8x8); vectorise when aligned
   if ((HW & 3) == 0) {
@@ -102,10 +108,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 using namespace pdes;
 
+extern "C" int pdes_stat_replicas(void) { return PDES_NREP; }
+
 extern "C" int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
                                          int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
                                          long long rep_stride, void* stream) {
-  if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0 || nrep < 1) return PDES_EINVAL;
+  if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   if (!aligned16(t) || !aligned16(x)) return PDES_EALIGN;
   dim3 grid(cdiv(cdiv(HW, 4), 256), c1 - c0, B), block(256);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, static_cast<hipStream_t>(stream), t, x, x_stats, t_stats,
@@ -125,7 +133,7 @@ extern "C" int pdes_pack_weights(const pdes_pack_item* items, int n, int max_ele
 
 extern "C" int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_c, float momentum, int nrep,
                                       long long rep_stride, void* stream) {
-  if (!items || n <= 0 || max_c <= 0 || nrep < 1) return PDES_EINVAL;
+  if (!items || n <= 0 || max_c <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   hipLaunchKernelGGL(bn_update_running_kernel, dim3(cdiv(max_c, 256), n), dim3(256), 0,
                      static_cast<hipStream_t>(stream), items, momentum, nrep, rep_stride);
   PDES_LAUNCH_CHECK();
@@ -134,7 +142,7 @@ extern "C" int pdes_bn_update_running(const pdes_bn_item* items, int n, int max_
 
 extern "C" int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, int nrep, long long rep_stride,
                                    void* stream) {
-  if (!items || n <= 0 || max_c <= 0 || nrep < 1) return PDES_EINVAL;
+  if (!items || n <= 0 || max_c <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(max_c, 256), n), dim3(256), 0,
                      static_cast<hipStream_t>(stream), items, nrep, rep_stride);
   PDES_LAUNCH_CHECK();

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct(pdes_conv_desc d, 
 
 // ------------------------------------------------------------------------------- host dispatch
 static int validate(const pdes_conv_desc& d, int mode) {
-  if (d.nrep < 1) return PDES_EINVAL;
+  if (d.nrep != PDES_NREP) return PDES_EINVAL;
   if (d.B <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return PDES_EINVAL;
   if (!d.x) return PDES_EINVAL;
   if (!(d.ksize == 1 || d.ksize == 3 || d.ksize == 5 || d.ksize == 7)) return PDES_ENOSUP;

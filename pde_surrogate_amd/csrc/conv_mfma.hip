@@ -175,22 +175,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   __syncthreads();
 
   const int a_lane = (lane >> 4) * G::CS + (lane & 15);
+  float bnext[KK];
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int buf = chunk & 1;
     // B operand of this chunk, packed image [(kstep*KK + tap)*nt_total + nt][64].  These loads are
     // issued BEFORE the next chunk's activation prefetch: vmcnt retires loads in order, so the
     // MFMAs (which wait for B) would otherwise also wait for the whole prefetch.
     float bw[KSW][KK][NT_W];
+    if (WAVES_K == 4 && chunk > 0) {
 #pragma unroll
-    for (int s = 0; s < KSW; ++s) {
-      const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
+      for (int t = 0; t < KK; ++t) bw[0][t][0] = bnext[t];     // prefetched during the previous chunk
+    } else {
+#pragma unroll
+      for (int s = 0; s < KSW; ++s) {
+        const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT_W; ++nt) {
+            const int ntg = nt_base + nt;
+            bw[s][t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
+          }
+      }
+    }
+    if (WAVES_K == 4 && chunk + 1 < nchunk) {
+      const int kstep = (chunk + 1) * 4 + wk;
 #pragma unroll
       for (int t = 0; t < KK; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT_W; ++nt) {
-          const int ntg = nt_base + nt;
-          bw[s][t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
-        }
+        bnext[t] = nt_base < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + nt_base) * 64 + lane] : 0.f;
     }
     if (chunk + 1 < nchunk) issue(chunk + 1);
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
@@ -427,7 +439,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, hipStream_t st)
 
 // returns PDES_ENOSUP when the shape is not covered (caller falls back to the direct kernels)
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st) {
-  if (d.nrep < 1) return PDES_EINVAL;
+  if (d.nrep != PDES_NREP) return PDES_EINVAL;
   if (!d.wm_fwd || !mfma_shape_ok(d, false) || d.Cin < 16) return PDES_ENOSUP;
   if (d.ksize == 5) return d.upsample ? PDES_ENOSUP : launch_mfma<5, MODE_FWD>(d, d.wm_fwd, st);
   return d.ksize == 3 ? launch_mfma<3, MODE_FWD>(d, d.wm_fwd, st) : launch_mfma<1, MODE_FWD>(d, d.wm_fwd, st);

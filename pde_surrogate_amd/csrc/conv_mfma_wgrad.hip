@@ -238,6 +238,7 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
   if (!d.ws || !d.has_bn || !(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.stride != 1 ||
       d.pad != (d.ksize - 1) / 2)
     return PDES_ENOSUP;
+  if (d.nrep != PDES_NREP) return PDES_EINVAL;
   if (d.Cin < 16) return PDES_ENOSUP;
   const int W = d.Wout, H = d.Hout;
   if (W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8))) return PDES_ENOSUP;

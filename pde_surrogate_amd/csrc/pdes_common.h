@@ -40,9 +40,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // fp64 statistics are accumulated into one of `nrep` replicas of the arena (replica stride in
 // doubles) to keep same-address atomic contention low; readers sum the replicas.
-__device__ __forceinline__ double rep_sum(const double* p, int idx, int nrep, long long stride) {
+// The replica count is a compile-time constant (descriptors must carry nrep == PDES_NREP) so the
+// loads below are issued back to back and their latency is paid once, not nrep times.
+#define PDES_NREP 16
+__device__ __forceinline__ double rep_sum(const double* p, int idx, int /*nrep*/, long long stride) {
+  double a[PDES_NREP];
+#pragma unroll
+  for (int r = 0; r < PDES_NREP; ++r) a[r] = p[(long long)r * stride + idx];
   double s = 0.0;
-  for (int r = 0; r < nrep; ++r) s += p[(long long)r * stride + idx];
+#pragma unroll
+  for (int r = 0; r < PDES_NREP; ++r) s += a[r];
   return s;
 }
 __device__ __forceinline__ int rep_of_block(int nrep) {

@@ -234,7 +234,7 @@ class _Engine:
                 bn_off[s.norm] = n_bn
                 n_bn += 2 * s.cin
         # NREP replicas of the whole arena spread same-address fp64 atomics (readers sum them)
-        self.nrep, self.rep_stride = 16, 2 * n_stat + n_bn
+        self.nrep, self.rep_stride = _lib.lib().pdes_stat_replicas(), 2 * n_stat + n_bn
         self.arena = torch.zeros(self.nrep * self.rep_stride, device=dev, dtype=torch.float64)
         a0 = self.arena.data_ptr()
         xs = lambda k: a0 + 8 * self.stat_off[k]
