@@ -1,28 +1,30 @@
 // Implicit-GEMM convolutions on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 = an fmaf
-// chain) for the 3x3 and 1x1 convolutions of DenseED (reference models/codec.py:43-188), gfx950.
+// chain) for the 1x1 / 3x3 / 5x5 convolutions of DenseED (reference models/codec.py:43-188), gfx950.
 //
 // A k x k convolution is k*k pointwise (1x1) contractions over shifted views of one LDS tile:
-//     out[pixel][co] += sum_ci z[ci][pixel + tap] * W[co][ci][tap]
-// GEMM roles per MFMA (16x16x4): M = 16 consecutive pixels of one image row (A operand, one
+//     out[pixel][co] += sum_ci z[ci][pixel*stride + tap] * W[co][ci][tap]
+// GEMM roles per MFMA (16x16x4): M = 16 consecutive output pixels of one image row (A operand, one
 // ds_read_b32 per lane from the LDS tile), N = 16 output channels (B operand, one coalesced global
 // load per lane from a pre-packed weight image), K = 4 input channels.  Accumulator lane layout:
 // col = lane&15 = output channel, rows (lane>>4)*4+r = 4 consecutive pixels -> one float4 store.
 //
-// Workgroup = 256 threads = 4 waves, output tile = 8 M-tiles (4 rows x 32 px, or 8 rows x 16 px
-// for 16-wide maps) of ONE sample -> 256 workgroups for a 32x32 map at batch 32 (one per CU).
-// Input channels are processed in chunks of 16: the chunk's (rows+2) x (cols+2) halo tile is
-// BatchNorm+ReLU'd (and nearest-x2 upsampled) on the way into LDS, double buffered, the next
-// chunk's global loads being issued before the current chunk's MFMAs (register prefetch).
-// LDS channel stride is == 16 (mod 32) dwords so the 2 x 16 lanes of a ds_read_b32 group never
-// collide.  Waves split the work either by K (dense layers, Cout = 16: each wave takes one k-step
-// of every chunk, partial sums are combined through LDS once at the end) or by N (wide layers:
-// each wave owns NT_W of the output-channel tiles).
+// Workgroup = 256 threads = 4 waves, output tile = MT M-tiles (MT = 8: 4 rows x 32 px or 8 rows x
+// 16 px; MT = 4 halves the rows when the grid would otherwise not fill the 256 CUs) of ONE sample.
+// Input channels are processed in chunks of 16: the chunk's halo tile is BatchNorm+ReLU'd (and
+// nearest-x2 upsampled) on the way into LDS, double buffered; the next chunk's global loads are
+// issued before the current chunk's MFMAs and committed after them (register prefetch).
+// LDS channel stride is == 16 (mod 32) dwords (odd for stride 2) so the 2 x 16 lanes of a
+// ds_read_b32 group never collide.  Waves split the work either by K (dense layers, Cout = 16:
+// each wave takes one k-step of every chunk, partial sums are combined through LDS once at the
+// end) or by N (wide layers: each wave owns NT_W of the output-channel tiles).
 // The epilogue accumulates the fp64 {sum, sum^2} per output channel that the consumer BatchNorms
-// need (one double atomic per channel per workgroup).
+// need (replicated accumulators, one atomic per channel per workgroup).
 //
-// The same kernel computes the data gradient (MODE_BWD): the "input" is dL/d(out) (raw, no BN),
-// the weights are the transposed / tap-flipped image, and the epilogue applies the ReLU mask and
-// gamma, accumulates into T, and reduces dgamma / dbeta / {sum T, sum T xhat}.
+// The same kernel computes the data gradient (MODE_BWD): the "input" is dL/d(out) (raw, no BN;
+// zero-inserted for a stride-2 convolution), the weights are the transposed / tap-flipped image,
+// and the epilogue applies the ReLU mask and gamma, accumulates into T, and reduces dgamma / dbeta /
+// {sum T, sum T xhat}.
+#include <stdlib.h>
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
 
@@ -49,38 +51,29 @@ __device__ __forceinline__ BnC bn_coef_m(const pdes_conv_desc& d, int c) {
   return o;
 }
 
-template <int KS, int TWG>
+template <int KS, int TWG, int MT, int S>
 struct TileGeo {
-  static constexpr int TH = 8 / TWG, TW = 16 * TWG;          // output tile (pixels)
-  static constexpr int ROWS = TH + KS - 1, COLS = TW + KS - 1;
-  static constexpr int LDW = (KS == 5) ? (TWG == 2 ? 38 : 20)
-                             : (KS == 3) ? (TWG == 2 ? 40 : 24) : (TWG == 2 ? 36 : 18);
-  static constexpr int CS = ROWS * LDW;                       // channel stride in LDS (dwords)
+  static constexpr int TH = MT / TWG, TW = 16 * TWG;          // output tile (pixels)
+  static constexpr int ROWS = (TH - 1) * S + KS, COLS = (TW - 1) * S + KS;
+  // channel stride: 16 (mod 32) dwords for unit stride, odd for stride 2 (lanes step by 2 dwords)
+  static constexpr int CS = (S == 1) ? ((ROWS * COLS - 16 + 31) / 32) * 32 + 16 : ((ROWS * COLS) | 1);
   static constexpr int KC = 16;                               // input channels per chunk
   static constexpr int NELEM = KC * ROWS * COLS;
   static constexpr int NPF = (NELEM + 255) / 256;             // prefetch registers per thread
-  static_assert(CS % 32 == 16, "LDS channel stride must be 16 mod 32 dwords");
-  static_assert(LDW >= COLS, "row pitch");
+  static_assert(MT % TWG == 0 && CS >= ROWS * COLS, "tile geometry");
 };
 
 enum { MODE_FWD = 0, MODE_BWD = 1 };
+enum { KV_PLAIN = 0, KV_NEAREST2 = 1, KV_ZEROINS2 = 2 };
 
-// K-operand ("input") view of the kernel: FWD reads x (BN+ReLU, optional nearest x2); BWD reads g.
-struct KView {
-  const float* base;   // sample base pointer (channel 0)
-  int C;               // channels
-  int H, W;            // stored size
-  int Hc, Wc;          // logical (conv-input) size: 2x stored when upsampled
-  int up;
-};
-
-template <int KS, int TWG, int WAVES_K, int NT_W, int MODE>
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                        int nt_total) {
-  using G = TileGeo<KS, TWG>;
+  using G = TileGeo<KS, TWG, MT, S>;
   constexpr int KK = KS * KS;
   constexpr int KSW = 4 / WAVES_K;          // k-steps of a chunk handled by one wave
-  constexpr int PADL = (KS - 1) / 2;        // 'same' convolution (pad = (k-1)/2, stride 1)
+  constexpr int PADL = (KS - 1) / 2;        // pad = (k-1)/2
+  static_assert(WAVES_K == 1 || MT >= 4, "K-split waves each own MT/4 M-tiles at the end");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,21 +81,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   const int b = blockIdx.y;
   const int nt_base = (blockIdx.z * (4 / WAVES_K) + wn) * NT_W;   // first N-tile of this wave
 
-  // ---- views: K operand (staged through LDS) and the N/output side
-  KView kv;
-  int Hout, Wout, Cn;                        // output map size, number of N channels
+  // ---- K operand (staged through LDS) and the output side
+  const float* kbase;
+  int kC, kH, kW, kHc, kWc, kmode;
+  int Hout, Wout;
   if (MODE == MODE_FWD) {
-    kv.C = d.Cin; kv.H = d.Hin; kv.W = d.Win; kv.up = d.upsample;
-    kv.base = d.x + (size_t)b * d.x_ctot * d.Hin * d.Win;
-    Hout = d.Hout; Wout = d.Wout; Cn = d.Cout;
+    kC = d.Cin; kH = d.Hin; kW = d.Win; kmode = d.upsample ? KV_NEAREST2 : KV_PLAIN;
+    kbase = d.x + (size_t)b * d.x_ctot * d.Hin * d.Win;
+    Hout = d.Hout; Wout = d.Wout;
   } else {
-    kv.C = d.Cout; kv.H = d.Hout; kv.W = d.Wout; kv.up = 0;
-    kv.base = d.g + ((size_t)b * d.g_ctot + d.g_coff) * d.Hout * d.Wout;
-    Hout = d.upsample ? 2 * d.Hin : d.Hin; Wout = d.upsample ? 2 * d.Win : d.Win; Cn = d.Cin;
+    kC = d.Cout; kH = d.Hout; kW = d.Wout; kmode = d.stride == 2 ? KV_ZEROINS2 : KV_PLAIN;
+    kbase = d.g + ((size_t)b * d.g_ctot + d.g_coff) * d.Hout * d.Wout;
+    Hout = d.upsample ? 2 * d.Hin : d.Hin; Wout = d.upsample ? 2 * d.Win : d.Win;
   }
-  kv.Hc = kv.up ? 2 * kv.H : kv.H;
-  kv.Wc = kv.up ? 2 * kv.W : kv.W;
-  const int kpad = (kv.C + 15) & ~15;
+  kHc = kmode ? 2 * kH : kH;
+  kWc = kmode ? 2 * kW : kW;
+  const int kpad = (kC + 15) & ~15;
   const int nchunk = kpad / 16;
   float* cf = smem;                          // FWD: [kpad][3] mean, scale, beta
   float* tile = smem + ((MODE == MODE_FWD) ? 3 * kpad : 0);
@@ -118,54 +112,47 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     }
   }
 
-  // ---- per-thread staging geometry (independent of the chunk)
-  const int HWs = kv.H * kv.W;
-  int goff[G::NPF], loff[G::NPF];
-  unsigned vmask = 0;
-#pragma unroll
-  for (int i = 0; i < G::NPF; ++i) {
-    const int e = tid + 256 * i;
-    const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
-    const int r = rem / G::COLS, c = rem % G::COLS;
-    const int cy = oy0 - PADL + r, cx = ox0 - PADL + c;
-    const bool v = (e < G::NELEM) && cy >= 0 && cy < kv.Hc && cx >= 0 && cx < kv.Wc;
-    const int sy = kv.up ? (cy >> 1) : cy, sx = kv.up ? (cx >> 1) : cx;
-    goff[i] = v ? (ch * HWs + sy * kv.W + sx) : 0;
-    loff[i] = (e < G::NELEM) ? (ch * G::CS + r * G::LDW + c) : -1;
-    if (v) vmask |= 1u << i;
-  }
-
+  const int HWs = kH * kW;
+  const float NANF = __int_as_float(0x7fc00000);     // "outside the image / channel range" marker
   float pf[G::NPF];
   auto issue = [&](int chunk) {
-    const float* src = kv.base + (size_t)chunk * 16 * HWs;
-    const int crem = kv.C - chunk * 16;               // channels available in this chunk
+    const float* src = kbase + (size_t)chunk * 16 * HWs;
+    const int crem = kC - chunk * 16;               // channels available in this chunk
 #pragma unroll
     for (int i = 0; i < G::NPF; ++i) {
       const int e = tid + 256 * i;
-      const int ch = e / (G::ROWS * G::COLS);
-      pf[i] = ((vmask >> i) & 1u) && ch < crem ? src[goff[i]] : 0.f;
+      const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
+      const int r = rem / G::COLS, c = rem % G::COLS;
+      const int cy = oy0 * S - PADL + r, cx = ox0 * S - PADL + c;
+      bool v = (e < G::NELEM) && ch < crem && cy >= 0 && cy < kHc && cx >= 0 && cx < kWc;
+      if (kmode == KV_ZEROINS2) v = v && !((cy | cx) & 1);
+      const int sy = kmode ? (cy >> 1) : cy, sx = kmode ? (cx >> 1) : cx;
+      pf[i] = v ? src[ch * HWs + sy * kW + sx] : NANF;
     }
   };
   auto commit = [&](int chunk, int buf) {
     float* t = tile + buf * (G::KC * G::CS);
-    const int crem = kv.C - chunk * 16;
 #pragma unroll
     for (int i = 0; i < G::NPF; ++i) {
       const int e = tid + 256 * i;
-      const int ch = e / (G::ROWS * G::COLS);
-      float z = pf[i];
-      if (MODE == MODE_FWD) {
-        const float* k = cf + 3 * (chunk * 16 + ch);
-        const bool v = ((vmask >> i) & 1u) && ch < crem;
-        z = v ? fmaxf(0.f, (z - k[0]) * k[1] + k[2]) : 0.f;
+      if (e < G::NELEM) {
+        const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
+        const float x = pf[i];
+        float z;
+        if (MODE == MODE_FWD) {
+          const float* k = cf + 3 * (chunk * 16 + ch);
+          z = (x != x) ? 0.f : fmaxf(0.f, (x - k[0]) * k[1] + k[2]);
+        } else {
+          z = (x != x) ? 0.f : x;
+        }
+        t[ch * G::CS + rem] = z;
       }
-      if (loff[i] >= 0) t[loff[i]] = z;
     }
   };
 
-  v4f acc[8][NT_W];
+  v4f acc[MT][NT_W];
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
@@ -174,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   commit(0, 0);
   __syncthreads();
 
-  const int a_lane = (lane >> 4) * G::CS + (lane & 15);
+  const int a_lane = (lane >> 4) * G::CS + (lane & 15) * S;
   float bnext[KK];
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int buf = chunk & 1;
@@ -209,15 +196,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
       const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-      if (kstep * 4 >= kv.C) continue;          // wave-uniform: k-step entirely in the zero padding
+      if (kstep * 4 >= kC) continue;            // wave-uniform: k-step entirely in the zero padding
       const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-          for (int mt = 0; mt < 8; ++mt) {
-            const float a = tk[((mt / TWG) + ky) * G::LDW + (mt % TWG) * 16 + kx];
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = tk[((mt / TWG) * S + ky) * G::COLS + (mt % TWG) * 16 * S + kx];
 #pragma unroll
             for (int nt = 0; nt < NT_W; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
@@ -228,24 +215,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     __syncthreads();
   }
 
-  // ---- combine the K-split partial sums: wave w ends up owning M-tiles {2w, 2w+1}
-  constexpr int MT_OWN = (WAVES_K == 4) ? 2 : 8;
-  const int mt0 = (WAVES_K == 4) ? 2 * wave : 0;
+  // ---- combine the K-split partial sums: wave w ends up owning M-tiles [w*MT/4, (w+1)*MT/4)
+  constexpr int MT_OWN = (WAVES_K == 4) ? MT / 4 : MT;
+  const int mt0 = (WAVES_K == 4) ? MT_OWN * wave : 0;
   if (WAVES_K == 4) {
-    float* red = tile;                         // [4 waves][8 mt][4 r][64 lanes] = 8192 floats
+    float* red = tile;                         // [4 waves][MT][4 r][64 lanes]
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave * 8 + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
+      for (int r = 0; r < 4; ++r) red[((wave * MT + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MT_OWN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[((w * 8 + mt0 + j) * 4 + r) * 64 + lane];
-        acc[j][0][r] = s;                      // acc[0..1] now hold the wave's own two M-tiles
+        for (int w = 0; w < 4; ++w) s += red[((w * MT + mt0 + j) * 4 + r) * 64 + lane];
+        acc[j][0][r] = s;                      // acc[0..MT_OWN) now hold the wave's own M-tiles
       }
   }
 
@@ -275,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
         if (WAVES_K == 4) {
           // the four waves hold partial sums of the SAME 16 channels: combine through LDS -> one
           // pair of atomics per channel per workgroup
-          float* sred = tile + 8192;                 // past the accumulator exchange area
+          float* sred = tile + 4 * MT * 4 * 64;      // past the accumulator exchange area
           if (lane < 16) { sred[(wave * 16 + lane) * 2] = s; sred[(wave * 16 + lane) * 2 + 1] = q; }
           __syncthreads();
           if (wave == 0 && lane < 32) {
@@ -326,16 +313,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
             }
             *reinterpret_cast<float4*>(tb2 + idx) = make_float4(ts[0], ts[1], ts[2], ts[3]);
           }
-        } else {
-          // rows come in pairs (mt, mt+TWG) -> requires TH even and M-tiles ordered row-major
+        } else if (WAVES_K == 1 && (MT / TWG) % 2 == 0) {
+          // rows come in pairs (mt, mt+TWG): needs every M-tile in this wave and an even tile height
 #pragma unroll
-          for (int j = 0; j < MT_OWN; ++j) {
-            const int mt = mt0 + j;
-            if ((mt / TWG) & 1) continue;                     // odd rows are folded into the even row above
-            const v4f v0 = acc[j][nt], v1 = acc[(j + TWG < 8) ? j + TWG : j][nt];
+          for (int j = 0; j < MT; ++j) {
+            if ((j / TWG) & 1) continue;                      // odd rows are folded into the even row above
+            const v4f v0 = acc[j][nt], v1 = acc[(j + TWG < MT) ? j + TWG : j][nt];
             const float lo = (v0[0] + v0[1]) + (v1[0] + v1[1]);
             const float hi = (v0[2] + v0[3]) + (v1[2] + v1[3]);
-            const int iy = (oy0 + mt / TWG) >> 1, ix = (ox0 + (mt % TWG) * 16 + px) >> 1;
+            const int iy = (oy0 + j / TWG) >> 1, ix = (ox0 + (j % TWG) * 16 + px) >> 1;
             const size_t idx = (size_t)ci * HWi + (size_t)iy * d.Win + ix;
             const float2 xv = *reinterpret_cast<const float2*>(xb + idx);
             float2 tv = d.t_accumulate ? *reinterpret_cast<const float2*>(tb2 + idx) : make_float2(0.f, 0.f);
@@ -395,44 +381,73 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const pdes_mfma_pack_ite
 }
 
 // ------------------------------------------------------------------------------- host dispatch
-static bool mfma_shape_ok(const pdes_conv_desc& d, bool bwd) {
-  if (!(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.stride != 1 || d.pad != (d.ksize - 1) / 2) return false;
+// (W, H) = size of the map the kernel tiles: the output map (forward) or the input map (data gradient)
+static bool mfma_shape_ok(const pdes_conv_desc& d, bool bwd, int* W, int* H) {
+  if (!(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.pad != (d.ksize - 1) / 2) return false;
+  if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample && d.Hin == 2 * d.Hout && d.Win == 2 * d.Wout))
+    return false;
   if (!d.has_bn) return false;
-  const int W = bwd ? (d.upsample ? 2 * d.Win : d.Win) : d.Wout;
-  const int H = bwd ? (d.upsample ? 2 * d.Hin : d.Hin) : d.Hout;
-  if (W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8))) return false;
-  return true;
+  *W = bwd ? (d.upsample ? 2 * d.Win : d.Win) : d.Wout;
+  *H = bwd ? (d.upsample ? 2 * d.Hin : d.Hin) : d.Hout;
+  if (*W % 16 || (*W >= 32 && *W % 32)) return false;
+  const int twg = *W >= 32 ? 2 : 1;
+  return *H % (8 / twg) == 0;
 }
 
-template <int KS, int MODE>
-static int launch_mfma(const pdes_conv_desc& d, const float* wm, hipStream_t st) {
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int KS, int S, int MODE>
+static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st) {
   const bool bwd = MODE == MODE_BWD;
-  const int W = bwd ? (d.upsample ? 2 * d.Win : d.Win) : d.Wout;
-  const int H = bwd ? (d.upsample ? 2 * d.Hin : d.Hin) : d.Hout;
   const int kC = bwd ? d.Cout : d.Cin, nC = bwd ? d.Cin : d.Cout;
   const int kpad = (kC + 15) & ~15;
   const int nt_total = (nC + 15) / 16;
   const int twg = W >= 32 ? 2 : 1;
-  const int tiles = (W / (16 * twg)) * (H / (8 / twg));
-  dim3 grid(tiles, d.B), block(256);
-  const int cs = twg == 2 ? TileGeo<KS, 2>::CS : TileGeo<KS, 1>::CS;
-  size_t lds_f = (size_t)(bwd ? 0 : 3 * kpad) + (size_t)2 * 16 * cs;
-  const size_t red_f = (size_t)(bwd ? 0 : 3 * kpad) + 8192 + 128;
-#define PDES_MFMA_LAUNCH(TWG_, WK_, NTW_)                                                                    \
-  hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, WK_, NTW_, MODE>), grid, block,                              \
-                     ((WK_) == 4 && red_f > lds_f ? red_f : lds_f) * sizeof(float), st, d, wm, nt_total)
-  if (nt_total == 1) {
-    if (bwd && d.upsample) return PDES_ENOSUP;          // K-split waves do not own both rows of a pair
-    if (twg == 2) PDES_MFMA_LAUNCH(2, 4, 1); else PDES_MFMA_LAUNCH(1, 4, 1);
-  } else if (kpad <= 16 || nt_total <= 4) {
-    // cheap operand staging (one chunk) or few N-tiles: one N-tile per wave, split N over blockIdx.z
-    grid.z = (nt_total + 3) / 4;
-    if (twg == 2) PDES_MFMA_LAUNCH(2, 1, 1); else PDES_MFMA_LAUNCH(1, 1, 1);
-  } else {
-    grid.z = (nt_total + 7) / 8;
-    if (twg == 2) PDES_MFMA_LAUNCH(2, 1, 2); else PDES_MFMA_LAUNCH(1, 1, 2);
+  // wave roles
+  int wk, ntw, gz = 1;
+  if (nt_total == 1) { wk = 4; ntw = 1; }
+  else if (kpad <= 16 || nt_total <= 4) { wk = 1; ntw = 1; gz = (nt_total + 3) / 4; }   // cheap staging: split N over z
+  else { wk = 1; ntw = 2; gz = (nt_total + 7) / 8; }
+  const bool up_bwd = bwd && d.upsample;
+  if (up_bwd && wk == 4) return PDES_ENOSUP;            // K-split waves do not own both rows of a 2x2 pair
+  // M-tiles per workgroup: 8, or 4 when that is needed to put >= 1 workgroup on every CU
+  int mt = 8;
+  const long long wg8 = (long long)(W / (16 * twg)) * (H / (8 / twg)) * d.B * gz;
+  if (wg8 < 256) mt = 4;
+  mt = env_int("PDES_MFMA_MT", mt);
+  if (!(mt == 8 || mt == 4) || up_bwd || KS == 5 || S == 2) mt = 8;
+  const int th = mt / twg;
+  if (H % th) return PDES_ENOSUP;
+  dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
+  size_t lds = 0;
+  int rc = PDES_ENOSUP;
+#define PDES_TRY(TWG_, MT_, WK_, NTW_)                                                                       \
+  if (twg == TWG_ && mt == MT_ && wk == WK_ && ntw == NTW_) {                                                 \
+    using G = TileGeo<KS, TWG_, MT_, S>;                                                                      \
+    const size_t cf_f = bwd ? 0 : 3 * (size_t)kpad;                                                           \
+    size_t fl = cf_f + 2 * (size_t)G::KC * G::CS;                                                             \
+    const size_t red = cf_f + (size_t)4 * MT_ * 4 * 64 + 128;                                                 \
+    if (WK_ == 4 && red > fl) fl = red;                                                                       \
+    lds = fl * sizeof(float);                                                                                 \
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE>), grid, block, lds, st, d, wm,    \
+                       nt_total);                                                                             \
+    rc = PDES_OK;                                                                                             \
   }
-#undef PDES_MFMA_LAUNCH
+  if constexpr (S == 1) {
+    PDES_TRY(2, 8, 4, 1) PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2)
+    PDES_TRY(1, 8, 4, 1) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)
+    if constexpr (KS != 5) {
+      PDES_TRY(2, 4, 4, 1) PDES_TRY(2, 4, 1, 1) PDES_TRY(2, 4, 1, 2)
+      PDES_TRY(1, 4, 4, 1) PDES_TRY(1, 4, 1, 1) PDES_TRY(1, 4, 1, 2)
+    }
+  } else {
+    PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)
+  }
+#undef PDES_TRY
+  if (rc) return rc;
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
@@ -440,16 +455,25 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, hipStream_t st)
 // returns PDES_ENOSUP when the shape is not covered (caller falls back to the direct kernels)
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st) {
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
-  if (!d.wm_fwd || !mfma_shape_ok(d, false) || d.Cin < 16) return PDES_ENOSUP;
-  if (d.ksize == 5) return d.upsample ? PDES_ENOSUP : launch_mfma<5, MODE_FWD>(d, d.wm_fwd, st);
-  return d.ksize == 3 ? launch_mfma<3, MODE_FWD>(d, d.wm_fwd, st) : launch_mfma<1, MODE_FWD>(d, d.wm_fwd, st);
+  int W, H;
+  if (!d.wm_fwd || !mfma_shape_ok(d, false, &W, &H) || d.Cin < 16) return PDES_ENOSUP;
+  if (d.stride == 2) {
+    if ((d.Cout + 15) / 16 == 1) return PDES_ENOSUP;
+    return launch_mfma<3, 2, MODE_FWD>(d, d.wm_fwd, W, H, st);
+  }
+  if (d.ksize == 5) return d.upsample ? PDES_ENOSUP : launch_mfma<5, 1, MODE_FWD>(d, d.wm_fwd, W, H, st);
+  return d.ksize == 3 ? launch_mfma<3, 1, MODE_FWD>(d, d.wm_fwd, W, H, st)
+                      : launch_mfma<1, 1, MODE_FWD>(d, d.wm_fwd, W, H, st);
 }
 
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st) {
-  if (!d.wm_bwd || !mfma_shape_ok(d, true) || d.eval_mode) return PDES_ENOSUP;
+  int W, H;
+  if (!d.wm_bwd || !mfma_shape_ok(d, true, &W, &H) || d.eval_mode) return PDES_ENOSUP;
   if (d.upsample && d.ksize != 3) return PDES_ENOSUP;
-  if (d.ksize == 5) return launch_mfma<5, MODE_BWD>(d, d.wm_bwd, st);
-  return d.ksize == 3 ? launch_mfma<3, MODE_BWD>(d, d.wm_bwd, st) : launch_mfma<1, MODE_BWD>(d, d.wm_bwd, st);
+  // a stride-2 convolution's data gradient is the unit-stride gather over the zero-inserted dL/d(out)
+  if (d.ksize == 5) return launch_mfma<5, 1, MODE_BWD>(d, d.wm_bwd, W, H, st);
+  return d.ksize == 3 ? launch_mfma<3, 1, MODE_BWD>(d, d.wm_bwd, W, H, st)
+                      : launch_mfma<1, 1, MODE_BWD>(d, d.wm_bwd, W, H, st);
 }
 
 }  // namespace pdes

@@ -17,10 +17,10 @@ namespace pdes {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int KS, int TWG>
+template <int KS, int TWG, int S>
 struct WGeo {
   static constexpr int TH = 8 / TWG, TW = 16 * TWG;
-  static constexpr int ROWS = TH + KS - 1, COLS = TW + KS - 1;
+  static constexpr int ROWS = (TH - 1) * S + KS, COLS = (TW - 1) * S + KS;
   static constexpr int LDW = COLS + (COLS & 1);               // even row pitch
   static constexpr int CS = ((ROWS * LDW + 29) / 32) * 32 + 2;  // channel stride rounded up to 2 (mod 32)
   static constexpr int GS = TH * TW + 2;                       // g image channel stride (130)
@@ -30,10 +30,10 @@ struct WGeo {
   static_assert(LDW >= COLS, "row pitch");
 };
 
-template <int KS, int TWG, int NTW>
+template <int KS, int TWG, int NTW, int S>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                              int n_ngroups) {
-  using G = WGeo<KS, TWG>;
+  using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS, PADL = (KS - 1) / 2;
   constexpr int NG = 16 * NTW * G::TH * G::TW;                 // g elements per tile
   constexpr int NPG = NG / 256;
@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   float* gt = smem + 16 * G::CS;                               // [16*NTW][GS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;   // == Hout, Wout
-  const int tiles_x = Wc / G::TW, tps = tiles_x * (Hc / G::TH);
+  const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;   // conv-input size
+  const int tiles_x = d.Wout / G::TW, tps = tiles_x * (d.Hout / G::TH);                 // tiles of the OUTPUT map
   const int groups = tps / tpw;
   const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
   const int mtile = blockIdx.y / n_ngroups, ng = blockIdx.y % n_ngroups;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       const int e = tid + 256 * i;
       const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
       const int r = rem / G::COLS, c = rem % G::COLS;
-      const int cy = oy0 - PADL + r, cx = ox0 - PADL + c;
+      const int cy = oy0 * S - PADL + r, cx = ox0 * S - PADL + c;
       const bool v = e < G::NZ && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
       const int sy = d.upsample ? (cy >> 1) : cy, sx = d.upsample ? (cx >> 1) : cx;
       // NaN marks "outside": the BN transform must map it to 0, not relu(beta - mean*scale)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
 
   // wave w owns rows [w*TH/4, (w+1)*TH/4) of each pixel tile
   constexpr int RPW = (G::TH >= 4) ? G::TH / 4 : 1;
-  const int a_lane = (lane & 15) * G::CS + (lane >> 4);       // A: i = ci, k = pixel offset
+  const int a_lane = (lane & 15) * G::CS + (lane >> 4) * S;   // A: i = ci, k = pixel offset
   const int b_lane = (lane & 15) * G::GS + (lane >> 4);       // B: j = co, k = pixel offset
 
   const int tile0 = tg * tpw;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
-            const float a = zt[a_lane + (row + ky) * G::LDW + 4 * ks + kx];
+            const float a = zt[a_lane + (row * S + ky) * G::LDW + 4 * ks * S + kx];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
               acc[ky * KS + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[ky * KS + kx][nt], 0, 0, 0);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void wgrad_reduce_kernel(const float* __restric
   dw[i] += (s0 + s1) + (s2 + s3);
 }
 
-template <int KS>
+template <int KS, int S>
 static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   const int Hc = d.Hout, Wc = d.Wout;
   const int twg = Wc >= 32 ? 2 : 1;
@@ -219,11 +219,11 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   dim3 grid(nsplit, gy), block(256);
 #define PDES_WG_LAUNCH(TWG_, NTW_)                                                                          \
   do {                                                                                                        \
-    using G = WGeo<KS, TWG_>;                                                                                 \
+    using G = WGeo<KS, TWG_, S>;                                                                              \
     size_t lds = (size_t)(16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                                    \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
-    hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+    hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
   } while (0)
   if (twg == 2) { if (ntw == 2) PDES_WG_LAUNCH(2, 2); else PDES_WG_LAUNCH(2, 1); }
   else { if (ntw == 2) PDES_WG_LAUNCH(1, 2); else PDES_WG_LAUNCH(1, 1); }
@@ -235,15 +235,16 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
 }
 
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
-  if (!d.ws || !d.has_bn || !(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.stride != 1 ||
-      d.pad != (d.ksize - 1) / 2)
+  if (!d.ws || !d.has_bn || !(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.pad != (d.ksize - 1) / 2)
     return PDES_ENOSUP;
+  if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample)) return PDES_ENOSUP;
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
   if (d.Cin < 16) return PDES_ENOSUP;
   const int W = d.Wout, H = d.Hout;
   if (W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8))) return PDES_ENOSUP;
-  if (d.ksize == 5) return launch_wgrad<5>(d, st);
-  return d.ksize == 3 ? launch_wgrad<3>(d, st) : launch_wgrad<1>(d, st);
+  if (d.stride == 2) return launch_wgrad<3, 2>(d, st);
+  if (d.ksize == 5) return launch_wgrad<5, 1>(d, st);
+  return d.ksize == 3 ? launch_wgrad<3, 1>(d, st) : launch_wgrad<1, 1>(d, st);
 }
 
 }  // namespace pdes
