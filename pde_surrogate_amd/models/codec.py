@@ -442,7 +442,7 @@ class _HipNet(nn.Module):
         # matrix-core weight images for the 1x1 / 3x3 stride-1 convolutions with >= 16 input channels
         self._packed_mfma, mitems, mmx = {}, [], 0
         for s in self._specs:
-            if s.k not in (1, 3, 5) or s.stride != 1 or s.norm is None:
+            if s.k not in (1, 3, 5) or s.norm is None or (s.stride != 1 and not (s.stride == 2 and s.k == 3)):
                 continue
             kk = s.k * s.k
             nf = _pad16(s.cin) * kk * _pad16(s.cout)          # = ksteps*kk*ntiles*64
