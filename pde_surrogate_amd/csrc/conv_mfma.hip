@@ -67,7 +67,7 @@ enum { MODE_FWD = 0, MODE_BWD = 1 };
 enum { KV_PLAIN = 0, KV_NEAREST2 = 1, KV_ZEROINS2 = 2 };
 
 template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
+__global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                        int nt_total) {
   using G = TileGeo<KS, TWG, MT, S>;
   constexpr int KK = KS * KS;
@@ -76,7 +76,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   static_assert(WAVES_K == 1 || MT >= 4, "K-split waves each own MT/4 M-tiles at the end");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // 8 waves: waves 0-3 issue the MFMAs, waves 4-7 ("loaders") stage the next chunks into LDS.
+  // One loader and one MFMA wave share a SIMD, so the staging VALU/address work and its memory
+  // latency run underneath the matrix pipe instead of in series with it.
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+  const bool loader = threadIdx.x >= 256;
+  const int tid = threadIdx.x & 255;                       // index within the role
   const int wk = wave % WAVES_K, wn = wave / WAVES_K;
   const int b = blockIdx.y;
   const int nt_base = (blockIdx.z * (4 / WAVES_K) + wn) * NT_W;   // first N-tile of this wave
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   const int tiles_x = Wout / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
 
-  if (MODE == MODE_FWD) {
+  if (MODE == MODE_FWD && loader) {
     for (int c = tid; c < kpad; c += 256) {
       float m = 0.f, s = 0.f, bt = 0.f;
       if (c < d.Cin) { const BnC k = bn_coef_m(d, c); m = k.mean; s = k.gamma * k.invstd; bt = k.beta; }
@@ -114,8 +119,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 
   const int HWs = kH * kW;
   const float NANF = __int_as_float(0x7fc00000);     // "outside the image / channel range" marker
-  float pf[G::NPF];
-  auto issue = [&](int chunk) {
+  float pfA[G::NPF], pfB[G::NPF];
+  auto issue = [&](int chunk, float (&pf)[G::NPF]) {
     const float* src = kbase + (size_t)chunk * 16 * HWs;
     const int crem = kC - chunk * 16;               // channels available in this chunk
 #pragma unroll
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       pf[i] = v ? src[ch * HWs + sy * kW + sx] : NANF;
     }
   };
-  auto commit = [&](int chunk, int buf) {
+  auto commit = [&](int chunk, int buf, const float (&pf)[G::NPF]) {
     float* t = tile + buf * (G::KC * G::CS);
 #pragma unroll
     for (int i = 0; i < G::NPF; ++i) {
@@ -156,47 +161,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 #pragma unroll
     for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  __syncthreads();                 // cf visible
-  commit(0, 0);
-  __syncthreads();
-
   const int a_lane = (lane >> 4) * G::CS + (lane & 15) * S;
   float bnext[KK];
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const int buf = chunk & 1;
-    // B operand of this chunk, packed image [(kstep*KK + tap)*nt_total + nt][64].  These loads are
-    // issued BEFORE the next chunk's activation prefetch: vmcnt retires loads in order, so the
-    // MFMAs (which wait for B) would otherwise also wait for the whole prefetch.
-    float bw[KSW][KK][NT_W];
-    if (WAVES_K == 4 && chunk > 0) {
-#pragma unroll
-      for (int t = 0; t < KK; ++t) bw[0][t][0] = bnext[t];     // prefetched during the previous chunk
-    } else {
-#pragma unroll
-      for (int s = 0; s < KSW; ++s) {
-        const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-#pragma unroll
-        for (int t = 0; t < KK; ++t)
-#pragma unroll
-          for (int nt = 0; nt < NT_W; ++nt) {
-            const int ntg = nt_base + nt;
-            bw[s][t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
-          }
-      }
-    }
-    if (WAVES_K == 4 && chunk + 1 < nchunk) {
-      const int kstep = (chunk + 1) * 4 + wk;
-#pragma unroll
-      for (int t = 0; t < KK; ++t)
-        bnext[t] = nt_base < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + nt_base) * 64 + lane] : 0.f;
-    }
-    if (chunk + 1 < nchunk) issue(chunk + 1);
+  // MFMAs of one chunk (waves 0-3)
+  auto compute = [&](int chunk, int buf) {
+    // B operand: packed image [(kstep*KK + tap)*nt_total + nt][64], one coalesced load per (tap, N-tile).
+    // K-split waves (one k-step per chunk) prefetch the next chunk's 9 values during this chunk;
+    // N-split waves load per k-step (9*NT_W values) to keep the register footprint small.
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
       const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
       if (kstep * 4 >= kC) continue;            // wave-uniform: k-step entirely in the zero padding
+      float bw[KK][NT_W];
+      if (WAVES_K == 4 && chunk > 0) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) bw[t][0] = bnext[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT_W; ++nt) {
+            const int ntg = nt_base + nt;
+            bw[t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
+          }
+      }
+      if (WAVES_K == 4 && chunk + 1 < nchunk) {
+        const int kn = (chunk + 1) * 4 + wk;
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+          bnext[t] = nt_base < nt_total ? wm[((size_t)(kn * KK + t) * nt_total + nt_base) * 64 + lane] : 0.f;
+      }
       const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky)
@@ -207,11 +202,47 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
             const float a = tk[((mt / TWG) * S + ky) * G::COLS + (mt % TWG) * 16 * S + kx];
 #pragma unroll
             for (int nt = 0; nt < NT_W; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
           }
         }
     }
-    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1);
+  };
+
+  // prologue: chunk 0 into LDS buffer 0 (and, two-deep, chunk 1 in flight in register set A).
+  // The big stride-2 tiles keep ONE register set: their loader fetches and commits within a chunk.
+  constexpr bool DEEP = (S == 1);
+  if (loader) issue(0, pfB);
+  __syncthreads();                 // cf visible to every loader thread
+  if (loader) {
+    if (DEEP && 1 < nchunk) issue(1, pfA);
+    commit(0, 0, pfB);
+  }
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunk; chunk += 2) {
+    if (loader) {
+      if (DEEP) {
+        if (chunk + 2 < nchunk) issue(chunk + 2, pfB);
+        if (chunk + 1 < nchunk) commit(chunk + 1, 1, pfA);
+      } else if (chunk + 1 < nchunk) {
+        issue(chunk + 1, pfA);
+        commit(chunk + 1, 1, pfA);
+      }
+    } else {
+      compute(chunk, 0);
+    }
+    __syncthreads();
+    if (chunk + 1 >= nchunk) break;
+    if (loader) {
+      if (DEEP) {
+        if (chunk + 3 < nchunk) issue(chunk + 3, pfA);
+        if (chunk + 2 < nchunk) commit(chunk + 2, 0, pfB);
+      } else if (chunk + 2 < nchunk) {
+        issue(chunk + 2, pfA);
+        commit(chunk + 2, 0, pfA);
+      }
+    } else {
+      compute(chunk + 1, 1);
+    }
     __syncthreads();
   }
 
@@ -220,11 +251,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   const int mt0 = (WAVES_K == 4) ? MT_OWN * wave : 0;
   if (WAVES_K == 4) {
     float* red = tile;                         // [4 waves][MT][4 r][64 lanes]
+    if (!loader) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave * MT + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
+        for (int r = 0; r < 4; ++r) red[((wave * MT + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
+    }
     __syncthreads();
+    if (!loader)
 #pragma unroll
     for (int j = 0; j < MT_OWN; ++j)
 #pragma unroll
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     for (int nt = 0; nt < NT_W; ++nt) {
       const int co = (nt_base + nt) * 16 + (lane & 15);
       float s = 0.f, q = 0.f;
-      if (co < d.Cout) {
+      if (co < d.Cout && !loader) {
         float* ob = d.out + ((size_t)b * d.out_ctot + d.out_coff + co) * HWo;
 #pragma unroll
         for (int j = 0; j < MT_OWN; ++j) {
@@ -263,16 +297,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
           // the four waves hold partial sums of the SAME 16 channels: combine through LDS -> one
           // pair of atomics per channel per workgroup
           float* sred = tile + 4 * MT * 4 * 64;      // past the accumulator exchange area
-          if (lane < 16) { sred[(wave * 16 + lane) * 2] = s; sred[(wave * 16 + lane) * 2 + 1] = q; }
+          if (lane < 16 && !loader) { sred[(wave * 16 + lane) * 2] = s; sred[(wave * 16 + lane) * 2 + 1] = q; }
           __syncthreads();
-          if (wave == 0 && lane < 32) {
+          if (wave == 0 && lane < 32 && !loader) {
             const int c = lane >> 1, w = lane & 1;
             const float t = (sred[(0 * 16 + c) * 2 + w] + sred[(1 * 16 + c) * 2 + w]) +
                             (sred[(2 * 16 + c) * 2 + w] + sred[(3 * 16 + c) * 2 + w]);
             const int cc = nt_base * 16 + c;
             if (cc < d.Cout) atomicAdd(&os[2 * (d.out_coff + cc) + w], (double)t);
           }
-        } else if (lane < 16 && co < d.Cout) {
+        } else if (lane < 16 && co < d.Cout && !loader) {
           atomicAdd(&os[2 * (d.out_coff + co)], (double)s);
           atomicAdd(&os[2 * (d.out_coff + co) + 1], (double)q);
         }
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     for (int nt = 0; nt < NT_W; ++nt) {
       const int ci = (nt_base + nt) * 16 + (lane & 15);
       float dg = 0.f, db = 0.f, st = 0.f, sx = 0.f;
-      if (ci < d.Cin) {
+      if (ci < d.Cin && !loader) {
         const BnC k = bn_coef_m(d, ci);
         const float scale = k.gamma * k.invstd;
         const bool fin = ci >= d.final_c0 && ci < d.final_c1;
@@ -344,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
       st += __shfl_xor(st, 16, 64); st += __shfl_xor(st, 32, 64);
       sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
-      if (lane < 16 && ci < d.Cin) {
+      if (lane < 16 && ci < d.Cin && !loader) {
         const long long ro = (long long)rep_of_block(d.nrep) * d.rep_stride;
         atomicAdd(&d.bn_grad[ro + 2 * ci], (double)dg);
         atomicAdd(&d.bn_grad[ro + 2 * ci + 1], (double)db);
@@ -411,6 +445,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (nt_total == 1) { wk = 4; ntw = 1; }
   else if (kpad <= 16 || nt_total <= 4) { wk = 1; ntw = 1; gz = (nt_total + 3) / 4; }   // cheap staging: split N over z
   else { wk = 1; ntw = 2; gz = (nt_total + 7) / 8; }
+  if (KS == 5 && ntw == 2) { ntw = 1; gz = (nt_total + 3) / 4; }     // 25 taps: keep the B registers small
   const bool up_bwd = bwd && d.upsample;
   if (up_bwd && wk == 4) return PDES_ENOSUP;            // K-split waves do not own both rows of a 2x2 pair
   // M-tiles per workgroup: 8, or 4 when that is needed to put >= 1 workgroup on every CU
@@ -421,7 +456,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (!(mt == 8 || mt == 4) || up_bwd || KS == 5 || S == 2) mt = 8;
   const int th = mt / twg;
   if (H % th) return PDES_ENOSUP;
-  dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
+  dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(512);
   size_t lds = 0;
   int rc = PDES_ENOSUP;
 #define PDES_TRY(TWG_, MT_, WK_, NTW_)                                                                       \
@@ -437,9 +472,10 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     rc = PDES_OK;                                                                                             \
   }
   if constexpr (S == 1) {
-    PDES_TRY(2, 8, 4, 1) PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2)
-    PDES_TRY(1, 8, 4, 1) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)
+    PDES_TRY(2, 8, 4, 1) PDES_TRY(2, 8, 1, 1)
+    PDES_TRY(1, 8, 4, 1) PDES_TRY(1, 8, 1, 1)
     if constexpr (KS != 5) {
+      PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 2)
       PDES_TRY(2, 4, 4, 1) PDES_TRY(2, 4, 1, 1) PDES_TRY(2, 4, 1, 2)
       PDES_TRY(1, 4, 4, 1) PDES_TRY(1, 4, 1, 1) PDES_TRY(1, 4, 1, 2)
     }
