@@ -162,49 +162,56 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
     for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   const int a_lane = (lane >> 4) * G::CS + (lane & 15) * S;
-  float bnext[KK];
+  float bcur[KK][NT_W];
   // MFMAs of one chunk (waves 0-3)
   auto compute = [&](int chunk, int buf) {
     // B operand: packed image [(kstep*KK + tap)*nt_total + nt][64], one coalesced load per (tap, N-tile).
-    // K-split waves (one k-step per chunk) prefetch the next chunk's 9 values during this chunk;
-    // N-split waves load per k-step (9*NT_W values) to keep the register footprint small.
+    // Rolling register prefetch: while k-step s runs on the matrix pipe the loads of the next k-step
+    // (of this chunk, or the first one of the next chunk) are in flight.
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
+    auto load_b = [&](int kstep, float (&dst)[KK][NT_W]) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT_W; ++nt) {
+          const int ntg = nt_base + nt;
+          dst[t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
+        }
+    };
+    // (only where a k-step is short: one N-tile per wave, <= 9 taps; wide tiles amortise the load)
+    constexpr bool PREFB = (NT_W == 1 && KS <= 3);
+    if (PREFB && chunk == 0) load_b(WAVES_K == 4 ? wk : 0, bcur);
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
       const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-      if (kstep * 4 >= kC) continue;            // wave-uniform: k-step entirely in the zero padding
-      float bw[KK][NT_W];
-      if (WAVES_K == 4 && chunk > 0) {
+      const int knext = (s + 1 < KSW) ? kstep + 1 : (chunk + 1) * 4 + (WAVES_K == 4 ? wk : 0);
+      float bnx[PREFB ? KK : 1][NT_W];
+      const bool more = PREFB && knext * 4 < kpad;
+      if (!PREFB) { if (kstep * 4 < kC) load_b(kstep, bcur); }
+      if constexpr (PREFB) { if (more) load_b(knext, bnx); }
+      if (kstep * 4 < kC) {                     // wave-uniform: skip k-steps entirely in the zero padding
+        const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
 #pragma unroll
-        for (int t = 0; t < KK; ++t) bw[t][0] = bnext[t];
-      } else {
+        for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-        for (int t = 0; t < KK; ++t)
+          for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-          for (int nt = 0; nt < NT_W; ++nt) {
-            const int ntg = nt_base + nt;
-            bw[t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
+            for (int mt = 0; mt < MT; ++mt) {
+              const float a = tk[((mt / TWG) * S + ky) * G::COLS + (mt % TWG) * 16 * S + kx];
+#pragma unroll
+              for (int nt = 0; nt < NT_W; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
+            }
           }
       }
-      if (WAVES_K == 4 && chunk + 1 < nchunk) {
-        const int kn = (chunk + 1) * 4 + wk;
+      if constexpr (PREFB) {
+        if (more) {
 #pragma unroll
-        for (int t = 0; t < KK; ++t)
-          bnext[t] = nt_base < nt_total ? wm[((size_t)(kn * KK + t) * nt_total + nt_base) * 64 + lane] : 0.f;
-      }
-      const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
+          for (int t = 0; t < KK; ++t)
 #pragma unroll
-      for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float a = tk[((mt / TWG) * S + ky) * G::COLS + (mt % TWG) * 16 * S + kx];
-#pragma unroll
-            for (int nt = 0; nt < NT_W; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
-          }
+            for (int nt = 0; nt < NT_W; ++nt) bcur[t][nt] = bnx[t][nt];
         }
+      }
     }
   };
 

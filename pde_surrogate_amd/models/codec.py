@@ -220,8 +220,9 @@ class _Engine:
         self.stat_off = {}
         for k, (c, sc) in bufs.items():
             h, w = self.buf_hw[k]
-            if k != 'in':
-                self.X[k] = torch.empty((B, c, h, w), device=dev, dtype=torch.float32)
+            # 'in' is an engine-owned copy of the input: backward (weight gradient of the first
+            # convolution) reads it after the caller's tensor may have been freed
+            self.X[k] = torch.empty((B, c, h, w), device=dev, dtype=torch.float32)
             if k not in ('in', 'out'):
                 self.T[k] = torch.empty((B, c, h, w), device=dev, dtype=torch.float32)
             self.stat_off[k] = n_stat
@@ -254,7 +255,7 @@ class _Engine:
             ho, wo = self.buf_hw[s.dst]
             d.B, d.Cin, d.Cout, d.Hin, d.Win, d.Hout, d.Wout = B, s.cin, s.cout, hi, wi, ho, wo
             d.ksize, d.stride, d.pad, d.upsample = s.k, s.stride, s.pad, s.up
-            d.x = self.X[s.src].data_ptr() if s.src != 'in' else None
+            d.x = self.X[s.src].data_ptr()
             d.x_ctot = bufs[s.src][0]
             d.has_bn = 1 if s.norm is not None else 0
             d.eval_mode = 0
@@ -315,7 +316,8 @@ class _Engine:
     def forward(self, x, training):
         L, st = _lib.lib(), _lib.stream_ptr()
         net = self.net
-        self.descs[0].x = x.data_ptr()
+        if x.data_ptr() != self.X['in'].data_ptr():
+            self.X['in'].copy_(x)
         ev = 0 if training else 1
         for d, os_ in zip(self.descs, self._out_stats):
             d.eval_mode = ev

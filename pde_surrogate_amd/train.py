@@ -36,9 +36,11 @@ class MixedResidualTrainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         cin = model._bufs['in'][0]
-        self.x_static = torch.zeros((batch_size, cin, imsize, imsize), device=self.dev)
         model.to(self.dev)
-        self.eng = model._engine(self.x_static)           # flattens parameters, allocates buffers
+        probe = torch.zeros((batch_size, cin, imsize, imsize), device=self.dev)
+        self.eng = model._engine(probe)                   # flattens parameters, allocates buffers
+        self.x_static = self.eng.X['in']                  # minibatches are gathered straight into it
+        self.x_static.zero_()
         self.flat, self.gflat = model._flat, model._gscratch
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
