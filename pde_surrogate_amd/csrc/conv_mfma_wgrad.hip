@@ -31,7 +31,7 @@ struct WGeo {
 };
 
 template <int KS, int TWG, int NTW, int S>
-__global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
+__global__ __launch_bounds__(512) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                              int n_ngroups) {
   using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS, PADL = (KS - 1) / 2;
@@ -39,10 +39,12 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   constexpr int NPG = NG / 256;
   constexpr int KSTEPS = G::TH * G::TW / 4 / 4;                // k-steps per wave per tile (8)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* zt = smem;                                            // [16][CS]
-  float* gt = smem + 16 * G::CS;                               // [16*NTW][GS]
+  constexpr int BUF = 16 * G::CS + 16 * NTW * G::GS;           // one LDS buffer: z image + g image
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // 8 waves: 0-3 issue the MFMAs (one image row each), 4-7 stage the next pixel tiles (see conv_mfma.hip)
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+  const bool loader = threadIdx.x >= 256;
+  const int tid = threadIdx.x & 255;
   const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;   // conv-input size
   const int tiles_x = d.Wout / G::TW, tps = tiles_x * (d.Hout / G::TH);                 // tiles of the OUTPUT map
   const int groups = tps / tpw;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
 
-  float pz[G::NPZ], pg[NPG];
-  auto issue = [&](int tile) {
+  float pzA[G::NPZ], pgA[NPG], pzB[G::NPZ], pgB[NPG];
+  auto issue = [&](int tile, float (&pz)[G::NPZ], float (&pg)[NPG]) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
 #pragma unroll
     for (int i = 0; i < G::NPZ; ++i) {
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       pg[i] = ch < corem ? gb[(size_t)ch * HWo + oy * d.Wout + ox] : 0.f;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf, const float (&pz)[G::NPZ], const float (&pg)[NPG]) {
+    float* zt = smem + buf * BUF;
+    float* gt = zt + 16 * G::CS;
 #pragma unroll
     for (int i = 0; i < G::NPZ; ++i) {
       const int e = tid + 256 * i;
@@ -129,13 +133,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   const int a_lane = (lane & 15) * G::CS + (lane >> 4) * S;   // A: i = ci, k = pixel offset
   const int b_lane = (lane & 15) * G::GS + (lane >> 4);       // B: j = co, k = pixel offset
 
-  const int tile0 = tg * tpw;
-  issue(tile0);
-  __syncthreads();                 // cf visible
-  for (int tt = 0; tt < tpw; ++tt) {
-    commit();
-    __syncthreads();
-    if (tt + 1 < tpw) issue(tile0 + tt + 1);
+  auto compute = [&](int buf) {
+    const float* zt = smem + buf * BUF;
+    const float* gt = zt + 16 * G::CS;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = wave * RPW + rr;
@@ -155,7 +155,45 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
           }
       }
     }
-    __syncthreads();               // every wave is done with the LDS images before the next commit
+  };
+
+  // two LDS buffers + two register sets: while the MFMA waves work on tile t (buffer t&1) the
+  // loaders commit tile t+1 (already in registers) to the other buffer and fetch tile t+2
+  constexpr bool DEEP = (S == 1 && KS <= 3 && NTW == 1);     // wide / big tiles keep one register set
+  const int tile0 = tg * tpw;
+  if (loader) issue(tile0, pzB, pgB);
+  __syncthreads();                 // cf visible
+  if (loader) {
+    if (DEEP && 1 < tpw) issue(tile0 + 1, pzA, pgA);
+    commit(0, pzB, pgB);
+  }
+  __syncthreads();
+  for (int tt = 0; tt < tpw; tt += 2) {
+    if (loader) {
+      if (DEEP) {
+        if (tt + 2 < tpw) issue(tile0 + tt + 2, pzB, pgB);
+        if (tt + 1 < tpw) commit(1, pzA, pgA);
+      } else if (tt + 1 < tpw) {
+        issue(tile0 + tt + 1, pzA, pgA);
+        commit(1, pzA, pgA);
+      }
+    } else {
+      compute(0);
+    }
+    __syncthreads();
+    if (tt + 1 >= tpw) break;
+    if (loader) {
+      if (DEEP) {
+        if (tt + 3 < tpw) issue(tile0 + tt + 3, pzA, pgA);
+        if (tt + 2 < tpw) commit(0, pzB, pgB);
+      } else if (tt + 2 < tpw) {
+        issue(tile0 + tt + 2, pzA, pgA);
+        commit(0, pzA, pgA);
+      }
+    } else {
+      compute(1);
+    }
+    __syncthreads();
   }
 
   // ---- sum the 4 waves through LDS, then write this pixel split's partial dW
@@ -166,10 +204,12 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * NR + (t * NTW + nt) * 4 + r) * 64 + lane] = acc[t][nt][r];
+      for (int r = 0; r < 4; ++r)
+        if (!loader) red[(wave * NR + (t * NTW + nt) * 4 + r) * 64 + lane] = acc[t][nt][r];
   __syncthreads();
   float* pout = part + (size_t)blockIdx.x * d.Cout * d.Cin * KK;
-  for (int q = wave; q < NR; q += 4) {
+  // all 8 waves share the final summation
+  for (int q = (threadIdx.x >> 6); q < NR; q += 8) {
     const float s = red[(0 * NR + q) * 64 + lane] + red[(1 * NR + q) * 64 + lane] +
                     red[(2 * NR + q) * 64 + lane] + red[(3 * NR + q) * 64 + lane];
     const int r = q & 3, nt = (q >> 2) % NTW, t = (q >> 2) / NTW;
@@ -216,11 +256,11 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   }
   const int nsplit = d.B * (tps / tpw);
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
-  dim3 grid(nsplit, gy), block(256);
+  dim3 grid(nsplit, gy), block(512);
 #define PDES_WG_LAUNCH(TWG_, NTW_)                                                                          \
   do {                                                                                                        \
     using G = WGeo<KS, TWG_, S>;                                                                              \
-    size_t lds = (size_t)(16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                                    \
+    size_t lds = (size_t)2 * (16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                                \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
     hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
