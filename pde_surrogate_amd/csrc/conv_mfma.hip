@@ -54,34 +54,37 @@ __device__ __forceinline__ BnC bn_coef_m(const pdes_conv_desc& d, int c) {
 template <int KS, int TWG, int MT, int S>
 struct TileGeo {
   static constexpr int TH = MT / TWG, TW = 16 * TWG;          // output tile (pixels)
-  static constexpr int ROWS = (TH - 1) * S + KS, COLS = (TW - 1) * S + KS;
-  // channel stride: 16 (mod 32) dwords for unit stride, odd for stride 2 (lanes step by 2 dwords)
-  static constexpr int CS = (S == 1) ? ((ROWS * COLS - 16 + 31) / 32) * 32 + 16 : ((ROWS * COLS) | 1);
+  static constexpr int PADL = (KS - 1) / 2;
+  static constexpr int ROWS = (TH - 1) * S + KS;              // input rows of the tile
+  static constexpr int TWI = S * TW;                          // "interior" input columns: 16-B aligned in
+                                                              // global memory and in LDS -> float4 traffic
+  static constexpr int NL = PADL, NR = KS - PADL - S;         // halo columns left / right of the interior
+  static constexpr int COL0 = 4;                              // LDS column of the first interior element
+  static constexpr int LDW = ((COL0 + TWI + NR + 3) / 4) * 4; // row pitch (multiple of 4 dwords)
+  // channel stride: == 16 (mod 32) dwords so the two 16-lane halves of a ds_read_b32 group hit
+  // disjoint banks (stride-2 lanes step by 2 dwords: 16 mod 32 keeps them disjoint as well)
+  static constexpr int CS = ((ROWS * LDW - 16 + 31) / 32) * 32 + 16;
   static constexpr int KC = 16;                               // input channels per chunk
-  static constexpr int NELEM = KC * ROWS * COLS;
-  static constexpr int NPF = (NELEM + 255) / 256;             // prefetch registers per thread
-  static_assert(MT % TWG == 0 && CS >= ROWS * COLS, "tile geometry");
+  static constexpr int NV4 = KC * ROWS * (TWI / 4);           // interior float4 per chunk
+  static constexpr int NPV = (NV4 + 255) / 256;
+  static constexpr int NH = KC * ROWS * (NL + NR);            // halo scalars per chunk
+  static constexpr int NPH = (NH + 255) / 256;
+  static_assert(MT % TWG == 0 && CS >= ROWS * LDW && NL <= COL0 && NR >= 0, "tile geometry");
 };
 
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 enum { KV_PLAIN = 0, KV_NEAREST2 = 1, KV_ZEROINS2 = 2 };
 
 template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE>
-__global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
+__global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                        int nt_total) {
   using G = TileGeo<KS, TWG, MT, S>;
   constexpr int KK = KS * KS;
   constexpr int KSW = 4 / WAVES_K;          // k-steps of a chunk handled by one wave
-  constexpr int PADL = (KS - 1) / 2;        // pad = (k-1)/2
   static_assert(WAVES_K == 1 || MT >= 4, "K-split waves each own MT/4 M-tiles at the end");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  // 8 waves: waves 0-3 issue the MFMAs, waves 4-7 ("loaders") stage the next chunks into LDS.
-  // One loader and one MFMA wave share a SIMD, so the staging VALU/address work and its memory
-  // latency run underneath the matrix pipe instead of in series with it.
-  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
-  const bool loader = threadIdx.x >= 256;
-  const int tid = threadIdx.x & 255;                       // index within the role
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave % WAVES_K, wn = wave / WAVES_K;
   const int b = blockIdx.y;
   const int nt_base = (blockIdx.z * (4 / WAVES_K) + wn) * NT_W;   // first N-tile of this wave
@@ -103,57 +106,125 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
   kWc = kmode ? 2 * kW : kW;
   const int kpad = (kC + 15) & ~15;
   const int nchunk = kpad / 16;
-  float* cf = smem;                          // FWD: [kpad][3] mean, scale, beta
-  float* tile = smem + ((MODE == MODE_FWD) ? 3 * kpad : 0);
+  float* tile = smem + ((MODE == MODE_FWD) ? 4 * kpad : 0);   // FWD: [kpad] float4 BN coefficients first
 
   const int tiles_x = Wout / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
 
-  if (MODE == MODE_FWD && loader) {
+  // FWD: per-channel {mean, gamma*invstd, beta, -} as one float4 (a single ds_read_b128 per staged float4)
+  float4* cf4 = reinterpret_cast<float4*>(smem);
+  if (MODE == MODE_FWD) {
     for (int c = tid; c < kpad; c += 256) {
-      float m = 0.f, s = 0.f, bt = 0.f;
-      if (c < d.Cin) { const BnC k = bn_coef_m(d, c); m = k.mean; s = k.gamma * k.invstd; bt = k.beta; }
-      cf[3 * c] = m; cf[3 * c + 1] = s; cf[3 * c + 2] = bt;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < d.Cin) { const BnC k = bn_coef_m(d, c); v = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f); }
+      cf4[c] = v;
     }
   }
 
+  // ---- staging: rows of the halo tile as aligned float4 (interior) + a few halo scalars.
+  // Geometry is per thread and chunk independent: compute it once.
   const int HWs = kH * kW;
-  const float NANF = __int_as_float(0x7fc00000);     // "outside the image / channel range" marker
-  float pfA[G::NPF], pfB[G::NPF];
-  auto issue = [&](int chunk, float (&pf)[G::NPF]) {
+  const bool halo_live = (G::NL + G::NR) > 0 && tiles_x > 1;    // full-width tiles: halo columns are padding
+  int vg[G::NPV], vl[G::NPV];        // interior float4: global offset (within the chunk), LDS offset (-1: none)
+  int hg[G::NPH > 0 ? G::NPH : 1], hl[G::NPH > 0 ? G::NPH : 1];
+  unsigned vrow = 0, hval = 0, hzero = 0;
+#pragma unroll
+  for (int i = 0; i < G::NPV; ++i) {
+    const int e = tid + 256 * i;
+    const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
+    const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
+    const int cy = oy0 * S - G::PADL + r, cx = ox0 * S + 4 * j;
+    const bool ok = e < G::NV4 && cy >= 0 && cy < kHc;
+    const int sy = kmode ? (cy >> 1) : cy, sx = kmode ? (cx >> 1) : cx;
+    vg[i] = ok ? ch * HWs + sy * kW + sx : 0;
+    vl[i] = e < G::NV4 ? ch * G::CS + r * G::LDW + G::COL0 + 4 * j : -1;
+    if (ok && !(kmode == KV_ZEROINS2 && (cy & 1))) vrow |= 1u << i;
+  }
+#pragma unroll
+  for (int i = 0; i < G::NPH; ++i) {
+    const int e = tid + 256 * i;
+    const int ch = e / (G::ROWS * (G::NL + G::NR)), rem = e % (G::ROWS * (G::NL + G::NR));
+    const int r = rem / (G::NL + G::NR), h = rem % (G::NL + G::NR);
+    const int cy = oy0 * S - G::PADL + r;
+    const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
+    const int lc = h < G::NL ? G::COL0 - G::NL + h : G::COL0 + G::TWI + (h - G::NL);
+    bool ok = e < G::NH && cy >= 0 && cy < kHc && cx >= 0 && cx < kWc;
+    if (kmode == KV_ZEROINS2) ok = ok && !((cy | cx) & 1);
+    const int sy = kmode ? (cy >> 1) : cy, sx = kmode ? (cx >> 1) : cx;
+    hg[i] = ok ? ch * HWs + sy * kW + sx : 0;
+    hl[i] = e < G::NH ? ch * G::CS + r * G::LDW + lc : -1;
+    if (ok) hval |= 1u << i;
+  }
+  (void)hzero;
+
+  float4 pv[G::NPV];
+  float ph[G::NPH > 0 ? G::NPH : 1];
+  auto issue = [&](int chunk) {
     const float* src = kbase + (size_t)chunk * 16 * HWs;
     const int crem = kC - chunk * 16;               // channels available in this chunk
 #pragma unroll
-    for (int i = 0; i < G::NPF; ++i) {
-      const int e = tid + 256 * i;
-      const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
-      const int r = rem / G::COLS, c = rem % G::COLS;
-      const int cy = oy0 * S - PADL + r, cx = ox0 * S - PADL + c;
-      bool v = (e < G::NELEM) && ch < crem && cy >= 0 && cy < kHc && cx >= 0 && cx < kWc;
-      if (kmode == KV_ZEROINS2) v = v && !((cy | cx) & 1);
-      const int sy = kmode ? (cy >> 1) : cy, sx = kmode ? (cx >> 1) : cx;
-      pf[i] = v ? src[ch * HWs + sy * kW + sx] : NANF;
-    }
-  };
-  auto commit = [&](int chunk, int buf, const float (&pf)[G::NPF]) {
-    float* t = tile + buf * (G::KC * G::CS);
-#pragma unroll
-    for (int i = 0; i < G::NPF; ++i) {
-      const int e = tid + 256 * i;
-      if (e < G::NELEM) {
-        const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
-        const float x = pf[i];
-        float z;
-        if (MODE == MODE_FWD) {
-          const float* k = cf + 3 * (chunk * 16 + ch);
-          z = (x != x) ? 0.f : fmaxf(0.f, (x - k[0]) * k[1] + k[2]);
+    for (int i = 0; i < G::NPV; ++i) {
+      const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (((vrow >> i) & 1u) && ch < crem) {
+        if (kmode == KV_PLAIN) {
+          v = *reinterpret_cast<const float4*>(src + vg[i]);
         } else {
-          z = (x != x) ? 0.f : x;
+          const float2 t = *reinterpret_cast<const float2*>(src + vg[i]);
+          v = kmode == KV_NEAREST2 ? make_float4(t.x, t.x, t.y, t.y) : make_float4(t.x, 0.f, t.y, 0.f);
         }
-        t[ch * G::CS + rem] = z;
+      }
+      pv[i] = v;
+    }
+    if (halo_live) {
+#pragma unroll
+      for (int i = 0; i < G::NPH; ++i) {
+        const int ch = (tid + 256 * i) / (G::ROWS * (G::NL + G::NR));
+        ph[i] = (((hval >> i) & 1u) && ch < crem) ? src[hg[i]] : 0.f;
       }
     }
   };
+  auto commit = [&](int chunk, int buf) {
+    float* t = tile + buf * (G::KC * G::CS);
+    const int crem = kC - chunk * 16;
+#pragma unroll
+    for (int i = 0; i < G::NPV; ++i) {
+      if (vl[i] >= 0) {
+        float4 z = pv[i];
+        if (MODE == MODE_FWD) {
+          const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
+          const bool ok = ((vrow >> i) & 1u) && ch < crem;
+          const float4 k = cf4[chunk * 16 + ch];
+          z.x = ok ? fmaxf(0.f, (z.x - k.x) * k.y + k.z) : 0.f;
+          z.y = ok ? fmaxf(0.f, (z.y - k.x) * k.y + k.z) : 0.f;
+          z.z = ok ? fmaxf(0.f, (z.z - k.x) * k.y + k.z) : 0.f;
+          z.w = ok ? fmaxf(0.f, (z.w - k.x) * k.y + k.z) : 0.f;
+        }
+        *reinterpret_cast<float4*>(t + vl[i]) = z;
+      }
+    }
+    if (halo_live) {
+#pragma unroll
+      for (int i = 0; i < G::NPH; ++i) {
+        if (hl[i] >= 0) {
+          float z = ph[i];
+          if (MODE == MODE_FWD) {
+            const int ch = (tid + 256 * i) / (G::ROWS * (G::NL + G::NR));
+            const bool ok = ((hval >> i) & 1u) && ch < crem;
+            const float4 k = cf4[chunk * 16 + ch];
+            z = ok ? fmaxf(0.f, (z - k.x) * k.y + k.z) : 0.f;
+          }
+          t[hl[i]] = z;
+        }
+      }
+    }
+  };
+  // halo columns that are always outside the image are zeroed once (both buffers)
+  if (!halo_live && (G::NL + G::NR) > 0) {
+#pragma unroll
+    for (int i = 0; i < G::NPH; ++i)
+      if (hl[i] >= 0) { tile[hl[i]] = 0.f; tile[G::KC * G::CS + hl[i]] = 0.f; }
+  }
 
   v4f acc[MT][NT_W];
 #pragma unroll
@@ -161,95 +232,62 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
 #pragma unroll
     for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+  issue(0);
+  __syncthreads();                 // cf visible
+  commit(0, 0);
+  __syncthreads();
+
   const int a_lane = (lane >> 4) * G::CS + (lane & 15) * S;
-  float bcur[KK][NT_W];
-  // MFMAs of one chunk (waves 0-3)
-  auto compute = [&](int chunk, int buf) {
-    // B operand: packed image [(kstep*KK + tap)*nt_total + nt][64], one coalesced load per (tap, N-tile).
-    // Rolling register prefetch: while k-step s runs on the matrix pipe the loads of the next k-step
-    // (of this chunk, or the first one of the next chunk) are in flight.
-    const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
-    auto load_b = [&](int kstep, float (&dst)[KK][NT_W]) {
+  float bnext[KK];
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int buf = chunk & 1;
+    // B operand of this chunk, packed image [(kstep*KK + tap)*nt_total + nt][64].  These loads are
+    // issued BEFORE the next chunk's activation prefetch: vmcnt retires loads in order, so the
+    // MFMAs (which wait for B) would otherwise also wait for the whole prefetch.
+    float bw[KSW][KK][NT_W];
+    if (WAVES_K == 4 && chunk > 0) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t) bw[0][t][0] = bnext[t];     // prefetched during the previous chunk
+    } else {
+#pragma unroll
+      for (int s = 0; s < KSW; ++s) {
+        const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT_W; ++nt) {
+            const int ntg = nt_base + nt;
+            bw[s][t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
+          }
+      }
+    }
+    if (WAVES_K == 4 && chunk + 1 < nchunk) {
+      const int kstep = (chunk + 1) * 4 + wk;
 #pragma unroll
       for (int t = 0; t < KK; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT_W; ++nt) {
-          const int ntg = nt_base + nt;
-          dst[t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
-        }
-    };
-    // (only where a k-step is short: one N-tile per wave, <= 9 taps; wide tiles amortise the load)
-    constexpr bool PREFB = (NT_W == 1 && KS <= 3);
-    if (PREFB && chunk == 0) load_b(WAVES_K == 4 ? wk : 0, bcur);
+        bnext[t] = nt_base < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + nt_base) * 64 + lane] : 0.f;
+    }
+    if (chunk + 1 < nchunk) issue(chunk + 1);
+    const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
       const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-      const int knext = (s + 1 < KSW) ? kstep + 1 : (chunk + 1) * 4 + (WAVES_K == 4 ? wk : 0);
-      float bnx[PREFB ? KK : 1][NT_W];
-      const bool more = PREFB && knext * 4 < kpad;
-      if (!PREFB) { if (kstep * 4 < kC) load_b(kstep, bcur); }
-      if constexpr (PREFB) { if (more) load_b(knext, bnx); }
-      if (kstep * 4 < kC) {                     // wave-uniform: skip k-steps entirely in the zero padding
-        const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
+      if (kstep * 4 >= kC) continue;            // wave-uniform: k-step entirely in the zero padding
+      const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
+      for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < KS; ++kx) {
+        for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              const float a = tk[((mt / TWG) * S + ky) * G::COLS + (mt % TWG) * 16 * S + kx];
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = tk[((mt / TWG) * S + ky) * G::LDW + (G::COL0 - G::PADL) + (mt % TWG) * 16 * S + kx];
 #pragma unroll
-              for (int nt = 0; nt < NT_W; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
-            }
+            for (int nt = 0; nt < NT_W; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
           }
-      }
-      if constexpr (PREFB) {
-        if (more) {
-#pragma unroll
-          for (int t = 0; t < KK; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT_W; ++nt) bcur[t][nt] = bnx[t][nt];
         }
-      }
     }
-  };
-
-  // prologue: chunk 0 into LDS buffer 0 (and, two-deep, chunk 1 in flight in register set A).
-  // The big stride-2 tiles keep ONE register set: their loader fetches and commits within a chunk.
-  constexpr bool DEEP = (S == 1);
-  if (loader) issue(0, pfB);
-  __syncthreads();                 // cf visible to every loader thread
-  if (loader) {
-    if (DEEP && 1 < nchunk) issue(1, pfA);
-    commit(0, 0, pfB);
-  }
-  __syncthreads();
-  for (int chunk = 0; chunk < nchunk; chunk += 2) {
-    if (loader) {
-      if (DEEP) {
-        if (chunk + 2 < nchunk) issue(chunk + 2, pfB);
-        if (chunk + 1 < nchunk) commit(chunk + 1, 1, pfA);
-      } else if (chunk + 1 < nchunk) {
-        issue(chunk + 1, pfA);
-        commit(chunk + 1, 1, pfA);
-      }
-    } else {
-      compute(chunk, 0);
-    }
-    __syncthreads();
-    if (chunk + 1 >= nchunk) break;
-    if (loader) {
-      if (DEEP) {
-        if (chunk + 3 < nchunk) issue(chunk + 3, pfA);
-        if (chunk + 2 < nchunk) commit(chunk + 2, 0, pfB);
-      } else if (chunk + 2 < nchunk) {
-        issue(chunk + 2, pfA);
-        commit(chunk + 2, 0, pfA);
-      }
-    } else {
-      compute(chunk + 1, 1);
-    }
+    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1);
     __syncthreads();
   }
 
@@ -258,14 +296,11 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
   const int mt0 = (WAVES_K == 4) ? MT_OWN * wave : 0;
   if (WAVES_K == 4) {
     float* red = tile;                         // [4 waves][MT][4 r][64 lanes]
-    if (!loader) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * MT + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
-    }
+      for (int r = 0; r < 4; ++r) red[((wave * MT + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
     __syncthreads();
-    if (!loader)
 #pragma unroll
     for (int j = 0; j < MT_OWN; ++j)
 #pragma unroll
@@ -284,7 +319,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
     for (int nt = 0; nt < NT_W; ++nt) {
       const int co = (nt_base + nt) * 16 + (lane & 15);
       float s = 0.f, q = 0.f;
-      if (co < d.Cout && !loader) {
+      if (co < d.Cout) {
         float* ob = d.out + ((size_t)b * d.out_ctot + d.out_coff + co) * HWo;
 #pragma unroll
         for (int j = 0; j < MT_OWN; ++j) {
@@ -304,16 +339,16 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
           // the four waves hold partial sums of the SAME 16 channels: combine through LDS -> one
           // pair of atomics per channel per workgroup
           float* sred = tile + 4 * MT * 4 * 64;      // past the accumulator exchange area
-          if (lane < 16 && !loader) { sred[(wave * 16 + lane) * 2] = s; sred[(wave * 16 + lane) * 2 + 1] = q; }
+          if (lane < 16) { sred[(wave * 16 + lane) * 2] = s; sred[(wave * 16 + lane) * 2 + 1] = q; }
           __syncthreads();
-          if (wave == 0 && lane < 32 && !loader) {
+          if (wave == 0 && lane < 32) {
             const int c = lane >> 1, w = lane & 1;
             const float t = (sred[(0 * 16 + c) * 2 + w] + sred[(1 * 16 + c) * 2 + w]) +
                             (sred[(2 * 16 + c) * 2 + w] + sred[(3 * 16 + c) * 2 + w]);
             const int cc = nt_base * 16 + c;
             if (cc < d.Cout) atomicAdd(&os[2 * (d.out_coff + cc) + w], (double)t);
           }
-        } else if (lane < 16 && co < d.Cout && !loader) {
+        } else if (lane < 16 && co < d.Cout) {
           atomicAdd(&os[2 * (d.out_coff + co)], (double)s);
           atomicAdd(&os[2 * (d.out_coff + co) + 1], (double)q);
         }
@@ -329,7 +364,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
     for (int nt = 0; nt < NT_W; ++nt) {
       const int ci = (nt_base + nt) * 16 + (lane & 15);
       float dg = 0.f, db = 0.f, st = 0.f, sx = 0.f;
-      if (ci < d.Cin && !loader) {
+      if (ci < d.Cin) {
         const BnC k = bn_coef_m(d, ci);
         const float scale = k.gamma * k.invstd;
         const bool fin = ci >= d.final_c0 && ci < d.final_c1;
@@ -385,7 +420,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(pdes_conv_desc d, const 
       db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
       st += __shfl_xor(st, 16, 64); st += __shfl_xor(st, 32, 64);
       sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
-      if (lane < 16 && ci < d.Cin && !loader) {
+      if (lane < 16 && ci < d.Cin) {
         const long long ro = (long long)rep_of_block(d.nrep) * d.rep_stride;
         atomicAdd(&d.bn_grad[ro + 2 * ci], (double)dg);
         atomicAdd(&d.bn_grad[ro + 2 * ci + 1], (double)db);
@@ -452,7 +487,6 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (nt_total == 1) { wk = 4; ntw = 1; }
   else if (kpad <= 16 || nt_total <= 4) { wk = 1; ntw = 1; gz = (nt_total + 3) / 4; }   // cheap staging: split N over z
   else { wk = 1; ntw = 2; gz = (nt_total + 7) / 8; }
-  if (KS == 5 && ntw == 2) { ntw = 1; gz = (nt_total + 3) / 4; }     // 25 taps: keep the B registers small
   const bool up_bwd = bwd && d.upsample;
   if (up_bwd && wk == 4) return PDES_ENOSUP;            // K-split waves do not own both rows of a 2x2 pair
   // M-tiles per workgroup: 8, or 4 when that is needed to put >= 1 workgroup on every CU
@@ -463,13 +497,13 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (!(mt == 8 || mt == 4) || up_bwd || KS == 5 || S == 2) mt = 8;
   const int th = mt / twg;
   if (H % th) return PDES_ENOSUP;
-  dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(512);
+  dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
   size_t lds = 0;
   int rc = PDES_ENOSUP;
 #define PDES_TRY(TWG_, MT_, WK_, NTW_)                                                                       \
   if (twg == TWG_ && mt == MT_ && wk == WK_ && ntw == NTW_) {                                                 \
     using G = TileGeo<KS, TWG_, MT_, S>;                                                                      \
-    const size_t cf_f = bwd ? 0 : 3 * (size_t)kpad;                                                           \
+    const size_t cf_f = bwd ? 0 : 4 * (size_t)kpad;                                                           \
     size_t fl = cf_f + 2 * (size_t)G::KC * G::CS;                                                             \
     const size_t red = cf_f + (size_t)4 * MT_ * 4 * 64 + 128;                                                 \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \
@@ -479,10 +513,9 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     rc = PDES_OK;                                                                                             \
   }
   if constexpr (S == 1) {
-    PDES_TRY(2, 8, 4, 1) PDES_TRY(2, 8, 1, 1)
-    PDES_TRY(1, 8, 4, 1) PDES_TRY(1, 8, 1, 1)
+    PDES_TRY(2, 8, 4, 1) PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2)
+    PDES_TRY(1, 8, 4, 1) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)
     if constexpr (KS != 5) {
-      PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 2)
       PDES_TRY(2, 4, 4, 1) PDES_TRY(2, 4, 1, 1) PDES_TRY(2, 4, 1, 2)
       PDES_TRY(1, 4, 4, 1) PDES_TRY(1, 4, 1, 1) PDES_TRY(1, 4, 1, 2)
     }

@@ -20,31 +20,34 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <int KS, int TWG, int S>
 struct WGeo {
   static constexpr int TH = 8 / TWG, TW = 16 * TWG;
-  static constexpr int ROWS = (TH - 1) * S + KS, COLS = (TW - 1) * S + KS;
-  static constexpr int LDW = COLS + (COLS & 1);               // even row pitch
-  static constexpr int CS = ((ROWS * LDW + 29) / 32) * 32 + 2;  // channel stride rounded up to 2 (mod 32)
+  static constexpr int PADL = (KS - 1) / 2;
+  static constexpr int ROWS = (TH - 1) * S + KS;
+  static constexpr int TWI = S * TW;                          // interior input columns (float4 traffic)
+  static constexpr int NL = PADL, NR = KS - PADL - S;         // halo columns
+  static constexpr int COL0 = 4;
+  static constexpr int LDW = ((COL0 + TWI + NR + 1) / 2) * 2; // even row pitch (8-byte aligned b64 stores)
+  static constexpr int CS = ((ROWS * LDW + 29) / 32) * 32 + 2;  // channel stride == 2 (mod 32) dwords
   static constexpr int GS = TH * TW + 2;                       // g image channel stride (130)
-  static constexpr int NZ = 16 * ROWS * COLS;                  // z elements per tile
-  static constexpr int NPZ = (NZ + 255) / 256;
-  static_assert(CS % 32 == 2 && GS % 32 == 2, "LDS channel strides must be 2 mod 32 dwords");
-  static_assert(LDW >= COLS, "row pitch");
+  static constexpr int NV4 = 16 * ROWS * (TWI / 4);
+  static constexpr int NPV = (NV4 + 255) / 256;
+  static constexpr int NH = 16 * ROWS * (NL + NR);
+  static constexpr int NPH = (NH + 255) / 256;
+  static_assert(CS % 32 == 2 && GS % 32 == 2 && CS >= ROWS * LDW && NR >= 0, "LDS geometry");
 };
 
 template <int KS, int TWG, int NTW, int S>
-__global__ __launch_bounds__(512) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                              int n_ngroups) {
   using G = WGeo<KS, TWG, S>;
-  constexpr int KK = KS * KS, PADL = (KS - 1) / 2;
-  constexpr int NG = 16 * NTW * G::TH * G::TW;                 // g elements per tile
-  constexpr int NPG = NG / 256;
+  constexpr int KK = KS * KS;
+  constexpr int NPG4 = 16 * NTW * G::TH * G::TW / 4 / 256;      // g float4 per thread per tile
+  const float NANF = __int_as_float(0x7fc00000);
   constexpr int KSTEPS = G::TH * G::TW / 4 / 4;                // k-steps per wave per tile (8)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int BUF = 16 * G::CS + 16 * NTW * G::GS;           // one LDS buffer: z image + g image
+  float* zt = smem;                                            // [16][CS]
+  float* gt = smem + 16 * G::CS;                               // [16*NTW][GS]
 
-  // 8 waves: 0-3 issue the MFMAs (one image row each), 4-7 stage the next pixel tiles (see conv_mfma.hip)
-  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
-  const bool loader = threadIdx.x >= 256;
-  const int tid = threadIdx.x & 255;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;   // conv-input size
   const int tiles_x = d.Wout / G::TW, tps = tiles_x * (d.Hout / G::TH);                 // tiles of the OUTPUT map
   const int groups = tps / tpw;
@@ -78,47 +81,84 @@ __global__ __launch_bounds__(512) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
 
-  float pzA[G::NPZ], pgA[NPG], pzB[G::NPZ], pgB[NPG];
-  auto issue = [&](int tile, float (&pz)[G::NPZ], float (&pg)[NPG]) {
+  const bool halo_live = (G::NL + G::NR) > 0 && tiles_x > 1;
+  float4 pv[G::NPV], pg[NPG4];
+  float ph[G::NPH > 0 ? G::NPH : 1];
+  auto issue = [&](int tile) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
 #pragma unroll
-    for (int i = 0; i < G::NPZ; ++i) {
+    for (int i = 0; i < G::NPV; ++i) {
       const int e = tid + 256 * i;
-      const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
-      const int r = rem / G::COLS, c = rem % G::COLS;
-      const int cy = oy0 * S - PADL + r, cx = ox0 * S - PADL + c;
-      const bool v = e < G::NZ && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
-      const int sy = d.upsample ? (cy >> 1) : cy, sx = d.upsample ? (cx >> 1) : cx;
-      // NaN marks "outside": the BN transform must map it to 0, not relu(beta - mean*scale)
-      pz[i] = v ? xb[(size_t)ch * HWi + sy * d.Win + sx] : __int_as_float(0x7fc00000);
+      const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
+      const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
+      const int cy = oy0 * S - G::PADL + r, cx = ox0 * S + 4 * j;
+      const bool v = e < G::NV4 && ch < crem && cy >= 0 && cy < Hc;
+      float4 x = make_float4(NANF, NANF, NANF, NANF);   // NaN = outside: maps to 0, not relu(bn(0))
+      if (v) {
+        if (d.upsample) {
+          const float2 t = *reinterpret_cast<const float2*>(xb + (size_t)ch * HWi + (cy >> 1) * d.Win + (cx >> 1));
+          x = make_float4(t.x, t.x, t.y, t.y);
+        } else {
+          x = *reinterpret_cast<const float4*>(xb + (size_t)ch * HWi + cy * d.Win + cx);
+        }
+      }
+      pv[i] = x;
     }
+    if (halo_live) {
 #pragma unroll
-    for (int i = 0; i < NPG; ++i) {
-      const int e = tid + 256 * i;
-      const int ch = e / (G::TH * G::TW), p = e % (G::TH * G::TW);
-      const int oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
-      pg[i] = ch < corem ? gb[(size_t)ch * HWo + oy * d.Wout + ox] : 0.f;
-    }
-  };
-  auto commit = [&](int buf, const float (&pz)[G::NPZ], const float (&pg)[NPG]) {
-    float* zt = smem + buf * BUF;
-    float* gt = zt + 16 * G::CS;
-#pragma unroll
-    for (int i = 0; i < G::NPZ; ++i) {
-      const int e = tid + 256 * i;
-      if (e < G::NZ) {
-        const int ch = e / (G::ROWS * G::COLS), rem = e % (G::ROWS * G::COLS);
-        const int r = rem / G::COLS, c = rem % G::COLS;
-        const float x = pz[i];
-        const float z = (x != x) ? 0.f : fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]);
-        zt[ch * G::CS + r * G::LDW + c] = z;
+      for (int i = 0; i < G::NPH; ++i) {
+        const int e = tid + 256 * i;
+        const int ch = e / (G::ROWS * (G::NL + G::NR)), rem = e % (G::ROWS * (G::NL + G::NR));
+        const int r = rem / (G::NL + G::NR), h = rem % (G::NL + G::NR);
+        const int cy = oy0 * S - G::PADL + r;
+        const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
+        const bool v = e < G::NH && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+        const int sy = d.upsample ? (cy >> 1) : cy, sx = d.upsample ? (cx >> 1) : cx;
+        ph[i] = v ? xb[(size_t)ch * HWi + sy * d.Win + sx] : NANF;
       }
     }
 #pragma unroll
-    for (int i = 0; i < NPG; ++i) {
+    for (int i = 0; i < NPG4; ++i) {
+      const int e = tid + 256 * i;                          // float4 index: channel-major, then pixel
+      const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
+      const int oy = oy0 + (4 * p4) / G::TW, ox = ox0 + (4 * p4) % G::TW;
+      pg[i] = ch < corem ? *reinterpret_cast<const float4*>(gb + (size_t)ch * HWo + oy * d.Wout + ox)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto bnrelu = [&](float x, int ch) {
+    return (x != x) ? 0.f : fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::NPV; ++i) {
       const int e = tid + 256 * i;
-      const int ch = e / (G::TH * G::TW), p = e % (G::TH * G::TW);
-      gt[ch * G::GS + p] = pg[i];
+      if (e < G::NV4) {
+        const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
+        const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
+        float* dst = zt + ch * G::CS + r * G::LDW + G::COL0 + 4 * j;      // 8-byte aligned
+        const float4 x = pv[i];
+        *reinterpret_cast<float2*>(dst) = make_float2(bnrelu(x.x, ch), bnrelu(x.y, ch));
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(bnrelu(x.z, ch), bnrelu(x.w, ch));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::NPH; ++i) {
+      const int e = tid + 256 * i;
+      if (e < G::NH) {
+        const int ch = e / (G::ROWS * (G::NL + G::NR)), rem = e % (G::ROWS * (G::NL + G::NR));
+        const int r = rem / (G::NL + G::NR), h = rem % (G::NL + G::NR);
+        const int lc = h < G::NL ? G::COL0 - G::NL + h : G::COL0 + G::TWI + (h - G::NL);
+        zt[ch * G::CS + r * G::LDW + lc] = halo_live ? bnrelu(ph[i], ch) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPG4; ++i) {
+      const int e = tid + 256 * i;
+      const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
+      float* dst = gt + ch * G::GS + 4 * p4;                               // 8-byte aligned (GS even)
+      *reinterpret_cast<float2*>(dst) = make_float2(pg[i].x, pg[i].y);
+      *reinterpret_cast<float2*>(dst + 2) = make_float2(pg[i].z, pg[i].w);
     }
   };
 
@@ -133,9 +173,13 @@ __global__ __launch_bounds__(512) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   const int a_lane = (lane & 15) * G::CS + (lane >> 4) * S;   // A: i = ci, k = pixel offset
   const int b_lane = (lane & 15) * G::GS + (lane >> 4);       // B: j = co, k = pixel offset
 
-  auto compute = [&](int buf) {
-    const float* zt = smem + buf * BUF;
-    const float* gt = zt + 16 * G::CS;
+  const int tile0 = tg * tpw;
+  issue(tile0);
+  __syncthreads();                 // cf visible
+  for (int tt = 0; tt < tpw; ++tt) {
+    commit();
+    __syncthreads();
+    if (tt + 1 < tpw) issue(tile0 + tt + 1);
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = wave * RPW + rr;
@@ -148,52 +192,14 @@ __global__ __launch_bounds__(512) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
-            const float a = zt[a_lane + (row * S + ky) * G::LDW + 4 * ks * S + kx];
+            const float a = zt[a_lane + (row * S + ky) * G::LDW + (G::COL0 - G::PADL) + 4 * ks * S + kx];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
               acc[ky * KS + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[ky * KS + kx][nt], 0, 0, 0);
           }
       }
     }
-  };
-
-  // two LDS buffers + two register sets: while the MFMA waves work on tile t (buffer t&1) the
-  // loaders commit tile t+1 (already in registers) to the other buffer and fetch tile t+2
-  constexpr bool DEEP = (S == 1 && KS <= 3 && NTW == 1);     // wide / big tiles keep one register set
-  const int tile0 = tg * tpw;
-  if (loader) issue(tile0, pzB, pgB);
-  __syncthreads();                 // cf visible
-  if (loader) {
-    if (DEEP && 1 < tpw) issue(tile0 + 1, pzA, pgA);
-    commit(0, pzB, pgB);
-  }
-  __syncthreads();
-  for (int tt = 0; tt < tpw; tt += 2) {
-    if (loader) {
-      if (DEEP) {
-        if (tt + 2 < tpw) issue(tile0 + tt + 2, pzB, pgB);
-        if (tt + 1 < tpw) commit(1, pzA, pgA);
-      } else if (tt + 1 < tpw) {
-        issue(tile0 + tt + 1, pzA, pgA);
-        commit(1, pzA, pgA);
-      }
-    } else {
-      compute(0);
-    }
-    __syncthreads();
-    if (tt + 1 >= tpw) break;
-    if (loader) {
-      if (DEEP) {
-        if (tt + 3 < tpw) issue(tile0 + tt + 3, pzA, pgA);
-        if (tt + 2 < tpw) commit(0, pzB, pgB);
-      } else if (tt + 2 < tpw) {
-        issue(tile0 + tt + 2, pzA, pgA);
-        commit(0, pzA, pgA);
-      }
-    } else {
-      compute(1);
-    }
-    __syncthreads();
+    __syncthreads();               // every wave is done with the LDS images before the next commit
   }
 
   // ---- sum the 4 waves through LDS, then write this pixel split's partial dW
@@ -204,12 +210,10 @@ __global__ __launch_bounds__(512) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (!loader) red[(wave * NR + (t * NTW + nt) * 4 + r) * 64 + lane] = acc[t][nt][r];
+      for (int r = 0; r < 4; ++r) red[(wave * NR + (t * NTW + nt) * 4 + r) * 64 + lane] = acc[t][nt][r];
   __syncthreads();
   float* pout = part + (size_t)blockIdx.x * d.Cout * d.Cin * KK;
-  // all 8 waves share the final summation
-  for (int q = (threadIdx.x >> 6); q < NR; q += 8) {
+  for (int q = wave; q < NR; q += 4) {
     const float s = red[(0 * NR + q) * 64 + lane] + red[(1 * NR + q) * 64 + lane] +
                     red[(2 * NR + q) * 64 + lane] + red[(3 * NR + q) * 64 + lane];
     const int r = q & 3, nt = (q >> 2) % NTW, t = (q >> 2) / NTW;
@@ -256,11 +260,11 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   }
   const int nsplit = d.B * (tps / tpw);
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
-  dim3 grid(nsplit, gy), block(512);
+  dim3 grid(nsplit, gy), block(256);
 #define PDES_WG_LAUNCH(TWG_, NTW_)                                                                          \
   do {                                                                                                        \
     using G = WGeo<KS, TWG_, S>;                                                                              \
-    size_t lds = (size_t)2 * (16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                                \
+    size_t lds = (size_t)(16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                                    \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
     hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
