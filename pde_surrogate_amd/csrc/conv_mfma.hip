@@ -79,6 +79,7 @@ template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                        int nt_total) {
   using G = TileGeo<KS, TWG, MT, S>;
+  const int ntp = (nt_total + 7) & ~7;       // N-tiles of the packed weight image (zero padded)
   constexpr int KK = KS * KS;
   constexpr int KSW = 4 / WAVES_K;          // k-steps of a chunk handled by one wave
   static_assert(WAVES_K == 1 || MT >= 4, "K-split waves each own MT/4 M-tiles at the end");
@@ -135,8 +136,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
     const int cy = oy0 * S - G::PADL + r, cx = ox0 * S + 4 * j;
     const bool ok = e < G::NV4 && cy >= 0 && cy < kHc;
-    const int sy = kmode ? (cy >> 1) : cy, sx = kmode ? (cx >> 1) : cx;
-    vg[i] = ok ? ch * HWs + sy * kW + sx : 0;
+    const int cyc = min(max(cy, 0), kHc - 1);
+    const int sy = kmode ? (cyc >> 1) : cyc, sx = kmode ? (cx >> 1) : cx;
+    vg[i] = sy * kW + sx;                               // always a valid address (row clamped)
     vl[i] = e < G::NV4 ? ch * G::CS + r * G::LDW + G::COL0 + 4 * j : -1;
     if (ok && !(kmode == KV_ZEROINS2 && (cy & 1))) vrow |= 1u << i;
   }
@@ -150,8 +152,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     const int lc = h < G::NL ? G::COL0 - G::NL + h : G::COL0 + G::TWI + (h - G::NL);
     bool ok = e < G::NH && cy >= 0 && cy < kHc && cx >= 0 && cx < kWc;
     if (kmode == KV_ZEROINS2) ok = ok && !((cy | cx) & 1);
-    const int sy = kmode ? (cy >> 1) : cy, sx = kmode ? (cx >> 1) : cx;
-    hg[i] = ok ? ch * HWs + sy * kW + sx : 0;
+    const int cyc = min(max(cy, 0), kHc - 1), cxc = min(max(cx, 0), kWc - 1);
+    const int sy = kmode ? (cyc >> 1) : cyc, sx = kmode ? (cxc >> 1) : cxc;
+    hg[i] = sy * kW + sx;
     hl[i] = e < G::NH ? ch * G::CS + r * G::LDW + lc : -1;
     if (ok) hval |= 1u << i;
   }
@@ -159,28 +162,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 
   float4 pv[G::NPV];
   float ph[G::NPH > 0 ? G::NPH : 1];
+  // loads are unconditional (row offsets are clamped into the image above, the channel is clamped
+  // here); validity is applied when the registers are committed to LDS
   auto issue = [&](int chunk) {
     const float* src = kbase + (size_t)chunk * 16 * HWs;
-    const int crem = kC - chunk * 16;               // channels available in this chunk
+    const int cmax = kC - chunk * 16 - 1;           // last valid channel of this chunk
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
-      const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (((vrow >> i) & 1u) && ch < crem) {
-        if (kmode == KV_PLAIN) {
-          v = *reinterpret_cast<const float4*>(src + vg[i]);
-        } else {
-          const float2 t = *reinterpret_cast<const float2*>(src + vg[i]);
-          v = kmode == KV_NEAREST2 ? make_float4(t.x, t.x, t.y, t.y) : make_float4(t.x, 0.f, t.y, 0.f);
-        }
+      const int ch = min((tid + 256 * i) / (G::ROWS * (G::TWI / 4)), cmax);
+      const float* p = src + ch * HWs + vg[i];
+      if (kmode == KV_PLAIN) {
+        pv[i] = *reinterpret_cast<const float4*>(p);
+      } else {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        pv[i] = kmode == KV_NEAREST2 ? make_float4(t.x, t.x, t.y, t.y) : make_float4(t.x, 0.f, t.y, 0.f);
       }
-      pv[i] = v;
     }
     if (halo_live) {
 #pragma unroll
       for (int i = 0; i < G::NPH; ++i) {
-        const int ch = (tid + 256 * i) / (G::ROWS * (G::NL + G::NR));
-        ph[i] = (((hval >> i) & 1u) && ch < crem) ? src[hg[i]] : 0.f;
+        const int ch = min((tid + 256 * i) / (G::ROWS * (G::NL + G::NR)), cmax);
+        ph[i] = src[ch * HWs + hg[i]];
       }
     }
   };
@@ -191,14 +193,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     for (int i = 0; i < G::NPV; ++i) {
       if (vl[i] >= 0) {
         float4 z = pv[i];
+        const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
+        const bool ok = ((vrow >> i) & 1u) && ch < crem;
         if (MODE == MODE_FWD) {
-          const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
-          const bool ok = ((vrow >> i) & 1u) && ch < crem;
           const float4 k = cf4[chunk * 16 + ch];
           z.x = ok ? fmaxf(0.f, (z.x - k.x) * k.y + k.z) : 0.f;
           z.y = ok ? fmaxf(0.f, (z.y - k.x) * k.y + k.z) : 0.f;
           z.z = ok ? fmaxf(0.f, (z.z - k.x) * k.y + k.z) : 0.f;
           z.w = ok ? fmaxf(0.f, (z.w - k.x) * k.y + k.z) : 0.f;
+        } else if (!ok) {
+          z = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         *reinterpret_cast<float4*>(t + vl[i]) = z;
       }
@@ -208,11 +212,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       for (int i = 0; i < G::NPH; ++i) {
         if (hl[i] >= 0) {
           float z = ph[i];
+          const int ch = (tid + 256 * i) / (G::ROWS * (G::NL + G::NR));
+          const bool ok = ((hval >> i) & 1u) && ch < crem;
           if (MODE == MODE_FWD) {
-            const int ch = (tid + 256 * i) / (G::ROWS * (G::NL + G::NR));
-            const bool ok = ((hval >> i) & 1u) && ch < crem;
             const float4 k = cf4[chunk * 16 + ch];
             z = ok ? fmaxf(0.f, (z - k.x) * k.y + k.z) : 0.f;
+          } else if (!ok) {
+            z = 0.f;
           }
           t[hl[i]] = z;
         }
@@ -238,54 +244,55 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   __syncthreads();
 
   const int a_lane = (lane >> 4) * G::CS + (lane & 15) * S;
-  float bnext[KK];
+  // B operand: packed image [(kstep*KK + tap)*ntp + nt][64] (ntp = N-tiles padded to a multiple of 8 with
+  // zero tiles, so no bounds test is needed), one coalesced load per (tap, N-tile).  Rolling register
+  // prefetch: while k-step s is on the matrix pipe the loads of the next k-step (of this chunk or the
+  // first one of the next chunk) are in flight.
+  constexpr bool PREFB = (KK * NT_W <= 25);
+  float bcur[KK][NT_W];
+  auto load_b = [&](int kstep, float (&dst)[KK][NT_W]) {
+    const float* wp = wm + ((size_t)kstep * KK * ntp + nt_base) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT_W; ++nt) dst[t][nt] = wp[(size_t)(t * ntp + nt) * 64];
+  };
+  if (PREFB) load_b(WAVES_K == 4 ? wk : 0, bcur);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int buf = chunk & 1;
-    // B operand of this chunk, packed image [(kstep*KK + tap)*nt_total + nt][64].  These loads are
-    // issued BEFORE the next chunk's activation prefetch: vmcnt retires loads in order, so the
-    // MFMAs (which wait for B) would otherwise also wait for the whole prefetch.
-    float bw[KSW][KK][NT_W];
-    if (WAVES_K == 4 && chunk > 0) {
-#pragma unroll
-      for (int t = 0; t < KK; ++t) bw[0][t][0] = bnext[t];     // prefetched during the previous chunk
-    } else {
-#pragma unroll
-      for (int s = 0; s < KSW; ++s) {
-        const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-#pragma unroll
-        for (int t = 0; t < KK; ++t)
-#pragma unroll
-          for (int nt = 0; nt < NT_W; ++nt) {
-            const int ntg = nt_base + nt;
-            bw[s][t][nt] = ntg < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + ntg) * 64 + lane] : 0.f;
-          }
-      }
-    }
-    if (WAVES_K == 4 && chunk + 1 < nchunk) {
-      const int kstep = (chunk + 1) * 4 + wk;
-#pragma unroll
-      for (int t = 0; t < KK; ++t)
-        bnext[t] = nt_base < nt_total ? wm[((size_t)(kstep * KK + t) * nt_total + nt_base) * 64 + lane] : 0.f;
-    }
     if (chunk + 1 < nchunk) issue(chunk + 1);
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
       const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-      if (kstep * 4 >= kC) continue;            // wave-uniform: k-step entirely in the zero padding
-      const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
+      const int knext = (s + 1 < KSW) ? kstep + 1 : (chunk + 1) * 4 + (WAVES_K == 4 ? wk : 0);
+      float bnx[PREFB ? KK : 1][NT_W];
+      const bool more = PREFB && knext * 4 < kpad;
+      if constexpr (PREFB) { if (more) load_b(knext, bnx); }
+      if (kstep * 4 < kC) {                     // wave-uniform: skip k-steps entirely in the zero padding
+        if constexpr (!PREFB) load_b(kstep, bcur);
+        const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
 #pragma unroll
-      for (int ky = 0; ky < KS; ++ky)
+        for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
+          for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float a = tk[((mt / TWG) * S + ky) * G::LDW + (G::COL0 - G::PADL) + (mt % TWG) * 16 * S + kx];
+            for (int mt = 0; mt < MT; ++mt) {
+              const float a = tk[((mt / TWG) * S + ky) * G::LDW + (G::COL0 - G::PADL) + (mt % TWG) * 16 * S + kx];
 #pragma unroll
-            for (int nt = 0; nt < NT_W; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
+              for (int nt = 0; nt < NT_W; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
+            }
           }
+      }
+      if constexpr (PREFB) {
+        if (more) {
+#pragma unroll
+          for (int t = 0; t < KK; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT_W; ++nt) bcur[t][nt] = bnx[t][nt];
         }
+      }
     }
     if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1);
     __syncthreads();
@@ -435,11 +442,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 
 // ------------------------------------------------------------------------------------------------
 // weight images for the MFMA kernels, rebuilt from the live weights every step (one launch for the
-// whole network): forward  [(kstep*KK + tap)*NT + nt][kq*16 + n] = W[n + 16 nt][4 kstep + kq][tap]
+// whole network; NT = N-tile count rounded up to a multiple of 8, padding tiles are zero):
+//                 forward  [(kstep*KK + tap)*NT + nt][kq*16 + n] = W[n + 16 nt][4 kstep + kq][tap]
 //                 backward [(kstep*KK + tap)*NT + nt][kq*16 + n] = W[4 kstep + kq][n + 16 nt][KK-1-tap]
 __global__ __launch_bounds__(256) void pack_mfma_kernel(const pdes_mfma_pack_item* __restrict__ items) {
   const pdes_mfma_pack_item it = items[blockIdx.y];
-  const int ntf = (it.Cout + 15) / 16, ksf = ((it.Cin + 15) / 16) * 4;
+  const int ntf = (((it.Cout + 15) / 16) + 7) & ~7, ksf = ((it.Cin + 15) / 16) * 4;
   const int totf = ksf * it.kk * ntf * 64;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < totf; i += gridDim.x * 256) {
     const int l = i & 63, nt = (i >> 6) % ntf, t = ((i >> 6) / ntf) % it.kk, ks = (i >> 6) / (ntf * it.kk);
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const pdes_mfma_pack_ite
     it.wm_fwd[i] = (co < it.Cout && ci < it.Cin) ? it.w[((size_t)co * it.Cin + ci) * it.kk + t] : 0.f;
   }
   if (!it.wm_bwd) return;
-  const int ntb = (it.Cin + 15) / 16, ksb = ((it.Cout + 15) / 16) * 4;
+  const int ntb = (((it.Cin + 15) / 16) + 7) & ~7, ksb = ((it.Cout + 15) / 16) * 4;
   const int totb = ksb * it.kk * ntb * 64;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < totb; i += gridDim.x * 256) {
     const int l = i & 63, nt = (i >> 6) % ntb, t = ((i >> 6) / ntb) % it.kk, ks = (i >> 6) / (ntb * it.kk);
@@ -487,6 +495,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (nt_total == 1) { wk = 4; ntw = 1; }
   else if (kpad <= 16 || nt_total <= 4) { wk = 1; ntw = 1; gz = (nt_total + 3) / 4; }   // cheap staging: split N over z
   else { wk = 1; ntw = 2; gz = (nt_total + 7) / 8; }
+  if (wk == 1 && ntw == 2 && env_int("PDES_MFMA_NTW", 2) == 1) { ntw = 1; gz = (nt_total + 3) / 4; }   // tuning knob
   const bool up_bwd = bwd && d.upsample;
   if (up_bwd && wk == 4) return PDES_ENOSUP;            // K-split waves do not own both rows of a 2x2 pair
   // M-tiles per workgroup: 8, or 4 when that is needed to put >= 1 workgroup on every CU

@@ -93,16 +93,17 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
       const int cy = oy0 * S - G::PADL + r, cx = ox0 * S + 4 * j;
       const bool v = e < G::NV4 && ch < crem && cy >= 0 && cy < Hc;
-      float4 x = make_float4(NANF, NANF, NANF, NANF);   // NaN = outside: maps to 0, not relu(bn(0))
-      if (v) {
-        if (d.upsample) {
-          const float2 t = *reinterpret_cast<const float2*>(xb + (size_t)ch * HWi + (cy >> 1) * d.Win + (cx >> 1));
-          x = make_float4(t.x, t.x, t.y, t.y);
-        } else {
-          x = *reinterpret_cast<const float4*>(xb + (size_t)ch * HWi + cy * d.Win + cx);
-        }
+      // unconditional load from a clamped (always valid) address; NaN marks "outside" afterwards
+      // (it must become 0 in LDS, not relu(bn(0)))
+      const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hc - 1);
+      float4 x;
+      if (d.upsample) {
+        const float2 t = *reinterpret_cast<const float2*>(xb + (size_t)chc * HWi + (cyc >> 1) * d.Win + (cx >> 1));
+        x = make_float4(t.x, t.x, t.y, t.y);
+      } else {
+        x = *reinterpret_cast<const float4*>(xb + (size_t)chc * HWi + cyc * d.Win + cx);
       }
-      pv[i] = x;
+      pv[i] = v ? x : make_float4(NANF, NANF, NANF, NANF);
     }
     if (halo_live) {
 #pragma unroll
@@ -113,8 +114,10 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
         const int cy = oy0 * S - G::PADL + r;
         const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
         const bool v = e < G::NH && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
-        const int sy = d.upsample ? (cy >> 1) : cy, sx = d.upsample ? (cx >> 1) : cx;
-        ph[i] = v ? xb[(size_t)ch * HWi + sy * d.Win + sx] : NANF;
+        const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hc - 1), cxc = min(max(cx, 0), Wc - 1);
+        const int sy = d.upsample ? (cyc >> 1) : cyc, sx = d.upsample ? (cxc >> 1) : cxc;
+        const float xv = xb[(size_t)chc * HWi + sy * d.Win + sx];
+        ph[i] = v ? xv : NANF;
       }
     }
 #pragma unroll
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       const int e = tid + 256 * i;                          // float4 index: channel-major, then pixel
       const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
       const int oy = oy0 + (4 * p4) / G::TW, ox = ox0 + (4 * p4) % G::TW;
-      pg[i] = ch < corem ? *reinterpret_cast<const float4*>(gb + (size_t)ch * HWo + oy * d.Wout + ox)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 gv = *reinterpret_cast<const float4*>(gb + (size_t)min(ch, corem - 1) * HWo + oy * d.Wout + ox);
+      pg[i] = ch < corem ? gv : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto bnrelu = [&](float x, int ch) {
@@ -256,7 +259,7 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     if (tps % cand) continue;
     const long long nsplit = (long long)d.B * (tps / cand);
     if (nsplit * per * 4 > d.ws_bytes) continue;
-    if (nsplit * gy <= 768 || cand == tps) { tpw = cand; break; }
+    if (nsplit * gy <= 512 || cand == tps) { tpw = cand; break; }
   }
   const int nsplit = d.B * (tps / tpw);
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;

@@ -447,16 +447,18 @@ class _HipNet(nn.Module):
             if s.k not in (1, 3, 5) or s.norm is None or (s.stride != 1 and not (s.stride == 2 and s.k == 3)):
                 continue
             kk = s.k * s.k
-            nf = _pad16(s.cin) * kk * _pad16(s.cout)          # = ksteps*kk*ntiles*64
+            pad128 = lambda n: (n + 127) // 128 * 128            # N-tiles are padded to a multiple of 8
+            nf = _pad16(s.cin) * kk * pad128(s.cout)            # = ksteps * kk * ntiles_padded * 64
+            nb = _pad16(s.cout) * kk * pad128(s.cin)
             wf = torch.zeros(nf, device=device)
-            wb = torch.zeros(nf, device=device)
+            wb = torch.zeros(nb, device=device)
             self._packed_mfma[s.conv] = (wf, wb)
             it = MfmaPackItem()
             it.w = _get(self.features, s.conv).weight.data_ptr()
             it.wm_fwd, it.wm_bwd = wf.data_ptr(), wb.data_ptr()
             it.Cout, it.Cin, it.kk = s.cout, s.cin, kk
             mitems.append(it)
-            mmx = max(mmx, nf)
+            mmx = max(mmx, nf, nb)
         self._mpack_n, self._mpack_max = len(mitems), mmx
         self._ws = torch.empty(8 << 20, device=device)       # 32 MiB split-K scratch (weight gradients)
         if mitems:
