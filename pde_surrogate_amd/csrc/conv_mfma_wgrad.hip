@@ -259,7 +259,7 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     if (tps % cand) continue;
     const long long nsplit = (long long)d.B * (tps / cand);
     if (nsplit * per * 4 > d.ws_bytes) continue;
-    if (nsplit * gy <= 512 || cand == tps) { tpw = cand; break; }
+    if (nsplit * gy <= 768 || cand == tps) { tpw = cand; break; }
   }
   const int nsplit = d.B * (tps / tpw);
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;

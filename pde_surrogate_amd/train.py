@@ -15,7 +15,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from .models.darcy import darcy_loss_launch  # noqa: F401  (re-exported for callers)
 
 
@@ -93,7 +93,7 @@ class MixedResidualTrainer:
             self._compute()
         self.n_accum += 1
         if self.world > 1:
-            torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            parallel.allreduce_sum_(self.gflat, self.pg)      # ONE flat RCCL all-reduce per step
         rc = self._L.pdes_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
                                     self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), 1.0 / self.world,
                                     self.flat.numel(), _lib.stream_ptr())

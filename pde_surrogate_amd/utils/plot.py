@@ -1,0 +1,63 @@
+"""Output files of the training harness -- same names/formats as the reference's utils/plot.py
+(`save_stats` :261-273 writes {metric}.txt via np.savetxt + {metric}.pdf; `plot_prediction_det`
+:17-94 writes pred_epoch{e}_{i}.png with rows simulation / prediction / difference)."""
+import numpy as np
+
+from .misc import to_numpy
+
+
+def _plt():
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    return plt
+
+
+def save_stats(save_dir, logger, *metrics):
+    plt = _plt()
+    for metric in metrics:
+        values = logger[metric]
+        np.savetxt(save_dir + f'/{metric}.txt', values)
+        arr = np.loadtxt(save_dir + f'/{metric}.txt')
+        if arr.ndim == 0:
+            arr = arr[None]
+        if arr.ndim == 1:
+            arr = arr[:, None]
+        lines = plt.plot(range(1, len(arr) + 1), arr)
+        plt.legend(lines, [f'{arr[-5:, i].mean():.4f}' for i in range(arr.shape[-1])])
+        plt.savefig(save_dir + f'/{metric}.pdf')
+        plt.close()
+
+
+def plot_prediction_det(save_dir, target, prediction, epoch, index, plot_fn='contourf', cmap='jet',
+                        same_scale=False, row_labels=None, col_labels=None):
+    """one figure per test input: 3 rows (simulation, prediction, difference) x n_fields columns"""
+    plt = _plt()
+    target, prediction = to_numpy(target), to_numpy(prediction)
+    rows = row_labels or ['Simulation', 'Prediction', r'Simulation $-$ Prediction']
+    cols = col_labels or ['Pressure', 'Horizontal Flux', 'Vertical Flux']
+    nf = target.shape[0]
+    fields = np.concatenate((target, prediction, target - prediction), axis=0)
+    lo = [min(fields[i].min(), fields[i + nf].min()) for i in range(nf)]
+    hi = [max(fields[i].max(), fields[i + nf].max()) for i in range(nf)]
+    fig, axes = plt.subplots(3, nf, figsize=(3.75 * nf, 9))
+    for j, ax in enumerate(np.atleast_1d(axes).ravel()):
+        ax.set_aspect('equal')
+        ax.set_xticks([])
+        ax.set_yticks([])
+        shared = j < 2 * nf or same_scale
+        kw = dict(vmin=lo[j % nf], vmax=hi[j % nf]) if shared else {}
+        if plot_fn == 'contourf':
+            im = ax.contourf(fields[j], 50, cmap=cmap, **kw)
+        else:
+            im = ax.imshow(fields[j], cmap=cmap, origin='upper', **kw)
+        cbar = fig.colorbar(im, ax=ax, fraction=0.046, pad=0.04)
+        cbar.formatter.set_powerlimits((-2, 2))
+        cbar.update_ticks()
+    for ax, c in zip(np.atleast_2d(axes)[0], cols):
+        ax.set_title(c, size='large')
+    for ax, r in zip(np.atleast_2d(axes)[:, 0], rows):
+        ax.set_ylabel(r, rotation=90, size='large')
+    fig.tight_layout(pad=0.05, w_pad=0.05, h_pad=0.05)
+    fig.savefig(save_dir + '/pred_epoch{}_{}.png'.format(epoch, index), bbox_inches='tight')
+    plt.close(fig)

@@ -1,0 +1,125 @@
+"""GPU tests of the fused training step and the CLI harness (configs 1, 2 and 4 of BASELINE.json in
+miniature): the fused step equals the reference loop body on the drop-in modules, hipGraph replay
+equals eager launches, the flat Adam kernel equals torch.optim.Adam, and the script writes the
+reference's output files."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _net(dev, seed=1, blocks=(6, 8, 6)):
+    from pde_surrogate_amd.models.codec import DenseED
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return DenseED(1, 3, 64, list(blocks)).to(dev)
+
+
+def test_adam_kernel_matches_torch_optim(dev):
+    from pde_surrogate_amd import _lib, parallel
+    torch.manual_seed(0)
+    n = 100003
+    p = torch.randn(n, device=dev)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-3, weight_decay=0.05)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    hyper = torch.zeros(8, device=dev)
+    L = _lib.lib()
+    for step in range(1, 5):
+        g = torch.randn(n, device=dev)
+        ref.grad = g.clone()
+        opt.step()
+        hyper.copy_(torch.tensor([2e-3, 0.9, 0.999, 1e-8, 0.05, 1 - 0.9 ** step, (1 - 0.999 ** step) ** 0.5, 0.0]))
+        rc = L.pdes_adam_step(p.data_ptr(), (2 * g).data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(), 0.5, n,
+                              _lib.stream_ptr())
+        assert rc == 0
+    torch.testing.assert_close(p, ref.detach(), rtol=2e-6, atol=2e-7)
+
+
+def test_fused_step_equals_reference_loop_body_and_graph_equals_eager(dev):
+    from pde_surrogate_amd.models import darcy
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    g = golden('G7_trajectory.npz')
+    x = torch.from_numpy(g['data'][:8]).to(dev)
+    # (a) reference loop body on the drop-in modules
+    net_a = _net(dev).train()
+    opt = torch.optim.Adam(net_a.parameters(), lr=1e-3)
+    sob = SobelFilter(64, device=dev)
+    out = net_a(x)
+    loss = darcy.conv_constitutive_constraint(x, out, sob) + darcy.conv_continuity_constraint(out, sob)
+    ld, ln = darcy.conv_boundary_condition(out)
+    loss = loss + (ld + ln) * 10.0
+    loss.backward()
+    opt.step()
+    # (b) fused step, eager  (c) fused step, hipGraph
+    finals = {}
+    for tag, graph in (('eager', False), ('graph', True)):
+        net = _net(dev).train()
+        tr = MixedResidualTrainer(net, 8, 64, lr=1e-3, weight_bound=10.0, device=dev, use_graph=graph)
+        tr.step(x, 1e-3)
+        means = tr.epoch_means()
+        assert abs(means[0] - g['losses'][0]) < 1e-5 * g['losses'][0]          # step-1 loss == reference (G7)
+        assert abs(means[0] - loss.item()) < 1e-5 * loss.item()
+        finals[tag] = tr.flat.clone()
+        bn = net.features.LastTransUp.norm3
+        assert int(bn.num_batches_tracked) == 1                                 # graph warm-up left no trace
+    flat_a = torch.cat([p.detach().reshape(-1) for p in net_a.parameters()])
+    # Adam's first step is lr*sign(g): elements whose gradient is pure rounding noise may flip, so
+    # compare the update direction on the bulk of the parameters
+    for tag in finals:
+        d = (finals[tag] - flat_a).abs()
+        assert float((d > 1e-6).float().mean()) < 0.02, tag
+    d = (finals['eager'] - finals['graph']).abs()
+    assert float((d > 1e-6).float().mean()) < 0.02
+
+
+def test_training_descends_on_grf_and_channelized(dev):
+    """configs 2 and 4 in miniature: 12 fused steps at bs=32 lower the loss on both input families"""
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.data import channelized_fields, grf_kle_fields
+    for name, x in (('grf', grf_kle_fields(64, n_kle=64, cache_dir='/tmp')), ('channelized', channelized_fields(64))):
+        data = torch.from_numpy(x).to(dev)
+        tr = MixedResidualTrainer(_net(dev).train(), 32, 64, lr=1e-3, device=dev, use_graph=True)
+        losses = []
+        for i in range(12):
+            tr.step(data[(i % 2) * 32:(i % 2 + 1) * 32], 1e-3)
+            losses.append(tr.epoch_means()[0])
+        assert np.isfinite(losses).all(), name
+        assert losses[-1] < 0.5 * losses[0], (name, losses)
+
+
+def test_cli_end_to_end_writes_reference_files(dev, tmp_path, monkeypatch):
+    """config 1 in miniature through the CLI (synthetic inputs): files, args.txt, checkpoint keys"""
+    import train_codec_mixed_residual as t
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    argv = ['--exp-dir', str(tmp_path), '--ntrain', '32', '--ntest', '16', '--batch-size', '8', '--test-batch-size', '8',
+            '--epochs', '2', '--ckpt-freq', '2', '--cuda', '0', '--synthetic', '--data', 'channelized',
+            '--blocks', '111', '--growth-rate', '8', '--init-features', '16']
+    with contextlib.redirect_stdout(io.StringIO()):
+        t.main(argv)
+    run = tmp_path / 'codec/mixed_residual/channelized_ntrain32_run1_bs8_lr0.001_epochs2'
+    for f in ('args.txt', 'checkpoints/model_epoch2.pth', 'training/loss_train.txt', 'training/loss_test.txt',
+              'training/nrmse_test.txt', 'training/r2_test.txt', 'training/loss_train.pdf'):
+        assert os.path.exists(run / f), f
+    a = json.load(open(run / 'args.txt'))
+    assert a['n_params'] > 0 and a['n_layers'] == 11 and a['training_time'] > 0
+    lt = np.loadtxt(run / 'training/loss_train.txt')
+    assert lt.shape == (2,) and lt[1] < lt[0]
+    sd = torch.load(run / 'checkpoints/model_epoch2.pth', map_location='cpu')
+    assert 'features.In_conv.weight' in sd and 'features.LastTransUp.norm3.running_var' in sd
+    assert int(sd['features.LastTransUp.norm3.num_batches_tracked']) == 8
