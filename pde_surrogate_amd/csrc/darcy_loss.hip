@@ -24,6 +24,7 @@
 // stencils, so HBM traffic is exactly the algorithmic 7 planes (4 read, 3 written) per sample.
 // Loss sums: fp32 per strip -> wave shuffle -> per-image partials; a second tiny kernel reduces
 // the per-image partials in fp64 in a fixed order (deterministic, no float atomics).
+#include <stdlib.h>
 #include "pdes_common.h"
 
 namespace pdes {
@@ -34,6 +35,7 @@ struct LossParams {
   float b_dir;     // w_dir   * 2 / (B n)
   float b_neu;     // w_neu   * 2 / (2 B n)
   float beta1, beta2;
+  int nt;          // 1: streaming (non-temporal) global loads / stores
 };
 
 struct F4 {
@@ -192,10 +194,17 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS)
 #pragma unroll
   for (int k = 0; k < SPT; ++k) {
     const int s = tid + NT * k;
-    kk[k] = F4(K4[s]);
-    lds[s] = y4[s];
-    lds[NSTRIP + s] = y4[NSTRIP + s];
-    lds[2 * NSTRIP + s] = y4[2 * NSTRIP + s];
+    if (p.nt) {
+      kk[k] = F4(nt_load4(K4 + s));
+      lds[s] = nt_load4(y4 + s);
+      lds[NSTRIP + s] = nt_load4(y4 + NSTRIP + s);
+      lds[2 * NSTRIP + s] = nt_load4(y4 + 2 * NSTRIP + s);
+    } else {
+      kk[k] = F4(K4[s]);
+      lds[s] = y4[s];
+      lds[NSTRIP + s] = y4[NSTRIP + s];
+      lds[2 * NSTRIP + s] = y4[2 * NSTRIP + s];
+    }
   }
   __syncthreads();
 
@@ -308,9 +317,15 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS)
     }
     if (first) du.v[0] += dub[k];
     if (last) du.v[3] += dub[k];
-    g4[s] = du.f4();
-    g4[NSTRIP + s] = d1.f4();
-    g4[2 * NSTRIP + s] = d2.f4();
+    if (p.nt) {
+      nt_store4(g4 + s, du.f4());
+      nt_store4(g4 + NSTRIP + s, d1.f4());
+      nt_store4(g4 + 2 * NSTRIP + s, d2.f4());
+    } else {
+      g4[s] = du.f4();
+      g4[NSTRIP + s] = d1.f4();
+      g4[2 * NSTRIP + s] = d2.f4();
+    }
   }
 }
 
@@ -453,6 +468,9 @@ extern "C" int pdes_darcy_loss(const float* K, const float* y, float* grad_y, fl
   p.b_neu = (float)(2.0 * w_neu / (2.0 * B * W));
   p.beta1 = beta1;
   p.beta2 = beta2;
+  // streaming accesses once the 7 planes/sample no longer fit the 256 MiB Infinity Cache; at training
+  // batch sizes y was just produced and grad_y is consumed next, so those stay cacheable
+  { const char* e = getenv("PDES_LOSS_NT"); p.nt = e ? atoi(e) : ((long long)B * H * W * 28 > (200ll << 20)); }
   if (H == 64) launch_loss<64>(K, y, grad_y, partials, B, p, nonlinear, st);
   else if (H == 32) launch_loss<32>(K, y, grad_y, partials, B, p, nonlinear, st);
   else launch_loss<16>(K, y, grad_y, partials, B, p, nonlinear, st);

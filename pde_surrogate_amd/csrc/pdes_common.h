@@ -27,6 +27,18 @@ __device__ __forceinline__ float dpp_row_shl1(float v) {   // lane i <- lane i+1
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
 }
 
+// streaming (non-temporal) 16-byte global accesses: data touched exactly once should not displace
+// reusable lines in L2 / Infinity Cache
+typedef float nvec4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+  const nvec4 v = __builtin_nontemporal_load(reinterpret_cast<const nvec4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
+  nvec4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<nvec4*>(p));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -38,6 +38,9 @@ def time_loss(B, n=64, iters=50, bwd=True):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'pmc':      # one configuration, few launches: for rocprofv3 --pmc
+        print(json.dumps(time_loss(16384, bwd=True, iters=5)), flush=True)
+        sys.exit(0)
     for bwd in (True, False):
         for B in (32, 256, 2048, 16384):
             print(json.dumps(time_loss(B, bwd=bwd, iters=200 if B <= 256 else 30)), flush=True)
