@@ -140,6 +140,12 @@ def main():
     means = trainer.epoch_means()
 
     if rank == 0:
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_loss_kernel_pmc.json')
+        if os.path.exists(pmc):                              # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            with open(pmc) as f:
+                pj = json.load(f)
+            traffic, traffic_src = pj['hbm_bytes_per_launch'], 'profiles/r01_loss_kernel_pmc.json (B=16384)'
         us32, gb32 = loss_kernel_timing(dev, B, 200)
         usL, gbL = loss_kernel_timing(dev, 16384, 20)
         out = {
@@ -154,7 +160,7 @@ def main():
             'loss_mean_over_run': round(means[0], 4),
             'roofline': {'bound': 'hbm', 'kernel': 'darcy_loss_kernel<64,bwd> (fused Sobel+Darcy residual+boundary, fwd+bwd)',
                          'achieved': round(gbL, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': round(gbL / HBM_PEAK_GBPS, 4), 'traffic': None,
+                         'frac': round(gbL / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                          'batch': 16384, 'us_per_launch': round(usL, 2),
                          'algorithmic_bytes_per_launch': LOSS_BYTES_FWD_BWD * 16384,
                          'note': 'HBM regime (1.88 GB working set > 256 MiB Infinity Cache), HIP events on the launch stream',
