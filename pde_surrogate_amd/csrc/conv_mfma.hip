@@ -260,7 +260,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   if (PREFB) load_b(WAVES_K == 4 ? wk : 0, bcur);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int buf = chunk & 1;
+#ifndef PDES_ABL_NOSTAGE
     if (chunk + 1 < nchunk) issue(chunk + 1);
+#endif
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
@@ -294,8 +296,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
         }
       }
     }
+#ifndef PDES_ABL_NOSTAGE
     if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1);
     __syncthreads();
+#endif
   }
 
   // ---- combine the K-split partial sums: wave w ends up owning M-tiles [w*MT/4, (w+1)*MT/4)
