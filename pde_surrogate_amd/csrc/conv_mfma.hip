@@ -67,6 +67,7 @@ struct TileGeo {
   static constexpr int KC = 16;                               // input channels per chunk
   static constexpr int NV4 = KC * ROWS * (TWI / 4);           // interior float4 per chunk
   static constexpr int NPV = (NV4 + 255) / 256;
+  static constexpr int NHC = (NL + NR) > 0 ? (NL + NR) : 1;   // halo columns per row (>= 1 to keep index math defined)
   static constexpr int NH = KC * ROWS * (NL + NR);            // halo scalars per chunk
   static constexpr int NPH = (NH + 255) / 256;
   static_assert(MT % TWG == 0 && CS >= ROWS * LDW && NL <= COL0 && NR >= 0, "tile geometry");
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 #pragma unroll
   for (int i = 0; i < G::NPH; ++i) {
     const int e = tid + 256 * i;
-    const int ch = e / (G::ROWS * (G::NL + G::NR)), rem = e % (G::ROWS * (G::NL + G::NR));
-    const int r = rem / (G::NL + G::NR), h = rem % (G::NL + G::NR);
+    const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
+    const int r = rem / G::NHC, h = rem % G::NHC;
     const int cy = oy0 * S - G::PADL + r;
     const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
     const int lc = h < G::NL ? G::COL0 - G::NL + h : G::COL0 + G::TWI + (h - G::NL);
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     if (halo_live) {
 #pragma unroll
       for (int i = 0; i < G::NPH; ++i) {
-        const int ch = min((tid + 256 * i) / (G::ROWS * (G::NL + G::NR)), cmax);
+        const int ch = min((tid + 256 * i) / (G::ROWS * G::NHC), cmax);
         ph[i] = src[ch * HWs + hg[i]];
       }
     }
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       for (int i = 0; i < G::NPH; ++i) {
         if (hl[i] >= 0) {
           float z = ph[i];
-          const int ch = (tid + 256 * i) / (G::ROWS * (G::NL + G::NR));
+          const int ch = (tid + 256 * i) / (G::ROWS * G::NHC);
           const bool ok = ((hval >> i) & 1u) && ch < crem;
           if (MODE == MODE_FWD) {
             const float4 k = cf4[chunk * 16 + ch];
@@ -260,9 +261,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   if (PREFB) load_b(WAVES_K == 4 ? wk : 0, bcur);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int buf = chunk & 1;
-#ifndef PDES_ABL_NOSTAGE
     if (chunk + 1 < nchunk) issue(chunk + 1);
-#endif
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
 #pragma unroll
     for (int s = 0; s < KSW; ++s) {
@@ -296,10 +295,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
         }
       }
     }
-#ifndef PDES_ABL_NOSTAGE
     if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1);
     __syncthreads();
-#endif
   }
 
   // ---- combine the K-split partial sums: wave w ends up owning M-tiles [w*MT/4, (w+1)*MT/4)

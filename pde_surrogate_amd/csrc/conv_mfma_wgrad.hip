@@ -30,6 +30,7 @@ struct WGeo {
   static constexpr int GS = TH * TW + 2;                       // g image channel stride (130)
   static constexpr int NV4 = 16 * ROWS * (TWI / 4);
   static constexpr int NPV = (NV4 + 255) / 256;
+  static constexpr int NHC = (NL + NR) > 0 ? (NL + NR) : 1;
   static constexpr int NH = 16 * ROWS * (NL + NR);
   static constexpr int NPH = (NH + 255) / 256;
   static_assert(CS % 32 == 2 && GS % 32 == 2 && CS >= ROWS * LDW && NR >= 0, "LDS geometry");
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
 #pragma unroll
       for (int i = 0; i < G::NPH; ++i) {
         const int e = tid + 256 * i;
-        const int ch = e / (G::ROWS * (G::NL + G::NR)), rem = e % (G::ROWS * (G::NL + G::NR));
-        const int r = rem / (G::NL + G::NR), h = rem % (G::NL + G::NR);
+        const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
+        const int r = rem / G::NHC, h = rem % G::NHC;
         const int cy = oy0 * S - G::PADL + r;
         const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
         const bool v = e < G::NH && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
     for (int i = 0; i < G::NPH; ++i) {
       const int e = tid + 256 * i;
       if (e < G::NH) {
-        const int ch = e / (G::ROWS * (G::NL + G::NR)), rem = e % (G::ROWS * (G::NL + G::NR));
-        const int r = rem / (G::NL + G::NR), h = rem % (G::NL + G::NR);
+        const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
+        const int r = rem / G::NHC, h = rem % G::NHC;
         const int lc = h < G::NL ? G::COL0 - G::NL + h : G::COL0 + G::TWI + (h - G::NL);
         zt[ch * G::CS + r * G::LDW + lc] = halo_live ? bnrelu(ph[i], ch) : 0.f;
       }

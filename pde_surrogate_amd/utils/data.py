@@ -43,8 +43,10 @@ def kle_basis(imsize=64, n_kle=512, ell=0.25, cache_dir=None):
     basis = (phi * np.sqrt(np.maximum(lam, 0.0))[None, :]).T.copy()
     _KLE_CACHE[key] = basis
     if path:
-        try:
-            np.save(path, basis)
+        try:                                     # atomic publish: concurrent ranks may race on the cache file
+            tmp = f'{path}.{os.getpid()}.tmp.npy'
+            np.save(tmp, basis)
+            os.replace(tmp, path)
         except OSError:
             pass
     return basis
