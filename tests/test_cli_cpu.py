@@ -92,3 +92,15 @@ def test_synthetic_generators_shapes_and_determinism():
     a, b = channelized_fields(3, 32, seed=1), channelized_fields(3, 32, seed=1)
     assert a.shape == (3, 1, 32, 32) and a.dtype == np.float32 and np.array_equal(a, b)
     assert set(np.unique(a)) == {1.0, 10.0}
+
+
+def test_solver_flags_match_reference():
+    import solve_conv_mixed_residual as s
+    a = s.build_parser().parse_args([])
+    ref = dict(exp_dir='./experiments/solver', nonlinear=False, data_dir='./datasets', data='grf', kle=512, imsize=64,
+               idx=8, alpha1=1.0, alpha2=1.0, nz=1, blocks=[8, 6], weight_bound=10, lr=0.5, epochs=500, test_freq=50,
+               ckpt_freq=250, cmap='jet', same_scale=False, animate=False, cuda=1, verbose=False)
+    for k, v in ref.items():
+        assert getattr(a, k) == v, k
+    a.kle = 1024
+    assert s.dataset_file(a) == './datasets/64x64/kle1024_lhs1024_test.hdf5'

@@ -123,3 +123,16 @@ def test_cli_end_to_end_writes_reference_files(dev, tmp_path, monkeypatch):
     sd = torch.load(run / 'checkpoints/model_epoch2.pth', map_location='cpu')
     assert 'features.In_conv.weight' in sd and 'features.LastTransUp.norm3.running_var' in sd
     assert int(sd['features.LastTransUp.norm3.num_batches_tracked']) == 8
+
+
+def test_solver_script_nonlinear_lbfgs(dev, tmp_path):
+    """config 5 in miniature: Decoder + L-BFGS closure on the nonlinear mixed residual (B = 1)"""
+    import solve_conv_mixed_residual as s
+    argv = ['--exp-dir', str(tmp_path), '--nonlinear', '--alpha1', '0.1', '--alpha2', '0.1', '--epochs', '3',
+            '--test-freq', '3', '--ckpt-freq', '3', '--cuda', '0', '--synthetic', '--data', 'channelized', '--idx', '2']
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses, rate = s.main(argv)
+    assert len(losses) == 3 and np.isfinite(losses).all() and losses[-1] < losses[0]
+    run = [p for p in (tmp_path / 'conv_mixed_residual_nonlinear').iterdir()][0]
+    assert (run / 'epoch3.npy').exists() and np.load(run / 'epoch3.npy').shape == (3, 64, 64)
+    assert (run / 'model_epoch3.pth').exists() and (run / 'loss.txt').exists()
