@@ -115,6 +115,7 @@ typedef struct pdes_conv_desc {
   float* dw;             /* (Cout, Cin, k, k) weight gradient, ACCUMULATED (zero it first) */
   float* ws;             /* scratch for split-K partial weight gradients (may be NULL) */
   long long ws_bytes;
+  int ws_defer;          /* 1: leave the partials in `ws` for ONE pdes_wgrad_reduce_all at the end */
   /* the fp64 accumulators (x_stats, out_stats, t_stats, bn_grad) exist in `nrep` replicas,
      `rep_stride` doubles apart, to spread same-address atomics; readers sum the replicas */
   int nrep;
@@ -136,6 +137,14 @@ int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void* stream);
 int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
                               int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
                               long long rep_stride, void* stream);
+
+/* Split plan of the matrix-core weight-gradient kernel for `d` (uses d->ws_bytes as the scratch
+ * limit): number of pixel splits and floats of scratch it writes.  PDES_ENOSUP: this layer runs on
+ * the generic kernel (fp32 atomics straight into dw, no scratch). */
+int pdes_conv_wgrad_plan(const pdes_conv_desc* d, int* nsplit, long long* floats);
+typedef struct pdes_reduce_item { const float* part; float* dw; int n; int nsplit; } pdes_reduce_item;
+/* dw[i] += sum_s part[s][i] (fixed order) for every item; items: DEVICE array. */
+int pdes_wgrad_reduce_all(const pdes_reduce_item* items, int n, int max_n, void* stream);
 
 /* Table-driven helpers: one launch for the whole network. */
 typedef struct pdes_pack_item {  /* one convolution's weights */

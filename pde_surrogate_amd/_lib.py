@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -23,6 +23,8 @@ SIGNATURES = {
     'pdes_conv_backward_data': [_c_p, _c_i, _c_p],
     'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i,
                                   ctypes.c_longlong, _c_p],
+    'pdes_conv_wgrad_plan': [_c_p, _c_p, _c_p],
+    'pdes_wgrad_reduce_all': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_weights': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_weights_mfma': [_c_p, _c_i, _c_i, _c_p],
     'pdes_bn_update_running': [_c_p, _c_i, _c_i, _c_f, _c_i, ctypes.c_longlong, _c_p],

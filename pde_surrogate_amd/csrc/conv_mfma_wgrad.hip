@@ -243,8 +243,54 @@ __global__ __launch_bounds__(64) void wgrad_reduce_kernel(const float* __restric
   dw[i] += (s0 + s1) + (s2 + s3);
 }
 
+// dw[i] += sum_s part[s][i] for a whole table of layers: ONE launch at the end of the backward pass
+__global__ __launch_bounds__(64) void wgrad_reduce_all_kernel(const pdes_reduce_item* __restrict__ items) {
+  const pdes_reduce_item it = items[blockIdx.y];
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < it.n; i += gridDim.x * 64) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= it.nsplit; k += 4) {
+      s0 += it.part[(size_t)k * it.n + i];
+      s1 += it.part[(size_t)(k + 1) * it.n + i];
+      s2 += it.part[(size_t)(k + 2) * it.n + i];
+      s3 += it.part[(size_t)(k + 3) * it.n + i];
+    }
+    for (; k < it.nsplit; ++k) s0 += it.part[(size_t)k * it.n + i];
+    it.dw[i] += (s0 + s1) + (s2 + s3);
+  }
+}
+
+// tile / split plan shared by the launcher and pdes_conv_wgrad_plan
+struct WgradPlan { int twg, tps, tpw, nsplit, ntw, ngroups, gy; long long per; };
+static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
+  const int KK = d.ksize * d.ksize;
+  p->twg = d.Wout >= 32 ? 2 : 1;
+  p->tps = (d.Wout / (16 * p->twg)) * (d.Hout / (8 / p->twg));
+  const int mtiles = (d.Cin + 15) / 16, ntiles = (d.Cout + 15) / 16;
+  p->ntw = ntiles >= 2 ? 2 : 1;
+  p->ngroups = (ntiles + p->ntw - 1) / p->ntw;
+  p->gy = mtiles * p->ngroups;
+  p->per = (long long)d.Cout * d.Cin * KK;
+  // pixel tiles per workgroup: as few as possible while (a) ~768 workgroups are reached and
+  // (b) the partial buffer fits the scratch
+  p->tpw = p->tps;
+  for (int cand = 1; cand <= p->tps; cand *= 2) {
+    if (p->tps % cand) continue;
+    const long long ns = (long long)d.B * (p->tps / cand);
+    if (ns * p->per * 4 > d.ws_bytes) continue;
+    if (ns * p->gy <= 768 || cand == p->tps) { p->tpw = cand; break; }
+  }
+  p->nsplit = d.B * (p->tps / p->tpw);
+  return (long long)p->nsplit * p->per * 4 <= d.ws_bytes;
+}
+
 template <int KS, int S>
 static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
+  WgradPlan pl;
+  if (!wgrad_plan(d, &pl)) return PDES_ENOSUP;
+  const int twg = pl.twg, ntw = pl.ntw, ngroups = pl.ngroups, gy = pl.gy, tpw = pl.tpw, nsplit = pl.nsplit;
+  const long long per = pl.per;
+#if 0
   const int Hc = d.Hout, Wc = d.Wout;
   const int twg = Wc >= 32 ? 2 : 1;
   const int tps = (Wc / (16 * twg)) * (Hc / (8 / twg));
@@ -264,6 +310,7 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   }
   const int nsplit = d.B * (tps / tpw);
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
+#endif
   dim3 grid(nsplit, gy), block(256);
 #define PDES_WG_LAUNCH(TWG_, NTW_)                                                                          \
   do {                                                                                                        \
@@ -277,9 +324,19 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   else { if (ntw == 2) PDES_WG_LAUNCH(1, 2); else PDES_WG_LAUNCH(1, 1); }
 #undef PDES_WG_LAUNCH
   PDES_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)per, nsplit);
-  PDES_LAUNCH_CHECK();
+  if (!d.ws_defer) {      // otherwise the caller reduces every layer at once with pdes_wgrad_reduce_all
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)per, nsplit);
+    PDES_LAUNCH_CHECK();
+  }
   return PDES_OK;
+}
+
+static bool wgrad_shape_ok(const pdes_conv_desc& d) {
+  if (!d.has_bn || !(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.pad != (d.ksize - 1) / 2) return false;
+  if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample)) return false;
+  if (d.Cin < 16) return false;
+  const int W = d.Wout, H = d.Hout;
+  return !(W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8)));
 }
 
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
@@ -296,3 +353,23 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
 }
 
 }  // namespace pdes
+
+using namespace pdes;
+
+extern "C" int pdes_conv_wgrad_plan(const pdes_conv_desc* d, int* nsplit, long long* floats) {
+  if (!d || !nsplit || !floats) return PDES_EINVAL;
+  WgradPlan pl;
+  if (!wgrad_shape_ok(*d) || !wgrad_plan(*d, &pl)) return PDES_ENOSUP;
+  *nsplit = pl.nsplit;
+  *floats = (long long)pl.nsplit * pl.per;
+  return PDES_OK;
+}
+
+extern "C" int pdes_wgrad_reduce_all(const pdes_reduce_item* items, int n, int max_n, void* stream) {
+  if (!items || n <= 0 || max_n <= 0) return PDES_EINVAL;
+  int gx = cdiv(max_n, 64);
+  gx = gx > 1024 ? 1024 : gx;
+  hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(gx, n), dim3(64), 0, static_cast<hipStream_t>(stream), items);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}

@@ -38,7 +38,7 @@ class ConvDesc(ctypes.Structure):
         ('g', _P), ('g_ctot', _I), ('g_coff', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
         ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
-        ('nrep', _I), ('rep_stride', ctypes.c_longlong),
+        ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong),
     ]
 
 
@@ -49,6 +49,10 @@ class PackItem(ctypes.Structure):
 
 class MfmaPackItem(ctypes.Structure):
     _fields_ = [('w', _P), ('wm_fwd', _P), ('wm_bwd', _P), ('Cout', _I), ('Cin', _I), ('kk', _I)]
+
+
+class ReduceItem(ctypes.Structure):
+    _fields_ = [('part', _P), ('dw', _P), ('n', _I), ('nsplit', _I)]
 
 
 class BnItem(ctypes.Structure):
@@ -268,7 +272,7 @@ class _Engine:
             d.wm_fwd = mf[0].data_ptr() if mf else None
             d.wm_bwd = mf[1].data_ptr() if mf and mf[1] is not None else None
             d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
-            d.ws, d.ws_bytes = net._ws.data_ptr(), net._ws.numel() * 4
+            d.ws, d.ws_bytes, d.ws_defer = net._ws.data_ptr(), net._ws.numel() * 4, 0
             d.nrep, d.rep_stride = self.nrep, self.rep_stride
             if s.norm is not None:
                 bn = _get(net.features, s.norm)
@@ -312,6 +316,30 @@ class _Engine:
         arr = (BnItem * len(items))(*items)
         self.bn_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
 
+    def _plan_wgrad_scratch(self):
+        """per-layer split-K scratch so that ONE reduce launch finishes every weight gradient"""
+        L = _lib.lib()
+        self._wgrad_ws, items, mx = [], [], 0
+        for i, s in enumerate(self.net._specs):
+            d = self.descs[i]
+            d.ws_bytes = 1 << 40                       # plan without a scratch limit
+            ns, fl = _I(0), ctypes.c_longlong(0)
+            rc = L.pdes_conv_wgrad_plan(ctypes.byref(d), ctypes.byref(ns), ctypes.byref(fl))
+            if rc != 0:                                # generic kernel: atomics into dw, shared scratch unused
+                d.ws, d.ws_bytes, d.ws_defer = self.net._ws.data_ptr(), self.net._ws.numel() * 4, 0
+                continue
+            buf = torch.empty(fl.value, device=self.dev, dtype=torch.float32)
+            self._wgrad_ws.append(buf)
+            d.ws, d.ws_bytes, d.ws_defer = buf.data_ptr(), fl.value * 4, 1
+            it = ReduceItem()
+            it.part, it.dw, it.n, it.nsplit = buf.data_ptr(), d.dw, s.cout * s.cin * s.k * s.k, ns.value
+            items.append(it)
+            mx = max(mx, it.n)
+        self._reduce_n, self._reduce_max = len(items), mx
+        if items:
+            arr = (ReduceItem * len(items))(*items)
+            self._reduce_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+
     # -- launches -------------------------------------------------------------------------------
     def forward(self, x, training):
         L, st = _lib.lib(), _lib.stream_ptr()
@@ -336,6 +364,8 @@ class _Engine:
         """parameter gradients are ACCUMULATED into net._gflat (zero it first for plain gradients)"""
         L, st = _lib.lib(), _lib.stream_ptr()
         n = len(self.descs)
+        if not hasattr(self, '_reduce_n'):
+            self._plan_wgrad_scratch()
         self.descs[n - 1].g = grad_y.data_ptr()
         specs, bufs = self.net._specs, self.net._bufs
         one = ConvDesc * 1
@@ -353,6 +383,9 @@ class _Engine:
             _lib.check(L.pdes_conv_backward_weight(ref, 1, st), 'pdes_conv_backward_weight')
             if s.norm is not None:
                 _lib.check(L.pdes_conv_backward_data(ref, 1, st), 'pdes_conv_backward_data')
+        if self._reduce_n:
+            _lib.check(L.pdes_wgrad_reduce_all(self._reduce_table.data_ptr(), self._reduce_n, self._reduce_max, st),
+                       'pdes_wgrad_reduce_all')
         _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, self.nrep, self.rep_stride,
                                          st), 'pdes_bn_param_grads')
 
