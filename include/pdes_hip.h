@@ -99,6 +99,8 @@ typedef struct pdes_conv_desc {
   int cout_pad, cin_pad; /* multiples of 16 */
   const float* wm_fwd;   /* MFMA image of w for the forward, or NULL (pdes_pack_weights_mfma) */
   const float* wm_bwd;   /* MFMA image of w for the data gradient, or NULL */
+  const float* wu_fwd;   /* upsample+3x3 only: effective 2x2 weights (sub-pixel decomposition), or NULL */
+  const float* wu_bwd;   /* same for the data gradient, or NULL (pdes_pack_weights_up) */
   /* output */
   float* out;            /* (B, out_ctot, Hout, Wout); channels [out_coff, out_coff+Cout) written */
   int out_ctot, out_coff;
@@ -162,6 +164,15 @@ typedef struct pdes_mfma_pack_item { /* one convolution's matrix-core weight ima
 } pdes_mfma_pack_item;
 /* items: DEVICE array; rebuilds both images from the live weights (zero padded). */
 int pdes_pack_weights_mfma(const pdes_mfma_pack_item* items, int n, int max_elems, void* stream);
+
+typedef struct pdes_up_pack_item { /* one nearest-x2 + 3x3 convolution: effective-weight images */
+  const float* w;        /* (Cout, Cin, 3, 3) */
+  float* wu_fwd;         /* (ceil(Cin/16)*4, 16, ceil8(ceil(Cout/16)), 64) */
+  float* wu_bwd;         /* (ceil(Cout/16)*4, 16, ceil8(ceil(Cin/16)), 64) */
+  int Cout, Cin;
+} pdes_up_pack_item;
+/* items: DEVICE array; see csrc/conv_mfma_up.hip for the image layout. */
+int pdes_pack_weights_up(const pdes_up_pack_item* items, int n, int max_elems, void* stream);
 
 typedef struct pdes_bn_item {    /* one BatchNorm layer */
   const double* x_stats;  /* (>=C, 2) batch sums of its input channels */

@@ -12,6 +12,8 @@ int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st);        // PDES_ENOSUP: shape not covered
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st);
+int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st);        // nearest-x2 + 3x3, sub-pixel form
+int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st);
 
 // PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
 // the matrix-core kernels against them); anything else = automatic selection.
@@ -27,7 +29,8 @@ extern "C" int pdes_conv_forward(const pdes_conv_desc* descs, int n, void* strea
   if (!descs || n <= 0) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
-    int rc = force_direct() ? PDES_ENOSUP : conv_forward_mfma(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_forward_up_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_mfma(descs[i], st);
     if (rc == PDES_ENOSUP) rc = conv_forward_direct(descs[i], st);
     if (rc) return rc;
   }
@@ -49,7 +52,8 @@ extern "C" int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void*
   if (!descs || n <= 0) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
-    int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_mfma(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_up_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_mfma(descs[i], st);
     if (rc == PDES_ENOSUP) rc = conv_backward_data_direct(descs[i], st);
     if (rc) return rc;
   }

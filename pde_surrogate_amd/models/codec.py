@@ -33,7 +33,7 @@ class ConvDesc(ctypes.Structure):
         ('x', _P), ('x_ctot', _I), ('has_bn', _I), ('eval_mode', _I), ('eps', _F),
         ('gamma', _P), ('beta', _P), ('x_stats', _P), ('run_mean', _P), ('run_var', _P),
         ('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('cout_pad', _I), ('cin_pad', _I),
-        ('wm_fwd', _P), ('wm_bwd', _P),
+        ('wm_fwd', _P), ('wm_bwd', _P), ('wu_fwd', _P), ('wu_bwd', _P),
         ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P),
         ('g', _P), ('g_ctot', _I), ('g_coff', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
@@ -49,6 +49,10 @@ class PackItem(ctypes.Structure):
 
 class MfmaPackItem(ctypes.Structure):
     _fields_ = [('w', _P), ('wm_fwd', _P), ('wm_bwd', _P), ('Cout', _I), ('Cin', _I), ('kk', _I)]
+
+
+class UpPackItem(ctypes.Structure):
+    _fields_ = [('w', _P), ('wu_fwd', _P), ('wu_bwd', _P), ('Cout', _I), ('Cin', _I)]
 
 
 class ReduceItem(ctypes.Structure):
@@ -271,6 +275,9 @@ class _Engine:
             mf = net._packed_mfma.get(s.conv)
             d.wm_fwd = mf[0].data_ptr() if mf else None
             d.wm_bwd = mf[1].data_ptr() if mf and mf[1] is not None else None
+            uf = net._packed_up.get(s.conv)
+            d.wu_fwd = uf[0].data_ptr() if uf else None
+            d.wu_bwd = uf[1].data_ptr() if uf else None
             d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
             d.ws, d.ws_bytes, d.ws_defer = net._ws.data_ptr(), net._ws.numel() * 4, 0
             d.nrep, d.rep_stride = self.nrep, self.rep_stride
@@ -493,6 +500,24 @@ class _HipNet(nn.Module):
             mitems.append(it)
             mmx = max(mmx, nf, nb)
         self._mpack_n, self._mpack_max = len(mitems), mmx
+        # effective 2x2 weight images of the nearest-x2 + 3x3 convolutions (sub-pixel decomposition)
+        self._packed_up, uitems, umx = {}, [], 0
+        pad128 = lambda n: (n + 127) // 128 * 128
+        for s in self._specs:
+            if not (s.up and s.k == 3 and s.stride == 1 and s.norm is not None):
+                continue
+            nf, nb = _pad16(s.cin) * pad128(s.cout) * 16, _pad16(s.cout) * pad128(s.cin) * 16
+            uf, ub = torch.zeros(nf, device=device), torch.zeros(nb, device=device)
+            self._packed_up[s.conv] = (uf, ub)
+            it = UpPackItem()
+            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.wu_fwd, it.wu_bwd, it.Cout, it.Cin = uf.data_ptr(), ub.data_ptr(), s.cout, s.cin
+            uitems.append(it)
+            umx = max(umx, nf, nb)
+        self._upack_n, self._upack_max = len(uitems), umx
+        if uitems:
+            arr = (UpPackItem * len(uitems))(*uitems)
+            self._upack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._ws = torch.empty(8 << 20, device=device)       # 32 MiB split-K scratch (weight gradients)
         if mitems:
             arr = (MfmaPackItem * len(mitems))(*mitems)
@@ -506,6 +531,10 @@ class _HipNet(nn.Module):
             rc = _lib.lib().pdes_pack_weights_mfma(self._mpack_table.data_ptr(), self._mpack_n, self._mpack_max,
                                                    _lib.stream_ptr())
             _lib.check(rc, 'pdes_pack_weights_mfma')
+        if self._upack_n:
+            rc = _lib.lib().pdes_pack_weights_up(self._upack_table.data_ptr(), self._upack_n, self._upack_max,
+                                                 _lib.stream_ptr())
+            _lib.check(rc, 'pdes_pack_weights_up')
 
     def _is_flat(self, device):
         if self._flat is None or self._flat.device != device:
