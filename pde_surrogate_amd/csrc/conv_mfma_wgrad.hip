@@ -226,6 +226,220 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of nearest-x2 + 3x3 convolutions in sub-pixel form (see conv_mfma_up.hip):
+//   dWeff[p][a][b][co][ci] = sum_{y,x} G_p[co][y][x] * z[ci][y+a+dy-1][x+b+dx-1],  G_p[Y][X] = G[2Y+dy][2X+dx]
+//   dW[ky][kx] = sum_{dy,dx} dWeff[(dy,dx)][a(ky,dy)][b(kx,dx)]
+// 16 MFMAs per low-res pixel k-step instead of 36; the operand images are the low-res z halo tile
+// and the four de-interleaved parity sub-images of the hi-res gradient.
+template <int TWG, int NTW>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
+                                                                int n_ngroups) {
+  using G = WGeo<3, TWG, 1>;
+  constexpr int NPX = G::TH * G::TW;                            // low-res pixels per tile (128)
+  constexpr int NPG = 16 * NTW * (NPX / 4) * 2 / 256;          // (channel, pixel quad, dy) items per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* zt = smem;                                            // [16][CS]
+  float* gt = smem + 16 * G::CS;                               // [4 parities][16*NTW][GS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hl = d.Hin, Wl = d.Win, HWl = Hl * Wl, Wh = d.Wout, HWh = d.Hout * d.Wout;
+  const int tiles_x = Wl / G::TW, tps = tiles_x * (Hl / G::TH);
+  const int groups = tps / tpw;
+  const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
+  const int mtile = blockIdx.y / n_ngroups, ng = blockIdx.y % n_ngroups;
+  const int ci0 = mtile * 16, co0 = ng * 16 * NTW;
+  const float NANF = __int_as_float(0x7fc00000);
+
+  __shared__ float cf[16][3];
+  if (tid < 16) {
+    const int c = ci0 + tid;
+    float m = 0.f, sc = 0.f, bt = 0.f;
+    if (c < d.Cin) {
+      double mean, invstd;
+      if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
+      else {
+        const double n = (double)d.B * HWl;
+        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
+        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        invstd = 1.0 / sqrt(var + (double)d.eps);
+      }
+      m = (float)mean; sc = d.gamma[c] * (float)invstd; bt = d.beta[c];
+    }
+    cf[tid][0] = m; cf[tid][1] = sc; cf[tid][2] = bt;
+  }
+  const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWl;
+  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWh;
+  const int crem = d.Cin - ci0, corem = d.Cout - co0;
+  const bool halo_live = tiles_x > 1;
+
+  float4 pv[G::NPV], pg0[NPG], pg1[NPG];
+  float ph[G::NPH];
+  auto issue = [&](int tile) {
+    const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
+#pragma unroll
+    for (int i = 0; i < G::NPV; ++i) {
+      const int e = tid + 256 * i;
+      const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
+      const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
+      const int cy = oy0 - 1 + r, cx = ox0 + 4 * j;
+      const bool v = e < G::NV4 && ch < crem && cy >= 0 && cy < Hl;
+      const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hl - 1);
+      const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)chc * HWl + cyc * Wl + cx);
+      pv[i] = v ? x : make_float4(NANF, NANF, NANF, NANF);
+    }
+    if (halo_live) {
+#pragma unroll
+      for (int i = 0; i < G::NPH; ++i) {
+        const int e = tid + 256 * i;
+        const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
+        const int r = rem / G::NHC, h = rem % G::NHC;
+        const int cy = oy0 - 1 + r, cx = h == 0 ? ox0 - 1 : ox0 + G::TW;
+        const bool v = e < G::NH && ch < crem && cy >= 0 && cy < Hl && cx >= 0 && cx < Wl;
+        const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hl - 1), cxc = min(max(cx, 0), Wl - 1);
+        const float xv = xb[(size_t)chc * HWl + cyc * Wl + cxc];
+        ph[i] = v ? xv : NANF;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPG; ++i) {
+      const int e = tid + 256 * i;                       // (channel, low-res pixel quad, dy)
+      const int dy = e & 1, q = e >> 1;
+      const int ch = q / (NPX / 4), p4 = q % (NPX / 4);
+      const int y = oy0 + (4 * p4) / G::TW, x = ox0 + (4 * p4) % G::TW;
+      const float* src = gb + (size_t)min(ch, corem - 1) * HWh + (size_t)(2 * y + dy) * Wh + 2 * x;
+      const float4 h0 = *reinterpret_cast<const float4*>(src), h1 = *reinterpret_cast<const float4*>(src + 4);
+      const bool v = ch < corem;
+      pg0[i] = v ? make_float4(h0.x, h0.z, h1.x, h1.z) : make_float4(0.f, 0.f, 0.f, 0.f);   // dx = 0
+      pg1[i] = v ? make_float4(h0.y, h0.w, h1.y, h1.w) : make_float4(0.f, 0.f, 0.f, 0.f);   // dx = 1
+    }
+  };
+  auto bnrelu = [&](float x, int ch) {
+    return (x != x) ? 0.f : fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::NPV; ++i) {
+      const int e = tid + 256 * i;
+      if (e < G::NV4) {
+        const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
+        const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
+        float* dst = zt + ch * G::CS + r * G::LDW + G::COL0 + 4 * j;
+        const float4 x = pv[i];
+        *reinterpret_cast<float2*>(dst) = make_float2(bnrelu(x.x, ch), bnrelu(x.y, ch));
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(bnrelu(x.z, ch), bnrelu(x.w, ch));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::NPH; ++i) {
+      const int e = tid + 256 * i;
+      if (e < G::NH) {
+        const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
+        const int r = rem / G::NHC, h = rem % G::NHC;
+        zt[ch * G::CS + r * G::LDW + (h == 0 ? G::COL0 - 1 : G::COL0 + G::TW)] = halo_live ? bnrelu(ph[i], ch) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPG; ++i) {
+      const int e = tid + 256 * i;
+      const int dy = e & 1, q = e >> 1;
+      const int ch = q / (NPX / 4), p4 = q % (NPX / 4);
+      float* d0 = gt + ((dy * 2 + 0) * 16 * NTW + ch) * G::GS + 4 * p4;
+      float* d1 = gt + ((dy * 2 + 1) * 16 * NTW + ch) * G::GS + 4 * p4;
+      *reinterpret_cast<float2*>(d0) = make_float2(pg0[i].x, pg0[i].y);
+      *reinterpret_cast<float2*>(d0 + 2) = make_float2(pg0[i].z, pg0[i].w);
+      *reinterpret_cast<float2*>(d1) = make_float2(pg1[i].x, pg1[i].y);
+      *reinterpret_cast<float2*>(d1 + 2) = make_float2(pg1[i].z, pg1[i].w);
+    }
+  };
+
+  v4f acc[16][NTW];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  constexpr int RPW = (G::TH >= 4) ? G::TH / 4 : 1;
+  const int a_lane = (lane & 15) * G::CS + (lane >> 4);
+  const int b_lane = (lane & 15) * G::GS + (lane >> 4);
+  const int tile0 = tg * tpw;
+  issue(tile0);
+  __syncthreads();
+  for (int tt = 0; tt < tpw; ++tt) {
+    commit();
+    __syncthreads();
+    if (tt + 1 < tpw) issue(tile0 + tt + 1);
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = wave * RPW + rr;
+#pragma unroll
+      for (int ks = 0; ks < G::TW / 4; ++ks) {
+        float bv[4][NTW];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            bv[pp][nt] = gt[b_lane + (pp * 16 * NTW + nt * 16) * G::GS + row * G::TW + 4 * ks];
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const float a = zt[a_lane + (row + ty) * G::LDW + (G::COL0 - 1) + 4 * ks + tx];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 2; ++dx) {
+                const int ia = ty - dy, ib = tx - dx;
+                if (ia < 0 || ia > 1 || ib < 0 || ib > 1) continue;
+                const int pp = dy * 2 + dx, q = pp * 4 + ia * 2 + ib;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                  acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[pp][nt], acc[q][nt], 0, 0, 0);
+              }
+          }
+      }
+    }
+    __syncthreads();
+  }
+
+  // fold the 16 effective-kernel gradients into the 9 taps, then sum the 4 waves through LDS
+  v4f w9[9][NTW];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        v4f s = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int ia = dy == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+            const int ib = dx == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+            s += acc[(dy * 2 + dx) * 4 + ia * 2 + ib][nt];
+          }
+        w9[ky * 3 + kx][nt] = s;
+      }
+  float* red = smem;
+  constexpr int NR = 9 * NTW * 4;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * NR + (t * NTW + nt) * 4 + r) * 64 + lane] = w9[t][nt][r];
+  __syncthreads();
+  float* pout = part + (size_t)blockIdx.x * d.Cout * d.Cin * 9;
+  for (int q = wave; q < NR; q += 4) {
+    const float s = red[(0 * NR + q) * 64 + lane] + red[(1 * NR + q) * 64 + lane] +
+                    red[(2 * NR + q) * 64 + lane] + red[(3 * NR + q) * 64 + lane];
+    const int r = q & 3, nt = (q >> 2) % NTW, t = (q >> 2) / NTW;
+    const int co = co0 + nt * 16 + (lane & 15), ci = ci0 + (lane >> 4) * 4 + r;
+    if (co < d.Cout && ci < d.Cin) pout[((size_t)co * d.Cin + ci) * 9 + t] = s;
+  }
+}
+
 // dw[i] += sum_s part[s][i], fixed order
 __global__ __launch_bounds__(64) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            int n, int nsplit) {
@@ -264,8 +478,10 @@ __global__ __launch_bounds__(64) void wgrad_reduce_all_kernel(const pdes_reduce_
 struct WgradPlan { int twg, tps, tpw, nsplit, ntw, ngroups, gy; long long per; };
 static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   const int KK = d.ksize * d.ksize;
-  p->twg = d.Wout >= 32 ? 2 : 1;
-  p->tps = (d.Wout / (16 * p->twg)) * (d.Hout / (8 / p->twg));
+  const bool up = d.upsample && d.ksize == 3;            // sub-pixel form: tiles of the LOW-res map
+  const int Wt = up ? d.Win : d.Wout, Ht = up ? d.Hin : d.Hout;
+  p->twg = Wt >= 32 ? 2 : 1;
+  p->tps = (Wt / (16 * p->twg)) * (Ht / (8 / p->twg));
   const int mtiles = (d.Cin + 15) / 16, ntiles = (d.Cout + 15) / 16;
   p->ntw = ntiles >= 2 ? 2 : 1;
   p->ngroups = (ntiles + p->ntw - 1) / p->ntw;
@@ -334,9 +550,34 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
 static bool wgrad_shape_ok(const pdes_conv_desc& d) {
   if (!d.has_bn || !(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.pad != (d.ksize - 1) / 2) return false;
   if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample)) return false;
+  if (d.upsample && d.ksize != 3) return false;
   if (d.Cin < 16) return false;
-  const int W = d.Wout, H = d.Hout;
+  const bool up = d.upsample && d.ksize == 3;
+  const int W = up ? d.Win : d.Wout, H = up ? d.Hin : d.Hout;
   return !(W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8)));
+}
+
+static int launch_wgrad_up(const pdes_conv_desc& d, hipStream_t st) {
+  WgradPlan pl;
+  if (!wgrad_plan(d, &pl)) return PDES_ENOSUP;
+  dim3 grid(pl.nsplit, pl.gy), block(256);
+#define PDES_WGU_LAUNCH(TWG_, NTW_)                                                                         \
+  do {                                                                                                        \
+    using G = WGeo<3, TWG_, 1>;                                                                               \
+    size_t lds = (size_t)(16 * G::CS + 4 * 16 * NTW_ * G::GS) * sizeof(float);                                \
+    const size_t red = (size_t)4 * 9 * NTW_ * 4 * 64 * sizeof(float);                                         \
+    if (red > lds) lds = red;                                                                                 \
+    hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_>), grid, block, lds, st, d, d.ws, pl.tpw, pl.ngroups); \
+  } while (0)
+  if (pl.twg == 2) { if (pl.ntw == 2) PDES_WGU_LAUNCH(2, 2); else PDES_WGU_LAUNCH(2, 1); }
+  else { if (pl.ntw == 2) PDES_WGU_LAUNCH(1, 2); else PDES_WGU_LAUNCH(1, 1); }
+#undef PDES_WGU_LAUNCH
+  PDES_LAUNCH_CHECK();
+  if (!d.ws_defer) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)pl.per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)pl.per, pl.nsplit);
+    PDES_LAUNCH_CHECK();
+  }
+  return PDES_OK;
 }
 
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
@@ -344,9 +585,8 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
     return PDES_ENOSUP;
   if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample)) return PDES_ENOSUP;
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
-  if (d.Cin < 16) return PDES_ENOSUP;
-  const int W = d.Wout, H = d.Hout;
-  if (W % 16 || (W >= 32 ? (W % 32 || H % 4) : (H % 8))) return PDES_ENOSUP;
+  if (!wgrad_shape_ok(d)) return PDES_ENOSUP;
+  if (d.upsample) return launch_wgrad_up(d, st);
   if (d.stride == 2) return launch_wgrad<3, 2>(d, st);
   if (d.ksize == 5) return launch_wgrad<5, 1>(d, st);
   return d.ksize == 3 ? launch_wgrad<3, 1>(d, st) : launch_wgrad<1, 1>(d, st);
