@@ -16,15 +16,26 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
                                                               int c0, int HW, float eps, int nrep, long long rs) {
   const int c = c0 + blockIdx.y, b = blockIdx.z;
   __shared__ float sc[4];
+  __shared__ double sums[4];
+  if (threadIdx.x < 64) {
+    // 4 quantities x PDES_NREP(=16) replicas: one load per lane, then a 16-lane shuffle reduction
+    const int q = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const double* src = (q < 2 ? x_stats : t_stats) + (long long)r * rs + 2 * c + (q & 1);
+    double v = *src;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    if (r == 0) sums[q] = v;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     const double n = (double)B * HW;
-    const double m = rep_sum(x_stats, 2 * c, nrep, rs) / n;
-    double var = rep_sum(x_stats, 2 * c + 1, nrep, rs) / n - m * m;
+    const double m = sums[0] / n;
+    double var = sums[1] / n - m * m;
     var = var < 0.0 ? 0.0 : var;
     sc[0] = (float)m;
     sc[1] = (float)(1.0 / sqrt(var + (double)eps));
-    sc[2] = (float)(rep_sum(t_stats, 2 * c, nrep, rs) / n);
-    sc[3] = (float)(rep_sum(t_stats, 2 * c + 1, nrep, rs) / n);
+    sc[2] = (float)(sums[2] / n);
+    sc[3] = (float)(sums[3] / n);
   }
   __syncthreads();
   const float mean = sc[0], invstd = sc[1], m1 = sc[2], m2 = sc[3];

@@ -288,6 +288,53 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct(pdes_conv_desc d, 
   }
 }
 
+
+// ---------------------------------------------------------------- bwd weight, first convolution
+// The first convolution (no BatchNorm in front, 1..4 input channels, e.g. 7x7 stride 2 on the
+// permeability field) has a tiny weight tensor but a 49-tap reduction over every output pixel.
+// One workgroup = one sample x 8 output channels: the zero-bordered input plane(s) and the 8
+// gradient planes sit in LDS, a thread owns (channel, tap) pairs and runs over the output pixels.
+template <int COT>
+__global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  const int k = d.ksize, KK = k * k, HWo = d.Hout * d.Wout, HWi = d.Hin * d.Win;
+  const int LH = d.Hin + 2 * d.pad + d.stride, LW = d.Win + 2 * d.pad + d.stride;   // bordered plane
+  float* xs = smf;                                   // [Cin][LH][LW]
+  float* gs = smf + d.Cin * LH * LW;                 // [COT][HWo]
+  const int tid = threadIdx.x, b = blockIdx.x, co0 = blockIdx.y * COT;
+  for (int i = tid; i < d.Cin * LH * LW; i += 256) {
+    const int c = i / (LH * LW), r = (i % (LH * LW)) / LW - d.pad, q = i % LW - d.pad;
+    xs[i] = (r >= 0 && r < d.Hin && q >= 0 && q < d.Win) ? d.x[((size_t)b * d.x_ctot + c) * HWi + r * d.Win + q] : 0.f;
+  }
+  for (int i = tid; i < COT * HWo; i += 256) {
+    const int c = i / HWo;
+    gs[i] = (co0 + c < d.Cout) ? d.g[((size_t)b * d.g_ctot + d.g_coff + co0 + c) * HWo + i % HWo] : 0.f;
+  }
+  __syncthreads();
+  const int npair = COT * d.Cin * KK;
+  for (int pr = tid; pr < npair; pr += 256) {
+    const int c = pr / (d.Cin * KK), ci = (pr / KK) % d.Cin, t = pr % KK;
+    const int ky = t / k, kx = t % k;
+    const float* xp = xs + ci * LH * LW + ky * LW + kx;     // pixel (oy,ox) reads xp[(oy*s)*LW + ox*s]
+    const float* gp = gs + c * HWo;
+    // 8 independent accumulators: the loop is LDS-latency bound, not bandwidth bound
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int st2 = d.stride;
+    for (int oy = 0; oy < d.Hout; ++oy) {
+      const float* xr = xp + oy * st2 * LW;
+      const float* gr = gp + oy * d.Wout;
+      int ox = 0;
+      for (; ox + 8 <= d.Wout; ox += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += gr[ox + u] * xr[(ox + u) * st2];
+      }
+      for (; ox < d.Wout; ++ox) a[0] += gr[ox] * xr[ox * st2];
+    }
+    const float a0 = (a[0] + a[1]) + (a[2] + a[3]), a1 = (a[4] + a[5]) + (a[6] + a[7]);
+    if (co0 + c < d.Cout) atomicAdd(&d.dw[((size_t)(co0 + c) * d.Cin + ci) * KK + t], a0 + a1);
+  }
+}
+
 // ------------------------------------------------------------------------------- host dispatch
 static int validate(const pdes_conv_desc& d, int mode) {
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
@@ -341,6 +388,16 @@ int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st) {
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st) {
   const int rc = validate(d, 1);
   if (rc) return rc;
+  if (!d.has_bn && !d.upsample && d.Cin <= 4) {
+    // first convolution: LDS-resident planes (see conv_bwd_weight_first)
+    const int LH = d.Hin + 2 * d.pad + d.stride, LW = d.Win + 2 * d.pad + d.stride;
+    const size_t lds = ((size_t)d.Cin * LH * LW + (size_t)8 * d.Hout * d.Wout) * sizeof(float);
+    if (lds <= 150 * 1024) {
+      hipLaunchKernelGGL(conv_bwd_weight_first<8>, dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d);
+      PDES_LAUNCH_CHECK();
+      return PDES_OK;
+    }
+  }
   int cot;
   switch (d.ksize) { case 1: cot = 16; break; case 3: cot = 8; break; case 5: cot = 4; break; default: cot = 2; }
   const int ncog = cdiv(d.Cout, cot);
