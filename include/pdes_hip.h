@@ -105,6 +105,8 @@ typedef struct pdes_conv_desc {
   float* out;            /* (B, out_ctot, Hout, Wout); channels [out_coff, out_coff+Cout) written */
   int out_ctot, out_coff;
   double* out_stats;     /* (out_ctot, 2) accumulated for the written channels; NULL: none */
+  const double* fin_xstats; /* pdes_backward only: {sum x, sum x^2} and {sum T, sum T xhat} tables of the */
+  const double* fin_tstats; /* OUTPUT buffer for its BN-backward finalize; NULL = `g` is already dL/d(out) */
   /* backward */
   const float* g;        /* dL/d(out): (B, g_ctot, Hout, Wout), channels [g_coff, g_coff+Cout) */
   int g_ctot, g_coff;
@@ -134,6 +136,14 @@ int pdes_conv_backward_weight(const pdes_conv_desc* descs, int n, void* stream);
 /* T_in (+)= gamma * (conv^T(g)) * 1[bn(x) > 0]; also dgamma/dbeta and the finished channels'
  * {sum T, sum T xhat} (autograd of conv2d wrt input, ReLU, BatchNorm wrt gamma/beta). */
 int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void* stream);
+/* The whole backward pass of a descriptor chain: for i = n-1 .. 0
+ *   [pdes_bn_backward_finalize of descs[i]'s output channels, when fin_tstats != NULL]
+ *   pdes_conv_backward_weight(descs[i])   -- on `wgrad_stream` when it is not NULL
+ *   pdes_conv_backward_data(descs[i])     -- when has_bn
+ * The weight gradients have no consumer before the final reduce, so with a second stream they
+ * overlap the finalize -> data-gradient dependency chain; the two streams are fork/joined with
+ * events inside this call (on return everything is ordered on `stream` again). */
+int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream);
 /* In place T -> dL/dx for channels [c0, c1) of a (B, ctot, H, W) buffer (BatchNorm backward wrt
  * its input, summed over every consumer BN). */
 int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,

@@ -45,7 +45,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 [os.path.getmtime(src)] + [os.path.getmtime(h) for h in headers()]):
-            cmd = [hipcc] + [f for f in FLAGS if f != '-shared'] + ['-c', src, '-o', obj]
+            cmd = [hipcc] + [f for f in FLAGS if f != '-shared'] + os.environ.get('PDES_EXTRA_FLAGS', '').split() + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -2,6 +2,7 @@
 // one kernel per descriptor on the caller's stream.  Kernel selection lives here so the Python
 // side never needs to know which implementation (MFMA or VALU) serves a shape.
 #include <stdlib.h>
+#include <vector>
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
 
@@ -56,6 +57,53 @@ extern "C" int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void*
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_mfma(descs[i], st);
     if (rc == PDES_ENOSUP) rc = conv_backward_data_direct(descs[i], st);
     if (rc) return rc;
+  }
+  return PDES_OK;
+}
+
+// Events used to fork/join the weight-gradient stream (timing disabled: they only order work).
+static hipEvent_t chain_event(size_t i) {
+  static std::vector<hipEvent_t> pool;
+  while (pool.size() <= i) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    pool.push_back(e);
+  }
+  return pool[i];
+}
+
+extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream) {
+  if (!descs || n <= 0) return PDES_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipStream_t ws = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : st;
+  const bool fork = ws != st;
+  for (int i = n - 1; i >= 0; --i) {
+    const pdes_conv_desc& d = descs[i];
+    if (d.fin_tstats) {
+      int rc = pdes_bn_backward_finalize(const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B, d.g_ctot,
+                                         d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep, d.rep_stride, st);
+      if (rc) return rc;
+    }
+    if (fork) {
+      hipEvent_t e = chain_event(static_cast<size_t>(i));
+      if (!e) return (int)hipErrorOutOfMemory;
+      hipError_t he = hipEventRecord(e, st);
+      if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
+      if (he != hipSuccess) return (int)he;
+    }
+    int rc = pdes_conv_backward_weight(&d, 1, ws);
+    if (rc) return rc;
+    if (d.has_bn) {
+      rc = pdes_conv_backward_data(&d, 1, st);
+      if (rc) return rc;
+    }
+  }
+  if (fork) {
+    hipEvent_t e = chain_event(static_cast<size_t>(n));
+    if (!e) return (int)hipErrorOutOfMemory;
+    hipError_t he = hipEventRecord(e, ws);
+    if (he == hipSuccess) he = hipStreamWaitEvent(st, e, 0);
+    if (he != hipSuccess) return (int)he;
   }
   return PDES_OK;
 }

@@ -73,10 +73,19 @@ struct TileGeo {
   static_assert(MT % TWG == 0 && CS >= ROWS * LDW && NL <= COL0 && NR >= 0, "tile geometry");
 };
 
-enum { MODE_FWD = 0, MODE_BWD = 1 };
-enum { KV_PLAIN = 0, KV_NEAREST2 = 1, KV_ZEROINS2 = 2 };
+#ifdef PDES_TRACE
+__device__ unsigned long long pdes_trace_buf[16];
+#define TR(i) do { if (trace_on) pdes_trace_buf[i] = wall_clock64(); } while (0)
+#define TRACC(i, t0) do { tacc[i - 8] += wall_clock64() - (t0); } while (0)
+#else
+#define TR(i)
+#define TRACC(i, t0)
+#endif
 
-template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE>
+enum { MODE_FWD = 0, MODE_BWD = 1 };
+enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-inserted x2 (stride-2 data gradient)
+
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                        int nt_total) {
   using G = TileGeo<KS, TWG, MT, S>;
@@ -87,22 +96,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PDES_TRACE
+  const bool trace_on = tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0;
+  if (trace_on) { for (int i = 0; i < 16; ++i) pdes_trace_buf[i] = 0; }
+  unsigned long long tt = 0, tacc[3] = {0, 0, 0};
+#endif
+  TR(0);
   const int wk = wave % WAVES_K, wn = wave / WAVES_K;
   const int b = blockIdx.y;
   const int nt_base = (blockIdx.z * (4 / WAVES_K) + wn) * NT_W;   // first N-tile of this wave
 
   // ---- K operand (staged through LDS) and the output side
   const float* kbase;
-  int kC, kH, kW, kHc, kWc, kmode;
+  int kC, kH, kW, kHc, kWc;
+  constexpr int kmode = KM;     // compile time: a runtime view switch inside the load path costs a vmcnt(0) per chunk
   int Hout, Wout;
   if (MODE == MODE_FWD) {
-    kC = d.Cin; kH = d.Hin; kW = d.Win; kmode = d.upsample ? KV_NEAREST2 : KV_PLAIN;
+    kC = d.Cin; kH = d.Hin; kW = d.Win;
     kbase = d.x + (size_t)b * d.x_ctot * d.Hin * d.Win;
     Hout = d.Hout; Wout = d.Wout;
   } else {
-    kC = d.Cout; kH = d.Hout; kW = d.Wout; kmode = d.stride == 2 ? KV_ZEROINS2 : KV_PLAIN;
+    kC = d.Cout; kH = d.Hout; kW = d.Wout;
     kbase = d.g + ((size_t)b * d.g_ctot + d.g_coff) * d.Hout * d.Wout;
-    Hout = d.upsample ? 2 * d.Hin : d.Hin; Wout = d.upsample ? 2 * d.Win : d.Win;
+    Hout = d.Hin; Wout = d.Win;
   }
   kHc = kmode ? 2 * kH : kH;
   kWc = kmode ? 2 * kW : kW;
@@ -161,22 +177,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   }
   (void)hzero;
 
-  float4 pv[G::NPV];
-  float ph[G::NPH > 0 ? G::NPH : 1];
+  // two register stages: the loads of chunk c+2 are issued before the MFMAs of chunk c, so a tile has
+  // two chunks of matrix work (not one) to arrive from L2/HBM before it is committed to LDS
+  constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
+  float4 pvA[G::NPV], pvB[G::NPV];
+  float phA[NPHS], phB[NPHS];
   // loads are unconditional (row offsets are clamped into the image above, the channel is clamped
   // here); validity is applied when the registers are committed to LDS
-  auto issue = [&](int chunk) {
+  auto issue = [&](int chunk, float4 (&pv)[G::NPV], float (&ph)[NPHS]) {
     const float* src = kbase + (size_t)chunk * 16 * HWs;
     const int cmax = kC - chunk * 16 - 1;           // last valid channel of this chunk
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
       const int ch = min((tid + 256 * i) / (G::ROWS * (G::TWI / 4)), cmax);
       const float* p = src + ch * HWs + vg[i];
-      if (kmode == KV_PLAIN) {
+      if constexpr (kmode == KV_PLAIN) {
         pv[i] = *reinterpret_cast<const float4*>(p);
-      } else {
+      } else {                                       // raw pair; expanded to (x, 0, y, 0) at commit time
         const float2 t = *reinterpret_cast<const float2*>(p);
-        pv[i] = kmode == KV_NEAREST2 ? make_float4(t.x, t.x, t.y, t.y) : make_float4(t.x, 0.f, t.y, 0.f);
+        pv[i].x = t.x; pv[i].y = t.y;
       }
     }
     if (halo_live) {
@@ -187,13 +206,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       }
     }
   };
-  auto commit = [&](int chunk, int buf) {
+  auto commit = [&](int chunk, int buf, const float4 (&pv)[G::NPV], const float (&ph)[NPHS]) {
     float* t = tile + buf * (G::KC * G::CS);
     const int crem = kC - chunk * 16;
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
       if (vl[i] >= 0) {
-        float4 z = pv[i];
+        float4 z = kmode == KV_PLAIN ? pv[i] : make_float4(pv[i].x, 0.f, pv[i].y, 0.f);
         const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
         const bool ok = ((vrow >> i) & 1u) && ch < crem;
         if (MODE == MODE_FWD) {
@@ -239,66 +258,94 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 #pragma unroll
     for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  __syncthreads();                 // cf visible
-  commit(0, 0);
-  __syncthreads();
-
+  TR(1);
   const int a_lane = (lane >> 4) * G::CS + (lane & 15) * S;
   // B operand: packed image [(kstep*KK + tap)*ntp + nt][64] (ntp = N-tiles padded to a multiple of 8 with
-  // zero tiles, so no bounds test is needed), one coalesced load per (tap, N-tile).  Rolling register
-  // prefetch: while k-step s is on the matrix pipe the loads of the next k-step (of this chunk or the
-  // first one of the next chunk) are in flight.
-  constexpr bool PREFB = (KK * NT_W <= 25);
-  float bcur[KK][NT_W];
+  // zero tiles, so no bounds test is needed), one coalesced load per (tap, N-tile), held in two register
+  // sets: while k-step s runs on the matrix pipe from one set, the next k-step streams into the other.
+  static_assert(KK * NT_W <= 25, "two B register sets must fit");
+  const int wks = WAVES_K == 4 ? __builtin_amdgcn_readfirstlane(wk) : 0;    // wave-uniform -> SGPR
+  const int ksteps = kpad / 4;
+  float bA[KK][NT_W], bB[KK][NT_W];
   auto load_b = [&](int kstep, float (&dst)[KK][NT_W]) {
-    const float* wp = wm + ((size_t)kstep * KK * ntp + nt_base) * 64 + lane;
+    const float* wp = wm + ((size_t)min(kstep, ksteps - 1) * KK * ntp + nt_base) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < KK; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT_W; ++nt) dst[t][nt] = wp[(size_t)(t * ntp + nt) * 64];
   };
-  if (PREFB) load_b(WAVES_K == 4 ? wk : 0, bcur);
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const int buf = chunk & 1;
-    if (chunk + 1 < nchunk) issue(chunk + 1);
-    const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
+  auto mfma_kstep = [&](const float* tk, const float (&bw)[KK][NT_W]) {
 #pragma unroll
-    for (int s = 0; s < KSW; ++s) {
-      const int kstep = chunk * 4 + (WAVES_K == 4 ? wk : s);
-      const int knext = (s + 1 < KSW) ? kstep + 1 : (chunk + 1) * 4 + (WAVES_K == 4 ? wk : 0);
-      float bnx[PREFB ? KK : 1][NT_W];
-      const bool more = PREFB && knext * 4 < kpad;
-      if constexpr (PREFB) { if (more) load_b(knext, bnx); }
-      if (kstep * 4 < kC) {                     // wave-uniform: skip k-steps entirely in the zero padding
-        if constexpr (!PREFB) load_b(kstep, bcur);
-        const float* tk = tb + (WAVES_K == 4 ? wk : s) * 4 * G::CS;
+    for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
+      for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-          for (int kx = 0; kx < KS; ++kx) {
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = tk[((mt / TWG) * S + ky) * G::LDW + (G::COL0 - G::PADL) + (mt % TWG) * 16 * S + kx];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              const float a = tk[((mt / TWG) * S + ky) * G::LDW + (G::COL0 - G::PADL) + (mt % TWG) * 16 * S + kx];
-#pragma unroll
-              for (int nt = 0; nt < NT_W; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
-            }
-          }
-      }
-      if constexpr (PREFB) {
-        if (more) {
-#pragma unroll
-          for (int t = 0; t < KK; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT_W; ++nt) bcur[t][nt] = bnx[t][nt];
+          for (int nt = 0; nt < NT_W; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ky * KS + kx][nt], acc[mt][nt], 0, 0, 0);
         }
       }
+  };
+
+  // The loop body below is straight-line (every global load is unconditional, indices are clamped
+  // instead): vmcnt is an in-order counter, and only without divergent paths can the compiler wait for
+  // exactly the loads a k-step needs instead of draining the prefetches that were just issued.
+  load_b(wks, bA);
+  issue(0, pvA, phA);
+  issue(min(1, nchunk - 1), pvB, phB);
+  __syncthreads();                 // cf visible
+  TR(2);
+  commit(0, 0, pvA, phA);
+  __syncthreads();
+  TR(3);
+
+  // one chunk: `pf`/`hf` = the (free) register stage that receives chunk+2, `pc`/`hc` = the stage holding
+  // chunk+1; `b0` holds the weights of this chunk's first k-step, `b1` is the other weight set
+  auto step = [&](int chunk, float4 (&pf)[G::NPV], float (&hf)[NPHS], const float4 (&pc)[G::NPV],
+                  const float (&hc)[NPHS], float (&b0)[KK][NT_W], float (&b1)[KK][NT_W]) {
+    const int buf = chunk & 1;
+#ifdef PDES_TRACE
+    tt = wall_clock64();
+#endif
+    const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
+    if constexpr (WAVES_K == 4) {
+      load_b((chunk + 1) * 4 + wks, b1);
+      issue(min(chunk + 2, nchunk - 1), pf, hf);
+      mfma_kstep(tb + wks * 4 * G::CS, b0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        load_b(chunk * 4 + s + 1, (s & 1) ? b0 : b1);
+        if (s == 0) issue(min(chunk + 2, nchunk - 1), pf, hf);
+        if ((chunk * 4 + s) * 4 < kC)            // scalar: skip k-steps that lie entirely in the zero padding
+          mfma_kstep(tb + s * 4 * G::CS, (s & 1) ? b1 : b0);
+      }
     }
-    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1);
+    TRACC(8, tt);      // issue + MFMAs
+#ifdef PDES_TRACE
+    tt = wall_clock64();
+#endif
+    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, pc, hc);
+    TRACC(9, tt);      // commit
+#ifdef PDES_TRACE
+    tt = wall_clock64();
+#endif
     __syncthreads();
+    TRACC(10, tt);     // barrier wait
+  };
+  {
+    int chunk = 0;
+    for (; chunk + 1 < nchunk; chunk += 2) {
+      step(chunk, pvA, phA, pvB, phB, bA, bB);
+      if constexpr (WAVES_K == 4) step(chunk + 1, pvB, phB, pvA, phA, bB, bA);
+      else step(chunk + 1, pvB, phB, pvA, phA, bA, bB);
+    }
+    if (chunk < nchunk) step(chunk, pvA, phA, pvB, phB, bA, bB);
   }
 
+  TR(4);
   // ---- combine the K-split partial sums: wave w ends up owning M-tiles [w*MT/4, (w+1)*MT/4)
   constexpr int MT_OWN = (WAVES_K == 4) ? MT / 4 : MT;
   const int mt0 = (WAVES_K == 4) ? MT_OWN * wave : 0;
@@ -320,6 +367,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       }
   }
 
+  TR(5);
   const int HWo = Hout * Wout;
   const int px = (lane >> 4) * 4;              // first of the lane's 4 consecutive pixels in the M-tile
   if (MODE == MODE_FWD) {
@@ -363,8 +411,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       }
     }
   } else {
-    // data gradient epilogue.  With upsample the 2x2 hi-res results of one stored pixel are summed:
-    // horizontally inside the float4, vertically between M-tiles mt and mt+TWG (rows oy, oy+1).
+    // data gradient epilogue (nearest-x2 layers run on the sub-pixel kernels of conv_mfma_up.hip)
     const int HWi = d.Hin * d.Win;
     const float* xb = d.x + (size_t)b * d.x_ctot * HWi;
     float* tb2 = d.t_in + (size_t)b * d.x_ctot * HWi;
@@ -376,7 +423,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
         const BnC k = bn_coef_m(d, ci);
         const float scale = k.gamma * k.invstd;
         const bool fin = ci >= d.final_c0 && ci < d.final_c1;
-        if (!d.upsample) {
+        {
 #pragma unroll
           for (int j = 0; j < MT_OWN; ++j) {
             const int mt = mt0 + j;
@@ -397,31 +444,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
             }
             *reinterpret_cast<float4*>(tb2 + idx) = make_float4(ts[0], ts[1], ts[2], ts[3]);
           }
-        } else if (WAVES_K == 1 && (MT / TWG) % 2 == 0) {
-          // rows come in pairs (mt, mt+TWG): needs every M-tile in this wave and an even tile height
-#pragma unroll
-          for (int j = 0; j < MT; ++j) {
-            if ((j / TWG) & 1) continue;                      // odd rows are folded into the even row above
-            const v4f v0 = acc[j][nt], v1 = acc[(j + TWG < MT) ? j + TWG : j][nt];
-            const float lo = (v0[0] + v0[1]) + (v1[0] + v1[1]);
-            const float hi = (v0[2] + v0[3]) + (v1[2] + v1[3]);
-            const int iy = (oy0 + j / TWG) >> 1, ix = (ox0 + (j % TWG) * 16 + px) >> 1;
-            const size_t idx = (size_t)ci * HWi + (size_t)iy * d.Win + ix;
-            const float2 xv = *reinterpret_cast<const float2*>(xb + idx);
-            float2 tv = d.t_accumulate ? *reinterpret_cast<const float2*>(tb2 + idx) : make_float2(0.f, 0.f);
-            const float xs[2] = {xv.x, xv.y}, vv[2] = {lo, hi};
-            float ts[2] = {tv.x, tv.y};
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              const float y = (xs[r] - k.mean) * scale + k.beta;
-              const float xh = (xs[r] - k.mean) * k.invstd;
-              const float dyv = (y > 0.f) ? vv[r] : 0.f;
-              db += dyv; dg += dyv * xh;
-              ts[r] += k.gamma * dyv;
-              if (fin) { st += ts[r]; sx += ts[r] * xh; }
-            }
-            *reinterpret_cast<float2*>(tb2 + idx) = make_float2(ts[0], ts[1]);
-          }
         }
       }
       dg += __shfl_xor(dg, 16, 64); dg += __shfl_xor(dg, 32, 64);
@@ -439,6 +461,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       }
     }
   }
+  TR(6);
+#ifdef PDES_TRACE
+  if (trace_on) { pdes_trace_buf[8] = tacc[0]; pdes_trace_buf[9] = tacc[1]; pdes_trace_buf[10] = tacc[2]; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,11 +495,12 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const pdes_mfma_pack_ite
 // (W, H) = size of the map the kernel tiles: the output map (forward) or the input map (data gradient)
 static bool mfma_shape_ok(const pdes_conv_desc& d, bool bwd, int* W, int* H) {
   if (!(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.pad != (d.ksize - 1) / 2) return false;
-  if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample && d.Hin == 2 * d.Hout && d.Win == 2 * d.Wout))
+  if (d.upsample) return false;     // conv_mfma_up.hip (sub-pixel form) or the direct kernels
+  if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && d.Hin == 2 * d.Hout && d.Win == 2 * d.Wout))
     return false;
   if (!d.has_bn) return false;
-  *W = bwd ? (d.upsample ? 2 * d.Win : d.Win) : d.Wout;
-  *H = bwd ? (d.upsample ? 2 * d.Hin : d.Hin) : d.Hout;
+  *W = bwd ? d.Win : d.Wout;
+  *H = bwd ? d.Hin : d.Hout;
   if (*W % 16 || (*W >= 32 && *W % 32)) return false;
   const int twg = *W >= 32 ? 2 : 1;
   return *H % (8 / twg) == 0;
@@ -484,7 +511,7 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <int KS, int S, int MODE>
+template <int KS, int S, int MODE, int KM>
 static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st) {
   const bool bwd = MODE == MODE_BWD;
   const int kC = bwd ? d.Cout : d.Cin, nC = bwd ? d.Cin : d.Cout;
@@ -496,15 +523,13 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (nt_total == 1) { wk = 4; ntw = 1; }
   else if (kpad <= 16 || nt_total <= 4) { wk = 1; ntw = 1; gz = (nt_total + 3) / 4; }   // cheap staging: split N over z
   else { wk = 1; ntw = 2; gz = (nt_total + 7) / 8; }
-  if (wk == 1 && ntw == 2 && env_int("PDES_MFMA_NTW", 2) == 1) { ntw = 1; gz = (nt_total + 3) / 4; }   // tuning knob
-  const bool up_bwd = bwd && d.upsample;
-  if (up_bwd && wk == 4) return PDES_ENOSUP;            // K-split waves do not own both rows of a 2x2 pair
+  if (wk == 1 && ntw == 2 && (KS == 5 || env_int("PDES_MFMA_NTW", 2) == 1)) { ntw = 1; gz = (nt_total + 3) / 4; }
   // M-tiles per workgroup: 8, or 4 when that is needed to put >= 1 workgroup on every CU
   int mt = 8;
   const long long wg8 = (long long)(W / (16 * twg)) * (H / (8 / twg)) * d.B * gz;
   if (wg8 < 256) mt = 4;
   mt = env_int("PDES_MFMA_MT", mt);
-  if (!(mt == 8 || mt == 4) || up_bwd || KS == 5 || S == 2) mt = 8;
+  if (!(mt == 8 || mt == 4) || KS == 5 || S == 2) mt = 8;
   const int th = mt / twg;
   if (H % th) return PDES_ENOSUP;
   dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
@@ -518,14 +543,15 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     const size_t red = cf_f + (size_t)4 * MT_ * 4 * 64 + 128;                                                 \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \
     lds = fl * sizeof(float);                                                                                 \
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE>), grid, block, lds, st, d, wm,    \
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM>), grid, block, lds, st, d, wm, \
                        nt_total);                                                                             \
     rc = PDES_OK;                                                                                             \
   }
   if constexpr (S == 1) {
-    PDES_TRY(2, 8, 4, 1) PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2)
-    PDES_TRY(1, 8, 4, 1) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)
+    PDES_TRY(2, 8, 4, 1) PDES_TRY(2, 8, 1, 1)
+    PDES_TRY(1, 8, 4, 1) PDES_TRY(1, 8, 1, 1)
     if constexpr (KS != 5) {
+      PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 2)
       PDES_TRY(2, 4, 4, 1) PDES_TRY(2, 4, 1, 1) PDES_TRY(2, 4, 1, 2)
       PDES_TRY(1, 4, 4, 1) PDES_TRY(1, 4, 1, 1) PDES_TRY(1, 4, 1, 2)
     }
@@ -545,26 +571,32 @@ int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st) {
   if (!d.wm_fwd || !mfma_shape_ok(d, false, &W, &H) || d.Cin < 16) return PDES_ENOSUP;
   if (d.stride == 2) {
     if ((d.Cout + 15) / 16 == 1) return PDES_ENOSUP;
-    return launch_mfma<3, 2, MODE_FWD>(d, d.wm_fwd, W, H, st);
+    return launch_mfma<3, 2, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st);
   }
-  if (d.ksize == 5) return d.upsample ? PDES_ENOSUP : launch_mfma<5, 1, MODE_FWD>(d, d.wm_fwd, W, H, st);
-  return d.ksize == 3 ? launch_mfma<3, 1, MODE_FWD>(d, d.wm_fwd, W, H, st)
-                      : launch_mfma<1, 1, MODE_FWD>(d, d.wm_fwd, W, H, st);
+  if (d.ksize == 5) return launch_mfma<5, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st);
+  return d.ksize == 3 ? launch_mfma<3, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st)
+                      : launch_mfma<1, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st);
 }
 
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st) {
   int W, H;
   if (!d.wm_bwd || !mfma_shape_ok(d, true, &W, &H) || d.eval_mode) return PDES_ENOSUP;
-  if (d.upsample && d.ksize != 3) return PDES_ENOSUP;
   // a stride-2 convolution's data gradient is the unit-stride gather over the zero-inserted dL/d(out)
-  if (d.ksize == 5) return launch_mfma<5, 1, MODE_BWD>(d, d.wm_bwd, W, H, st);
-  return d.ksize == 3 ? launch_mfma<3, 1, MODE_BWD>(d, d.wm_bwd, W, H, st)
-                      : launch_mfma<1, 1, MODE_BWD>(d, d.wm_bwd, W, H, st);
+  if (d.stride == 2) return launch_mfma<3, 1, MODE_BWD, KV_ZEROINS2>(d, d.wm_bwd, W, H, st);
+  if (d.ksize == 5) return launch_mfma<5, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st);
+  return d.ksize == 3 ? launch_mfma<3, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st)
+                      : launch_mfma<1, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st);
 }
 
 }  // namespace pdes
 
 using namespace pdes;
+
+#ifdef PDES_TRACE
+extern "C" int pdes_debug_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pdes_trace_buf), 16 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int pdes_pack_weights_mfma(const pdes_mfma_pack_item* items, int n, int max_elems, void* stream) {
   if (!items || n <= 0 || max_elems <= 0) return PDES_EINVAL;

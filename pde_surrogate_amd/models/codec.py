@@ -14,6 +14,7 @@ hand-written HIP kernels through the C ABI (include/pdes_hip.h) instead of aten 
 There is no CPU implementation: inputs must be CUDA (ROCm) tensors.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -34,7 +35,7 @@ class ConvDesc(ctypes.Structure):
         ('gamma', _P), ('beta', _P), ('x_stats', _P), ('run_mean', _P), ('run_var', _P),
         ('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('cout_pad', _I), ('cin_pad', _I),
         ('wm_fwd', _P), ('wm_bwd', _P), ('wu_fwd', _P), ('wu_bwd', _P),
-        ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P),
+        ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P), ('fin_xstats', _P), ('fin_tstats', _P),
         ('g', _P), ('g_ctot', _I), ('g_coff', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
         ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
@@ -297,6 +298,7 @@ class _Engine:
             d.out_ctot, d.out_coff = bufs[s.dst][0], s.dst_coff
             if s.dst != 'out':
                 d.out_stats = xs(s.dst)
+                d.fin_xstats, d.fin_tstats = xs(s.dst), ts(s.dst)
                 d.g = self.T[s.dst].data_ptr()      # finalised in place before use
                 d.g_ctot, d.g_coff = bufs[s.dst][0], s.dst_coff
             else:
@@ -347,6 +349,11 @@ class _Engine:
             arr = (ReduceItem * len(items))(*items)
             self._reduce_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
 
+    def _side_stream(self):
+        if not hasattr(self, '_side'):
+            self._side = torch.cuda.Stream(self.dev)
+        return self._side
+
     # -- launches -------------------------------------------------------------------------------
     def forward(self, x, training):
         L, st = _lib.lib(), _lib.stream_ptr()
@@ -374,22 +381,13 @@ class _Engine:
         if not hasattr(self, '_reduce_n'):
             self._plan_wgrad_scratch()
         self.descs[n - 1].g = grad_y.data_ptr()
-        specs, bufs = self.net._specs, self.net._bufs
-        one = ConvDesc * 1
-        for i in range(n - 1, -1, -1):
-            s, d = specs[i], self.descs[i]
-            if s.dst != 'out':
-                h, w = self.buf_hw[s.dst]
-                os_ = self._out_stats[i]
-                rc = L.pdes_bn_backward_finalize(self.T[s.dst].data_ptr(), self.X[s.dst].data_ptr(),
-                                                 os_, os_ + 8 * self.n_xstat,
-                                                 self.B, bufs[s.dst][0], s.dst_coff, s.dst_coff + s.cout, h * w,
-                                                 ctypes.c_float(1e-5), self.nrep, self.rep_stride, st)
-                _lib.check(rc, 'pdes_bn_backward_finalize')
-            ref = ctypes.byref(d)
-            _lib.check(L.pdes_conv_backward_weight(ref, 1, st), 'pdes_conv_backward_weight')
-            if s.norm is not None:
-                _lib.check(L.pdes_conv_backward_data(ref, 1, st), 'pdes_conv_backward_data')
+        # Weight gradients hang off the finalize -> dgrad chain (nothing reads them before the single
+        # reduce at the end), so pdes_backward runs them on a second HIP stream.  Not under hipGraph
+        # capture: the runtime serialises forked graph branches with heavier barriers than it saves.
+        side = None
+        if os.environ.get('PDES_WGRAD_STREAM', '1') != '0' and not torch.cuda.is_current_stream_capturing():
+            side = ctypes.c_void_p(self._side_stream().cuda_stream)
+        _lib.check(L.pdes_backward(self.descs, n, st, side), 'pdes_backward')
         if self._reduce_n:
             _lib.check(L.pdes_wgrad_reduce_all(self._reduce_table.data_ptr(), self._reduce_n, self._reduce_max, st),
                        'pdes_wgrad_reduce_all')
