@@ -85,7 +85,7 @@ __device__ unsigned long long pdes_trace_buf[16];
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-inserted x2 (stride-2 data gradient)
 
-template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM>
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                        int nt_total) {
   using G = TileGeo<KS, TWG, MT, S>;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   // exactly the loads a k-step needs instead of draining the prefetches that were just issued.
   load_b(wks, bA);
   issue(0, pvA, phA);
-  issue(min(1, nchunk - 1), pvB, phB);
+  if (nchunk > 1) issue(1, pvB, phB);
   __syncthreads();                 // cf visible
   TR(2);
   commit(0, 0, pvA, phA);
@@ -312,13 +312,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
     if constexpr (WAVES_K == 4) {
       load_b((chunk + 1) * 4 + wks, b1);
-      issue(min(chunk + 2, nchunk - 1), pf, hf);
+      if constexpr (PIPE) issue(min(chunk + 2, nchunk - 1), pf, hf);
       mfma_kstep(tb + wks * 4 * G::CS, b0);
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         load_b(chunk * 4 + s + 1, (s & 1) ? b0 : b1);
-        if (s == 0) issue(min(chunk + 2, nchunk - 1), pf, hf);
+        if constexpr (PIPE) { if (s == 0) issue(min(chunk + 2, nchunk - 1), pf, hf); }
         if ((chunk * 4 + s) * 4 < kC)            // scalar: skip k-steps that lie entirely in the zero padding
           mfma_kstep(tb + s * 4 * G::CS, (s & 1) ? b1 : b0);
       }
@@ -515,7 +515,7 @@ template <int KS, int S, int MODE, int KM>
 static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st) {
   const bool bwd = MODE == MODE_BWD;
   const int kC = bwd ? d.Cout : d.Cin, nC = bwd ? d.Cin : d.Cout;
-  const int kpad = (kC + 15) & ~15;
+  const int kpad = (kC + 15) & ~15, nchunk = kpad / 16;
   const int nt_total = (nC + 15) / 16;
   const int twg = W >= 32 ? 2 : 1;
   // wave roles
@@ -543,8 +543,12 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     const size_t red = cf_f + (size_t)4 * MT_ * 4 * 64 + 128;                                                 \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \
     lds = fl * sizeof(float);                                                                                 \
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM>), grid, block, lds, st, d, wm, \
-                       nt_total);                                                                             \
+    if (MODE == MODE_FWD || nchunk > 2)                                                                       \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true>), grid, block, lds, st, d, wm, \
+                         nt_total);                                                                           \
+    else if constexpr (MODE == MODE_BWD)       /* <= 2 chunks (dense layers: 16 gradient channels): no 2-ahead prefetch */ \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false>), grid, block, lds, st, d, wm, \
+                         nt_total);                                                                           \
     rc = PDES_OK;                                                                                             \
   }
   if constexpr (S == 1) {

@@ -36,20 +36,19 @@ struct WGeo {
   static_assert(CS % 32 == 2 && GS % 32 == 2 && CS >= ROWS * LDW && NR >= 0, "LDS geometry");
 };
 
-template <int KS, int TWG, int NTW, int S>
+template <int KS, int TWG, int NTW, int S, bool PIPE>     // PIPE: > 2 pixel tiles per workgroup, prefetch two ahead
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                              int n_ngroups) {
   using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS;
   constexpr int NPG4 = 16 * NTW * G::TH * G::TW / 4 / 256;      // g float4 per thread per tile
-  const float NANF = __int_as_float(0x7fc00000);
-  constexpr int KSTEPS = G::TH * G::TW / 4 / 4;                // k-steps per wave per tile (8)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* zt = smem;                                            // [16][CS]
-  float* gt = smem + 16 * G::CS;                               // [16*NTW][GS]
+  constexpr int LDSB = 16 * G::CS + 16 * NTW * G::GS;           // one buffer: z image then g image
+  float* zt = smem;                                            // [2][ [16][CS] | [16*NTW][GS] ]
+  float* gt = smem + 16 * G::CS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Hc = d.upsample ? 2 * d.Hin : d.Hin, Wc = d.upsample ? 2 * d.Win : d.Win;   // conv-input size
+  const int Hc = d.Hin, Wc = d.Win;                             // conv-input size (nearest-x2: the _up kernel)
   const int tiles_x = d.Wout / G::TW, tps = tiles_x * (d.Hout / G::TH);                 // tiles of the OUTPUT map
   const int groups = tps / tpw;
   const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
@@ -83,9 +82,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
 
   const bool halo_live = (G::NL + G::NR) > 0 && tiles_x > 1;
-  float4 pv[G::NPV], pg[NPG4];
-  float ph[G::NPH > 0 ? G::NPH : 1];
-  auto issue = [&](int tile) {
+  // Register stages hold RAW loads (addresses clamped into the image, no select on the loaded value):
+  // anything that consumes a load right after issuing it would drain vmcnt and serialise the prefetch
+  // with the matrix work.  Validity is applied when a stage is committed to LDS.
+  constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
+  struct Stage { float4 pv[G::NPV]; float4 pg[NPG4]; float ph[NPHS]; };
+  Stage sA, sB;
+  auto issue = [&](int tile, Stage& st) __attribute__((always_inline)) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
@@ -93,18 +96,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
       const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
       const int cy = oy0 * S - G::PADL + r, cx = ox0 * S + 4 * j;
-      const bool v = e < G::NV4 && ch < crem && cy >= 0 && cy < Hc;
-      // unconditional load from a clamped (always valid) address; NaN marks "outside" afterwards
-      // (it must become 0 in LDS, not relu(bn(0)))
       const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hc - 1);
-      float4 x;
-      if (d.upsample) {
-        const float2 t = *reinterpret_cast<const float2*>(xb + (size_t)chc * HWi + (cyc >> 1) * d.Win + (cx >> 1));
-        x = make_float4(t.x, t.x, t.y, t.y);
-      } else {
-        x = *reinterpret_cast<const float4*>(xb + (size_t)chc * HWi + cyc * d.Win + cx);
-      }
-      pv[i] = v ? x : make_float4(NANF, NANF, NANF, NANF);
+      st.pv[i] = *reinterpret_cast<const float4*>(xb + (size_t)chc * HWi + cyc * d.Win + cx);
     }
     if (halo_live) {
 #pragma unroll
@@ -114,11 +107,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
         const int r = rem / G::NHC, h = rem % G::NHC;
         const int cy = oy0 * S - G::PADL + r;
         const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
-        const bool v = e < G::NH && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
         const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hc - 1), cxc = min(max(cx, 0), Wc - 1);
-        const int sy = d.upsample ? (cyc >> 1) : cyc, sx = d.upsample ? (cxc >> 1) : cxc;
-        const float xv = xb[(size_t)chc * HWi + sy * d.Win + sx];
-        ph[i] = v ? xv : NANF;
+        st.ph[i] = xb[(size_t)chc * HWi + cyc * d.Win + cxc];
       }
     }
 #pragma unroll
@@ -126,24 +116,28 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       const int e = tid + 256 * i;                          // float4 index: channel-major, then pixel
       const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
       const int oy = oy0 + (4 * p4) / G::TW, ox = ox0 + (4 * p4) % G::TW;
-      const float4 gv = *reinterpret_cast<const float4*>(gb + (size_t)min(ch, corem - 1) * HWo + oy * d.Wout + ox);
-      pg[i] = ch < corem ? gv : make_float4(0.f, 0.f, 0.f, 0.f);
+      st.pg[i] = *reinterpret_cast<const float4*>(gb + (size_t)min(ch, corem - 1) * HWo + oy * d.Wout + ox);
     }
   };
-  auto bnrelu = [&](float x, int ch) {
-    return (x != x) ? 0.f : fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]);
+  auto bnrelu = [&](float x, int ch, bool ok) __attribute__((always_inline)) {
+    return ok ? fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]) : 0.f;
   };
-  auto commit = [&]() {
+  auto commit = [&](int tile, int buf, const Stage& st) __attribute__((always_inline)) {
+    const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
+    float* ztb = zt + buf * LDSB;
+    float* gtb = gt + buf * LDSB;
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
       const int e = tid + 256 * i;
       if (e < G::NV4) {
         const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
         const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
-        float* dst = zt + ch * G::CS + r * G::LDW + G::COL0 + 4 * j;      // 8-byte aligned
-        const float4 x = pv[i];
-        *reinterpret_cast<float2*>(dst) = make_float2(bnrelu(x.x, ch), bnrelu(x.y, ch));
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(bnrelu(x.z, ch), bnrelu(x.w, ch));
+        const int cy = oy0 * S - G::PADL + r;
+        const bool ok = ch < crem && cy >= 0 && cy < Hc;       // outside the image: 0, not relu(bn(0))
+        float* dst = ztb + ch * G::CS + r * G::LDW + G::COL0 + 4 * j;      // 8-byte aligned
+        const float4 x = st.pv[i];
+        *reinterpret_cast<float2*>(dst) = make_float2(bnrelu(x.x, ch, ok), bnrelu(x.y, ch, ok));
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(bnrelu(x.z, ch, ok), bnrelu(x.w, ch, ok));
       }
     }
 #pragma unroll
@@ -152,17 +146,21 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       if (e < G::NH) {
         const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
         const int r = rem / G::NHC, h = rem % G::NHC;
+        const int cy = oy0 * S - G::PADL + r;
+        const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
+        const bool ok = halo_live && ch < crem && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
         const int lc = h < G::NL ? G::COL0 - G::NL + h : G::COL0 + G::TWI + (h - G::NL);
-        zt[ch * G::CS + r * G::LDW + lc] = halo_live ? bnrelu(ph[i], ch) : 0.f;
+        ztb[ch * G::CS + r * G::LDW + lc] = bnrelu(st.ph[i], ch, ok);
       }
     }
 #pragma unroll
     for (int i = 0; i < NPG4; ++i) {
       const int e = tid + 256 * i;
       const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
-      float* dst = gt + ch * G::GS + 4 * p4;                               // 8-byte aligned (GS even)
-      *reinterpret_cast<float2*>(dst) = make_float2(pg[i].x, pg[i].y);
-      *reinterpret_cast<float2*>(dst + 2) = make_float2(pg[i].z, pg[i].w);
+      const bool ok = ch < corem;
+      float* dst = gtb + ch * G::GS + 4 * p4;                               // 8-byte aligned (GS even)
+      *reinterpret_cast<float2*>(dst) = ok ? make_float2(st.pg[i].x, st.pg[i].y) : make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(dst + 2) = ok ? make_float2(st.pg[i].z, st.pg[i].w) : make_float2(0.f, 0.f);
     }
   };
 
@@ -178,12 +176,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   const int b_lane = (lane & 15) * G::GS + (lane >> 4);       // B: j = co, k = pixel offset
 
   const int tile0 = tg * tpw;
-  issue(tile0);
-  __syncthreads();                 // cf visible
-  for (int tt = 0; tt < tpw; ++tt) {
-    commit();
-    __syncthreads();
-    if (tt + 1 < tpw) issue(tile0 + tt + 1);
+  auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
+    const float* ztb = zt + buf * LDSB;
+    const float* gtb = gt + buf * LDSB;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = wave * RPW + rr;
@@ -191,19 +186,49 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       for (int ks = 0; ks < G::TW / 4; ++ks) {
         float bv[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) bv[nt] = gt[b_lane + nt * 16 * G::GS + row * G::TW + 4 * ks];
+        for (int nt = 0; nt < NTW; ++nt) bv[nt] = gtb[b_lane + nt * 16 * G::GS + row * G::TW + 4 * ks];
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
-            const float a = zt[a_lane + (row * S + ky) * G::LDW + (G::COL0 - G::PADL) + 4 * ks * S + kx];
+            const float a = ztb[a_lane + (row * S + ky) * G::LDW + (G::COL0 - G::PADL) + 4 * ks * S + kx];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
               acc[ky * KS + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[ky * KS + kx][nt], 0, 0, 0);
           }
       }
     }
-    __syncthreads();               // every wave is done with the LDS images before the next commit
+  };
+  if constexpr (!PIPE) {
+    // <= 2 tiles per workgroup: one register stage, one LDS buffer (smaller footprint -> more resident workgroups)
+    issue(tile0, sA);
+    __syncthreads();               // cf visible
+    for (int tt = 0; tt < tpw; ++tt) {
+      commit(tile0 + tt, 0, sA);
+      __syncthreads();
+      if (tt + 1 < tpw) issue(tile0 + tt + 1, sA);
+      mfma_tile(0);
+      __syncthreads();             // every wave is done with the LDS images before the next commit
+    }
+  } else {
+    // double-buffered LDS images, two register stages: tile t+2 is requested before the MFMAs of tile t.
+    // The request is unconditional (index clamped): a runtime test would merge wait states at the join and
+    // over-wait, and peeled copies of the loop body cost registers (occupancy) -- both measured slower.
+    issue(tile0, sA);
+    issue(tile0 + 1, sB);
+    __syncthreads();               // cf visible
+    commit(tile0, 0, sA);
+    __syncthreads();
+    auto step = [&](int tt, Stage& sfree, const Stage& snext) __attribute__((always_inline)) {
+      const int buf = tt & 1;
+      issue(tile0 + min(tt + 2, tpw - 1), sfree);
+      mfma_tile(buf);
+      if (tt + 1 < tpw) commit(tile0 + tt + 1, buf ^ 1, snext);
+      __syncthreads();
+    };
+    int tt = 0;
+    for (; tt + 1 < tpw; tt += 2) { step(tt, sA, sB); step(tt + 1, sB, sA); }
+    if (tt < tpw) step(tt, sA, sB);
   }
 
   // ---- sum the 4 waves through LDS, then write this pixel split's partial dW
@@ -249,8 +274,6 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
   const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
   const int mtile = blockIdx.y / n_ngroups, ng = blockIdx.y % n_ngroups;
   const int ci0 = mtile * 16, co0 = ng * 16 * NTW;
-  const float NANF = __int_as_float(0x7fc00000);
-
   __shared__ float cf[16][3];
   if (tid < 16) {
     const int c = ci0 + tid;
@@ -274,9 +297,11 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
   const bool halo_live = tiles_x > 1;
 
-  float4 pv[G::NPV], pg0[NPG], pg1[NPG];
+  // raw loads only (clamped addresses, no select on loaded values: see conv_mfma_wgrad_kernel); validity and
+  // the parity de-interleave happen when the registers are committed to LDS
+  float4 pv[G::NPV], ph0[NPG], ph1[NPG];
   float ph[G::NPH];
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile) __attribute__((always_inline)) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
@@ -284,10 +309,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
       const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
       const int cy = oy0 - 1 + r, cx = ox0 + 4 * j;
-      const bool v = e < G::NV4 && ch < crem && cy >= 0 && cy < Hl;
       const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hl - 1);
-      const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)chc * HWl + cyc * Wl + cx);
-      pv[i] = v ? x : make_float4(NANF, NANF, NANF, NANF);
+      pv[i] = *reinterpret_cast<const float4*>(xb + (size_t)chc * HWl + cyc * Wl + cx);
     }
     if (halo_live) {
 #pragma unroll
@@ -296,10 +319,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
         const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
         const int r = rem / G::NHC, h = rem % G::NHC;
         const int cy = oy0 - 1 + r, cx = h == 0 ? ox0 - 1 : ox0 + G::TW;
-        const bool v = e < G::NH && ch < crem && cy >= 0 && cy < Hl && cx >= 0 && cx < Wl;
         const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hl - 1), cxc = min(max(cx, 0), Wl - 1);
-        const float xv = xb[(size_t)chc * HWl + cyc * Wl + cxc];
-        ph[i] = v ? xv : NANF;
+        ph[i] = xb[(size_t)chc * HWl + cyc * Wl + cxc];
       }
     }
 #pragma unroll
@@ -309,26 +330,27 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       const int ch = q / (NPX / 4), p4 = q % (NPX / 4);
       const int y = oy0 + (4 * p4) / G::TW, x = ox0 + (4 * p4) % G::TW;
       const float* src = gb + (size_t)min(ch, corem - 1) * HWh + (size_t)(2 * y + dy) * Wh + 2 * x;
-      const float4 h0 = *reinterpret_cast<const float4*>(src), h1 = *reinterpret_cast<const float4*>(src + 4);
-      const bool v = ch < corem;
-      pg0[i] = v ? make_float4(h0.x, h0.z, h1.x, h1.z) : make_float4(0.f, 0.f, 0.f, 0.f);   // dx = 0
-      pg1[i] = v ? make_float4(h0.y, h0.w, h1.y, h1.w) : make_float4(0.f, 0.f, 0.f, 0.f);   // dx = 1
+      ph0[i] = *reinterpret_cast<const float4*>(src);
+      ph1[i] = *reinterpret_cast<const float4*>(src + 4);
     }
   };
-  auto bnrelu = [&](float x, int ch) {
-    return (x != x) ? 0.f : fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]);
+  auto bnrelu = [&](float x, int ch, bool ok) __attribute__((always_inline)) {
+    return ok ? fmaxf(0.f, (x - cf[ch][0]) * cf[ch][1] + cf[ch][2]) : 0.f;
   };
-  auto commit = [&]() {
+  auto commit = [&](int tile) __attribute__((always_inline)) {
+    const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
       const int e = tid + 256 * i;
       if (e < G::NV4) {
         const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
         const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
+        const int cy = oy0 - 1 + r;
+        const bool ok = ch < crem && cy >= 0 && cy < Hl;
         float* dst = zt + ch * G::CS + r * G::LDW + G::COL0 + 4 * j;
         const float4 x = pv[i];
-        *reinterpret_cast<float2*>(dst) = make_float2(bnrelu(x.x, ch), bnrelu(x.y, ch));
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(bnrelu(x.z, ch), bnrelu(x.w, ch));
+        *reinterpret_cast<float2*>(dst) = make_float2(bnrelu(x.x, ch, ok), bnrelu(x.y, ch, ok));
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(bnrelu(x.z, ch, ok), bnrelu(x.w, ch, ok));
       }
     }
 #pragma unroll
@@ -337,7 +359,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       if (e < G::NH) {
         const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
         const int r = rem / G::NHC, h = rem % G::NHC;
-        zt[ch * G::CS + r * G::LDW + (h == 0 ? G::COL0 - 1 : G::COL0 + G::TW)] = halo_live ? bnrelu(ph[i], ch) : 0.f;
+        const int cy = oy0 - 1 + r, cx = h == 0 ? ox0 - 1 : ox0 + G::TW;
+        const bool ok = halo_live && ch < crem && cy >= 0 && cy < Hl && cx >= 0 && cx < Wl;
+        zt[ch * G::CS + r * G::LDW + (h == 0 ? G::COL0 - 1 : G::COL0 + G::TW)] = bnrelu(ph[i], ch, ok);
       }
     }
 #pragma unroll
@@ -345,12 +369,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       const int e = tid + 256 * i;
       const int dy = e & 1, q = e >> 1;
       const int ch = q / (NPX / 4), p4 = q % (NPX / 4);
+      const bool v = ch < corem;
+      const float4 h0 = ph0[i], h1 = ph1[i];
       float* d0 = gt + ((dy * 2 + 0) * 16 * NTW + ch) * G::GS + 4 * p4;
       float* d1 = gt + ((dy * 2 + 1) * 16 * NTW + ch) * G::GS + 4 * p4;
-      *reinterpret_cast<float2*>(d0) = make_float2(pg0[i].x, pg0[i].y);
-      *reinterpret_cast<float2*>(d0 + 2) = make_float2(pg0[i].z, pg0[i].w);
-      *reinterpret_cast<float2*>(d1) = make_float2(pg1[i].x, pg1[i].y);
-      *reinterpret_cast<float2*>(d1 + 2) = make_float2(pg1[i].z, pg1[i].w);
+      *reinterpret_cast<float2*>(d0) = v ? make_float2(h0.x, h0.z) : make_float2(0.f, 0.f);       // dx = 0
+      *reinterpret_cast<float2*>(d0 + 2) = v ? make_float2(h1.x, h1.z) : make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(d1) = v ? make_float2(h0.y, h0.w) : make_float2(0.f, 0.f);       // dx = 1
+      *reinterpret_cast<float2*>(d1 + 2) = v ? make_float2(h1.y, h1.w) : make_float2(0.f, 0.f);
     }
   };
 
@@ -366,9 +392,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
   issue(tile0);
   __syncthreads();
   for (int tt = 0; tt < tpw; ++tt) {
-    commit();
+    commit(tile0 + tt);
     __syncthreads();
-    if (tt + 1 < tpw) issue(tile0 + tt + 1);
+    issue(tile0 + min(tt + 1, tpw - 1));
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = wave * RPW + rr;
@@ -506,35 +532,17 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   if (!wgrad_plan(d, &pl)) return PDES_ENOSUP;
   const int twg = pl.twg, ntw = pl.ntw, ngroups = pl.ngroups, gy = pl.gy, tpw = pl.tpw, nsplit = pl.nsplit;
   const long long per = pl.per;
-#if 0
-  const int Hc = d.Hout, Wc = d.Wout;
-  const int twg = Wc >= 32 ? 2 : 1;
-  const int tps = (Wc / (16 * twg)) * (Hc / (8 / twg));
-  const int mtiles = (d.Cin + 15) / 16, ntiles = (d.Cout + 15) / 16;
-  const int ntw = ntiles >= 2 ? 2 : 1;
-  const int ngroups = (ntiles + ntw - 1) / ntw;
-  const int gy = mtiles * ngroups;
-  const long long per = (long long)d.Cout * d.Cin * KS * KS;
-  // pixel tiles per workgroup: as few as possible while (a) >= ~512 workgroups are not needed any more and
-  // (b) the partial buffer fits the scratch
-  int tpw = tps;
-  for (int cand = 1; cand <= tps; cand *= 2) {
-    if (tps % cand) continue;
-    const long long nsplit = (long long)d.B * (tps / cand);
-    if (nsplit * per * 4 > d.ws_bytes) continue;
-    if (nsplit * gy <= 768 || cand == tps) { tpw = cand; break; }
-  }
-  const int nsplit = d.B * (tps / tpw);
-  if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
-#endif
   dim3 grid(nsplit, gy), block(256);
 #define PDES_WG_LAUNCH(TWG_, NTW_)                                                                          \
   do {                                                                                                        \
     using G = WGeo<KS, TWG_, S>;                                                                              \
-    size_t lds = (size_t)(16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                                    \
+    size_t lds = (size_t)(tpw > 2 ? 2 : 1) * (16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
-    hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+    if (tpw > 2)                                                                                              \
+      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
   } while (0)
   if (twg == 2) { if (ntw == 2) PDES_WG_LAUNCH(2, 2); else PDES_WG_LAUNCH(2, 1); }
   else { if (ntw == 2) PDES_WG_LAUNCH(1, 2); else PDES_WG_LAUNCH(1, 1); }

@@ -11,7 +11,7 @@ HIP kernels (pde_surrogate_amd).  Two loop bodies are available:
                            continuity / boundary functions, loss.backward(), torch.optim.Adam)
                            on the drop-in modules.
 
-Additive flags (not in the reference): --mode, --no-graph, --synthetic (generate GRF-KLE /
+Additive flags (not in the reference): --mode, --graph, --synthetic (generate GRF-KLE /
 channelized inputs instead of reading the HDF5 files, which are not redistributed; R^2 / NRMSE need
 the FEniCS targets of the real files and are reported as nan in that mode).
 
@@ -72,8 +72,10 @@ class Parser(argparse.ArgumentParser):
         # additive flags of this build
         self.add_argument('--mode', type=str, default='fused', choices=['fused', 'dropin'],
                           help='loop body (see module docstring)')
-        self.add_argument('--no-graph', action='store_true', default=False,
-                          help='fused mode: do not capture the step in a hipGraph')
+        self.add_argument('--graph', action='store_true', default=False,
+                          help='fused mode: capture the step in a hipGraph (default: eager launches, weight '
+                               'gradients overlapped on a second HIP stream)')
+        self.add_argument('--no-graph', action='store_true', default=False, help='(default; kept for older scripts)')
         self.add_argument('--synthetic', action='store_true', default=False,
                           help='generate inputs instead of reading HDF5 files')
 
@@ -171,7 +173,7 @@ def main(argv=None):
     sobel_filter = SobelFilter(args.imsize, correct=True, device=device)
     if args.mode == 'fused':
         trainer = MixedResidualTrainer(model, args.batch_size, args.imsize, lr=args.lr, weight_decay=args.weight_decay,
-                                       weight_bound=args.weight_bound, device=device, use_graph=not args.no_graph)
+                                       weight_bound=args.weight_bound, device=device, use_graph=args.graph)
         parallel.broadcast_parameters(trainer.flat)
     else:
         if world > 1:
