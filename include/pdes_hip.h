@@ -136,14 +136,6 @@ int pdes_conv_backward_weight(const pdes_conv_desc* descs, int n, void* stream);
 /* T_in (+)= gamma * (conv^T(g)) * 1[bn(x) > 0]; also dgamma/dbeta and the finished channels'
  * {sum T, sum T xhat} (autograd of conv2d wrt input, ReLU, BatchNorm wrt gamma/beta). */
 int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void* stream);
-/* The whole backward pass of a descriptor chain: for i = n-1 .. 0
- *   [pdes_bn_backward_finalize of descs[i]'s output channels, when fin_tstats != NULL]
- *   pdes_conv_backward_weight(descs[i])   -- on `wgrad_stream` when it is not NULL
- *   pdes_conv_backward_data(descs[i])     -- when has_bn
- * The weight gradients have no consumer before the final reduce, so with a second stream they
- * overlap the finalize -> data-gradient dependency chain; the two streams are fork/joined with
- * events inside this call (on return everything is ordered on `stream` again). */
-int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream);
 /* In place T -> dL/dx for channels [c0, c1) of a (B, ctot, H, W) buffer (BatchNorm backward wrt
  * its input, summed over every consumer BN). */
 int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
@@ -157,6 +149,21 @@ int pdes_conv_wgrad_plan(const pdes_conv_desc* d, int* nsplit, long long* floats
 typedef struct pdes_reduce_item { const float* part; float* dw; int n; int nsplit; } pdes_reduce_item;
 /* dw[i] += sum_s part[s][i] (fixed order) for every item; items: DEVICE array. */
 int pdes_wgrad_reduce_all(const pdes_reduce_item* items, int n, int max_n, void* stream);
+
+/* The whole backward pass of a descriptor chain: for i = n-1 .. 0
+ *   [pdes_bn_backward_finalize of descs[i]'s output channels, when fin_tstats != NULL]
+ *   pdes_conv_backward_weight(descs[i])   -- on `wgrad_stream` when it is not NULL
+ *   pdes_conv_backward_data(descs[i])     -- when has_bn
+ * followed by the split-K reduce of the deferred weight-gradient partials (pdes_wgrad_reduce_all).
+ * The weight gradients have no consumer before that reduce, so with a second stream they overlap
+ * the finalize -> data-gradient dependency chain; they are released to it in batches of a few
+ * layers (one event per batch) and each batch is reduced on that stream; the two streams are
+ * joined before returning (everything is ordered on `stream` again).
+ * reduce_items: DEVICE table as for pdes_wgrad_reduce_all, in layer order; reduce_index: HOST
+ * array, reduce_index[i] = table index of descs[i] or -1 (no deferred scratch).  Both may be NULL
+ * (then the caller reduces). */
+int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
+                  const pdes_reduce_item* reduce_items, const int* reduce_index);
 
 /* Table-driven helpers: one launch for the whole network. */
 typedef struct pdes_pack_item {  /* one convolution's weights */

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -21,7 +21,7 @@ SIGNATURES = {
     'pdes_conv_forward': [_c_p, _c_i, _c_p],
     'pdes_conv_backward_weight': [_c_p, _c_i, _c_p],
     'pdes_conv_backward_data': [_c_p, _c_i, _c_p],
-    'pdes_backward': [_c_p, _c_i, _c_p, _c_p],
+    'pdes_backward': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p],
     'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i,
                                   ctypes.c_longlong, _c_p],
     'pdes_conv_wgrad_plan': [_c_p, _c_p, _c_p],

@@ -72,11 +72,53 @@ static hipEvent_t chain_event(size_t i) {
   return pool[i];
 }
 
-extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream) {
+extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
+                             const pdes_reduce_item* reduce_items, const int* reduce_index) {
   if (!descs || n <= 0) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipStream_t ws = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : st;
   const bool fork = ws != st;
+  // Weight gradients are released to the second stream in batches of PDES_WGRAD_BATCH layers (default 1:
+  // one event per layer; each event record is a barrier packet worth a ~6 us bubble on the main stream,
+  // but releasing the work early measured as good as batching it: 2.45 / 2.47 / 2.50 ms per step at
+  // batch 1 / 2 / 4).  PDES_WGRAD_REDUCE=batch reduces each batch's split-K partials on the second
+  // stream instead of once at the end (measured slower: 40 small launches).
+  static const int batch_layers = getenv("PDES_WGRAD_BATCH") ? atoi(getenv("PDES_WGRAD_BATCH")) : 1;
+  static const double batch_flops = getenv("PDES_WGRAD_BATCH_GF") ? 1e9 * atof(getenv("PDES_WGRAD_BATCH_GF")) : 1.5e9;
+  static const bool reduce_per_batch = getenv("PDES_WGRAD_REDUCE") && getenv("PDES_WGRAD_REDUCE")[0] == 'b';
+  int pend_hi = -1;                       // layers [i, pend_hi] are finalized but their weight gradient is not enqueued
+  double pend_flops = 0.0;
+  size_t nev = 0;
+  auto flush = [&](int lo) -> int {       // enqueue weight gradients (and their split-K reduce) of layers pend_hi .. lo
+    if (pend_hi < 0) return PDES_OK;
+    if (fork) {
+      hipEvent_t e = chain_event(nev++);
+      if (!e) return (int)hipErrorOutOfMemory;
+      hipError_t he = hipEventRecord(e, st);
+      if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
+      if (he != hipSuccess) return (int)he;
+    }
+    int r_lo = -1, r_hi = -1;
+    long long max_n = 0;
+    for (int i = pend_hi; i >= lo; --i) {
+      const int rc = pdes_conv_backward_weight(&descs[i], 1, ws);
+      if (rc) return rc;
+      if (fork && reduce_per_batch && reduce_items && reduce_index && reduce_index[i] >= 0) {
+        const int k = reduce_index[i];
+        r_lo = r_lo < 0 ? k : (k < r_lo ? k : r_lo);
+        r_hi = k > r_hi ? k : r_hi;
+        const long long per = (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
+        max_n = per > max_n ? per : max_n;
+      }
+    }
+    if (r_lo >= 0) {                      // item indices grow with the layer index: the batch is one contiguous slice
+      const int rc = pdes_wgrad_reduce_all(reduce_items + r_lo, r_hi - r_lo + 1, (int)max_n, ws);
+      if (rc) return rc;
+    }
+    pend_hi = -1;
+    pend_flops = 0.0;
+    return PDES_OK;
+  };
   for (int i = n - 1; i >= 0; --i) {
     const pdes_conv_desc& d = descs[i];
     if (d.fin_tstats) {
@@ -84,26 +126,37 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
                                          d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep, d.rep_stride, st);
       if (rc) return rc;
     }
-    if (fork) {
-      hipEvent_t e = chain_event(static_cast<size_t>(i));
-      if (!e) return (int)hipErrorOutOfMemory;
-      hipError_t he = hipEventRecord(e, st);
-      if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
-      if (he != hipSuccess) return (int)he;
+    if (pend_hi < 0) pend_hi = i;
+    pend_flops += 2.0 * d.B * d.Hout * d.Wout * (double)d.Cout * d.Cin * d.ksize * d.ksize;
+    if (!fork || pend_hi - i + 1 >= batch_layers || pend_flops >= batch_flops || i == 0) {
+      const int rc = flush(i);
+      if (rc) return rc;
     }
-    int rc = pdes_conv_backward_weight(&d, 1, ws);
-    if (rc) return rc;
     if (d.has_bn) {
-      rc = pdes_conv_backward_data(&d, 1, st);
+      const int rc = pdes_conv_backward_data(&d, 1, st);
       if (rc) return rc;
     }
   }
   if (fork) {
-    hipEvent_t e = chain_event(static_cast<size_t>(n));
+    hipEvent_t e = chain_event(nev++);
     if (!e) return (int)hipErrorOutOfMemory;
     hipError_t he = hipEventRecord(e, ws);
     if (he == hipSuccess) he = hipStreamWaitEvent(st, e, 0);
     if (he != hipSuccess) return (int)he;
+  }
+  if ((!fork || !reduce_per_batch) && reduce_items && reduce_index) {   // a single reduce over every layer at the end
+    int cnt = 0;
+    long long max_n = 0;
+    for (int i = 0; i < n; ++i)
+      if (reduce_index[i] >= 0) {
+        ++cnt;
+        const long long per = (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
+        max_n = per > max_n ? per : max_n;
+      }
+    if (cnt) {
+      const int rc = pdes_wgrad_reduce_all(reduce_items, cnt, (int)max_n, st);
+      if (rc) return rc;
+    }
   }
   return PDES_OK;
 }

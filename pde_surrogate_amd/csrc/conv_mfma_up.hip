@@ -124,9 +124,12 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
     if (ok) hval |= 1u << i;
   }
 
-  float4 pv[G::NPV], pw[MODE == UP_BWD ? G::NPV : 1];
-  float ph[G::NPH];
-  auto issue = [&](int vc) {
+  // Two register stages of RAW loads (clamped addresses, nothing consumes a load before its commit): the
+  // loop body below is straight-line so that the in-order vmcnt waits are exact (see conv_mfma.hip).
+  constexpr int NPW = MODE == UP_BWD ? G::NPV : 1;
+  struct Stage { float4 pv[G::NPV]; float4 pw[NPW]; float ph[G::NPH]; };
+  Stage sA, sB;
+  auto issue = [&](int vc, Stage& st) __attribute__((always_inline)) {
     const int chunk = MODE == UP_FWD ? vc : vc >> 2, p = vc & 3;
     const int dy = MODE == UP_FWD ? 0 : p >> 1, dx = MODE == UP_FWD ? 0 : p & 1;
     const float* src = kbase + (size_t)chunk * 16 * HWk + (MODE == UP_BWD ? dy * Wh : 0);
@@ -135,18 +138,18 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
     for (int i = 0; i < G::NPV; ++i) {
       const int ch = min((tid + 256 * i) / (G::ROWS * (G::TW / 4)), cmax);
       const float* q = src + ch * HWk + vg[i];
-      pv[i] = *reinterpret_cast<const float4*>(q);
-      if (MODE == UP_BWD) pw[i] = *reinterpret_cast<const float4*>(q + 4);      // 8 hi-res columns -> 4 of one parity
+      st.pv[i] = *reinterpret_cast<const float4*>(q);
+      if (MODE == UP_BWD) st.pw[i] = *reinterpret_cast<const float4*>(q + 4);      // 8 hi-res columns -> 4 of one parity
     }
     if (halo_live) {
 #pragma unroll
       for (int i = 0; i < G::NPH; ++i) {
         const int ch = min((tid + 256 * i) / (G::ROWS * 2), cmax);
-        ph[i] = src[ch * HWk + hg[i] + (MODE == UP_BWD ? dx : 0)];
+        st.ph[i] = src[ch * HWk + hg[i] + (MODE == UP_BWD ? dx : 0)];
       }
     }
   };
-  auto commit = [&](int vc, int buf) {
+  auto commit = [&](int vc, int buf, const Stage& st) __attribute__((always_inline)) {
     const int chunk = MODE == UP_FWD ? vc : vc >> 2, p = vc & 3;
     const int dx = p & 1;
     float* t = tile + buf * (G::KC * G::CS);
@@ -159,13 +162,14 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
         float4 z;
         if (MODE == UP_FWD) {
           const float4 k = cf4[chunk * 16 + ch];
-          z = pv[i];
+          z = st.pv[i];
           z.x = ok ? fmaxf(0.f, (z.x - k.x) * k.y + k.z) : 0.f;
           z.y = ok ? fmaxf(0.f, (z.y - k.x) * k.y + k.z) : 0.f;
           z.z = ok ? fmaxf(0.f, (z.z - k.x) * k.y + k.z) : 0.f;
           z.w = ok ? fmaxf(0.f, (z.w - k.x) * k.y + k.z) : 0.f;
         } else {
-          z = dx ? make_float4(pv[i].y, pv[i].w, pw[i].y, pw[i].w) : make_float4(pv[i].x, pv[i].z, pw[i].x, pw[i].z);
+          z = dx ? make_float4(st.pv[i].y, st.pv[i].w, st.pw[i].y, st.pw[i].w)
+                 : make_float4(st.pv[i].x, st.pv[i].z, st.pw[i].x, st.pw[i].z);
           if (!ok) z = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         *reinterpret_cast<float4*>(t + vl[i]) = z;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
       if (hl[i] >= 0) {
         const int ch = (tid + 256 * i) / (G::ROWS * 2);
         const bool ok = halo_live && ((hval >> i) & 1u) && ch < crem;
-        float z = halo_live ? ph[i] : 0.f;
+        float z = halo_live ? st.ph[i] : 0.f;
         if (MODE == UP_FWD) {
           const float4 k = cf4[chunk * 16 + ch];
           z = ok ? fmaxf(0.f, (z - k.x) * k.y + k.z) : 0.f;
@@ -195,85 +199,83 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
 #pragma unroll
     for (int q = 0; q < NACC; ++q) acc[mt][q] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  __syncthreads();                 // cf4 visible
-  commit(0, 0);
-  __syncthreads();
-
   // B operand image: [(kstep*16 + q)*ntp + nt][64], q = parity*4 + a*2 + b.  FWD uses all 16 per
-  // k-step, BWD the 4 of the staged parity.  Rolling register prefetch of the next k-step.
+  // k-step, BWD the 4 of the staged parity.  Two register sets: while one feeds the matrix pipe the
+  // next k-step streams into the other (every wave index is < ntp: the image is padded to 8 N-tiles).
   constexpr int NB = MODE == UP_FWD ? 16 : 4;
-  float bcur[NB];
-  auto load_b = [&](int kstep, int p, float (&dst)[NB]) {
-    const float* wp = wm + ((size_t)(kstep * 16 + (MODE == UP_FWD ? 0 : p * 4)) * ntp + nt_w) * 64 + lane;
+  const int ksteps = kpad / 4;
+  float bA[NB], bB[NB];
+  auto load_b = [&](int kstep, int p, float (&dst)[NB]) __attribute__((always_inline)) {
+    const float* wp = wm + ((size_t)(min(kstep, ksteps - 1) * 16 + (MODE == UP_FWD ? 0 : p * 4)) * ntp + nt_w) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < NB; ++t) dst[t] = wp[(size_t)t * ntp * 64];
   };
-  const bool nt_ok = nt_w < ntp;                         // waves beyond the padded image do nothing
-  if (nt_ok) load_b(0, 0, bcur);
   const int a_lane = (lane >> 4) * G::CS + (lane & 15);
-  for (int vc = 0; vc < nvc; ++vc) {
+  auto mfma_kstep = [&](const float* tk, int dy, int dx, const float (&bw)[NB]) __attribute__((always_inline)) {
+    if (MODE == UP_FWD) {
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = tk[((mt / TWG) + ty) * G::LDW + (G::COL0 - 1) + (mt % TWG) * 16 + tx];
+#pragma unroll
+            for (int ddy = 0; ddy < 2; ++ddy)
+#pragma unroll
+              for (int ddx = 0; ddx < 2; ++ddx) {
+                const int ia = ty - ddy, ib = tx - ddx;           // position inside the 2x2 effective kernel
+                if (ia < 0 || ia > 1 || ib < 0 || ib > 1) continue;
+                const int pp = ddy * 2 + ddx;
+                acc[mt][MODE == UP_FWD ? pp : 0] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[(MODE == UP_FWD ? pp * 4 : 0) + ia * 2 + ib],
+                                                         acc[mt][MODE == UP_FWD ? pp : 0], 0, 0, 0);
+              }
+          }
+        }
+    } else {
+#pragma unroll
+      for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          const int ro = 2 - ia - dy, co = 2 - ib - dx;          // tile offsets of G_p[y-a-dy+1][x-b-dx+1]
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = tk[((mt / TWG) + ro) * G::LDW + (G::COL0 - 1) + (mt % TWG) * 16 + co];
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[MODE == UP_FWD ? 0 : ia * 2 + ib], acc[mt][0], 0, 0, 0);
+          }
+        }
+    }
+  };
+
+  load_b(0, 0, bA);
+  issue(0, sA);
+  if (nvc > 1) issue(1, sB);
+  __syncthreads();                 // cf4 visible
+  commit(0, 0, sA);
+  __syncthreads();
+
+  auto step = [&](int vc, Stage& sfree, const Stage& snext) __attribute__((always_inline)) {
     const int buf = vc & 1;
     const int chunk = MODE == UP_FWD ? vc : vc >> 2, p = vc & 3;
     const int dy = p >> 1, dx = p & 1;
-    if (vc + 1 < nvc) issue(vc + 1);
+    const int vn = vc + 1, chunkn = MODE == UP_FWD ? vn : vn >> 2, pn = vn & 3;   // first k-step of the next staged tile
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int kstep = chunk * 4 + s;
-      // next (k-step, parity) in execution order
-      int kn = kstep + 1, pn = p;
-      if (s == 3) {
-        if (MODE == UP_FWD) { kn = (chunk + 1) * 4; }
-        else { pn = (p + 1) & 3; kn = ((vc + 1) >> 2) * 4; }
-      }
-      float bnx[NB];
-      const bool more = nt_ok && kn * 4 < kpad && (s < 3 || vc + 1 < nvc);
-      if (more) load_b(kn, pn, bnx);
-      if (nt_ok && kstep * 4 < kC) {
-        const float* tk = tb + s * 4 * G::CS;
-        if (MODE == UP_FWD) {
-#pragma unroll
-          for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                const float a = tk[((mt / TWG) + ty) * G::LDW + (G::COL0 - 1) + (mt % TWG) * 16 + tx];
-#pragma unroll
-                for (int ddy = 0; ddy < 2; ++ddy)
-#pragma unroll
-                  for (int ddx = 0; ddx < 2; ++ddx) {
-                    const int ia = ty - ddy, ib = tx - ddx;           // position inside the 2x2 effective kernel
-                    if (ia < 0 || ia > 1 || ib < 0 || ib > 1) continue;
-                    const int pp = ddy * 2 + ddx;
-                    acc[mt][MODE == UP_FWD ? pp : 0] =
-                        __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[(MODE == UP_FWD ? pp * 4 : 0) + ia * 2 + ib],
-                                                             acc[mt][MODE == UP_FWD ? pp : 0], 0, 0, 0);
-                  }
-              }
-            }
-        } else {
-#pragma unroll
-          for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-              const int ro = 2 - ia - dy, co = 2 - ib - dx;          // tile offsets of G_p[y-a-dy+1][x-b-dx+1]
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                const float a = tk[((mt / TWG) + ro) * G::LDW + (G::COL0 - 1) + (mt % TWG) * 16 + co];
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[MODE == UP_FWD ? 0 : ia * 2 + ib], acc[mt][0], 0, 0, 0);
-              }
-            }
-        }
-      }
-      if (more) {
-#pragma unroll
-        for (int t = 0; t < NB; ++t) bcur[t] = bnx[t];
-      }
+      if (s < 3) load_b(chunk * 4 + s + 1, p, (s & 1) ? bA : bB);
+      else load_b(chunkn * 4, pn, bA);
+      if (s == 0) issue(min(vc + 2, nvc - 1), sfree);
+      if ((chunk * 4 + s) * 4 < kC)              // scalar: skip k-steps that lie entirely in the zero padding
+        mfma_kstep(tb + s * 4 * G::CS, dy, dx, (s & 1) ? bB : bA);
     }
-    if (vc + 1 < nvc) commit(vc + 1, buf ^ 1);
+    if (vc + 1 < nvc) commit(vc + 1, buf ^ 1, snext);
     __syncthreads();
+  };
+  {
+    int vc = 0;
+    for (; vc + 1 < nvc; vc += 2) { step(vc, sA, sB); step(vc + 1, sB, sA); }
+    if (vc < nvc) step(vc, sA, sB);
   }
 
   const int px = (lane >> 4) * 4;

@@ -345,13 +345,27 @@ class _Engine:
             items.append(it)
             mx = max(mx, it.n)
         self._reduce_n, self._reduce_max = len(items), mx
+        # host map descriptor -> row of the reduce table (-1: no deferred scratch), for pdes_backward
+        idx, k = [], 0
+        for d in self.descs:
+            if d.ws_defer:
+                idx.append(k); k += 1
+            else:
+                idx.append(-1)
+        self._reduce_index = (_I * len(idx))(*idx)
         if items:
             arr = (ReduceItem * len(items))(*items)
             self._reduce_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
 
     def _side_stream(self):
+        """second HIP stream for the weight gradients, at the LOWEST queue priority: free workgroup slots go to
+        the finalize -> data-gradient chain on the main stream first, the weight gradients fill what is left"""
         if not hasattr(self, '_side'):
-            self._side = torch.cuda.Stream(self.dev)
+            try:
+                least = torch.cuda.Stream.priority_range()[0]
+            except Exception:
+                least = 0
+            self._side = torch.cuda.Stream(self.dev, priority=least)
         return self._side
 
     # -- launches -------------------------------------------------------------------------------
@@ -387,10 +401,8 @@ class _Engine:
         side = None
         if os.environ.get('PDES_WGRAD_STREAM', '1') != '0' and not torch.cuda.is_current_stream_capturing():
             side = ctypes.c_void_p(self._side_stream().cuda_stream)
-        _lib.check(L.pdes_backward(self.descs, n, st, side), 'pdes_backward')
-        if self._reduce_n:
-            _lib.check(L.pdes_wgrad_reduce_all(self._reduce_table.data_ptr(), self._reduce_n, self._reduce_max, st),
-                       'pdes_wgrad_reduce_all')
+        rt = self._reduce_table.data_ptr() if self._reduce_n else None
+        _lib.check(L.pdes_backward(self.descs, n, st, side, rt, self._reduce_index), 'pdes_backward')
         _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, self.nrep, self.rep_stride,
                                          st), 'pdes_bn_param_grads')
 

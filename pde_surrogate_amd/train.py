@@ -12,6 +12,7 @@ Adam -- without autograd, host synchronisation or per-parameter kernels.
   * the whole compute part of the step can be captured in a hipGraph (`use_graph=True`).
 """
 import math
+import os
 
 import torch
 
