@@ -110,6 +110,9 @@ typedef struct pdes_conv_desc {
   /* backward */
   const float* g;        /* dL/d(out): (B, g_ctot, Hout, Wout), channels [g_coff, g_coff+Cout) */
   int g_ctot, g_coff;
+  int g_fused;           /* 1: `g` still holds the accumulator T of the output buffer; the BN-backward finalize
+                            (fin_xstats / fin_tstats, raw activation = `out`) is applied by the consuming kernel
+                            on operand load.  Set by pdes_backward only (matrix-core paths); callers pass 0. */
   float* t_in;           /* T accumulator of the input buffer (B, x_ctot, Hin, Win) */
   int t_accumulate;      /* 0: T = ..., 1: T += ... */
   int final_c0, final_c1;/* input channels whose T is complete after this call: their

@@ -11,10 +11,10 @@ int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st);        // PDES_ENOSUP: shape not covered
-int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st);
-int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st);
+int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);   // dry: capability query only
+int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st);        // nearest-x2 + 3x3, sub-pixel form
-int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st);
+int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 
 // PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
 // the matrix-core kernels against them); anything else = automatic selection.
@@ -43,6 +43,7 @@ extern "C" int pdes_conv_backward_weight(const pdes_conv_desc* descs, int n, voi
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_weight_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP && descs[i].g_fused) return PDES_EINVAL;      // only the matrix-core kernels finalize on load
     if (rc == PDES_ENOSUP) rc = conv_backward_weight_direct(descs[i], st);
     if (rc) return rc;
   }
@@ -55,6 +56,7 @@ extern "C" int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void*
   for (int i = 0; i < n; ++i) {
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP && descs[i].g_fused) return PDES_EINVAL;
     if (rc == PDES_ENOSUP) rc = conv_backward_data_direct(descs[i], st);
     if (rc) return rc;
   }
@@ -119,9 +121,26 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
     pend_flops = 0.0;
     return PDES_OK;
   };
+  // BatchNorm-backward finalize: fused into the operand load of the layer's two consumers when both run on
+  // the matrix-core kernels (bn_fused.h), otherwise the in-place kernel.  PDES_FUSE_FINALIZE=0 disables.
+  static const bool fuse_on = !(getenv("PDES_FUSE_FINALIZE") && getenv("PDES_FUSE_FINALIZE")[0] == '0');
+  static const int fuse_maxc = getenv("PDES_FUSE_MAXC") ? atoi(getenv("PDES_FUSE_MAXC")) : 16;
+  std::vector<pdes_conv_desc> local(descs, descs + n);
+  for (int i = 0; i < n; ++i) {
+    pdes_conv_desc& d = local[i];
+    d.g_fused = 0;
+    if (!fuse_on || force_direct() || !d.fin_tstats || !d.fin_xstats || !d.out) continue;
+    if (d.Cout > fuse_maxc) continue;     // wide layers: staging x next to T costs the consumers more than the kernel saves
+    if (d.g_ctot != d.out_ctot || d.g_coff != d.out_coff || d.nrep != PDES_NREP) continue;
+    const bool w_ok = conv_backward_weight_mfma(d, st, true) == PDES_OK;
+    const bool d_ok = !d.has_bn || conv_backward_data_up_mfma(d, st, true) == PDES_OK ||
+                      conv_backward_data_mfma(d, st, true) == PDES_OK;
+    d.g_fused = (w_ok && d_ok) ? 1 : 0;
+  }
+  descs = local.data();
   for (int i = n - 1; i >= 0; --i) {
     const pdes_conv_desc& d = descs[i];
-    if (d.fin_tstats) {
+    if (d.fin_tstats && !d.g_fused) {
       int rc = pdes_bn_backward_finalize(const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B, d.g_ctot,
                                          d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep, d.rep_stride, st);
       if (rc) return rc;

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
+#include "bn_fused.h"
 
 namespace pdes {
 
@@ -85,8 +86,10 @@ __device__ unsigned long long pdes_trace_buf[16];
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-inserted x2 (stride-2 data gradient)
 
-template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
+// FUSED (data gradient only): d.g holds the raw accumulator T; the BatchNorm-backward finalize is applied
+// while the tile is committed to LDS (bn_fused.h) -- the raw output activation is staged next to it.
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, bool FUSED>
+__global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                        int nt_total) {
   using G = TileGeo<KS, TWG, MT, S>;
   const int ntp = (nt_total + 7) & ~7;       // N-tiles of the packed weight image (zero padded)
@@ -124,13 +127,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   kWc = kmode ? 2 * kW : kW;
   const int kpad = (kC + 15) & ~15;
   const int nchunk = kpad / 16;
-  float* tile = smem + ((MODE == MODE_FWD) ? 4 * kpad : 0);   // FWD: [kpad] float4 BN coefficients first
+  static_assert(!(FUSED && MODE == MODE_FWD), "the fused finalize belongs to the data gradient");
+  float* tile = smem + ((MODE == MODE_FWD || FUSED) ? 4 * kpad : 0);   // [kpad] float4 per-channel coefficients first
+  const float* xkbase = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff) * d.Hout * d.Wout : nullptr;
 
   const int tiles_x = Wout / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
 
   // FWD: per-channel {mean, gamma*invstd, beta, -} as one float4 (a single ds_read_b128 per staged float4)
   float4* cf4 = reinterpret_cast<float4*>(smem);
+  if (FUSED) {        // {mean, invstd, mean(T), mean(T xhat)} of the gradient channels
+    for (int c = tid; c < kpad; c += 256) cf4[c] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (MODE == MODE_FWD) {
     for (int c = tid; c < kpad; c += 256) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -180,12 +188,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   // two register stages: the loads of chunk c+2 are issued before the MFMAs of chunk c, so a tile has
   // two chunks of matrix work (not one) to arrive from L2/HBM before it is committed to LDS
   constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
-  float4 pvA[G::NPV], pvB[G::NPV];
-  float phA[NPHS], phB[NPHS];
+  struct Stage {
+    float4 pv[G::NPV]; float ph[NPHS];
+    float4 xv[FUSED ? G::NPV : 1]; float xh[FUSED ? NPHS : 1];     // FUSED: the raw activation at the same positions
+  };
+  Stage sA, sB;
   // loads are unconditional (row offsets are clamped into the image above, the channel is clamped
   // here); validity is applied when the registers are committed to LDS
-  auto issue = [&](int chunk, float4 (&pv)[G::NPV], float (&ph)[NPHS]) {
+  auto issue = [&](int chunk, Stage& st) __attribute__((always_inline)) {
+    float4 (&pv)[G::NPV] = st.pv;
+    float (&ph)[NPHS] = st.ph;
     const float* src = kbase + (size_t)chunk * 16 * HWs;
+    const float* xsrc = FUSED ? xkbase + (size_t)chunk * 16 * HWs : nullptr;
     const int cmax = kC - chunk * 16 - 1;           // last valid channel of this chunk
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
@@ -193,9 +207,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       const float* p = src + ch * HWs + vg[i];
       if constexpr (kmode == KV_PLAIN) {
         pv[i] = *reinterpret_cast<const float4*>(p);
+        if constexpr (FUSED) st.xv[i] = *reinterpret_cast<const float4*>(xsrc + ch * HWs + vg[i]);
       } else {                                       // raw pair; expanded to (x, 0, y, 0) at commit time
         const float2 t = *reinterpret_cast<const float2*>(p);
         pv[i].x = t.x; pv[i].y = t.y;
+        if constexpr (FUSED) {
+          const float2 u = *reinterpret_cast<const float2*>(xsrc + ch * HWs + vg[i]);
+          st.xv[i].x = u.x; st.xv[i].y = u.y;
+        }
       }
     }
     if (halo_live) {
@@ -203,10 +222,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
       for (int i = 0; i < G::NPH; ++i) {
         const int ch = min((tid + 256 * i) / (G::ROWS * G::NHC), cmax);
         ph[i] = src[ch * HWs + hg[i]];
+        if constexpr (FUSED) st.xh[i] = xsrc[ch * HWs + hg[i]];
       }
     }
   };
-  auto commit = [&](int chunk, int buf, const float4 (&pv)[G::NPV], const float (&ph)[NPHS]) {
+  auto commit = [&](int chunk, int buf, const Stage& st) __attribute__((always_inline)) {
+    const float4 (&pv)[G::NPV] = st.pv;
+    const float (&ph)[NPHS] = st.ph;
     float* t = tile + buf * (G::KC * G::CS);
     const int crem = kC - chunk * 16;
 #pragma unroll
@@ -215,7 +237,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
         float4 z = kmode == KV_PLAIN ? pv[i] : make_float4(pv[i].x, 0.f, pv[i].y, 0.f);
         const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
         const bool ok = ((vrow >> i) & 1u) && ch < crem;
-        if (MODE == MODE_FWD) {
+        if constexpr (FUSED) {
+          const float4 k = cf4[chunk * 16 + ch];
+          const float4 x = st.xv[i];
+          if (kmode == KV_PLAIN) {
+            z.x = ok ? fin_apply(k, z.x, x.x) : 0.f;
+            z.y = ok ? fin_apply(k, z.y, x.y) : 0.f;
+            z.z = ok ? fin_apply(k, z.z, x.z) : 0.f;
+            z.w = ok ? fin_apply(k, z.w, x.w) : 0.f;
+          } else {
+            z.x = ok ? fin_apply(k, z.x, x.x) : 0.f;
+            z.z = ok ? fin_apply(k, z.z, x.y) : 0.f;
+          }
+        } else if (MODE == MODE_FWD) {
           const float4 k = cf4[chunk * 16 + ch];
           z.x = ok ? fmaxf(0.f, (z.x - k.x) * k.y + k.z) : 0.f;
           z.y = ok ? fmaxf(0.f, (z.y - k.x) * k.y + k.z) : 0.f;
@@ -234,7 +268,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
           float z = ph[i];
           const int ch = (tid + 256 * i) / (G::ROWS * G::NHC);
           const bool ok = ((hval >> i) & 1u) && ch < crem;
-          if (MODE == MODE_FWD) {
+          if constexpr (FUSED) {
+            z = ok ? fin_apply(cf4[chunk * 16 + ch], z, st.xh[i]) : 0.f;
+          } else if (MODE == MODE_FWD) {
             const float4 k = cf4[chunk * 16 + ch];
             z = ok ? fmaxf(0.f, (z - k.x) * k.y + k.z) : 0.f;
           } else if (!ok) {
@@ -293,18 +329,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
   // instead): vmcnt is an in-order counter, and only without divergent paths can the compiler wait for
   // exactly the loads a k-step needs instead of draining the prefetches that were just issued.
   load_b(wks, bA);
-  issue(0, pvA, phA);
-  if (nchunk > 1) issue(1, pvB, phB);
+  issue(0, sA);
+  if constexpr (PIPE) issue(min(1, nchunk - 1), sB);      // !PIPE: exactly one chunk, no second stage at all
   __syncthreads();                 // cf visible
   TR(2);
-  commit(0, 0, pvA, phA);
+  commit(0, 0, sA);
   __syncthreads();
   TR(3);
 
-  // one chunk: `pf`/`hf` = the (free) register stage that receives chunk+2, `pc`/`hc` = the stage holding
+  // one chunk: `sfree` = the (free) register stage that receives chunk+2, `snext` = the stage holding
   // chunk+1; `b0` holds the weights of this chunk's first k-step, `b1` is the other weight set
-  auto step = [&](int chunk, float4 (&pf)[G::NPV], float (&hf)[NPHS], const float4 (&pc)[G::NPV],
-                  const float (&hc)[NPHS], float (&b0)[KK][NT_W], float (&b1)[KK][NT_W]) {
+  auto step = [&](int chunk, Stage& sfree, const Stage& snext, float (&b0)[KK][NT_W], float (&b1)[KK][NT_W])
+      __attribute__((always_inline)) {
     const int buf = chunk & 1;
 #ifdef PDES_TRACE
     tt = wall_clock64();
@@ -312,13 +348,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
     if constexpr (WAVES_K == 4) {
       load_b((chunk + 1) * 4 + wks, b1);
-      if constexpr (PIPE) issue(min(chunk + 2, nchunk - 1), pf, hf);
+      if constexpr (PIPE) issue(min(chunk + 2, nchunk - 1), sfree);
       mfma_kstep(tb + wks * 4 * G::CS, b0);
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         load_b(chunk * 4 + s + 1, (s & 1) ? b0 : b1);
-        if constexpr (PIPE) { if (s == 0) issue(min(chunk + 2, nchunk - 1), pf, hf); }
+        if constexpr (PIPE) { if (s == 0) issue(min(chunk + 2, nchunk - 1), sfree); }
         if ((chunk * 4 + s) * 4 < kC)            // scalar: skip k-steps that lie entirely in the zero padding
           mfma_kstep(tb + s * 4 * G::CS, (s & 1) ? b1 : b0);
       }
@@ -327,7 +363,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
 #ifdef PDES_TRACE
     tt = wall_clock64();
 #endif
-    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, pc, hc);
+    if constexpr (PIPE) { if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, snext); }
     TRACC(9, tt);      // commit
 #ifdef PDES_TRACE
     tt = wall_clock64();
@@ -335,14 +371,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(pdes_conv_desc d, const 
     __syncthreads();
     TRACC(10, tt);     // barrier wait
   };
-  {
+  if constexpr (!PIPE) {
+    step(0, sA, sA, bA, bB);
+  } else {
     int chunk = 0;
     for (; chunk + 1 < nchunk; chunk += 2) {
-      step(chunk, pvA, phA, pvB, phB, bA, bB);
-      if constexpr (WAVES_K == 4) step(chunk + 1, pvB, phB, pvA, phA, bB, bA);
-      else step(chunk + 1, pvB, phB, pvA, phA, bA, bB);
+      step(chunk, sA, sB, bA, bB);
+      if constexpr (WAVES_K == 4) step(chunk + 1, sB, sA, bB, bA);
+      else step(chunk + 1, sB, sA, bA, bB);
     }
-    if (chunk < nchunk) step(chunk, pvA, phA, pvB, phB, bA, bB);
+    if (chunk < nchunk) step(chunk, sA, sB, bA, bB);
   }
 
   TR(4);
@@ -512,8 +550,9 @@ static int env_int(const char* name, int dflt) {
 }
 
 template <int KS, int S, int MODE, int KM>
-static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st) {
+static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st, bool dry = false) {
   const bool bwd = MODE == MODE_BWD;
+  const bool fused = bwd && d.g_fused;
   const int kC = bwd ? d.Cout : d.Cin, nC = bwd ? d.Cin : d.Cout;
   const int kpad = (kC + 15) & ~15, nchunk = kpad / 16;
   const int nt_total = (nC + 15) / 16;
@@ -538,17 +577,30 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
 #define PDES_TRY(TWG_, MT_, WK_, NTW_)                                                                       \
   if (twg == TWG_ && mt == MT_ && wk == WK_ && ntw == NTW_) {                                                 \
     using G = TileGeo<KS, TWG_, MT_, S>;                                                                      \
-    const size_t cf_f = bwd ? 0 : 4 * (size_t)kpad;                                                           \
+    const size_t cf_f = (bwd && !fused) ? 0 : 4 * (size_t)kpad;                                              \
     size_t fl = cf_f + 2 * (size_t)G::KC * G::CS;                                                             \
     const size_t red = cf_f + (size_t)4 * MT_ * 4 * 64 + 128;                                                 \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \
     lds = fl * sizeof(float);                                                                                 \
-    if (MODE == MODE_FWD || nchunk > 2)                                                                       \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true>), grid, block, lds, st, d, wm, \
-                         nt_total);                                                                           \
-    else if constexpr (MODE == MODE_BWD)       /* <= 2 chunks (dense layers: 16 gradient channels): no 2-ahead prefetch */ \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false>), grid, block, lds, st, d, wm, \
-                         nt_total);                                                                           \
+    if (dry) {                                                                                                \
+    } else if constexpr (MODE == MODE_FWD) {                                                                         \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false>), grid, block, lds, st, \
+                         d, wm, nt_total);                                                                    \
+    } else if (fused) {                                                                                       \
+      if (nchunk > 1)                                                                                         \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, true>), grid, block, lds, st, \
+                           d, wm, nt_total);                                                                  \
+      else   /* one chunk (dense layers: 16 gradient channels): single stage */                     \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, true>), grid, block, lds, st, \
+                           d, wm, nt_total);                                                                  \
+    } else {                                                                                                  \
+      if (nchunk > 1)                                                                                         \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false>), grid, block, lds, st, \
+                           d, wm, nt_total);                                                                  \
+      else                                                                                                    \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, false>), grid, block, lds, st, \
+                           d, wm, nt_total);                                                                  \
+    }                                                                                                         \
     rc = PDES_OK;                                                                                             \
   }
   if constexpr (S == 1) {
@@ -563,7 +615,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)
   }
 #undef PDES_TRY
-  if (rc) return rc;
+  if (rc || dry) return rc;
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
@@ -582,14 +634,15 @@ int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st) {
                       : launch_mfma<1, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st);
 }
 
-int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st) {
+// dry = true: only report whether this implementation would take the descriptor (nothing is enqueued)
+int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   int W, H;
   if (!d.wm_bwd || !mfma_shape_ok(d, true, &W, &H) || d.eval_mode) return PDES_ENOSUP;
   // a stride-2 convolution's data gradient is the unit-stride gather over the zero-inserted dL/d(out)
-  if (d.stride == 2) return launch_mfma<3, 1, MODE_BWD, KV_ZEROINS2>(d, d.wm_bwd, W, H, st);
-  if (d.ksize == 5) return launch_mfma<5, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st);
-  return d.ksize == 3 ? launch_mfma<3, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st)
-                      : launch_mfma<1, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st);
+  if (d.stride == 2) return launch_mfma<3, 1, MODE_BWD, KV_ZEROINS2>(d, d.wm_bwd, W, H, st, dry);
+  if (d.ksize == 5) return launch_mfma<5, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st, dry);
+  return d.ksize == 3 ? launch_mfma<3, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st, dry)
+                      : launch_mfma<1, 1, MODE_BWD, KV_PLAIN>(d, d.wm_bwd, W, H, st, dry);
 }
 
 }  // namespace pdes

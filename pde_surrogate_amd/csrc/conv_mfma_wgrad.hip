@@ -12,6 +12,7 @@
 // the 16 channels x 2 pixels of a ds_read_b32 lane group hit 32 distinct banks.
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
+#include "bn_fused.h"
 
 namespace pdes {
 
@@ -36,8 +37,10 @@ struct WGeo {
   static_assert(CS % 32 == 2 && GS % 32 == 2 && CS >= ROWS * LDW && NR >= 0, "LDS geometry");
 };
 
-template <int KS, int TWG, int NTW, int S, bool PIPE>     // PIPE: > 2 pixel tiles per workgroup, prefetch two ahead
-__global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
+// PIPE: > 2 pixel tiles per workgroup, prefetch two ahead.  FUSED: d.g is the raw accumulator T; the
+// BatchNorm-backward finalize is applied while the gradient tile is committed to LDS (bn_fused.h).
+template <int KS, int TWG, int NTW, int S, bool PIPE, bool FUSED>
+__global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                              int n_ngroups) {
   using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS;
@@ -76,9 +79,15 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
     }
     cf[tid][0] = m; cf[tid][1] = s; cf[tid][2] = bt;
   }
+  __shared__ float4 cg[FUSED ? 16 * NTW : 1];     // finalize coefficients of this workgroup's gradient channels
+  if (FUSED && tid >= 64 && tid < 64 + 16 * NTW) {
+    const int c = co0 + (tid - 64);
+    cg[tid - 64] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWi;
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
+  const float* ob = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff + co0) * HWo : nullptr;
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
 
   const bool halo_live = (G::NL + G::NR) > 0 && tiles_x > 1;
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
   // anything that consumes a load right after issuing it would drain vmcnt and serialise the prefetch
   // with the matrix work.  Validity is applied when a stage is committed to LDS.
   constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
-  struct Stage { float4 pv[G::NPV]; float4 pg[NPG4]; float ph[NPHS]; };
+  struct Stage { float4 pv[G::NPV]; float4 pg[NPG4]; float ph[NPHS]; float4 px[FUSED ? NPG4 : 1]; };
   Stage sA, sB;
   auto issue = [&](int tile, Stage& st) __attribute__((always_inline)) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
@@ -116,7 +125,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       const int e = tid + 256 * i;                          // float4 index: channel-major, then pixel
       const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
       const int oy = oy0 + (4 * p4) / G::TW, ox = ox0 + (4 * p4) % G::TW;
-      st.pg[i] = *reinterpret_cast<const float4*>(gb + (size_t)min(ch, corem - 1) * HWo + oy * d.Wout + ox);
+      const size_t off = (size_t)min(ch, corem - 1) * HWo + oy * d.Wout + ox;
+      st.pg[i] = *reinterpret_cast<const float4*>(gb + off);
+      if constexpr (FUSED) st.px[i] = *reinterpret_cast<const float4*>(ob + off);
     }
   };
   auto bnrelu = [&](float x, int ch, bool ok) __attribute__((always_inline)) {
@@ -159,8 +170,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
       const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
       const bool ok = ch < corem;
       float* dst = gtb + ch * G::GS + 4 * p4;                               // 8-byte aligned (GS even)
-      *reinterpret_cast<float2*>(dst) = ok ? make_float2(st.pg[i].x, st.pg[i].y) : make_float2(0.f, 0.f);
-      *reinterpret_cast<float2*>(dst + 2) = ok ? make_float2(st.pg[i].z, st.pg[i].w) : make_float2(0.f, 0.f);
+      float4 gv = st.pg[i];
+      if constexpr (FUSED) {
+        const float4 k = cg[ch];
+        const float4 x = st.px[i];
+        gv = make_float4(fin_apply(k, gv.x, x.x), fin_apply(k, gv.y, x.y), fin_apply(k, gv.z, x.z), fin_apply(k, gv.w, x.w));
+      }
+      *reinterpret_cast<float2*>(dst) = ok ? make_float2(gv.x, gv.y) : make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(dst + 2) = ok ? make_float2(gv.z, gv.w) : make_float2(0.f, 0.f);
     }
   };
 
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(pdes_conv_desc d, 
 //   dW[ky][kx] = sum_{dy,dx} dWeff[(dy,dx)][a(ky,dy)][b(kx,dx)]
 // 16 MFMAs per low-res pixel k-step instead of 36; the operand images are the low-res z halo tile
 // and the four de-interleaved parity sub-images of the hi-res gradient.
-template <int TWG, int NTW>
+template <int TWG, int NTW, bool FUSED>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                                 int n_ngroups) {
   using G = WGeo<3, TWG, 1>;
@@ -292,14 +309,21 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
     }
     cf[tid][0] = m; cf[tid][1] = sc; cf[tid][2] = bt;
   }
+  __shared__ float4 cg[FUSED ? 16 * NTW : 1];
+  if (FUSED && tid >= 64 && tid < 64 + 16 * NTW) {
+    const int c = co0 + (tid - 64);
+    cg[tid - 64] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWl;
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWh;
+  const float* ob = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff + co0) * HWh : nullptr;
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
   const bool halo_live = tiles_x > 1;
 
   // raw loads only (clamped addresses, no select on loaded values: see conv_mfma_wgrad_kernel); validity and
   // the parity de-interleave happen when the registers are committed to LDS
   float4 pv[G::NPV], ph0[NPG], ph1[NPG];
+  float4 xh0[FUSED ? NPG : 1], xh1[FUSED ? NPG : 1];
   float ph[G::NPH];
   auto issue = [&](int tile) __attribute__((always_inline)) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
@@ -329,9 +353,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       const int dy = e & 1, q = e >> 1;
       const int ch = q / (NPX / 4), p4 = q % (NPX / 4);
       const int y = oy0 + (4 * p4) / G::TW, x = ox0 + (4 * p4) % G::TW;
-      const float* src = gb + (size_t)min(ch, corem - 1) * HWh + (size_t)(2 * y + dy) * Wh + 2 * x;
+      const size_t off = (size_t)min(ch, corem - 1) * HWh + (size_t)(2 * y + dy) * Wh + 2 * x;
+      const float* src = gb + off;
       ph0[i] = *reinterpret_cast<const float4*>(src);
       ph1[i] = *reinterpret_cast<const float4*>(src + 4);
+      if constexpr (FUSED) {
+        xh0[i] = *reinterpret_cast<const float4*>(ob + off);
+        xh1[i] = *reinterpret_cast<const float4*>(ob + off + 4);
+      }
     }
   };
   auto bnrelu = [&](float x, int ch, bool ok) __attribute__((always_inline)) {
@@ -370,7 +399,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       const int dy = e & 1, q = e >> 1;
       const int ch = q / (NPX / 4), p4 = q % (NPX / 4);
       const bool v = ch < corem;
-      const float4 h0 = ph0[i], h1 = ph1[i];
+      float4 h0 = ph0[i], h1 = ph1[i];
+      if constexpr (FUSED) {
+        const float4 k = cg[ch];
+        const float4 x0 = xh0[i], x1 = xh1[i];
+        h0 = make_float4(fin_apply(k, h0.x, x0.x), fin_apply(k, h0.y, x0.y), fin_apply(k, h0.z, x0.z), fin_apply(k, h0.w, x0.w));
+        h1 = make_float4(fin_apply(k, h1.x, x1.x), fin_apply(k, h1.y, x1.y), fin_apply(k, h1.z, x1.z), fin_apply(k, h1.w, x1.w));
+      }
       float* d0 = gt + ((dy * 2 + 0) * 16 * NTW + ch) * G::GS + 4 * p4;
       float* d1 = gt + ((dy * 2 + 1) * 16 * NTW + ch) * G::GS + 4 * p4;
       *reinterpret_cast<float2*>(d0) = v ? make_float2(h0.x, h0.z) : make_float2(0.f, 0.f);       // dx = 0
@@ -539,10 +574,17 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     size_t lds = (size_t)(tpw > 2 ? 2 : 1) * (16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
-    if (tpw > 2)                                                                                              \
-      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+    if (d.g_fused) {                                                                                          \
+      if (tpw > 2)                                                                                            \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+      else                                                                                                    \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+    } else {                                                                                                  \
+      if (tpw > 2)                                                                                            \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+      else                                                                                                    \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+    }                                                                                                         \
   } while (0)
   if (twg == 2) { if (ntw == 2) PDES_WG_LAUNCH(2, 2); else PDES_WG_LAUNCH(2, 1); }
   else { if (ntw == 2) PDES_WG_LAUNCH(1, 2); else PDES_WG_LAUNCH(1, 1); }
@@ -575,7 +617,10 @@ static int launch_wgrad_up(const pdes_conv_desc& d, hipStream_t st) {
     size_t lds = (size_t)(16 * G::CS + 4 * 16 * NTW_ * G::GS) * sizeof(float);                                \
     const size_t red = (size_t)4 * 9 * NTW_ * 4 * 64 * sizeof(float);                                         \
     if (red > lds) lds = red;                                                                                 \
-    hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_>), grid, block, lds, st, d, d.ws, pl.tpw, pl.ngroups); \
+    if (d.g_fused)                                                                                            \
+      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, true>), grid, block, lds, st, d, d.ws, pl.tpw, pl.ngroups); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, false>), grid, block, lds, st, d, d.ws, pl.tpw, pl.ngroups); \
   } while (0)
   if (pl.twg == 2) { if (pl.ntw == 2) PDES_WGU_LAUNCH(2, 2); else PDES_WGU_LAUNCH(2, 1); }
   else { if (pl.ntw == 2) PDES_WGU_LAUNCH(1, 2); else PDES_WGU_LAUNCH(1, 1); }
@@ -588,12 +633,14 @@ static int launch_wgrad_up(const pdes_conv_desc& d, hipStream_t st) {
   return PDES_OK;
 }
 
-int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st) {
+// dry = true: only report whether this implementation would take the descriptor (nothing is enqueued)
+int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   if (!d.ws || !d.has_bn || !(d.ksize == 5 || d.ksize == 3 || d.ksize == 1) || d.pad != (d.ksize - 1) / 2)
     return PDES_ENOSUP;
   if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample)) return PDES_ENOSUP;
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
   if (!wgrad_shape_ok(d)) return PDES_ENOSUP;
+  if (dry) { WgradPlan pl; return wgrad_plan(d, &pl) ? PDES_OK : PDES_ENOSUP; }
   if (d.upsample) return launch_wgrad_up(d, st);
   if (d.stride == 2) return launch_wgrad<3, 2>(d, st);
   if (d.ksize == 5) return launch_wgrad<5, 1>(d, st);

@@ -36,7 +36,7 @@ class ConvDesc(ctypes.Structure):
         ('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('cout_pad', _I), ('cin_pad', _I),
         ('wm_fwd', _P), ('wm_bwd', _P), ('wu_fwd', _P), ('wu_bwd', _P),
         ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P), ('fin_xstats', _P), ('fin_tstats', _P),
-        ('g', _P), ('g_ctot', _I), ('g_coff', _I),
+        ('g', _P), ('g_ctot', _I), ('g_coff', _I), ('g_fused', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
         ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
         ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong),
