@@ -193,6 +193,9 @@ typedef struct pdes_up_pack_item { /* one nearest-x2 + 3x3 convolution: effectiv
 } pdes_up_pack_item;
 /* items: DEVICE array; see csrc/conv_mfma_up.hip for the image layout. */
 int pdes_pack_weights_up(const pdes_up_pack_item* items, int n, int max_elems, void* stream);
+/* The three tables above in ONE launch (any of them may be empty: n = 0); max_elems = the largest packed image. */
+int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
+                  const pdes_up_pack_item* uitems, int nu, int max_elems, void* stream);
 
 typedef struct pdes_bn_item {    /* one BatchNorm layer */
   const double* x_stats;  /* (>=C, 2) batch sums of its input channels */

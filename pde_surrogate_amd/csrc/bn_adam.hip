@@ -5,6 +5,7 @@
 // torch.optim.Adam as called in train_codec_mixed_residual.py:151-152,239.
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
+#include "pack_kernels.h"
 
 namespace pdes {
 
@@ -61,14 +62,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
 
 // (Cout,Cin,kk) -> w_fwd (Cin,kk,cout_pad) and w_bwd (Cout,kk,cin_pad); pads are pre-zeroed once.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const pdes_pack_item* __restrict__ items) {
-  const pdes_pack_item it = items[blockIdx.y];
-  const int total = it.Cout * it.Cin * it.kk;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int t = i % it.kk, ci = (i / it.kk) % it.Cin, co = i / (it.kk * it.Cin);
-    const float v = it.w[i];
-    it.w_fwd[((size_t)ci * it.kk + t) * it.cout_pad + co] = v;
-    it.w_bwd[((size_t)co * it.kk + t) * it.cin_pad + ci] = v;
-  }
+  pack_direct_item(items[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
+// every packed image of the network in ONE launch: blockIdx.y walks the three tables back to back
+__global__ __launch_bounds__(256) void pack_all_kernel(const pdes_pack_item* __restrict__ a, int na,
+                                                       const pdes_mfma_pack_item* __restrict__ m, int nm,
+                                                       const pdes_up_pack_item* __restrict__ u) {
+  const int y = blockIdx.y;
+  if (y < na) pack_direct_item(a[y], blockIdx.x, gridDim.x);
+  else if (y < na + nm) pack_mfma_item(m[y - na], blockIdx.x, gridDim.x);
+  else pack_up_item(u[y - na - nm], blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void bn_update_running_kernel(const pdes_bn_item* __restrict__ items, float momentum,
@@ -138,6 +142,18 @@ extern "C" int pdes_pack_weights(const pdes_pack_item* items, int n, int max_ele
   int gx = cdiv(max_elems, 256);
   gx = gx > 64 ? 64 : gx;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, n), dim3(256), 0, static_cast<hipStream_t>(stream), items);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
+                             const pdes_up_pack_item* uitems, int nu, int max_elems, void* stream) {
+  if (n < 0 || nm < 0 || nu < 0 || n + nm + nu <= 0 || max_elems <= 0) return PDES_EINVAL;
+  if ((n && !items) || (nm && !mitems) || (nu && !uitems)) return PDES_EINVAL;
+  int gx = cdiv(max_elems, 256);
+  gx = gx > 128 ? 128 : gx;
+  hipLaunchKernelGGL(pack_all_kernel, dim3(gx, n + nm + nu), dim3(256), 0, static_cast<hipStream_t>(stream), items, n,
+                     mitems, nm, uitems);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

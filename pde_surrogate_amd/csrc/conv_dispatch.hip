@@ -88,6 +88,16 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
   static const int batch_layers = getenv("PDES_WGRAD_BATCH") ? atoi(getenv("PDES_WGRAD_BATCH")) : 1;
   static const double batch_flops = getenv("PDES_WGRAD_BATCH_GF") ? 1e9 * atof(getenv("PDES_WGRAD_BATCH_GF")) : 1.5e9;
   static const bool reduce_per_batch = getenv("PDES_WGRAD_REDUCE") && getenv("PDES_WGRAD_REDUCE")[0] == 'b';
+  // The split-K partials of the last layers (the widest ones: LastTransUp holds ~3/4 of the weights) are reduced
+  // on the second stream as soon as those layers are done; only the rest waits for the end of the chain.
+  long long per_total = 0, per_done = 0;
+  int n_items = 0, early_lo = -1;          // early_lo: first table row already reduced early (-1: none yet)
+  if (reduce_items && reduce_index)
+    for (int i = 0; i < n; ++i)
+      if (reduce_index[i] >= 0) {
+        per_total += (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
+        ++n_items;
+      }
   int pend_hi = -1;                       // layers [i, pend_hi] are finalized but their weight gradient is not enqueued
   double pend_flops = 0.0;
   size_t nev = 0;
@@ -116,6 +126,25 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
     if (r_lo >= 0) {                      // item indices grow with the layer index: the batch is one contiguous slice
       const int rc = pdes_wgrad_reduce_all(reduce_items + r_lo, r_hi - r_lo + 1, (int)max_n, ws);
       if (rc) return rc;
+    }
+    if (fork && !reduce_per_batch && early_lo < 0 && reduce_items && reduce_index && lo > 0) {
+      for (int i = pend_hi; i >= lo; --i)
+        if (reduce_index[i] >= 0) per_done += (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
+      if (5 * per_done >= 3 * per_total) {        // >= 60 % of the partials exist: reduce them now, off the critical path
+        int first = -1;
+        long long mx = 0;
+        for (int i = lo; i < n; ++i)
+          if (reduce_index[i] >= 0) {
+            if (first < 0) first = reduce_index[i];
+            const long long per = (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
+            mx = per > mx ? per : mx;
+          }
+        if (first >= 0) {
+          const int rc = pdes_wgrad_reduce_all(reduce_items + first, n_items - first, (int)mx, ws);
+          if (rc) return rc;
+          early_lo = first;
+        }
+      }
     }
     pend_hi = -1;
     pend_flops = 0.0;
@@ -167,7 +196,7 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
     int cnt = 0;
     long long max_n = 0;
     for (int i = 0; i < n; ++i)
-      if (reduce_index[i] >= 0) {
+      if (reduce_index[i] >= 0 && (early_lo < 0 || reduce_index[i] < early_lo)) {
         ++cnt;
         const long long per = (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
         max_n = per > max_n ? per : max_n;

@@ -28,6 +28,7 @@
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
 #include "bn_fused.h"
+#include "pack_kernels.h"
 
 namespace pdes {
 
@@ -511,22 +512,7 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
 //                 forward  [(kstep*KK + tap)*NT + nt][kq*16 + n] = W[n + 16 nt][4 kstep + kq][tap]
 //                 backward [(kstep*KK + tap)*NT + nt][kq*16 + n] = W[4 kstep + kq][n + 16 nt][KK-1-tap]
 __global__ __launch_bounds__(256) void pack_mfma_kernel(const pdes_mfma_pack_item* __restrict__ items) {
-  const pdes_mfma_pack_item it = items[blockIdx.y];
-  const int ntf = (((it.Cout + 15) / 16) + 7) & ~7, ksf = ((it.Cin + 15) / 16) * 4;
-  const int totf = ksf * it.kk * ntf * 64;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < totf; i += gridDim.x * 256) {
-    const int l = i & 63, nt = (i >> 6) % ntf, t = ((i >> 6) / ntf) % it.kk, ks = (i >> 6) / (ntf * it.kk);
-    const int co = nt * 16 + (l & 15), ci = 4 * ks + (l >> 4);
-    it.wm_fwd[i] = (co < it.Cout && ci < it.Cin) ? it.w[((size_t)co * it.Cin + ci) * it.kk + t] : 0.f;
-  }
-  if (!it.wm_bwd) return;
-  const int ntb = (((it.Cin + 15) / 16) + 7) & ~7, ksb = ((it.Cout + 15) / 16) * 4;
-  const int totb = ksb * it.kk * ntb * 64;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < totb; i += gridDim.x * 256) {
-    const int l = i & 63, nt = (i >> 6) % ntb, t = ((i >> 6) / ntb) % it.kk, ks = (i >> 6) / (ntb * it.kk);
-    const int ci = nt * 16 + (l & 15), co = 4 * ks + (l >> 4);
-    it.wm_bwd[i] = (co < it.Cout && ci < it.Cin) ? it.w[((size_t)co * it.Cin + ci) * it.kk + (it.kk - 1 - t)] : 0.f;
-  }
+  pack_mfma_item(items[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------- host dispatch
@@ -557,18 +543,32 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   const int kpad = (kC + 15) & ~15, nchunk = kpad / 16;
   const int nt_total = (nC + 15) / 16;
   const int twg = W >= 32 ? 2 : 1;
-  // wave roles
-  int wk, ntw, gz = 1;
-  if (nt_total == 1) { wk = 4; ntw = 1; }
-  else if (kpad <= 16 || nt_total <= 4) { wk = 1; ntw = 1; gz = (nt_total + 3) / 4; }   // cheap staging: split N over z
-  else { wk = 1; ntw = 2; gz = (nt_total + 7) / 8; }
-  if (wk == 1 && ntw == 2 && (KS == 5 || env_int("PDES_MFMA_NTW", 2) == 1)) { ntw = 1; gz = (nt_total + 3) / 4; }
-  // M-tiles per workgroup: 8, or 4 when that is needed to put >= 1 workgroup on every CU
-  int mt = 8;
-  const long long wg8 = (long long)(W / (16 * twg)) * (H / (8 / twg)) * d.B * gz;
-  if (wg8 < 256) mt = 4;
-  mt = env_int("PDES_MFMA_MT", mt);
-  if (!(mt == 8 || mt == 4) || KS == 5 || S == 2) mt = 8;
+  // wave roles and tile size.  One N-tile (dense layers): the four waves split K.  Otherwise the waves split
+  // N, NTW tiles each, the rest of N over gridDim.z; among (M-tiles per workgroup, NTW) = (8,2) (8,1) (4,2) (4,1)
+  // take the first that puts a workgroup on every CU (small maps: staging a tile twice is cheaper than idle CUs),
+  // else the one with the most workgroups.
+  int wk, ntw, gz = 1, mt = 8;
+  const long long tiles8 = (long long)(W / (16 * twg)) * (H / (8 / twg)) * d.B;
+  const bool mt4_ok = KS != 5 && H % (4 / twg) == 0;
+  if (nt_total == 1) {
+    wk = 4; ntw = 1;
+    if (tiles8 < 256 && mt4_ok) mt = 4;
+  } else {
+    wk = 1;
+    const bool ntw2_ok = KS != 5 && kpad > 16 && nt_total > 4 && env_int("PDES_MFMA_NTW", 2) != 1;
+    const int cand[4][2] = {{8, 2}, {8, 1}, {4, 2}, {4, 1}};
+    long long best = -1;
+    mt = 8; ntw = 1;
+    for (int c = 0; c < 4; ++c) {
+      const int cm = cand[c][0], cn = cand[c][1];
+      if ((cn == 2 && !ntw2_ok) || (cm == 4 && !mt4_ok)) continue;
+      const long long wgs = tiles8 * (8 / cm) * ((nt_total + 4 * cn - 1) / (4 * cn));
+      if (wgs >= 256) { mt = cm; ntw = cn; best = wgs; break; }
+      if (wgs > best) { mt = cm; ntw = cn; best = wgs; }
+    }
+    gz = (nt_total + 4 * ntw - 1) / (4 * ntw);
+  }
+  { const int e = env_int("PDES_MFMA_MT", 0); if ((e == 8 || e == 4) && (e == 8 || mt4_ok)) mt = e; }
   const int th = mt / twg;
   if (H % th) return PDES_ENOSUP;
   dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
@@ -613,6 +613,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     }
   } else {
     PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)
+    PDES_TRY(2, 4, 1, 1) PDES_TRY(2, 4, 1, 2) PDES_TRY(1, 4, 1, 1) PDES_TRY(1, 4, 1, 2)
   }
 #undef PDES_TRY
   if (rc || dry) return rc;

@@ -23,6 +23,7 @@
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
 #include "bn_fused.h"
+#include "pack_kernels.h"
 
 namespace pdes {
 
@@ -377,34 +378,9 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// effective-weight images.  R(d, i): the 3x3 taps that land on position i of the 2x2 kernel of parity d
-__device__ __forceinline__ float weff(const float* w9, int dy, int dx, int a, int b) {
-  const int y0 = dy == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), y1 = dy == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
-  const int x0 = dx == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), x1 = dx == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
-  float s = 0.f;
-  for (int ky = y0; ky <= y1; ++ky)
-    for (int kx = x0; kx <= x1; ++kx) s += w9[ky * 3 + kx];
-  return s;
-}
-
+// effective-weight images (pack_kernels.h)
 __global__ __launch_bounds__(256) void pack_up_kernel(const pdes_up_pack_item* __restrict__ items) {
-  const pdes_up_pack_item it = items[blockIdx.y];
-  const int ntf = (((it.Cout + 15) / 16) + 7) & ~7, ksf = ((it.Cin + 15) / 16) * 4;
-  const int totf = ksf * 16 * ntf * 64;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < totf; i += gridDim.x * 256) {
-    const int l = i & 63, nt = (i >> 6) % ntf, q = ((i >> 6) / ntf) % 16, ks = (i >> 6) / (ntf * 16);
-    const int co = nt * 16 + (l & 15), ci = 4 * ks + (l >> 4);
-    const int p = q >> 2, a = (q >> 1) & 1, b = q & 1;
-    it.wu_fwd[i] = (co < it.Cout && ci < it.Cin) ? weff(it.w + ((size_t)co * it.Cin + ci) * 9, p >> 1, p & 1, a, b) : 0.f;
-  }
-  const int ntb = (((it.Cin + 15) / 16) + 7) & ~7, ksb = ((it.Cout + 15) / 16) * 4;
-  const int totb = ksb * 16 * ntb * 64;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < totb; i += gridDim.x * 256) {
-    const int l = i & 63, nt = (i >> 6) % ntb, q = ((i >> 6) / ntb) % 16, ks = (i >> 6) / (ntb * 16);
-    const int ci = nt * 16 + (l & 15), co = 4 * ks + (l >> 4);
-    const int p = q >> 2, a = (q >> 1) & 1, b = q & 1;
-    it.wu_bwd[i] = (co < it.Cout && ci < it.Cin) ? weff(it.w + ((size_t)co * it.Cin + ci) * 9, p >> 1, p & 1, a, b) : 0.f;
-  }
+  pack_up_item(items[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------- host dispatch

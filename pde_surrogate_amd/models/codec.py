@@ -535,16 +535,13 @@ class _HipNet(nn.Module):
         self._engines = {}
 
     def _pack_weights(self):
-        rc = _lib.lib().pdes_pack_weights(self._pack_table.data_ptr(), self._pack_n, self._pack_max, _lib.stream_ptr())
-        _lib.check(rc, 'pdes_pack_weights')
-        if self._mpack_n:
-            rc = _lib.lib().pdes_pack_weights_mfma(self._mpack_table.data_ptr(), self._mpack_n, self._mpack_max,
-                                                   _lib.stream_ptr())
-            _lib.check(rc, 'pdes_pack_weights_mfma')
-        if self._upack_n:
-            rc = _lib.lib().pdes_pack_weights_up(self._upack_table.data_ptr(), self._upack_n, self._upack_max,
-                                                 _lib.stream_ptr())
-            _lib.check(rc, 'pdes_pack_weights_up')
+        """rebuild every packed weight image from the live weights: one launch (direct, MFMA and sub-pixel tables)"""
+        mx = max(self._pack_max, self._mpack_max if self._mpack_n else 0, self._upack_max if self._upack_n else 0)
+        rc = _lib.lib().pdes_pack_all(self._pack_table.data_ptr(), self._pack_n,
+                                      self._mpack_table.data_ptr() if self._mpack_n else None, self._mpack_n,
+                                      self._upack_table.data_ptr() if self._upack_n else None, self._upack_n,
+                                      mx, _lib.stream_ptr())
+        _lib.check(rc, 'pdes_pack_all')
 
     def _is_flat(self, device):
         if self._flat is None or self._flat.device != device:
