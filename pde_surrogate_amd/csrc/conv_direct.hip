@@ -292,46 +292,100 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct(pdes_conv_desc d, 
 // ---------------------------------------------------------------- bwd weight, first convolution
 // The first convolution (no BatchNorm in front, 1..4 input channels, e.g. 7x7 stride 2 on the
 // permeability field) has a tiny weight tensor but a 49-tap reduction over every output pixel.
-// One workgroup = one sample x 8 output channels: the zero-bordered input plane(s) and the 8
-// gradient planes sit in LDS, a thread owns (channel, tap) pairs and runs over the output pixels.
-template <int COT>
+// One workgroup = one sample x COT output channels: the zero-bordered input plane(s) and the COT gradient
+// planes sit in LDS.  A thread owns (channel, kernel row ky, row group) and keeps the k taps of that kernel row
+// in registers: per 4 output pixels it reads one float4 of the gradient and the 4*stride + k - 1 input values
+// they touch (aligned float4 LDS reads), i.e. ~5 LDS reads per 28 FMAs for the 7x7 stride-2 first layer.
+// The row groups of one (channel, ky) are adjacent lanes and are combined with two shuffles.
+template <int COT, int K, int S>
 __global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
-  const int k = d.ksize, KK = k * k, HWo = d.Hout * d.Wout, HWi = d.Hin * d.Win;
-  const int LH = d.Hin + 2 * d.pad + d.stride, LW = d.Win + 2 * d.pad + d.stride;   // bordered plane
+  constexpr int KK = K * K;
+  constexpr int RG = 4;                                 // row groups per (channel, ky)
+  constexpr int NX = 4 * S + K - 1;                     // input values touched by 4 consecutive outputs
+  constexpr int NX4 = (NX + 3) / 4;
+  const int HWo = d.Hout * d.Wout, HWi = d.Hin * d.Win;
+  const int LH = d.Hin + 2 * d.pad + S, LW = ((d.Win + 2 * d.pad + S + 4 + 3) / 4) * 4;   // bordered plane, 16-B rows
   float* xs = smf;                                   // [Cin][LH][LW]
   float* gs = smf + d.Cin * LH * LW;                 // [COT][HWo]
   const int tid = threadIdx.x, b = blockIdx.x, co0 = blockIdx.y * COT;
-  for (int i = tid; i < d.Cin * LH * LW; i += 256) {
-    const int c = i / (LH * LW), r = (i % (LH * LW)) / LW - d.pad, q = i % LW - d.pad;
-    xs[i] = (r >= 0 && r < d.Hin && q >= 0 && q < d.Win) ? d.x[((size_t)b * d.x_ctot + c) * HWi + r * d.Win + q] : 0.f;
+  // staging: global loads are issued in batches of 4 (x) / 8 (g) float4 per thread before any LDS write, so the
+  // workgroup pays the memory latency once per batch instead of once per element
+  for (int i = tid; i < d.Cin * LH * LW / 4; i += 256) reinterpret_cast<float4*>(xs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int W4 = d.Win / 4, nx4 = d.Cin * d.Hin * W4;            // Win % 4 == 0 (checked on the host)
+  for (int i0 = 0; i0 < nx4; i0 += 4 * 256) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + tid + 256 * u, nx4 - 1);
+      const int cc = i / (d.Hin * W4), yy = (i / W4) % d.Hin, x4 = i % W4;
+      v[u] = *reinterpret_cast<const float4*>(d.x + ((size_t)b * d.x_ctot + cc) * HWi + yy * d.Win + 4 * x4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + tid + 256 * u;
+      if (i < nx4) {
+        const int cc = i / (d.Hin * W4), yy = (i / W4) % d.Hin, x4 = i % W4;
+        float* dst = xs + (cc * LH + yy + d.pad) * LW + d.pad + 4 * x4;
+        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+      }
+    }
   }
-  for (int i = tid; i < COT * HWo; i += 256) {
-    const int c = i / HWo;
-    gs[i] = (co0 + c < d.Cout) ? d.g[((size_t)b * d.g_ctot + d.g_coff + co0 + c) * HWo + i % HWo] : 0.f;
+  const int ng4 = COT * HWo / 4;
+  for (int i0 = 0; i0 < ng4; i0 += 8 * 256) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + tid + 256 * u, ng4 - 1);
+      const int cc = min((4 * i) / HWo, d.Cout - 1 - co0);
+      v[u] = *reinterpret_cast<const float4*>(d.g + ((size_t)b * d.g_ctot + d.g_coff + co0 + cc) * HWo + (4 * i) % HWo);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + tid + 256 * u;
+      if (i < ng4) {
+        const bool ok = co0 + (4 * i) / HWo < d.Cout;
+        *reinterpret_cast<float4*>(gs + 4 * i) = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
   }
   __syncthreads();
-  const int npair = COT * d.Cin * KK;
-  for (int pr = tid; pr < npair; pr += 256) {
-    const int c = pr / (d.Cin * KK), ci = (pr / KK) % d.Cin, t = pr % KK;
-    const int ky = t / k, kx = t % k;
-    const float* xp = xs + ci * LH * LW + ky * LW + kx;     // pixel (oy,ox) reads xp[(oy*s)*LW + ox*s]
-    const float* gp = gs + c * HWo;
-    // 8 independent accumulators: the loop is LDS-latency bound, not bandwidth bound
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int st2 = d.stride;
-    for (int oy = 0; oy < d.Hout; ++oy) {
-      const float* xr = xp + oy * st2 * LW;
-      const float* gr = gp + oy * d.Wout;
-      int ox = 0;
-      for (; ox + 8 <= d.Wout; ox += 8) {
+  const int c = tid / (K * RG), ky = (tid / RG) % K, grp = tid % RG;
+  const bool live = c < COT;
+  const int rows = d.Hout / RG;                         // output rows per group (Hout % 4 == 0 checked on the host)
+  for (int ci = 0; ci < d.Cin; ++ci) {
+    float a[K];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] += gr[ox + u] * xr[(ox + u) * st2];
+    for (int kx = 0; kx < K; ++kx) a[kx] = 0.f;
+    if (live) {
+      const float* gp = gs + c * HWo;
+      for (int oy = grp * rows; oy < (grp + 1) * rows; ++oy) {
+        const float* xr = xs + (ci * LH + oy * S + ky) * LW;
+        const float* gr = gp + oy * d.Wout;
+        for (int ox = 0; ox < d.Wout; ox += 4) {
+          const float4 gv = *reinterpret_cast<const float4*>(gr + ox);
+          float xv[4 * NX4];
+#pragma unroll
+          for (int j = 0; j < NX4; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + ox * S + 4 * j);
+            xv[4 * j] = t.x; xv[4 * j + 1] = t.y; xv[4 * j + 2] = t.z; xv[4 * j + 3] = t.w;
+          }
+          const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) a[kx] += g4[u] * xv[u * S + kx];
+        }
       }
-      for (; ox < d.Wout; ++ox) a[0] += gr[ox] * xr[ox * st2];
     }
-    const float a0 = (a[0] + a[1]) + (a[2] + a[3]), a1 = (a[4] + a[5]) + (a[6] + a[7]);
-    if (co0 + c < d.Cout) atomicAdd(&d.dw[((size_t)(co0 + c) * d.Cin + ci) * KK + t], a0 + a1);
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      float v = a[kx];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      if (live && grp == 0 && co0 + c < d.Cout) atomicAdd(&d.dw[((size_t)(co0 + c) * d.Cin + ci) * KK + ky * K + kx], v);
+    }
   }
 }
 
@@ -388,12 +442,13 @@ int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st) {
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st) {
   const int rc = validate(d, 1);
   if (rc) return rc;
-  if (!d.has_bn && !d.upsample && d.Cin <= 4) {
-    // first convolution: LDS-resident planes (see conv_bwd_weight_first)
-    const int LH = d.Hin + 2 * d.pad + d.stride, LW = d.Win + 2 * d.pad + d.stride;
+  if (!d.has_bn && !d.upsample && d.Cin <= 4 && d.ksize == 7 && d.stride == 2 && d.Wout % 4 == 0 && d.Hout % 4 == 0 &&
+      d.Win % 4 == 0) {
+    // first convolution (7x7, stride 2): LDS-resident planes, register-tiled kernel rows (conv_bwd_weight_first)
+    const int LH = d.Hin + 2 * d.pad + 2, LW = ((d.Win + 2 * d.pad + 2 + 4 + 3) / 4) * 4;
     const size_t lds = ((size_t)d.Cin * LH * LW + (size_t)8 * d.Hout * d.Wout) * sizeof(float);
     if (lds <= 150 * 1024) {
-      hipLaunchKernelGGL(conv_bwd_weight_first<8>, dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d);
+      hipLaunchKernelGGL((conv_bwd_weight_first<8, 7, 2>), dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d);
       PDES_LAUNCH_CHECK();
       return PDES_OK;
     }
