@@ -14,6 +14,7 @@ int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st);        // PDES_E
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);   // dry: capability query only
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st);        // nearest-x2 + 3x3, sub-pixel form
+int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st);         // 5x5 with <= 3 output channels
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 
 // PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
@@ -31,6 +32,7 @@ extern "C" int pdes_conv_forward(const pdes_conv_desc* descs, int n, void* strea
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
     int rc = force_direct() ? PDES_ENOSUP : conv_forward_up_mfma(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_fewout(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_mfma(descs[i], st);
     if (rc == PDES_ENOSUP) rc = conv_forward_direct(descs[i], st);
     if (rc) return rc;

@@ -39,14 +39,21 @@ struct WGeo {
 
 // PIPE: > 2 pixel tiles per workgroup, prefetch two ahead.  FUSED: d.g is the raw accumulator T; the
 // BatchNorm-backward finalize is applied while the gradient tile is committed to LDS (bn_fused.h).
-template <int KS, int TWG, int NTW, int S, bool PIPE, bool FUSED>
+// FEW (5x5, Cout*5 <= 16): the N dimension is (output channel, kernel column kx) instead of 16 output channels
+// (conv_mfma_fewout.hip): 5 accumulators (kernel rows) and 5 MFMAs per pixel k-step instead of 25, the B
+// operand is the gradient tile read with a per-lane column shift of -kx.
+template <int KS, int TWG, int NTW, int S, bool PIPE, bool FUSED, bool FEW>
 __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                              int n_ngroups) {
   using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS;
   constexpr int NPG4 = 16 * NTW * G::TH * G::TW / 4 / 256;      // g float4 per thread per tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int LDSB = 16 * G::CS + 16 * NTW * G::GS;           // one buffer: z image then g image
+  static_assert(!FEW || (KS == 5 && NTW == 1 && S == 1 && !FUSED), "few-output form: 5x5, stride 1");
+  constexpr int GROW = G::TW + 8;                                // FEW: gradient row with 4 zero columns either side
+  constexpr int GPL = ((G::TH * GROW - 8 + 31) / 32) * 32 + 8;  // FEW: plane stride == 8 (mod 32); plane 3 stays zero
+  constexpr int GAREA = FEW ? 4 * GPL : 16 * NTW * G::GS;
+  constexpr int LDSB = 16 * G::CS + GAREA;                       // one buffer: z image then g image
   float* zt = smem;                                            // [2][ [16][CS] | [16*NTW][GS] ]
   float* gt = smem + 16 * G::CS;
 
@@ -85,6 +92,9 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
     cg[tid - 64] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
+  if (FEW) {                     // pad columns and the zero plane are never written by the staging
+    for (int i = tid; i < GAREA; i += 256) { gt[i] = 0.f; if (PIPE) gt[LDSB + i] = 0.f; }
+  }
   const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWi;
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
   const float* ob = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff + co0) * HWo : nullptr;
@@ -169,6 +179,13 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
       const int e = tid + 256 * i;
       const int ch = e / (G::TH * G::TW / 4), p4 = e % (G::TH * G::TW / 4);
       const bool ok = ch < corem;
+      if constexpr (FEW) {
+        if (ok) {
+          const int row = (4 * p4) / G::TW, col = (4 * p4) % G::TW;
+          *reinterpret_cast<float4*>(gtb + ch * GPL + row * GROW + 4 + col) = st.pg[i];
+        }
+        continue;
+      }
       float* dst = gtb + ch * G::GS + 4 * p4;                               // 8-byte aligned (GS even)
       float4 gv = st.pg[i];
       if constexpr (FUSED) {
@@ -181,9 +198,10 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
     }
   };
 
-  v4f acc[KK][NTW];
+  constexpr int NACC = FEW ? KS : KK;
+  v4f acc[NACC][NTW];
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
@@ -196,6 +214,24 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
   auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
     const float* ztb = zt + buf * LDSB;
     const float* gtb = gt + buf * LDSB;
+    if constexpr (FEW) {
+      const int n = lane & 15, bco = n < 15 ? min(n / 5, 3) : 3, bkx = n % 5;     // column 15: the zero plane
+      const int few_b = bco * GPL + 4 + (lane >> 4) - bkx;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
+#pragma unroll
+        for (int ks = 0; ks <= G::TW / 4; ++ks) {            // x' = ox0 - 2 + 4 ks + k: one k-step of halo
+          const float bv = gtb[few_b + row * GROW + 4 * ks];
+#pragma unroll
+          for (int ky = 0; ky < KS; ++ky) {
+            const float a = ztb[a_lane + (row + ky) * G::LDW + (G::COL0 - G::PADL) + 4 * ks];
+            acc[ky][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[ky][0], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = wave * RPW + rr;
@@ -249,10 +285,10 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
   }
 
   // ---- sum the 4 waves through LDS, then write this pixel split's partial dW
-  float* red = smem;               // [4][KK*NTW*4][64]
-  constexpr int NR = KK * NTW * 4;
+  float* red = smem;               // [4][NACC*NTW*4][64]
+  constexpr int NR = NACC * NTW * 4;
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -263,8 +299,14 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
     const float s = red[(0 * NR + q) * 64 + lane] + red[(1 * NR + q) * 64 + lane] +
                     red[(2 * NR + q) * 64 + lane] + red[(3 * NR + q) * 64 + lane];
     const int r = q & 3, nt = (q >> 2) % NTW, t = (q >> 2) / NTW;
-    const int co = co0 + nt * 16 + (lane & 15), ci = ci0 + (lane >> 4) * 4 + r;
-    if (co < d.Cout && ci < d.Cin) pout[((size_t)co * d.Cin + ci) * KK + t] = s;
+    const int ci = ci0 + (lane >> 4) * 4 + r;
+    if constexpr (FEW) {             // t = kernel row ky, column n = (co, kx)
+      const int n = lane & 15, co = n / 5, kx = n % 5;
+      if (n < 15 && co < d.Cout && ci < d.Cin) pout[(((size_t)co * d.Cin + ci) * KS + t) * KS + kx] = s;
+    } else {
+      const int co = co0 + nt * 16 + (lane & 15);
+      if (co < d.Cout && ci < d.Cin) pout[((size_t)co * d.Cin + ci) * KK + t] = s;
+    }
   }
 }
 
@@ -574,16 +616,25 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     size_t lds = (size_t)(tpw > 2 ? 2 : 1) * (16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
+    if constexpr (KS == 5 && NTW_ == 1 && S == 1) {                                                           \
+      if (d.Cout * 5 <= 16 && !d.g_fused) {      /* few-output form; its LDS need is below the generic one */ \
+        if (tpw > 2)                                                                                          \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        else                                                                                                  \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        break;                                                                                                \
+      }                                                                                                       \
+    }                                                                                                         \
     if (d.g_fused) {                                                                                          \
       if (tpw > 2)                                                                                            \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
     } else {                                                                                                  \
       if (tpw > 2)                                                                                            \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
     }                                                                                                         \
   } while (0)
   if (twg == 2) { if (ntw == 2) PDES_WG_LAUNCH(2, 2); else PDES_WG_LAUNCH(2, 1); }
