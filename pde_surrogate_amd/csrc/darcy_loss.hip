@@ -329,6 +329,154 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS)
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Large batches (n = 64, forward + backward): persistent workgroups with asynchronous global -> LDS
+// copies (global_load_lds_dwordx4, no staging registers).  One 1024-thread workgroup per CU walks
+// images b, b + gridDim.x, ...; while image i is being processed out of one 64 KiB LDS buffer
+// (K, u, sigma1, sigma2), the four planes of image i+1 stream into the other, so every CU always has
+// a full image of reads (plus the previous image's 48 KiB of writes) in flight instead of
+// alternating load and compute phases.  The copies retire in order on the wave's VM counter:
+// younger than image i's four copies are at most the 3 gradient stores of image i-1 and the 4 copies
+// of image i+1, hence the counted vmcnt waits below.  Barriers are raw s_barrier + lgkmcnt(0): a
+// __syncthreads() fence would drain vmcnt and with it the prefetch.
+__device__ __forceinline__ void glds16(const float4* g, float4* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool NONLIN>
+__global__ __launch_bounds__(1024) void darcy_loss_dma_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
+                                                             float* __restrict__ gyp, float* __restrict__ partials,
+                                                             LossParams p, int B) {
+  constexpr int N = 64, SPR = 16, NSTRIP = 1024, NW = 16;
+  // TWO separate LDS objects: the compiler orders LDS accesses against in-flight LDS-DMA by alias analysis, and
+  // only distinct objects let it see that the copy into one buffer does not touch the other (with a single
+  // array it drains vmcnt(0) -- the whole prefetch -- before the first ds_write of every image)
+  __shared__ __attribute__((aligned(16))) float4 bufA[4 * NSTRIP];
+  __shared__ __attribute__((aligned(16))) float4 bufB[4 * NSTRIP];
+  __shared__ float red[NW * 4];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float fn = (float)N;
+  auto dma = [&](int b, float4* bufp) __attribute__((always_inline)) {
+    const float4* K4 = reinterpret_cast<const float4*>(Kp + (size_t)b * N * N);
+    const float4* y4 = reinterpret_cast<const float4*>(yp + (size_t)b * 3 * N * N);
+    float4* dst = bufp + wave * 64;                               // wave-uniform base; lane l lands at dst[l]
+    glds16(K4 + tid, dst);
+    glds16(y4 + tid, dst + NSTRIP);
+    glds16(y4 + NSTRIP + tid, dst + 2 * NSTRIP);
+    glds16(y4 + 2 * NSTRIP + tid, dst + 3 * NSTRIP);
+  };
+  int b = blockIdx.x;
+  if (b >= B) return;
+  const int s = tid, r = s / SPR, cs = s % SPR;
+  const bool first = cs == 0, last = cs == SPR - 1;
+  const RowGeom g = row_geom<N>(r, true);
+  const bool tb = (r == 0) || (r == N - 1);
+  dma(b, bufA);
+  // one image out of `pl`, the next one streaming into `nx`
+  auto process = [&](int b, int it, float4* pl, float4* nx) __attribute__((always_inline)) {
+    const bool more = b + (int)gridDim.x < B;
+    if (more) dma(b + gridDim.x, nx);
+    if (more) { if (it == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+    else { if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    lds_barrier();                       // every wave's copies of image b have landed
+    float4* lds = pl + NSTRIP;           // planes u, sigma1, sigma2 (same indexing as darcy_loss_kernel)
+
+    float sum_const = 0.f, sum_cont = 0.f, sum_dir = 0.f, sum_neu = 0.f;
+    F4 R1, R2, P1, P2, CC;
+    float dub;
+    {
+      const F4 kk(pl[s]);
+      const F4 u_own(lds[s]), s1_own(lds[NSTRIP + s]), s2_own(lds[2 * NSTRIP + s]);
+      const F4 u_up(lds[g.up * SPR + cs]), u_dn(lds[g.dn * SPR + cs]), u_far(lds[g.farF * SPR + cs]);
+      const F4 a_up(lds[NSTRIP + g.up * SPR + cs]), a_dn(lds[NSTRIP + g.dn * SPR + cs]);
+      const F4 b_up(lds[2 * NSTRIP + g.up * SPR + cs]), b_dn(lds[2 * NSTRIP + g.dn * SPR + cs]),
+          b_far(lds[2 * NSTRIP + g.farF * SPR + cs]);
+      const F4 ghu = hdiff(vsmooth3(u_up, u_own, u_dn), first, last, true, fn);
+      const F4 gvu = hsmooth(comb4(g.f_own, u_own, g.f_up, u_up, g.f_dn, u_dn, g.f_far, u_far), first, last, fn);
+      const F4 gh1 = hdiff(vsmooth3(a_up, s1_own, a_dn), first, last, true, fn);
+      const F4 gv2 = hsmooth(comb4(g.f_own, s2_own, g.f_up, b_up, g.f_dn, b_dn, g.f_far, b_far), first, last, fn);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float K = kk.v[i];
+        float r1 = s1_own.v[i] + K * ghu.v[i];
+        float r2 = s2_own.v[i] + K * gvu.v[i];
+        float q1 = 1.f, q2 = 1.f;
+        if (NONLIN) {
+          const float sq = sqrtf(K), x1 = s1_own.v[i], x2 = s2_own.v[i];
+          r1 += p.beta1 * sq * x1 * x1 + p.beta2 * K * x1 * x1 * x1;
+          r2 += p.beta1 * sq * x2 * x2 + p.beta2 * K * x2 * x2 * x2;
+          q1 += 2.f * p.beta1 * sq * x1 + 3.f * p.beta2 * K * x1 * x1;
+          q2 += 2.f * p.beta1 * sq * x2 + 3.f * p.beta2 * K * x2 * x2;
+        }
+        const float c = gh1.v[i] + gv2.v[i];
+        sum_const += r1 * r1 + r2 * r2;
+        sum_cont += c * c;
+        if (tb) sum_neu += s2_own.v[i] * s2_own.v[i];
+        R1.v[i] = p.a_const * r1 * q1;
+        R2.v[i] = p.a_const * r2 * q2 + (tb ? p.b_neu * s2_own.v[i] : 0.f);
+        P1.v[i] = p.a_const * K * r1;
+        P2.v[i] = p.a_const * K * r2;
+        CC.v[i] = p.a_cont * c;
+      }
+      float db = 0.f;
+      if (first) { const float e = u_own.v[0] - 1.f; sum_dir += e * e; db = p.b_dir * e; }
+      if (last) { const float e = u_own.v[3]; sum_dir += e * e; db = p.b_dir * e; }
+      dub = db;
+    }
+    {
+      const float t0 = wave_sum(sum_const), t1 = wave_sum(sum_cont), t2 = wave_sum(sum_dir), t3 = wave_sum(sum_neu);
+      if ((tid & 63) == 0) { red[wave * 4 + 0] = t0; red[wave * 4 + 1] = t1; red[wave * 4 + 2] = t2; red[wave * 4 + 3] = t3; }
+    }
+    lds_barrier();                       // also: every read of the input planes is done
+    if (tid < 4) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w * 4 + tid];
+      partials[(size_t)b * 4 + tid] = t;
+    }
+    lds[s] = P1.f4();
+    lds[NSTRIP + s] = P2.f4();
+    lds[2 * NSTRIP + s] = CC.f4();
+    lds_barrier();
+    {
+      const F4 p1_own(lds[s]), p2_own(lds[NSTRIP + s]), c_own(lds[2 * NSTRIP + s]);
+      const F4 p1_up(lds[g.up * SPR + cs]), p1_dn(lds[g.dn * SPR + cs]);
+      const F4 p2_up(lds[NSTRIP + g.up * SPR + cs]), p2_dn(lds[NSTRIP + g.dn * SPR + cs]),
+          p2_far(lds[NSTRIP + g.farA * SPR + cs]);
+      const F4 c_up(lds[2 * NSTRIP + g.up * SPR + cs]), c_dn(lds[2 * NSTRIP + g.dn * SPR + cs]),
+          c_far(lds[2 * NSTRIP + g.farA * SPR + cs]);
+      const F4 ghT_c = hdiff_adj(vsmooth3(c_up, c_own, c_dn), first, last, fn);
+      const F4 gvT_c = hsmooth(comb4(g.a_own, c_own, g.a_up, c_up, g.a_dn, c_dn, g.a_far, c_far), first, last, fn);
+      const F4 ghT_p1 = hdiff_adj(vsmooth3(p1_up, p1_own, p1_dn), first, last, fn);
+      const F4 gvT_p2 = hsmooth(comb4(g.a_own, p2_own, g.a_up, p2_up, g.a_dn, p2_dn, g.a_far, p2_far), first, last, fn);
+      F4 du, d1, d2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        du.v[i] = ghT_p1.v[i] + gvT_p2.v[i];
+        d1.v[i] = R1.v[i] + ghT_c.v[i];
+        d2.v[i] = R2.v[i] + gvT_c.v[i];
+      }
+      if (first) du.v[0] += dub;
+      if (last) du.v[3] += dub;
+      float4* g4 = reinterpret_cast<float4*>(gyp + (size_t)b * 3 * N * N);
+      nt_store4(g4 + s, du.f4());
+      nt_store4(g4 + NSTRIP + s, d1.f4());
+      nt_store4(g4 + 2 * NSTRIP + s, d2.f4());
+    }
+    lds_barrier();                       // the next iteration's copies overwrite this buffer
+  };
+  for (int it = 0; b < B; it += 2) {
+    process(b, it, bufA, bufB);
+    b += gridDim.x;
+    if (b >= B) break;
+    process(b, it + 1, bufB, bufA);
+    b += gridDim.x;
+  }
+}
+
 // The adjoint of hsmooth is hsmooth (S is symmetric) and the adjoint of vsmooth3 is vsmooth3,
 // so the backward above reuses them; only the difference operators have distinct adjoints.
 
@@ -471,7 +619,22 @@ extern "C" int pdes_darcy_loss(const float* K, const float* y, float* grad_y, fl
   // streaming accesses once the 7 planes/sample no longer fit the 256 MiB Infinity Cache; at training
   // batch sizes y was just produced and grad_y is consumed next, so those stay cacheable
   { const char* e = getenv("PDES_LOSS_NT"); p.nt = e ? atoi(e) : ((long long)B * H * W * 28 > (200ll << 20)); }
-  if (H == 64) launch_loss<64>(K, y, grad_y, partials, B, p, nonlinear, st);
+  // PDES_LOSS_DMA=1: persistent workgroups + asynchronous global->LDS copies (n = 64, with gradients).  Off by
+  // default: measured 5.0-5.1 TB/s at B = 16384 against 5.1-5.6 TB/s for the register-staged kernel on the same
+  // box (it is steadier, and faster at B = 2048: 4.7-4.9 vs 4.0-4.9 TB/s) -- with 16 waves per CU the stencil
+  // arithmetic and LDS traffic of one image take about as long as its HBM traffic.
+  { const char* e = getenv("PDES_LOSS_DMA");
+    const bool dma = e ? atoi(e) != 0 : false;
+    if (dma && H == 64 && grad_y) {
+      const int nwg = B < 256 ? B : 256;
+      const size_t lds = 0;      // static LDS: two 64 KiB image buffers
+      if (nonlinear) hipLaunchKernelGGL(darcy_loss_dma_kernel<true>, dim3(nwg), dim3(1024), lds, st, K, y, grad_y, partials, p, B);
+      else hipLaunchKernelGGL(darcy_loss_dma_kernel<false>, dim3(nwg), dim3(1024), lds, st, K, y, grad_y, partials, p, B);
+      H = 0;    // launched
+    }
+  }
+  if (H == 0) { H = 64; }
+  else if (H == 64) launch_loss<64>(K, y, grad_y, partials, B, p, nonlinear, st);
   else if (H == 32) launch_loss<32>(K, y, grad_y, partials, B, p, nonlinear, st);
   else launch_loss<16>(K, y, grad_y, partials, B, p, nonlinear, st);
   PDES_LAUNCH_CHECK();

@@ -139,6 +139,26 @@ def test_fused_loss_vs_oracle(dev, n, B, nl):
     np.testing.assert_allclose(terms.cpu().numpy(), terms2.cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize('nl', [False, True])
+def test_lds_dma_variant_equals_default_kernel(dev, nl, monkeypatch):
+    """PDES_LOSS_DMA=1 (persistent workgroups, global_load_lds double buffering) against the default kernel:
+    B = 300 > 256 workgroups, so some workgroups walk two images and exercise the counted vmcnt waits"""
+    from pde_surrogate_amd.models.darcy import darcy_loss_launch
+    torch.manual_seed(11)
+    B, n = 300, 64
+    K = torch.exp(0.5 * torch.randn(B, 1, n, n, device=dev))
+    y = torch.randn(B, 3, n, n, device=dev)
+    args = ((1, 1, 10, 10), True, nl, 0.1 if nl else 0.0, 0.1 if nl else 0.0)
+    monkeypatch.setenv('PDES_LOSS_DMA', '0')
+    terms0, gy0 = darcy_loss_launch(K, y, *args)
+    monkeypatch.setenv('PDES_LOSS_DMA', '1')
+    terms1, gy1 = darcy_loss_launch(K, y, *args)
+    # same formulas per strip; the two kernels are compiled separately (fma contraction differs in the last bit)
+    assert rel_l2(gy1.cpu().numpy(), gy0.cpu().numpy()) < 1e-6
+    assert float((gy1 - gy0).abs().max()) <= 1e-5 * float(gy0.abs().max())
+    assert torch.allclose(terms0, terms1, rtol=1e-6, atol=0)
+
+
 def test_edge_pixels_sharp_interface(dev):
     """channelized-like inputs (config 4): two-valued K, step fields -- exercises every edge formula"""
     from oracle import darcy as od
