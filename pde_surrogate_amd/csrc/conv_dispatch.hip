@@ -46,7 +46,15 @@ extern "C" int pdes_conv_backward_weight(const pdes_conv_desc* descs, int n, voi
   for (int i = 0; i < n; ++i) {
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_weight_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && descs[i].g_fused) return PDES_EINVAL;      // only the matrix-core kernels finalize on load
-    if (rc == PDES_ENOSUP) rc = conv_backward_weight_direct(descs[i], st);
+    if (rc == PDES_ENOSUP) {
+      // the VALU kernel adds straight into dw.  If the caller planned deferred split-K partials for this layer
+      // (pdes_conv_wgrad_plan said yes, e.g. before PDES_CONV_IMPL changed), its reduce must then add zeros
+      if (descs[i].ws_defer && descs[i].ws && descs[i].ws_bytes > 0) {
+        const hipError_t he = hipMemsetAsync(descs[i].ws, 0, (size_t)descs[i].ws_bytes, st);
+        if (he != hipSuccess) return (int)he;
+      }
+      rc = conv_backward_weight_direct(descs[i], st);
+    }
     if (rc) return rc;
   }
   return PDES_OK;

@@ -10,6 +10,7 @@
 // scratch buffer and are reduced in a fixed order by a second kernel (deterministic, no float
 // atomics).  LDS images are [channel][pixel] with a channel stride == 2 (mod 32) dwords so that
 // the 16 channels x 2 pixels of a ds_read_b32 lane group hit 32 distinct banks.
+#include <stdlib.h>
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
 #include "bn_fused.h"
@@ -705,6 +706,7 @@ using namespace pdes;
 extern "C" int pdes_conv_wgrad_plan(const pdes_conv_desc* d, int* nsplit, long long* floats) {
   if (!d || !nsplit || !floats) return PDES_EINVAL;
   WgradPlan pl;
+  { const char* e = getenv("PDES_CONV_IMPL"); if (e && e[0] == 'd') return PDES_ENOSUP; }   // VALU kernels forced: no partials
   if (!wgrad_shape_ok(*d) || !wgrad_plan(*d, &pl)) return PDES_ENOSUP;
   *nsplit = pl.nsplit;
   *floats = (long long)pl.nsplit * pl.per;

@@ -150,15 +150,15 @@ def test_rejects_unsupported_options(dev):
         net(torch.zeros(1, 1, 64, 64))
 
 
-def _run_default(dev, B=4, seed=5):
-    """forward + loss + backward of the default net; returns output, loss terms and the gradients"""
+def _run_default(dev, B=4, seed=5, imsize=64, blocks=(6, 8, 6)):
+    """forward + loss + backward of a DenseED (default: the default net); returns output, loss and the gradients"""
     import contextlib
     import io
     from pde_surrogate_amd.models.codec import DenseED
     from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
     torch.manual_seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = DenseED(1, 3, 64, [6, 8, 6])
+        net = DenseED(1, 3, imsize, list(blocks))
     with torch.no_grad():
         for k, v in net.state_dict().items():
             if 'norm' in k and k.endswith('.weight'):
@@ -166,7 +166,7 @@ def _run_default(dev, B=4, seed=5):
             if 'norm' in k and k.endswith('.bias'):
                 v.copy_(0.1 * torch.randn_like(v))
     net = net.to(dev).train()
-    x = torch.exp(0.5 * torch.randn(B, 1, 64, 64)).to(dev)
+    x = torch.exp(0.5 * torch.randn(B, 1, imsize, imsize)).to(dev)
     y = net(x)
     loss, *_ = darcy_mixed_residual_loss(x, y, 10.0)
     loss.backward()
@@ -174,12 +174,16 @@ def _run_default(dev, B=4, seed=5):
     return y.detach().clone(), float(loss.detach()), grads
 
 
-def test_mfma_kernels_match_direct_kernels(dev, monkeypatch):
-    """matrix-core implicit-GEMM convolutions vs the VALU reference kernels, same weights/inputs"""
+@pytest.mark.parametrize('cfg', [dict(B=4), dict(B=32), dict(B=8, imsize=32, blocks=(3, 4, 3)),
+                                 dict(B=3, imsize=64, blocks=(2, 3, 2))])
+def test_mfma_kernels_match_direct_kernels(dev, monkeypatch, cfg):
+    """matrix-core implicit-GEMM convolutions vs the VALU reference kernels, same weights/inputs.
+    The configurations walk different tile shapes, split plans, pipelined / single-chunk variants, the
+    sub-pixel and few-output kernels at 64 and 32 pixels, and 8x8 maps that stay on the VALU kernels."""
     monkeypatch.setenv('PDES_CONV_IMPL', 'direct')
-    y0, l0, g0 = _run_default(dev)
+    y0, l0, g0 = _run_default(dev, **cfg)
     monkeypatch.setenv('PDES_CONV_IMPL', 'auto')
-    y1, l1, g1 = _run_default(dev)
+    y1, l1, g1 = _run_default(dev, **cfg)
     assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
     assert abs(l1 - l0) < 1e-5 * abs(l0)
     # parameter gradients: fp32 rounding flips individual ReLU masks, so two correct fp32
@@ -187,3 +191,16 @@ def test_mfma_kernels_match_direct_kernels(dev, monkeypatch):
     # with tools/debug_layers.py); a wrong stencil / layout would be O(1)
     errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
     assert errs[0][0] < 1e-2, errs[:8]
+
+
+@pytest.mark.parametrize('knob', ['PDES_FUSE_FINALIZE', 'PDES_WGRAD_STREAM'])
+def test_backward_variants_agree(dev, monkeypatch, knob):
+    """finalize fused into the operand load vs the in-place kernel; weight gradients on a second stream vs one
+    stream: same gradients (fp64 atomics of the statistics are order dependent in the last bits only)"""
+    monkeypatch.setenv(knob, '0')
+    y0, l0, g0 = _run_default(dev, B=32)
+    monkeypatch.setenv(knob, '1')
+    y1, l1, g1 = _run_default(dev, B=32)
+    assert torch.equal(y0, y1) or rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-6
+    errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
+    assert errs[0][0] < (1e-2 if knob == 'PDES_FUSE_FINALIZE' else 1e-5), errs[:8]

@@ -79,7 +79,7 @@ def main(blocks=(1, 1, 1), growth=4, init=8, imsize=16, B=4, decoder=False):
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'default':
-        main((6, 8, 6), 16, 48, 64, 4)
+        main((6, 8, 6), 16, 48, 64, int(sys.argv[2]) if len(sys.argv) > 2 else 4)
     elif len(sys.argv) > 1 and sys.argv[1] == 'decoder':
         main((8, 6), 16, 48, 16, 1, decoder=True)
     else:
