@@ -150,8 +150,10 @@ extern "C" int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma
                              const pdes_up_pack_item* uitems, int nu, int max_elems, void* stream) {
   if (n < 0 || nm < 0 || nu < 0 || n + nm + nu <= 0 || max_elems <= 0) return PDES_EINVAL;
   if ((n && !items) || (nm && !mitems) || (nu && !uitems)) return PDES_EINVAL;
+  // one element per thread per iteration is a dependent div/mod + gather chain: enough blocks that the
+  // largest image (~0.5 M elements) needs 4 iterations, the small ones exit after one
   int gx = cdiv(max_elems, 256);
-  gx = gx > 128 ? 128 : gx;
+  gx = gx > 512 ? 512 : gx;
   hipLaunchKernelGGL(pack_all_kernel, dim3(gx, n + nm + nu), dim3(256), 0, static_cast<hipStream_t>(stream), items, n,
                      mitems, nm, uitems);
   PDES_LAUNCH_CHECK();

@@ -289,6 +289,93 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct(pdes_conv_desc d, 
 }
 
 
+// ------------------------------------------------------------------------- fwd, first convolution
+// 7x7 stride-2 convolution of a 1-channel field (reference models/codec.py:236-238, no BatchNorm in front):
+// out[co][oy][ox] = sum_{ky,kx} x[2 oy + ky - 3][2 ox + kx - 3] w[co][ky][kx].  One workgroup = 4 output rows
+// of one sample, all output channels: the 13 zero-bordered input rows and the transposed weights [tap][co] sit
+// in LDS; a thread owns 4 consecutive output pixels x 8 channels (32 accumulators), reads per kernel row the 14
+// input values they touch as aligned float4 and the 8 channel weights of a tap as two float4 broadcasts.
+// grid (Hout/4, B), block = 32 pixel groups x Cout/8 channel groups (<= 256 threads).
+__global__ __launch_bounds__(256) void conv_fwd_first7(pdes_conv_desc d) {
+  constexpr int K = 7, RB = 4, XR = 2 * RB + K - 2;               // 13 input rows
+  extern __shared__ __attribute__((aligned(16))) float smq[];
+  const int LW = ((d.Win + 2 * 3 + 2 + 3) / 4) * 4;                // bordered row, 16-B pitch (72 for 64 columns)
+  float* xs = smq;                                                 // [XR][LW]
+  float* wt = smq + XR * LW;                                       // [49][Cout]
+  const int tid = threadIdx.x, b = blockIdx.y, oy0 = blockIdx.x * RB;
+  const int nthr = 32 * (d.Cout / 8);
+  const float* xin = d.x + (size_t)b * d.x_ctot * d.Hin * d.Win;
+  // staging in two unrolled batches (all global loads of a batch are in flight together)
+  {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                     // XR * LW <= 13 * 76 < 4 * 256
+      const int i = tid + 256 * k, r = i / LW, q = i % LW;
+      const int yy = 2 * oy0 - 3 + r, xx = q - 3;
+      const bool ok = i < XR * LW && yy >= 0 && yy < d.Hin && xx >= 0 && xx < d.Win;
+      v[k] = ok ? xin[yy * d.Win + xx] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = tid + 256 * k; if (i < XR * LW) xs[i] = v[k]; }
+    float w[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {                    // 49 * Cout <= 49 * 64 < 13 * 256; coalesced reads
+      const int i = tid + 256 * k;
+      w[k] = i < 49 * d.Cout ? d.w[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) { const int i = tid + 256 * k; if (i < 49 * d.Cout) wt[(i % 49) * d.Cout + i / 49] = w[k]; }
+  }
+  __syncthreads();
+  if (tid >= nthr) return;
+  const int pg = tid & 31, cg = tid >> 5;
+  const int row = pg >> 3, ox0 = 4 * (pg & 7);
+  float acc[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const float* xr = xs + (2 * row + ky) * LW + 2 * ox0;
+    float xv[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + 4 * j);
+      xv[4 * j] = t.x; xv[4 * j + 1] = t.y; xv[4 * j + 2] = t.z; xv[4 * j + 3] = t.w;
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float* wp = wt + (ky * K + kx) * d.Cout + 8 * cg;
+      const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[u][j] += xv[2 * u + kx] * wv[j];
+    }
+  }
+  const int HWo = d.Hout * d.Wout;
+  float* ob = d.out + ((size_t)b * d.out_ctot + d.out_coff + 8 * cg) * HWo + (size_t)(oy0 + row) * d.Wout + ox0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    *reinterpret_cast<float4*>(ob + (size_t)j * HWo) = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
+  if (d.out_stats) {
+    double* os = d.out_stats + (long long)rep_of_block(d.nrep) * d.rep_stride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+      float q = (acc[0][j] * acc[0][j] + acc[1][j] * acc[1][j]) + (acc[2][j] * acc[2][j] + acc[3][j] * acc[3][j]);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 32); q += __shfl_xor(q, o, 32); }
+      if (pg == 0) {
+        atomicAdd(&os[2 * (d.out_coff + 8 * cg + j)], (double)s);
+        atomicAdd(&os[2 * (d.out_coff + 8 * cg + j) + 1], (double)q);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- bwd weight, first convolution
 // The first convolution (no BatchNorm in front, 1..4 input channels, e.g. 7x7 stride 2 on the
 // permeability field) has a tiny weight tensor but a 49-tap reduction over every output pixel.
@@ -409,6 +496,14 @@ static int validate(const pdes_conv_desc& d, int mode) {
 int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st) {
   const int rc = validate(d, 0);
   if (rc) return rc;
+  if (!d.has_bn && !d.upsample && d.Cin == 1 && d.ksize == 7 && d.stride == 2 && d.pad == 3 && d.w && d.Wout == 32 &&
+      d.Win == 64 && d.Hout % 4 == 0 && d.Hin == 2 * d.Hout && d.Cout % 8 == 0 && d.Cout <= 64) {
+    const int LW = ((d.Win + 2 * 3 + 2 + 3) / 4) * 4;
+    const size_t lds = ((size_t)13 * LW + (size_t)49 * d.Cout) * sizeof(float);
+    hipLaunchKernelGGL(conv_fwd_first7, dim3(d.Hout / 4, d.B), dim3(256), lds, st, d);
+    PDES_LAUNCH_CHECK();
+    return PDES_OK;
+  }
   const int HWo = d.Hout * d.Wout;
   // fewer channels per thread when that is needed to fill the chip (>= 2 waves per SIMD)
   const long long px_blocks = (long long)cdiv(HWo, 256) * d.B;
