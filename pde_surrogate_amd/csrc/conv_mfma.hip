@@ -89,9 +89,13 @@ enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-in
 
 // FUSED (data gradient only): d.g holds the raw accumulator T; the BatchNorm-backward finalize is applied
 // while the tile is committed to LDS (bn_fused.h) -- the raw output activation is staged next to it.
-template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, bool FUSED>
-__global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
-                                                       int nt_total) {
+// NG = 2 (forward of the 16-output-channel layers only): TWO K-split wave groups of 4 waves each; group g stages and
+// multiplies the chunks g, g+2, ... out of its own double-buffered LDS tile, halving the serial chunk chain of a
+// workgroup (a dense layer at batch 32 has one workgroup per CU, i.e. otherwise one wave per SIMD).
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, bool FUSED, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : ((NT_W == 1 && KS != 5 && S == 1) ? 3 : 1))
+void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
+  static_assert(NG == 1 || (NG == 2 && WAVES_K == 4 && MODE == MODE_FWD && PIPE), "wave groups: K-split forward only");
   using G = TileGeo<KS, TWG, MT, S>;
   const int ntp = (nt_total + 7) & ~7;       // N-tiles of the packed weight image (zero padded)
   constexpr int KK = KS * KS;
@@ -99,7 +103,9 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
   static_assert(WAVES_K == 1 || MT >= 4, "K-split waves each own MT/4 M-tiles at the end");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // ids inside the wave group
+  const int grp = NG == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  const int gwave = (int)threadIdx.x >> 6;                                  // wave id inside the workgroup
 #ifdef PDES_TRACE
   const bool trace_on = tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0;
   if (trace_on) { for (int i = 0; i < 16; ++i) pdes_trace_buf[i] = 0; }
@@ -129,7 +135,8 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
   const int kpad = (kC + 15) & ~15;
   const int nchunk = kpad / 16;
   static_assert(!(FUSED && MODE == MODE_FWD), "the fused finalize belongs to the data gradient");
-  float* tile = smem + ((MODE == MODE_FWD || FUSED) ? 4 * kpad : 0);   // [kpad] float4 per-channel coefficients first
+  float* tile0 = smem + ((MODE == MODE_FWD || FUSED) ? 4 * kpad : 0);  // [kpad] float4 per-channel coefficients first
+  float* tile = tile0 + grp * (2 * G::KC * G::CS);                     // this wave group's two tile buffers
   const float* xkbase = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff) * d.Hout * d.Wout : nullptr;
 
   const int tiles_x = Wout / G::TW;
@@ -138,10 +145,10 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
   // FWD: per-channel {mean, gamma*invstd, beta, -} as one float4 (a single ds_read_b128 per staged float4)
   float4* cf4 = reinterpret_cast<float4*>(smem);
   if (FUSED) {        // {mean, invstd, mean(T), mean(T xhat)} of the gradient channels
-    for (int c = tid; c < kpad; c += 256) cf4[c] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = threadIdx.x; c < kpad; c += 256 * NG) cf4[c] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (MODE == MODE_FWD) {
-    for (int c = tid; c < kpad; c += 256) {
+    for (int c = threadIdx.x; c < kpad; c += 256 * NG) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < d.Cin) { const BnC k = bn_coef_m(d, c); v = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f); }
       cf4[c] = v;
@@ -329,28 +336,31 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
   // The loop body below is straight-line (every global load is unconditional, indices are clamped
   // instead): vmcnt is an in-order counter, and only without divergent paths can the compiler wait for
   // exactly the loads a k-step needs instead of draining the prefetches that were just issued.
-  load_b(wks, bA);
-  issue(0, sA);
-  if constexpr (PIPE) issue(min(1, nchunk - 1), sB);      // !PIPE: exactly one chunk, no second stage at all
+  // virtual step v of this wave group <-> chunk grp + NG * v (clamped for the loads, tested for the work)
+  auto cidx = [&](int v) __attribute__((always_inline)) { return min(grp + NG * v, nchunk - 1); };
+  load_b(cidx(0) * 4 + wks, bA);
+  issue(cidx(0), sA);
+  if constexpr (PIPE) issue(cidx(1), sB);      // !PIPE: exactly one chunk, no second stage at all
   __syncthreads();                 // cf visible
   TR(2);
-  commit(0, 0, sA);
+  if (grp < nchunk) commit(cidx(0), 0, sA);
   __syncthreads();
   TR(3);
 
-  // one chunk: `sfree` = the (free) register stage that receives chunk+2, `snext` = the stage holding
-  // chunk+1; `b0` holds the weights of this chunk's first k-step, `b1` is the other weight set
-  auto step = [&](int chunk, Stage& sfree, const Stage& snext, float (&b0)[KK][NT_W], float (&b1)[KK][NT_W])
+  // one chunk: `sfree` = the (free) register stage that receives step v+2, `snext` = the stage holding
+  // step v+1; `b0` holds the weights of this chunk's first k-step, `b1` is the other weight set
+  auto step = [&](int v, Stage& sfree, const Stage& snext, float (&b0)[KK][NT_W], float (&b1)[KK][NT_W])
       __attribute__((always_inline)) {
-    const int buf = chunk & 1;
+    const int buf = v & 1;
+    const int chunk = grp + NG * v;            // may lie past the last chunk for the group with fewer chunks
 #ifdef PDES_TRACE
     tt = wall_clock64();
 #endif
     const float* tb = tile + buf * (G::KC * G::CS) + a_lane;
     if constexpr (WAVES_K == 4) {
-      load_b((chunk + 1) * 4 + wks, b1);
-      if constexpr (PIPE) issue(min(chunk + 2, nchunk - 1), sfree);
-      mfma_kstep(tb + wks * 4 * G::CS, b0);
+      load_b(cidx(v + 1) * 4 + wks, b1);
+      if constexpr (PIPE) issue(cidx(v + 2), sfree);
+      if (NG == 1 || chunk < nchunk) mfma_kstep(tb + wks * 4 * G::CS, b0);
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
 #ifdef PDES_TRACE
     tt = wall_clock64();
 #endif
-    if constexpr (PIPE) { if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, snext); }
+    if constexpr (PIPE) { if (chunk + NG < nchunk) commit(chunk + NG, buf ^ 1, snext); }
     TRACC(9, tt);      // commit
 #ifdef PDES_TRACE
     tt = wall_clock64();
@@ -375,35 +385,41 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
   if constexpr (!PIPE) {
     step(0, sA, sA, bA, bB);
   } else {
-    int chunk = 0;
-    for (; chunk + 1 < nchunk; chunk += 2) {
-      step(chunk, sA, sB, bA, bB);
-      if constexpr (WAVES_K == 4) step(chunk + 1, sB, sA, bB, bA);
-      else step(chunk + 1, sB, sA, bA, bB);
+    const int nv = (nchunk + NG - 1) / NG;     // the same number of steps (barriers) for every wave group
+    int v = 0;
+    for (; v + 1 < nv; v += 2) {
+      step(v, sA, sB, bA, bB);
+      if constexpr (WAVES_K == 4) step(v + 1, sB, sA, bB, bA);
+      else step(v + 1, sB, sA, bA, bB);
     }
-    if (chunk < nchunk) step(chunk, sA, sB, bA, bB);
+    if (v < nv) step(v, sA, sB, bA, bB);
   }
 
   TR(4);
   // ---- combine the K-split partial sums: wave w ends up owning M-tiles [w*MT/4, (w+1)*MT/4)
-  constexpr int MT_OWN = (WAVES_K == 4) ? MT / 4 : MT;
-  const int mt0 = (WAVES_K == 4) ? MT_OWN * wave : 0;
+  constexpr int NWV = 4 * NG;                                        // K-split waves of the workgroup
+  constexpr int NOWN = (WAVES_K == 4) ? ((MT >= NWV) ? NWV : 4) : 1;   // waves that own output M-tiles afterwards
+  constexpr int MT_OWN = (WAVES_K == 4) ? MT / NOWN : MT;
+  const int mt0 = (WAVES_K == 4) ? MT_OWN * gwave : 0;
+  const bool owner = WAVES_K != 4 || gwave < NOWN;
   if (WAVES_K == 4) {
-    float* red = tile;                         // [4 waves][MT][4 r][64 lanes]
+    float* red = tile0;                        // [NWV waves][MT][4 r][64 lanes]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave * MT + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
+      for (int r = 0; r < 4; ++r) red[((gwave * MT + mt) * 4 + r) * 64 + lane] = acc[mt][0][r];
     __syncthreads();
+    if (owner) {
 #pragma unroll
-    for (int j = 0; j < MT_OWN; ++j)
+      for (int j = 0; j < MT_OWN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = 0.f;
+        for (int r = 0; r < 4; ++r) {
+          float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[((w * MT + mt0 + j) * 4 + r) * 64 + lane];
-        acc[j][0][r] = s;                      // acc[0..MT_OWN) now hold the wave's own M-tiles
-      }
+          for (int w = 0; w < NWV; ++w) s += red[((w * MT + mt0 + j) * 4 + r) * 64 + lane];
+          acc[j][0][r] = s;                    // acc[0..MT_OWN) now hold the wave's own M-tiles
+        }
+    }
   }
 
   TR(5);
@@ -414,7 +430,7 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
     for (int nt = 0; nt < NT_W; ++nt) {
       const int co = (nt_base + nt) * 16 + (lane & 15);
       float s = 0.f, q = 0.f;
-      if (co < d.Cout) {
+      if (co < d.Cout && owner) {
         float* ob = d.out + ((size_t)b * d.out_ctot + d.out_coff + co) * HWo;
 #pragma unroll
         for (int j = 0; j < MT_OWN; ++j) {
@@ -433,13 +449,14 @@ __global__ __launch_bounds__(256, (NT_W == 1 && KS != 5 && S == 1) ? 3 : 1) void
         if (WAVES_K == 4) {
           // the four waves hold partial sums of the SAME 16 channels: combine through LDS -> one
           // pair of atomics per channel per workgroup
-          float* sred = tile + 4 * MT * 4 * 64;      // past the accumulator exchange area
-          if (lane < 16) { sred[(wave * 16 + lane) * 2] = s; sred[(wave * 16 + lane) * 2 + 1] = q; }
+          float* sred = tile0 + NWV * MT * 4 * 64;   // past the accumulator exchange area
+          if (lane < 16 && owner) { sred[(gwave * 16 + lane) * 2] = s; sred[(gwave * 16 + lane) * 2 + 1] = q; }
           __syncthreads();
-          if (wave == 0 && lane < 32) {
+          if (gwave == 0 && lane < 32) {
             const int c = lane >> 1, w = lane & 1;
-            const float t = (sred[(0 * 16 + c) * 2 + w] + sred[(1 * 16 + c) * 2 + w]) +
-                            (sred[(2 * 16 + c) * 2 + w] + sred[(3 * 16 + c) * 2 + w]);
+            float t = 0.f;
+#pragma unroll
+            for (int ow = 0; ow < NOWN; ++ow) t += sred[(ow * 16 + c) * 2 + w];
             const int cc = nt_base * 16 + c;
             if (cc < d.Cout) atomicAdd(&os[2 * (d.out_coff + cc) + w], (double)t);
           }
@@ -574,31 +591,42 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
   size_t lds = 0;
   int rc = PDES_ENOSUP;
+  bool break_out = false;
 #define PDES_TRY(TWG_, MT_, WK_, NTW_)                                                                       \
   if (twg == TWG_ && mt == MT_ && wk == WK_ && ntw == NTW_) {                                                 \
     using G = TileGeo<KS, TWG_, MT_, S>;                                                                      \
     const size_t cf_f = (bwd && !fused) ? 0 : 4 * (size_t)kpad;                                              \
-    size_t fl = cf_f + 2 * (size_t)G::KC * G::CS;                                                             \
-    const size_t red = cf_f + (size_t)4 * MT_ * 4 * 64 + 128;                                                 \
+    const int ng = (WK_ == 4 && !bwd && S == 1 && nchunk >= 3 && env_int("PDES_MFMA_NG", 2) == 2) ? 2 : 1;  \
+    size_t fl = cf_f + (size_t)ng * 2 * G::KC * G::CS;                                                        \
+    const size_t red = cf_f + (size_t)4 * ng * MT_ * 4 * 64 + 256;                                            \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \
     lds = fl * sizeof(float);                                                                                 \
     if (dry) {                                                                                                \
-    } else if constexpr (MODE == MODE_FWD) {                                                                         \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false>), grid, block, lds, st, \
+    } else if constexpr (MODE == MODE_FWD) {                                                                  \
+      if constexpr (WK_ == 4 && S == 1) {                                                                     \
+        if (ng == 2) {                                                                                        \
+          hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false, 2>), grid, dim3(512), \
+                             lds, st, d, wm, nt_total);                                                       \
+          rc = PDES_OK;                                                                                       \
+          break_out = true;                                                                                   \
+        }                                                                                                     \
+      }                                                                                                       \
+      if (!break_out)                                                                                         \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false, 1>), grid, block, lds, st, \
                          d, wm, nt_total);                                                                    \
     } else if (fused) {                                                                                       \
       if (nchunk > 1)                                                                                         \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, true>), grid, block, lds, st, \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, true, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
       else   /* one chunk (dense layers: 16 gradient channels): single stage */                     \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, true>), grid, block, lds, st, \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, true, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
     } else {                                                                                                  \
       if (nchunk > 1)                                                                                         \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false>), grid, block, lds, st, \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, false>), grid, block, lds, st, \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, false, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
     }                                                                                                         \
     rc = PDES_OK;                                                                                             \
