@@ -7,7 +7,7 @@ import sqlite3
 import sys
 
 
-def main(path, nlast=400):
+def main(path, nlast=0):
     c = sqlite3.connect(path)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
     kd = [t for t in tabs if 'kernel_dispatch' in t and 'rocpd_kernel_dispatch' in t]
@@ -16,8 +16,7 @@ def main(path, nlast=400):
         rows = c.execute('select name, start, end, queue_id, stream_id from kernels order by start').fetchall()
     else:
         raise SystemExit('no kernels view; tables: %s' % tabs)
-    rows = rows[-nlast:]
-    # find the last adam kernel before the end: a step = (after previous adam) .. adam
+    # a step = (after the previous adam launch) .. adam launch; take the last complete one
     idx = [i for i, r in enumerate(rows) if 'adam' in r[0]]
     if len(idx) >= 2:
         rows = rows[idx[-2] + 1: idx[-1] + 1]
