@@ -45,7 +45,7 @@ struct WGeo {
 // operand is the gradient tile read with a per-lane column shift of -kx.
 template <int KS, int TWG, int NTW, int S, bool PIPE, bool FUSED, bool FEW>
 __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
-                                                             int n_ngroups) {
+                                                             int n_ngroups, int co_off) {
   using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS;
   constexpr int NPG4 = 16 * NTW * G::TH * G::TW / 4 / 256;      // g float4 per thread per tile
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
   const int groups = tps / tpw;
   const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
   const int mtile = blockIdx.y / n_ngroups, ng = blockIdx.y % n_ngroups;
-  const int ci0 = mtile * 16, co0 = ng * 16 * NTW;
+  const int ci0 = mtile * 16, co0 = co_off + ng * 16 * NTW;   // co_off: first channel of this launch's N range
   const int HWi = d.Hin * d.Win, HWo = d.Hout * d.Wout;
 
   // BN coefficients of this thread's staging channels are per element; keep the 16 channels' in LDS-free regs:
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
 // and the four de-interleaved parity sub-images of the hi-res gradient.
 template <int TWG, int NTW, bool FUSED>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
-                                                                int n_ngroups) {
+                                                                int n_ngroups, int co_off) {
   using G = WGeo<3, TWG, 1>;
   constexpr int NPX = G::TH * G::TW;                            // low-res pixels per tile (128)
   constexpr int NPG = 16 * NTW * (NPX / 4) * 2 / 256;          // (channel, pixel quad, dy) items per thread
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
   const int groups = tps / tpw;
   const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
   const int mtile = blockIdx.y / n_ngroups, ng = blockIdx.y % n_ngroups;
-  const int ci0 = mtile * 16, co0 = ng * 16 * NTW;
+  const int ci0 = mtile * 16, co0 = co_off + ng * 16 * NTW;   // co_off: first channel of this launch's N range
   __shared__ float cf[16][3];
   if (tid < 16) {
     const int c = ci0 + tid;
@@ -610,9 +610,14 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   if (!wgrad_plan(d, &pl)) return PDES_ENOSUP;
   const int twg = pl.twg, ntw = pl.ntw, ngroups = pl.ngroups, gy = pl.gy, tpw = pl.tpw, nsplit = pl.nsplit;
   const long long per = pl.per;
-  dim3 grid(nsplit, gy), block(256);
-#define PDES_WG_LAUNCH(TWG_, NTW_)                                                                          \
+  (void)gy;
+  const int mtiles = (d.Cin + 15) / 16, ntiles = (d.Cout + 15) / 16;
+  dim3 block(256);
+  // GY_: grid.y = M-tiles x N-groups of this launch; NGR_: N-groups; COFF_: first output channel of the launch
+#define PDES_WG_LAUNCH(TWG_, NTW_, NGR_, COFF_)                                                             \
   do {                                                                                                        \
+    const int ngroups_l = (NGR_);                                                                             \
+    dim3 grid(nsplit, mtiles * ngroups_l);                                                                    \
     using G = WGeo<KS, TWG_, S>;                                                                              \
     size_t lds = (size_t)(tpw > 2 ? 2 : 1) * (16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
@@ -620,26 +625,33 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     if constexpr (KS == 5 && NTW_ == 1 && S == 1) {                                                           \
       if (d.Cout * 5 <= 16 && !d.g_fused) {      /* few-output form; its LDS need is below the generic one */ \
         if (tpw > 2)                                                                                          \
-          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
         else                                                                                                  \
-          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
         break;                                                                                                \
       }                                                                                                       \
     }                                                                                                         \
     if (d.g_fused) {                                                                                          \
       if (tpw > 2)                                                                                            \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
     } else {                                                                                                  \
       if (tpw > 2)                                                                                            \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups); \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
     }                                                                                                         \
   } while (0)
-  if (twg == 2) { if (ntw == 2) PDES_WG_LAUNCH(2, 2); else PDES_WG_LAUNCH(2, 1); }
-  else { if (ntw == 2) PDES_WG_LAUNCH(1, 2); else PDES_WG_LAUNCH(1, 1); }
+  // an odd number of N-tiles >= 3: pairs with the two-tile kernel, the last tile with the one-tile kernel
+  // (instead of a padding tile: 98 output channels are 7 tiles, not 8)
+  // (only when the padding tile is a small share of a big layer: a second launch costs a few us)
+  const bool split_odd = ntw == 2 && (ntiles & 1) && ntiles >= 7 && !(KS == 5);
+  if (split_odd) {
+    if (twg == 2) { PDES_WG_LAUNCH(2, 2, ntiles / 2, 0); PDES_WG_LAUNCH(2, 1, 1, 16 * (ntiles - 1)); }
+    else { PDES_WG_LAUNCH(1, 2, ntiles / 2, 0); PDES_WG_LAUNCH(1, 1, 1, 16 * (ntiles - 1)); }
+  } else if (twg == 2) { if (ntw == 2) PDES_WG_LAUNCH(2, 2, ngroups, 0); else PDES_WG_LAUNCH(2, 1, ngroups, 0); }
+  else { if (ntw == 2) PDES_WG_LAUNCH(1, 2, ngroups, 0); else PDES_WG_LAUNCH(1, 1, ngroups, 0); }
 #undef PDES_WG_LAUNCH
   PDES_LAUNCH_CHECK();
   if (!d.ws_defer) {      // otherwise the caller reduces every layer at once with pdes_wgrad_reduce_all
@@ -662,20 +674,27 @@ static bool wgrad_shape_ok(const pdes_conv_desc& d) {
 static int launch_wgrad_up(const pdes_conv_desc& d, hipStream_t st) {
   WgradPlan pl;
   if (!wgrad_plan(d, &pl)) return PDES_ENOSUP;
-  dim3 grid(pl.nsplit, pl.gy), block(256);
-#define PDES_WGU_LAUNCH(TWG_, NTW_)                                                                         \
+  const int mtiles = (d.Cin + 15) / 16, ntiles = (d.Cout + 15) / 16;
+  dim3 block(256);
+#define PDES_WGU_LAUNCH(TWG_, NTW_, NGR_, COFF_)                                                            \
   do {                                                                                                        \
+    const int ngroups_l = (NGR_);                                                                             \
+    dim3 grid(pl.nsplit, mtiles * ngroups_l);                                                                 \
     using G = WGeo<3, TWG_, 1>;                                                                               \
     size_t lds = (size_t)(16 * G::CS + 4 * 16 * NTW_ * G::GS) * sizeof(float);                                \
     const size_t red = (size_t)4 * 9 * NTW_ * 4 * 64 * sizeof(float);                                         \
     if (red > lds) lds = red;                                                                                 \
     if (d.g_fused)                                                                                            \
-      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, true>), grid, block, lds, st, d, d.ws, pl.tpw, pl.ngroups); \
+      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, true>), grid, block, lds, st, d, d.ws, pl.tpw, ngroups_l, (COFF_)); \
     else                                                                                                      \
-      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, false>), grid, block, lds, st, d, d.ws, pl.tpw, pl.ngroups); \
+      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, false>), grid, block, lds, st, d, d.ws, pl.tpw, ngroups_l, (COFF_)); \
   } while (0)
-  if (pl.twg == 2) { if (pl.ntw == 2) PDES_WGU_LAUNCH(2, 2); else PDES_WGU_LAUNCH(2, 1); }
-  else { if (pl.ntw == 2) PDES_WGU_LAUNCH(1, 2); else PDES_WGU_LAUNCH(1, 1); }
+  const bool split_odd = pl.ntw == 2 && (ntiles & 1) && ntiles >= 7;
+  if (split_odd) {
+    if (pl.twg == 2) { PDES_WGU_LAUNCH(2, 2, ntiles / 2, 0); PDES_WGU_LAUNCH(2, 1, 1, 16 * (ntiles - 1)); }
+    else { PDES_WGU_LAUNCH(1, 2, ntiles / 2, 0); PDES_WGU_LAUNCH(1, 1, 1, 16 * (ntiles - 1)); }
+  } else if (pl.twg == 2) { if (pl.ntw == 2) PDES_WGU_LAUNCH(2, 2, pl.ngroups, 0); else PDES_WGU_LAUNCH(2, 1, pl.ngroups, 0); }
+  else { if (pl.ntw == 2) PDES_WGU_LAUNCH(1, 2, pl.ngroups, 0); else PDES_WGU_LAUNCH(1, 1, pl.ngroups, 0); }
 #undef PDES_WGU_LAUNCH
   PDES_LAUNCH_CHECK();
   if (!d.ws_defer) {
