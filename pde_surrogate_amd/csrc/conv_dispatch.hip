@@ -95,9 +95,9 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
   // but releasing the work early measured as good as batching it: 2.45 / 2.47 / 2.50 ms per step at
   // batch 1 / 2 / 4).  PDES_WGRAD_REDUCE=batch reduces each batch's split-K partials on the second
   // stream instead of once at the end (measured slower: 40 small launches).
-  static const int batch_layers = getenv("PDES_WGRAD_BATCH") ? atoi(getenv("PDES_WGRAD_BATCH")) : 1;
-  static const double batch_flops = getenv("PDES_WGRAD_BATCH_GF") ? 1e9 * atof(getenv("PDES_WGRAD_BATCH_GF")) : 1.5e9;
-  static const bool reduce_per_batch = getenv("PDES_WGRAD_REDUCE") && getenv("PDES_WGRAD_REDUCE")[0] == 'b';
+  const int batch_layers = getenv("PDES_WGRAD_BATCH") ? atoi(getenv("PDES_WGRAD_BATCH")) : 1;
+  const double batch_flops = getenv("PDES_WGRAD_BATCH_GF") ? 1e9 * atof(getenv("PDES_WGRAD_BATCH_GF")) : 1.5e9;
+  const bool reduce_per_batch = getenv("PDES_WGRAD_REDUCE") && getenv("PDES_WGRAD_REDUCE")[0] == 'b';
   // The split-K partials of the last layers (the widest ones: LastTransUp holds ~3/4 of the weights) are reduced
   // on the second stream as soon as those layers are done; only the rest waits for the end of the chain.
   long long per_total = 0, per_done = 0;
@@ -162,8 +162,8 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
   };
   // BatchNorm-backward finalize: fused into the operand load of the layer's two consumers when both run on
   // the matrix-core kernels (bn_fused.h), otherwise the in-place kernel.  PDES_FUSE_FINALIZE=0 disables.
-  static const bool fuse_on = !(getenv("PDES_FUSE_FINALIZE") && getenv("PDES_FUSE_FINALIZE")[0] == '0');
-  static const int fuse_maxc = getenv("PDES_FUSE_MAXC") ? atoi(getenv("PDES_FUSE_MAXC")) : 16;
+  const bool fuse_on = !(getenv("PDES_FUSE_FINALIZE") && getenv("PDES_FUSE_FINALIZE")[0] == '0');
+  const int fuse_maxc = getenv("PDES_FUSE_MAXC") ? atoi(getenv("PDES_FUSE_MAXC")) : 16;
   std::vector<pdes_conv_desc> local(descs, descs + n);
   for (int i = 0; i < n; ++i) {
     pdes_conv_desc& d = local[i];
