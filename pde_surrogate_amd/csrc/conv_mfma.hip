@@ -480,15 +480,23 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
         const float scale = k.gamma * k.invstd;
         const bool fin = ci >= d.final_c0 && ci < d.final_c1;
         {
+          // all loads of this N-tile first, then the arithmetic and the stores: the store to T may alias the next
+          // loads for the compiler, which otherwise serialises MT_OWN load -> wait -> store round trips
+          float4 xq[MT_OWN], tq[MT_OWN];
+#pragma unroll
+          for (int j = 0; j < MT_OWN; ++j) {
+            const int mt = mt0 + j;
+            const size_t idx = (size_t)ci * HWi + (size_t)(oy0 + mt / TWG) * d.Win + ox0 + (mt % TWG) * 16 + px;
+            xq[j] = *reinterpret_cast<const float4*>(xb + idx);
+            tq[j] = d.t_accumulate ? *reinterpret_cast<const float4*>(tb2 + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
 #pragma unroll
           for (int j = 0; j < MT_OWN; ++j) {
             const int mt = mt0 + j;
             const v4f v = acc[j][nt];
             const size_t idx = (size_t)ci * HWi + (size_t)(oy0 + mt / TWG) * d.Win + ox0 + (mt % TWG) * 16 + px;
-            const float4 xv = *reinterpret_cast<const float4*>(xb + idx);
-            float4 tv = d.t_accumulate ? *reinterpret_cast<const float4*>(tb2 + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            float ts[4] = {tv.x, tv.y, tv.z, tv.w};
+            const float xs[4] = {xq[j].x, xq[j].y, xq[j].z, xq[j].w};
+            float ts[4] = {tq[j].x, tq[j].y, tq[j].z, tq[j].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float y = (xs[r] - k.mean) * scale + k.beta;

@@ -341,14 +341,19 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
       const BnU k = bn_coef_u(d, cn);
       const float scale = k.gamma * k.invstd;
       const bool fin = cn >= d.final_c0 && cn < d.final_c1;
+      float4 xq[MT], tq[MT];        // loads first, then arithmetic + stores (see conv_mfma.hip)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const size_t idx = (size_t)cn * HWl + (size_t)(oy0 + mt / TWG) * Wl + ox0 + (mt % TWG) * 16 + px;
+        xq[mt] = *reinterpret_cast<const float4*>(xb + idx);
+        tq[mt] = d.t_accumulate ? *reinterpret_cast<const float4*>(tb2 + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const v4f v = acc[mt][0];
         const size_t idx = (size_t)cn * HWl + (size_t)(oy0 + mt / TWG) * Wl + ox0 + (mt % TWG) * 16 + px;
-        const float4 xv = *reinterpret_cast<const float4*>(xb + idx);
-        float4 tv = d.t_accumulate ? *reinterpret_cast<const float4*>(tb2 + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        float ts[4] = {tv.x, tv.y, tv.z, tv.w};
+        const float xs[4] = {xq[mt].x, xq[mt].y, xq[mt].z, xq[mt].w};
+        float ts[4] = {tq[mt].x, tq[mt].y, tq[mt].z, tq[mt].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y = (xs[r] - k.mean) * scale + k.beta;
