@@ -340,6 +340,16 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   auto cidx = [&](int v) __attribute__((always_inline)) { return min(grp + NG * v, nchunk - 1); };
   load_b(cidx(0) * 4 + wks, bA);
   issue(cidx(0), sA);
+  // data gradient: the BatchNorm coefficients of this wave's input channels are only needed in the epilogue;
+  // their 32 replica loads + fp64 arithmetic are issued here so that they overlap the matrix work
+  BnC kepi[MODE == MODE_BWD ? NT_W : 1];
+  if constexpr (MODE == MODE_BWD) {
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) {
+      const int ci = min((nt_base + nt) * 16 + (lane & 15), d.Cin - 1);
+      kepi[nt] = bn_coef_m(d, ci);
+    }
+  }
   if constexpr (PIPE) issue(cidx(1), sB);      // !PIPE: exactly one chunk, no second stage at all
   __syncthreads();                 // cf visible
   TR(2);
@@ -476,7 +486,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       const int ci = (nt_base + nt) * 16 + (lane & 15);
       float dg = 0.f, db = 0.f, st = 0.f, sx = 0.f;
       if (ci < d.Cin) {
-        const BnC k = bn_coef_m(d, ci);
+        const BnC k = kepi[nt];
         const float scale = k.gamma * k.invstd;
         const bool fin = ci >= d.final_c0 && ci < d.final_c1;
         {
