@@ -325,6 +325,9 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          // zero-inserted view (stride-2 data gradient): tile rows start on an even row, data sits on even rows of
+          // the view only, so for half of the (M-tile row, ky) pairs the A operand is identically zero: skip them
+          if constexpr (KM == KV_ZEROINS2) { if ((((mt / TWG) + ky) & 1) == 0) continue; }
           const float a = tk[((mt / TWG) * S + ky) * G::LDW + (G::COL0 - G::PADL) + (mt % TWG) * 16 * S + kx];
 #pragma unroll
           for (int nt = 0; nt < NT_W; ++nt)
