@@ -153,7 +153,8 @@ typedef struct pdes_reduce_item { const float* part; float* dw; int n; int nspli
 /* dw[i] += sum_s part[s][i] (fixed order) for every item; items: DEVICE array. */
 int pdes_wgrad_reduce_all(const pdes_reduce_item* items, int n, int max_n, void* stream);
 
-/* The whole backward pass of a descriptor chain: for i = n-1 .. 0
+/* The whole backward pass of a descriptor chain -- what `loss.backward()` (train_codec_mixed_residual.py:233)
+ * runs through autograd for models/codec.py:43-188 in the reference: for i = n-1 .. 0
  *   [pdes_bn_backward_finalize of descs[i]'s output channels, when fin_tstats != NULL]
  *   pdes_conv_backward_weight(descs[i])   -- on `wgrad_stream` when it is not NULL
  *   pdes_conv_backward_data(descs[i])     -- when has_bn
@@ -193,7 +194,9 @@ typedef struct pdes_up_pack_item { /* one nearest-x2 + 3x3 convolution: effectiv
 } pdes_up_pack_item;
 /* items: DEVICE array; see csrc/conv_mfma_up.hip for the image layout. */
 int pdes_pack_weights_up(const pdes_up_pack_item* items, int n, int max_elems, void* stream);
-/* The three tables above in ONE launch (any of them may be empty: n = 0); max_elems = the largest packed image. */
+/* The three tables above in ONE launch (any of them may be empty: n = 0); max_elems = the largest packed image.
+ * No reference counterpart: the packed images replace the (Cout,Cin,k,k) weight reads of nn.Conv2d
+ * (models/codec.py:57-58, 106-146, 170-186) with coalesced 256-B operand loads. */
 int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
                   const pdes_up_pack_item* uitems, int nu, int max_elems, void* stream);
 
