@@ -591,14 +591,18 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   p->ngroups = (ntiles + p->ntw - 1) / p->ntw;
   p->gy = mtiles * p->ngroups;
   p->per = (long long)d.Cout * d.Cin * KK;
-  // pixel tiles per workgroup: as few as possible while (a) ~768 workgroups are reached and
+  // pixel tiles per workgroup: as few as possible while (a) the grid has at most ~320 workgroups (PDES_WGRAD_WGS;
+  // stand-alone the kernels are fastest with ~768, but they run beside the data-gradient chain on a second
+  // stream and smaller grids leave it more of the chip: 2.203 / 2.182 / 2.179 / 2.177 / 2.204 ms per step at
+  // 768 / 512 / 384 / 256 / 128) and
   // (b) the partial buffer fits the scratch
   p->tpw = p->tps;
+  static const int wg_target = getenv("PDES_WGRAD_WGS") ? atoi(getenv("PDES_WGRAD_WGS")) : 320;
   for (int cand = 1; cand <= p->tps; cand *= 2) {
     if (p->tps % cand) continue;
     const long long ns = (long long)d.B * (p->tps / cand);
     if (ns * p->per * 4 > d.ws_bytes) continue;
-    if (ns * p->gy <= 768 || cand == p->tps) { p->tpw = cand; break; }
+    if (ns * p->gy <= wg_target || cand == p->tps) { p->tpw = cand; break; }
   }
   p->nsplit = d.B * (p->tps / p->tpw);
   return (long long)p->nsplit * p->per * 4 <= d.ws_bytes;
