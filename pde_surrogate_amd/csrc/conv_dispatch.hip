@@ -113,7 +113,10 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
   size_t nev = 0;
   auto flush = [&](int lo) -> int {       // enqueue weight gradients (and their split-K reduce) of layers pend_hi .. lo
     if (pend_hi < 0) return PDES_OK;
-    if (fork) {
+    // the very last weight gradient (first layer) has nothing left to overlap with: keep it on the main stream
+    // and save the event hop (its scratch / dw are disjoint from what the second stream still works on)
+    const bool last_on_main = fork && lo == 0 && pend_hi == 0 && !reduce_per_batch;
+    if (fork && !last_on_main) {
       hipEvent_t e = chain_event(nev++);
       if (!e) return (int)hipErrorOutOfMemory;
       hipError_t he = hipEventRecord(e, st);
@@ -123,7 +126,7 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
     int r_lo = -1, r_hi = -1;
     long long max_n = 0;
     for (int i = pend_hi; i >= lo; --i) {
-      const int rc = pdes_conv_backward_weight(&descs[i], 1, ws);
+      const int rc = pdes_conv_backward_weight(&descs[i], 1, last_on_main ? st : ws);
       if (rc) return rc;
       if (fork && reduce_per_batch && reduce_items && reduce_index && reduce_index[i] >= 0) {
         const int k = reduce_index[i];
