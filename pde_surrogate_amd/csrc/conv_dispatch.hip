@@ -90,79 +90,61 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipStream_t ws = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : st;
   const bool fork = ws != st;
-  // Weight gradients are released to the second stream in batches of PDES_WGRAD_BATCH layers (default 1:
-  // one event per layer; each event record is a barrier packet worth a ~6 us bubble on the main stream,
-  // but releasing the work early measured as good as batching it: 2.45 / 2.47 / 2.50 ms per step at
-  // batch 1 / 2 / 4).  PDES_WGRAD_REDUCE=batch reduces each batch's split-K partials on the second
-  // stream instead of once at the end (measured slower: 40 small launches).
-  const int batch_layers = getenv("PDES_WGRAD_BATCH") ? atoi(getenv("PDES_WGRAD_BATCH")) : 1;
-  const double batch_flops = getenv("PDES_WGRAD_BATCH_GF") ? 1e9 * atof(getenv("PDES_WGRAD_BATCH_GF")) : 1.5e9;
-  const bool reduce_per_batch = getenv("PDES_WGRAD_REDUCE") && getenv("PDES_WGRAD_REDUCE")[0] == 'b';
-  // The split-K partials of the last layers (the widest ones: LastTransUp holds ~3/4 of the weights) are reduced
-  // on the second stream as soon as those layers are done; only the rest waits for the end of the chain.
+  const bool have_red = reduce_items && reduce_index;
+  auto per_of = [&](int i) { return (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize; };
+
+  // ---- second-stream schedule.  A layer's weight gradient is released (one event) as soon as its output gradient
+  // exists.  Measured alternatives, all slower: releasing in batches of 2/4/8 layers, reducing the split-K partials
+  // per batch, several early reduces, and holding the heavy layers' weight gradients back until the main chain is
+  // among the small dense layers (2.24 vs 2.12 ms per step, same box).
   long long per_total = 0, per_done = 0;
   int n_items = 0, early_lo = -1;          // early_lo: first table row already reduced early (-1: none yet)
-  if (reduce_items && reduce_index)
+  if (have_red)
     for (int i = 0; i < n; ++i)
-      if (reduce_index[i] >= 0) {
-        per_total += (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
-        ++n_items;
-      }
-  int pend_hi = -1;                       // layers [i, pend_hi] are finalized but their weight gradient is not enqueued
-  double pend_flops = 0.0;
+      if (reduce_index[i] >= 0) { per_total += per_of(i); ++n_items; }
+  std::vector<char> enq(n, 0);
   size_t nev = 0;
-  auto flush = [&](int lo) -> int {       // enqueue weight gradients (and their split-K reduce) of layers pend_hi .. lo
-    if (pend_hi < 0) return PDES_OK;
-    // the very last weight gradient (first layer) has nothing left to overlap with: keep it on the main stream
-    // and save the event hop (its scratch / dw are disjoint from what the second stream still works on)
-    const bool last_on_main = fork && lo == 0 && pend_hi == 0 && !reduce_per_batch;
-    if (fork && !last_on_main) {
+  auto release = [&](const int* layers, int cnt, bool on_main) -> int {
+    if (cnt <= 0) return PDES_OK;
+    if (fork && !on_main) {
       hipEvent_t e = chain_event(nev++);
       if (!e) return (int)hipErrorOutOfMemory;
       hipError_t he = hipEventRecord(e, st);
       if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
       if (he != hipSuccess) return (int)he;
     }
-    int r_lo = -1, r_hi = -1;
-    long long max_n = 0;
-    for (int i = pend_hi; i >= lo; --i) {
-      const int rc = pdes_conv_backward_weight(&descs[i], 1, last_on_main ? st : ws);
+    for (int k = 0; k < cnt; ++k) {
+      const int i = layers[k];
+      const int rc = pdes_conv_backward_weight(&descs[i], 1, on_main ? st : ws);
       if (rc) return rc;
-      if (fork && reduce_per_batch && reduce_items && reduce_index && reduce_index[i] >= 0) {
-        const int k = reduce_index[i];
-        r_lo = r_lo < 0 ? k : (k < r_lo ? k : r_lo);
-        r_hi = k > r_hi ? k : r_hi;
-        const long long per = (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
-        max_n = per > max_n ? per : max_n;
-      }
+      enq[i] = 1;
+      if (have_red && reduce_index[i] >= 0) per_done += per_of(i);
     }
-    if (r_lo >= 0) {                      // item indices grow with the layer index: the batch is one contiguous slice
-      const int rc = pdes_wgrad_reduce_all(reduce_items + r_lo, r_hi - r_lo + 1, (int)max_n, ws);
-      if (rc) return rc;
-    }
-    if (fork && !reduce_per_batch && early_lo < 0 && reduce_items && reduce_index && lo > 0) {
-      for (int i = pend_hi; i >= lo; --i)
-        if (reduce_index[i] >= 0) per_done += (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
-      if (5 * per_done >= 3 * per_total) {        // >= 60 % of the partials exist: reduce them now, off the critical path
-        int first = -1;
-        long long mx = 0;
-        for (int i = lo; i < n; ++i)
-          if (reduce_index[i] >= 0) {
-            if (first < 0) first = reduce_index[i];
-            const long long per = (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
-            mx = per > mx ? per : mx;
-          }
-        if (first >= 0) {
+    // The split-K partials of the last layers (the widest ones: LastTransUp holds ~3/4 of the weights) are reduced
+    // on the second stream as soon as >= 60 % of the weights' partials exist; the rest waits for the end.
+    if (fork && !on_main && have_red && early_lo < 0 && 5 * per_done >= 3 * per_total) {
+      int k0 = n;                                   // longest suffix of layers that are all enqueued
+      while (k0 > 0 && enq[k0 - 1]) --k0;
+      int first = -1;
+      long long mx = 0;
+      for (int i = k0; i < n; ++i)
+        if (reduce_index[i] >= 0) {
+          if (first < 0) first = reduce_index[i];
+          mx = per_of(i) > mx ? per_of(i) : mx;
+        }
+      if (first > 0 && 5 * per_done >= 3 * per_total) {
+        long long cover = 0;
+        for (int i = k0; i < n; ++i) if (reduce_index[i] >= 0) cover += per_of(i);
+        if (5 * cover >= 3 * per_total) {
           const int rc = pdes_wgrad_reduce_all(reduce_items + first, n_items - first, (int)mx, ws);
           if (rc) return rc;
           early_lo = first;
         }
       }
     }
-    pend_hi = -1;
-    pend_flops = 0.0;
     return PDES_OK;
   };
+
   // BatchNorm-backward finalize: the in-place kernel by default.  PDES_FUSE_FINALIZE=1 fuses it into the operand
   // load of the layer's two consumers when both run on the matrix-core kernels (bn_fused.h; layers with up to
   // PDES_FUSE_MAXC = 16 output channels).  Same-box A/B of the final kernel set: 2.188 ms per step fused vs 2.151 ms
@@ -182,6 +164,7 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
     d.g_fused = (w_ok && d_ok) ? 1 : 0;
   }
   descs = local.data();
+
   for (int i = n - 1; i >= 0; --i) {
     const pdes_conv_desc& d = descs[i];
     if (d.fin_tstats && !d.g_fused) {
@@ -189,10 +172,10 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
                                          d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep, d.rep_stride, st);
       if (rc) return rc;
     }
-    if (pend_hi < 0) pend_hi = i;
-    pend_flops += 2.0 * d.B * d.Hout * d.Wout * (double)d.Cout * d.Cin * d.ksize * d.ksize;
-    if (!fork || pend_hi - i + 1 >= batch_layers || pend_flops >= batch_flops || i == 0) {
-      const int rc = flush(i);
+    // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
+    // (saves the event hop; its scratch / dw are disjoint from what the second stream still works on)
+    {
+      const int rc = release(&i, 1, fork && i == 0);
       if (rc) return rc;
     }
     if (d.has_bn) {
@@ -207,14 +190,13 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
     if (he == hipSuccess) he = hipStreamWaitEvent(st, e, 0);
     if (he != hipSuccess) return (int)he;
   }
-  if ((!fork || !reduce_per_batch) && reduce_items && reduce_index) {   // a single reduce over every layer at the end
+  if (have_red) {                          // the rows that were not reduced early: one launch at the end
     int cnt = 0;
     long long max_n = 0;
     for (int i = 0; i < n; ++i)
       if (reduce_index[i] >= 0 && (early_lo < 0 || reduce_index[i] < early_lo)) {
         ++cnt;
-        const long long per = (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize;
-        max_n = per > max_n ? per : max_n;
+        max_n = per_of(i) > max_n ? per_of(i) : max_n;
       }
     if (cnt) {
       const int rc = pdes_wgrad_reduce_all(reduce_items, cnt, (int)max_n, st);
