@@ -174,7 +174,7 @@ def _run_default(dev, B=4, seed=5, imsize=64, blocks=(6, 8, 6)):
     return y.detach().clone(), float(loss.detach()), grads
 
 
-@pytest.mark.parametrize('cfg', [dict(B=4), dict(B=32), dict(B=8, imsize=32, blocks=(3, 4, 3)),
+@pytest.mark.parametrize('cfg', [dict(B=4), dict(B=32), dict(B=1), dict(B=8, imsize=32, blocks=(3, 4, 3)),
                                  dict(B=3, imsize=64, blocks=(2, 3, 2))])
 def test_mfma_kernels_match_direct_kernels(dev, monkeypatch, cfg):
     """matrix-core implicit-GEMM convolutions vs the VALU reference kernels, same weights/inputs.
