@@ -101,6 +101,8 @@ typedef struct pdes_conv_desc {
   const float* wm_bwd;   /* MFMA image of w for the data gradient, or NULL */
   const float* wu_fwd;   /* upsample+3x3 only: effective 2x2 weights (sub-pixel decomposition), or NULL */
   const float* wu_bwd;   /* same for the data gradient, or NULL (pdes_pack_weights_up) */
+  const unsigned short* wb_fwd; /* wide 3x3 layers: bf16 hi/mid/lo split image for the forward, or NULL (pdes_pack_weights_b3) */
+  const unsigned short* wb_bwd; /* same for the data gradient, or NULL */
   /* output */
   float* out;            /* (B, out_ctot, Hout, Wout); channels [out_coff, out_coff+Cout) written */
   int out_ctot, out_coff;
@@ -194,11 +196,21 @@ typedef struct pdes_up_pack_item { /* one nearest-x2 + 3x3 convolution: effectiv
 } pdes_up_pack_item;
 /* items: DEVICE array; see csrc/conv_mfma_up.hip for the image layout. */
 int pdes_pack_weights_up(const pdes_up_pack_item* items, int n, int max_elems, void* stream);
-/* The three tables above in ONE launch (any of them may be empty: n = 0); max_elems = the largest packed image.
+typedef struct pdes_b3_pack_item { /* one wide 3x3 convolution: three-way bf16 split weight images (conv_mfma_b3.hip) */
+  const float* w; unsigned short* wb_fwd; unsigned short* wb_bwd;   /* either image may be NULL */
+  int Cout, Cin;
+} pdes_b3_pack_item;
+/* fp32 weights -> hi/mid/lo bf16 planes in the B-operand layout of v_mfma_f32_16x16x32_bf16; sizes from
+ * pdes_b3_image_elems (bf16 elements; buffers 16-byte aligned).  total = max elements / 24 over the items. */
+int pdes_pack_weights_b3(const pdes_b3_pack_item* items, int n, int max_elems, void* stream);
+int pdes_b3_image_elems(int Cout, int Cin, long long* fwd_elems, long long* bwd_elems);
+/* The four tables above in ONE launch (any of them may be empty: n = 0); max_elems = the largest packed image
+ * (work items: elements, or elements / 24 for the bf16 split images).
  * No reference counterpart: the packed images replace the (Cout,Cin,k,k) weight reads of nn.Conv2d
- * (models/codec.py:57-58, 106-146, 170-186) with coalesced 256-B operand loads. */
+ * (models/codec.py:57-58, 106-146, 170-186) with coalesced 256-B / 1-KiB operand loads. */
 int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
-                  const pdes_up_pack_item* uitems, int nu, int max_elems, void* stream);
+                  const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
+                  int max_elems, void* stream);
 
 typedef struct pdes_bn_item {    /* one BatchNorm layer */
   const double* x_stats;  /* (>=C, 2) batch sums of its input channels */

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 10
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -29,7 +29,9 @@ SIGNATURES = {
     'pdes_pack_weights': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_weights_mfma': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_weights_up': [_c_p, _c_i, _c_i, _c_p],
-    'pdes_pack_all': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
+    'pdes_pack_all': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
+    'pdes_pack_weights_b3': [_c_p, _c_i, _c_i, _c_p],
+    'pdes_b3_image_elems': [_c_i, _c_i, _c_p, _c_p],
     'pdes_bn_update_running': [_c_p, _c_i, _c_i, _c_f, _c_i, ctypes.c_longlong, _c_p],
     'pdes_bn_param_grads': [_c_p, _c_i, _c_i, _c_i, ctypes.c_longlong, _c_p],
     'pdes_adam_step': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, ctypes.c_longlong, _c_p],

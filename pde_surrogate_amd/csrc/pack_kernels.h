@@ -67,4 +67,53 @@ __device__ __forceinline__ void pack_up_item(const pdes_up_pack_item& it, int bx
   }
 }
 
+typedef unsigned int u32;
+// Three-way bf16 split of a PAIR of fp32 values with the hardware conversion (v_cvt_pk_bf16_f32, round to nearest
+// even): each returned word holds the two bf16 terms (x0 in the low half, x1 in the high half) of one plane.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 cvt_pk_bf16(float a, float b) {
+  const v2bf t = __builtin_convertvector((v2f){a, b}, v2bf);
+  return *reinterpret_cast<const u32*>(&t);
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, u32& h, u32& m, u32& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(s0, s1);
+}
+
+// split weight images of the wide 3x3 layers (conv_mfma_b3.hip)
+__device__ __forceinline__ void pack_b3_item(const pdes_b3_pack_item& it, int bx, int nbx) {
+  for (int dir = 0; dir < 2; ++dir) {
+    unsigned short* img = dir == 0 ? it.wb_fwd : it.wb_bwd;
+    if (!img) continue;
+    const int kC = dir == 0 ? it.Cin : it.Cout, nC = dir == 0 ? it.Cout : it.Cin;
+    const int ntp = (((nC + 15) / 16) + 7) & ~7, nch = (kC + 31) / 32;
+    const int total = nch * 9 * ntp * 64;                 // one thread per (chunk, tap, N-tile, lane)
+    for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+      const int l = e & 63, nt = (e >> 6) % ntp, t = ((e >> 6) / ntp) % 9, ch = (e >> 6) / (ntp * 9);
+      const int n = nt * 16 + (l & 15), k0 = ch * 32 + 8 * (l >> 4);
+      u32 hw[4], mw[4], lw[4];
+      float xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        float x = 0.f;
+        if (n < nC && k < kC)
+          x = dir == 0 ? it.w[((size_t)n * it.Cin + k) * 9 + t] : it.w[((size_t)k * it.Cin + n) * 9 + (8 - t)];
+        xv[j] = x;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3_pair(xv[2 * j], xv[2 * j + 1], hw[j], mw[j], lw[j]);
+      unsigned short* q = img + (((size_t)(ch * 9 + t) * ntp + nt) * 3 * 64 + l) * 8;
+      *reinterpret_cast<uint4*>(q) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      *reinterpret_cast<uint4*>(q + 64 * 8) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+      *reinterpret_cast<uint4*>(q + 2 * 64 * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+  }
+}
+
+
 }  // namespace pdes

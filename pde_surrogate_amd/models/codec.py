@@ -34,7 +34,7 @@ class ConvDesc(ctypes.Structure):
         ('x', _P), ('x_ctot', _I), ('has_bn', _I), ('eval_mode', _I), ('eps', _F),
         ('gamma', _P), ('beta', _P), ('x_stats', _P), ('run_mean', _P), ('run_var', _P),
         ('w', _P), ('w_fwd', _P), ('w_bwd', _P), ('cout_pad', _I), ('cin_pad', _I),
-        ('wm_fwd', _P), ('wm_bwd', _P), ('wu_fwd', _P), ('wu_bwd', _P),
+        ('wm_fwd', _P), ('wm_bwd', _P), ('wu_fwd', _P), ('wu_bwd', _P), ('wb_fwd', _P), ('wb_bwd', _P),
         ('out', _P), ('out_ctot', _I), ('out_coff', _I), ('out_stats', _P), ('fin_xstats', _P), ('fin_tstats', _P),
         ('g', _P), ('g_ctot', _I), ('g_coff', _I), ('g_fused', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
@@ -54,6 +54,10 @@ class MfmaPackItem(ctypes.Structure):
 
 class UpPackItem(ctypes.Structure):
     _fields_ = [('w', _P), ('wu_fwd', _P), ('wu_bwd', _P), ('Cout', _I), ('Cin', _I)]
+
+
+class B3PackItem(ctypes.Structure):
+    _fields_ = [('w', _P), ('wb_fwd', _P), ('wb_bwd', _P), ('Cout', _I), ('Cin', _I)]
 
 
 class ReduceItem(ctypes.Structure):
@@ -279,6 +283,9 @@ class _Engine:
             uf = net._packed_up.get(s.conv)
             d.wu_fwd = uf[0].data_ptr() if uf else None
             d.wu_bwd = uf[1].data_ptr() if uf else None
+            b3 = net._packed_b3.get(s.conv)
+            d.wb_fwd = b3[0].data_ptr() if b3 else None
+            d.wb_bwd = b3[1].data_ptr() if b3 else None
             d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
             d.ws, d.ws_bytes, d.ws_defer = net._ws.data_ptr(), net._ws.numel() * 4, 0
             d.nrep, d.rep_stride = self.nrep, self.rep_stride
@@ -528,6 +535,25 @@ class _HipNet(nn.Module):
         if uitems:
             arr = (UpPackItem * len(uitems))(*uitems)
             self._upack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        # three-way bf16 split images of the wide 3x3 layers (conv_mfma_b3.hip: fp32 accuracy on the bf16 matrix pipe)
+        self._packed_b3, bitems, bmx = {}, [], 0
+        for s in self._specs:
+            if not (s.k == 3 and s.stride == 1 and not s.up and s.norm is not None and s.cin >= 64 and s.cout >= 80):
+                continue
+            nf, nb = ctypes.c_longlong(0), ctypes.c_longlong(0)
+            _lib.check(_lib.lib().pdes_b3_image_elems(s.cout, s.cin, ctypes.byref(nf), ctypes.byref(nb)), 'pdes_b3_image_elems')
+            bf = torch.zeros(nf.value, device=device, dtype=torch.int16)
+            bb = torch.zeros(nb.value, device=device, dtype=torch.int16)
+            self._packed_b3[s.conv] = (bf, bb)
+            it = B3PackItem()
+            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.wb_fwd, it.wb_bwd, it.Cout, it.Cin = bf.data_ptr(), bb.data_ptr(), s.cout, s.cin
+            bitems.append(it)
+            bmx = max(bmx, nf.value // 24, nb.value // 24)
+        self._bpack_n, self._bpack_max = len(bitems), bmx
+        if bitems:
+            arr = (B3PackItem * len(bitems))(*bitems)
+            self._bpack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._ws = torch.empty(8 << 20, device=device)       # 32 MiB split-K scratch (weight gradients)
         if mitems:
             arr = (MfmaPackItem * len(mitems))(*mitems)
@@ -535,11 +561,13 @@ class _HipNet(nn.Module):
         self._engines = {}
 
     def _pack_weights(self):
-        """rebuild every packed weight image from the live weights: one launch (direct, MFMA and sub-pixel tables)"""
-        mx = max(self._pack_max, self._mpack_max if self._mpack_n else 0, self._upack_max if self._upack_n else 0)
+        """rebuild every packed weight image from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables)"""
+        mx = max(self._pack_max, self._mpack_max if self._mpack_n else 0, self._upack_max if self._upack_n else 0,
+                 self._bpack_max if self._bpack_n else 0)
         rc = _lib.lib().pdes_pack_all(self._pack_table.data_ptr(), self._pack_n,
                                       self._mpack_table.data_ptr() if self._mpack_n else None, self._mpack_n,
                                       self._upack_table.data_ptr() if self._upack_n else None, self._upack_n,
+                                      self._bpack_table.data_ptr() if self._bpack_n else None, self._bpack_n,
                                       mx, _lib.stream_ptr())
         _lib.check(rc, 'pdes_pack_all')
 
