@@ -183,7 +183,11 @@ def main():
             'data': 'synthetic GRF-KLE512 (exp. covariance ell=0.25, 512 KLE terms), random-init DenseED',
             'config': {'workload': 'configs[1]: GRF KLE512 64x64, ntrain=%d, bs=%d per GPU, DenseED blocks [6,8,6] '
                                    'growth 16 init 48 (740,091 params), fp32, Adam + one-cycle LR' % (args.ntrain, B),
-                       'global_batch': GB, 'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph), 'wgrad_stream': not args.graph},
+                       'global_batch': GB, 'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph), 'wgrad_stream': not args.graph,
+                       'arithmetic': 'fp32 end to end; convolutions on v_mfma_f32_16x16x4_f32, except the 196->98 3x3 layer '
+                                     '(forward + data gradient): both operands split into three bf16 terms, six cross '
+                                     'products accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (24-bit significand '
+                                     'coverage, error vs fp64 equal to the f32 pipe; PDES_MFMA_B3=0 disables)'},
             'loss_mean_over_run': round(means[0], 4),
             'roofline': {'bound': 'hbm', 'kernel': 'darcy_loss_kernel<64,bwd> (fused Sobel+Darcy residual+boundary, fwd+bwd)',
                          'achieved': round(gbL, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
