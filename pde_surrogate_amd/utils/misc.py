@@ -1,33 +1,34 @@
-"""Directory / tensor helpers -- same API as the reference's utils/misc.py:10-34."""
-import os
+"""Host helpers with the call surface of the reference's utils/misc.py (mkdirs :10-18, to_numpy :21-28,
+module_size :31-38), written for this package: pathlib for the run directories, one pass over
+`named_parameters()` for the (parameter count, conv-layer count) pair that goes into args.txt."""
+from pathlib import Path
 
 import numpy as np
 import torch
 
 
-def mkdir(path):
-    if not os.path.exists(path):
-        os.makedirs(path, exist_ok=True)
-
-
 def mkdirs(*paths):
-    for path in paths:
-        mkdir(path)
+    """create every run directory (parents included); existing ones are left alone"""
+    for p in paths:
+        Path(p).mkdir(parents=True, exist_ok=True)
 
 
-def to_numpy(input):
-    if isinstance(input, torch.Tensor):
-        return input.detach().cpu().numpy()
-    if isinstance(input, np.ndarray):
-        return input
-    raise TypeError('Unknown type of input, expected torch.Tensor or np.ndarray, but got {}'.format(type(input)))
+mkdir = mkdirs
+
+
+def to_numpy(value):
+    """device or host tensor / ndarray -> ndarray on the host (no copy for an ndarray)"""
+    if torch.is_tensor(value):
+        return value.detach().to('cpu').numpy()
+    if not isinstance(value, np.ndarray):
+        raise TypeError(f'to_numpy expects a torch.Tensor or np.ndarray, got {type(value).__name__}')
+    return value
 
 
 def module_size(module):
-    assert isinstance(module, torch.nn.Module)
-    n_params, n_conv_layers = 0, 0
-    for name, param in module.named_parameters():
-        if 'conv' in name:
-            n_conv_layers += 1
-        n_params += param.numel()
-    return n_params, n_conv_layers
+    """(number of scalar parameters, number of parameter tensors whose qualified name contains 'conv');
+    DenseED keeps the reference's layer names so the second figure is 28 for the default net."""
+    if not isinstance(module, torch.nn.Module):
+        raise TypeError('module_size expects an nn.Module')
+    sizes = {name: p.numel() for name, p in module.named_parameters()}
+    return sum(sizes.values()), sum('conv' in name for name in sizes)
