@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from ..utils.misc import module_size  # noqa: F401  (the reference's codec.py:14-21)
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -67,17 +68,6 @@ class ReduceItem(ctypes.Structure):
 class BnItem(ctypes.Structure):
     _fields_ = [('x_stats', _P), ('bn_grad', _P), ('run_mean', _P), ('run_var', _P), ('dgamma', _P),
                 ('dbeta', _P), ('num_batches_tracked', _P), ('C', _I), ('count', _I)]
-
-
-def module_size(module):
-    """(n_params, n_conv_layers): counts parameter names containing 'conv' (codec.py:14-21)"""
-    assert isinstance(module, torch.nn.Module)
-    n_params, n_conv_layers = 0, 0
-    for name, param in module.named_parameters():
-        if 'conv' in name:
-            n_conv_layers += 1
-        n_params += param.numel()
-    return n_params, n_conv_layers
 
 
 def _pad16(n):
