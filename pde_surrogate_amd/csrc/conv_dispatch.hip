@@ -18,6 +18,8 @@ int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st);         // 5x5
 int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st);             // wide 3x3 layers: bf16 x3 split (conv_mfma_b3.hip)
 int conv_backward_data_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
+int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
+int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 
 // PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
 // the matrix-core kernels against them); anything else = automatic selection.
@@ -36,6 +38,7 @@ extern "C" int pdes_conv_forward(const pdes_conv_desc* descs, int n, void* strea
     int rc = force_direct() ? PDES_ENOSUP : conv_forward_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_fewout(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_b3(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_1x1(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_mfma(descs[i], st);
     if (rc == PDES_ENOSUP) rc = conv_forward_direct(descs[i], st);
     if (rc) return rc;
@@ -69,6 +72,7 @@ extern "C" int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void*
   for (int i = 0; i < n; ++i) {
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_b3(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_1x1(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && descs[i].g_fused) return PDES_EINVAL;
     if (rc == PDES_ENOSUP) rc = conv_backward_data_direct(descs[i], st);
