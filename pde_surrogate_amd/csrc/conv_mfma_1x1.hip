@@ -249,6 +249,116 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_mfma_kernel(pdes_conv_desc
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a 1x1 convolution: dW[co][ci] = sum over pixels of g[co][p] * relu(bn(x[ci][p])) -- a GEMM with
+// K = pixels, whose operands are both pixel-contiguous in NCHW: lane (row/col = lane & 15, kq = lane >> 4) loads ONE
+// float4 = pixels p + 4 kq .. + 3 of its channel per operand tile, and component t of the float4s is K-step t (the
+// K index (kq, t) <-> pixel p + 4 kq + t is the same permutation on both sides).  No LDS tile, no barrier in the
+// loop.  A workgroup = KSW waves that split the pixels of ONE image for MTW x NTW output tiles (all output-channel
+// tiles x a group of input-channel tiles); their accumulators meet in LDS and go to the split-K partial buffer of
+// image b (the plan of conv_mfma_wgrad.hip with one split per image), reduced later with every other layer.
+template <int MTW, int NTW, int KSW>
+__global__ __launch_bounds__(64 * KSW, 2) void conv1x1_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w1[];
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, nt0 = blockIdx.y * NTW;
+  const int HW = d.Hin * d.Win;
+  const int npx = HW / KSW, nst = npx >> 4;            // pixels and 16-pixel stages of this wave
+  float4* cf4 = reinterpret_cast<float4*>(smem_w1);   // [NTW * 16] BatchNorm coefficients of the B-operand channels
+  v4f* red = reinterpret_cast<v4f*>(smem_w1 + 16 * NTW * 16);
+
+  if (tid < NTW * 16) {
+    const BnP k = bn_coef_p(d, min(nt0 * 16 + tid, d.Cin - 1));
+    cf4[tid] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
+  }
+  const float* ga[MTW];
+  const float* xb[NTW];
+  const size_t poff = (size_t)wave * npx + 4 * kq;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+    ga[mt] = d.g + ((size_t)b * d.g_ctot + d.g_coff + min(mt * 16 + i16, d.Cout - 1)) * HW + poff;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+    xb[nt] = d.x + ((size_t)b * d.x_ctot + min((nt0 + nt) * 16 + i16, d.Cin - 1)) * HW + poff;
+
+  struct Stage { float4 a[MTW]; float4 x[NTW]; };
+  auto issue = [&](int st, Stage& s) __attribute__((always_inline)) {
+    const int o = min(st, nst - 1) << 4;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) s.a[mt] = *reinterpret_cast<const float4*>(ga[mt] + o);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) s.x[nt] = *reinterpret_cast<const float4*>(xb[nt] + o);
+  };
+  v4f acc[MTW][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float4 kc[NTW];
+  auto compute = [&](const Stage& s) __attribute__((always_inline)) {
+    float bv[NTW][4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const float xs[4] = {s.x[nt].x, s.x[nt].y, s.x[nt].z, s.x[nt].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[nt][t] = fmaxf(0.f, (xs[t] - kc[nt].x) * kc[nt].y + kc[nt].z);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const float av = t == 0 ? s.a[mt].x : (t == 1 ? s.a[mt].y : (t == 2 ? s.a[mt].z : s.a[mt].w));
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt][t], acc[mt][nt], 0, 0, 0);
+      }
+  };
+
+#define PDES_W1_ISSUE(st_, s_) do { issue(st_, s_); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PDES_W1_COMPUTE(s_) do { compute(s_); __builtin_amdgcn_sched_barrier(0); } while (0)
+  Stage s0, s1, s2;
+  PDES_W1_ISSUE(0, s0);
+  PDES_W1_ISSUE(1, s1);
+  __syncthreads();                    // coefficients visible
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) kc[nt] = cf4[nt * 16 + i16];
+  {
+    int st = 0;
+    for (; st + 2 < nst; st += 3) {
+      PDES_W1_ISSUE(st + 2, s2); PDES_W1_COMPUTE(s0);
+      PDES_W1_ISSUE(st + 3, s0); PDES_W1_COMPUTE(s1);
+      PDES_W1_ISSUE(st + 4, s1); PDES_W1_COMPUTE(s2);
+    }
+    if (st < nst) {
+      PDES_W1_COMPUTE(s0);
+      if (st + 1 < nst) PDES_W1_COMPUTE(s1);
+    }
+  }
+#undef PDES_W1_ISSUE
+#undef PDES_W1_COMPUTE
+
+  // ---- the pixel-split partial sums meet in LDS; wave w finishes tiles w, w + KSW, ...
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) red[((wave * MTW + mt) * NTW + nt) * 64 + lane] = acc[mt][nt];
+  __syncthreads();
+  float* pb = part + (size_t)b * d.Cout * d.Cin;
+  for (int tt = wave; tt < MTW * NTW; tt += KSW) {
+    v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < KSW; ++w) v += red[(w * MTW * NTW + tt) * 64 + lane];
+    const int mt = tt / NTW, nt = tt % NTW;
+    const int ci = (nt0 + nt) * 16 + i16, co0 = mt * 16 + 4 * kq;
+    if (ci < d.Cin) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co0 + r < d.Cout) pb[(size_t)(co0 + r) * d.Cin + ci] = v[r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- host dispatch
 // PDES_MFMA_1X1: 0 = off (conv_mfma.hip serves the 1x1 layers), 1 = forward and data gradient (default),
 // 2 = forward only, 3 = data gradient only
@@ -306,6 +416,29 @@ int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   if (!p1_enabled(true) || !d.wm_bwd || !p1_shape_ok(d, true) || d.eval_mode || d.g_fused) return PDES_ENOSUP;
   if (dry) return PDES_OK;
   return launch_p1<P1_BWD>(d, d.wm_bwd, st);
+}
+
+
+// weight gradient into the split-K partial buffer d.ws, ONE split per image (the caller checked that the plan of
+// conv_mfma_wgrad.hip says so); PDES_ENOSUP leaves the layer to the generic kernel
+int conv_backward_weight_1x1(const pdes_conv_desc& d, hipStream_t st) {
+  { const char* e = getenv("PDES_MFMA_1X1W"); if (e && e[0] == '0') return PDES_ENOSUP; }
+  if (!p1_shape_ok(d, false) || !d.ws || d.eval_mode || d.g_fused) return PDES_ENOSUP;
+  const int mtiles = (d.Cout + 15) / 16, ntiles = (d.Cin + 15) / 16, HW = d.Hin * d.Win;
+  if ((long long)d.B * d.Cout * d.Cin * 4 > d.ws_bytes) return PDES_ENOSUP;
+  if (mtiles == 5 && HW % 128 == 0) {
+    dim3 grid(d.B, (ntiles + 2) / 3), block(512);
+    const size_t lds = 16 * 3 * 16 + (size_t)8 * 5 * 3 * 64 * 16;
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<5, 3, 8>), grid, block, lds, st, d, d.ws);
+  } else if (mtiles == 7 && HW % 64 == 0) {
+    dim3 grid(d.B, (ntiles + 1) / 2), block(256);
+    const size_t lds = 16 * 2 * 16 + (size_t)4 * 7 * 2 * 64 * 16;
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<7, 2, 4>), grid, block, lds, st, d, d.ws);
+  } else {
+    return PDES_ENOSUP;
+  }
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
 }
 
 }  // namespace pdes

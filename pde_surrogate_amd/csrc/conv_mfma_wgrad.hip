@@ -16,6 +16,7 @@
 #include "bn_fused.h"
 
 namespace pdes {
+int conv_backward_weight_1x1(const pdes_conv_desc& d, hipStream_t st);   // conv_mfma_1x1.hip
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -716,6 +717,17 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry)
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
   if (!wgrad_shape_ok(d)) return PDES_ENOSUP;
   if (dry) { WgradPlan pl; return wgrad_plan(d, &pl) ? PDES_OK : PDES_ENOSUP; }
+  if (d.ksize == 1 && d.stride == 1 && !d.upsample && !d.g_fused) {      // conv_mfma_1x1.hip: one split per image
+    WgradPlan pl;
+    if (wgrad_plan(d, &pl) && pl.nsplit == d.B) {
+      const int rc = conv_backward_weight_1x1(d, st);
+      if (rc == PDES_OK && !d.ws_defer) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)pl.per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)pl.per, pl.nsplit);
+        PDES_LAUNCH_CHECK();
+      }
+      if (rc != PDES_ENOSUP) return rc;
+    }
+  }
   if (d.upsample) return launch_wgrad_up(d, st);
   if (d.stride == 2) return launch_wgrad<3, 2>(d, st);
   if (d.ksize == 5) return launch_wgrad<5, 1>(d, st);
