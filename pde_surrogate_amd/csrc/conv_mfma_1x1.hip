@@ -256,15 +256,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_mfma_kernel(pdes_conv_desc
 // K index (kq, t) <-> pixel p + 4 kq + t is the same permutation on both sides).  No LDS tile, no barrier in the
 // loop.  A workgroup = KSW waves that split the pixels of ONE image for MTW x NTW output tiles (all output-channel
 // tiles x a group of input-channel tiles); their accumulators meet in LDS and go to the split-K partial buffer of
-// image b (the plan of conv_mfma_wgrad.hip with one split per image), reduced later with every other layer.
+// split blockIdx.x (the plan of conv_mfma_wgrad.hip: spi splits per image), reduced later with every other layer.
 template <int MTW, int NTW, int KSW>
-__global__ __launch_bounds__(64 * KSW, 2) void conv1x1_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part) {
+__global__ __launch_bounds__(64 * KSW, 2) void conv1x1_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int spi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w1[];
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x, nt0 = blockIdx.y * NTW;
+  const int b = blockIdx.x / spi, nt0 = blockIdx.y * NTW;        // spi splits (workgroups) per image
   const int HW = d.Hin * d.Win;
-  const int npx = HW / KSW, nst = npx >> 4;            // pixels and 16-pixel stages of this wave
+  const int npx = HW / (spi * KSW), nst = npx >> 4;    // pixels and 16-pixel stages of this wave
   float4* cf4 = reinterpret_cast<float4*>(smem_w1);   // [NTW * 16] BatchNorm coefficients of the B-operand channels
   v4f* red = reinterpret_cast<v4f*>(smem_w1 + 16 * NTW * 16);
 
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * KSW, 2) void conv1x1_wgrad_kernel(pdes_conv_de
   }
   const float* ga[MTW];
   const float* xb[NTW];
-  const size_t poff = (size_t)wave * npx + 4 * kq;
+  const size_t poff = (size_t)((blockIdx.x % spi) * KSW + wave) * npx + 4 * kq;
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt)
     ga[mt] = d.g + ((size_t)b * d.g_ctot + d.g_coff + min(mt * 16 + i16, d.Cout - 1)) * HW + poff;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * KSW, 2) void conv1x1_wgrad_kernel(pdes_conv_de
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) red[((wave * MTW + mt) * NTW + nt) * 64 + lane] = acc[mt][nt];
   __syncthreads();
-  float* pb = part + (size_t)b * d.Cout * d.Cin;
+  float* pb = part + (size_t)blockIdx.x * d.Cout * d.Cin;
   for (int tt = wave; tt < MTW * NTW; tt += KSW) {
     v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -419,21 +419,25 @@ int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry) {
 }
 
 
-// weight gradient into the split-K partial buffer d.ws, ONE split per image (the caller checked that the plan of
-// conv_mfma_wgrad.hip says so); PDES_ENOSUP leaves the layer to the generic kernel
-int conv_backward_weight_1x1(const pdes_conv_desc& d, hipStream_t st) {
+// weight gradient into the split-K partial buffer d.ws, spi splits per image (the plan of conv_mfma_wgrad.hip);
+// PDES_ENOSUP leaves the layer to the generic kernel
+int conv_backward_weight_1x1(const pdes_conv_desc& d, int spi, hipStream_t st) {
   { const char* e = getenv("PDES_MFMA_1X1W"); if (e && e[0] == '0') return PDES_ENOSUP; }
-  if (!p1_shape_ok(d, false) || !d.ws || d.eval_mode || d.g_fused) return PDES_ENOSUP;
+  if (!p1_shape_ok(d, false) || !d.ws || d.eval_mode || d.g_fused || spi < 1) return PDES_ENOSUP;
   const int mtiles = (d.Cout + 15) / 16, ntiles = (d.Cin + 15) / 16, HW = d.Hin * d.Win;
-  if ((long long)d.B * d.Cout * d.Cin * 4 > d.ws_bytes) return PDES_ENOSUP;
-  if (mtiles == 5 && HW % 128 == 0) {
+  if ((long long)d.B * spi * d.Cout * d.Cin * 4 > d.ws_bytes) return PDES_ENOSUP;
+  if (mtiles == 5 && spi == 4 && HW % (4 * 4 * 16) == 0) {
+    dim3 grid(d.B * spi, (ntiles + 2) / 3), block(256);
+    const size_t lds = 16 * 3 * 16 + (size_t)4 * 5 * 3 * 64 * 16;
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<5, 3, 4>), grid, block, lds, st, d, d.ws, spi);
+  } else if (mtiles == 5 && spi == 1 && HW % 128 == 0) {
     dim3 grid(d.B, (ntiles + 2) / 3), block(512);
     const size_t lds = 16 * 3 * 16 + (size_t)8 * 5 * 3 * 64 * 16;
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<5, 3, 8>), grid, block, lds, st, d, d.ws);
-  } else if (mtiles == 7 && HW % 64 == 0) {
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<5, 3, 8>), grid, block, lds, st, d, d.ws, spi);
+  } else if (mtiles == 7 && spi == 1 && HW % 64 == 0) {
     dim3 grid(d.B, (ntiles + 1) / 2), block(256);
     const size_t lds = 16 * 2 * 16 + (size_t)4 * 7 * 2 * 64 * 16;
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<7, 2, 4>), grid, block, lds, st, d, d.ws);
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<7, 2, 4>), grid, block, lds, st, d, d.ws, spi);
   } else {
     return PDES_ENOSUP;
   }

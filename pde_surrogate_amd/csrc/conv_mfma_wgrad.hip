@@ -16,7 +16,7 @@
 #include "bn_fused.h"
 
 namespace pdes {
-int conv_backward_weight_1x1(const pdes_conv_desc& d, hipStream_t st);   // conv_mfma_1x1.hip
+int conv_backward_weight_1x1(const pdes_conv_desc& d, int splits_per_image, hipStream_t st);   // conv_mfma_1x1.hip
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -605,6 +605,14 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
     if (ns * p->per * 4 > d.ws_bytes) continue;
     if (ns * p->gy <= wg_target || cand == p->tps) { p->tpw = cand; break; }
   }
+  // 1x1 layers on big maps (conv_mfma_1x1.hip: a workgroup per (split, group of input-channel tiles)):
+  // PDES_1X1W_SPI=4 asks for four splits per image, which puts a workgroup on every CU -- 23.4 -> 16.6 us stand-alone
+  // for the 144->72 layer, but no gain inside the step (2.0375 vs 2.0389 ms, three same-box runs each: the bigger
+  // grid takes more of the chip from the data-gradient chain), so one split per image stays the default
+  if (d.ksize == 1 && d.stride == 1 && !d.upsample && d.Hout * d.Wout >= 1024 && p->tps % 4 == 0 &&
+      getenv("PDES_1X1W_SPI") && atoi(getenv("PDES_1X1W_SPI")) == 4 &&
+      (long long)d.B * 4 * p->per * 4 <= d.ws_bytes)
+    p->tpw = p->tps / 4;
   p->nsplit = d.B * (p->tps / p->tpw);
   return (long long)p->nsplit * p->per * 4 <= d.ws_bytes;
 }
@@ -719,8 +727,8 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry)
   if (dry) { WgradPlan pl; return wgrad_plan(d, &pl) ? PDES_OK : PDES_ENOSUP; }
   if (d.ksize == 1 && d.stride == 1 && !d.upsample && !d.g_fused) {      // conv_mfma_1x1.hip: one split per image
     WgradPlan pl;
-    if (wgrad_plan(d, &pl) && pl.nsplit == d.B) {
-      const int rc = conv_backward_weight_1x1(d, st);
+    if (wgrad_plan(d, &pl) && pl.nsplit % d.B == 0) {
+      const int rc = conv_backward_weight_1x1(d, pl.nsplit / d.B, st);
       if (rc == PDES_OK && !d.ws_defer) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)pl.per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)pl.per, pl.nsplit);
         PDES_LAUNCH_CHECK();
