@@ -3,6 +3,7 @@
 // References: nn.BatchNorm2d semantics as used by models/codec.py (train: batch stats, biased var
 // for normalisation, unbiased var into running_var, momentum 0.1, eps 1e-5);
 // torch.optim.Adam as called in train_codec_mixed_residual.py:151-152,239.
+#include <stdlib.h>
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
 #include "pack_kernels.h"
@@ -14,10 +15,21 @@ namespace pdes {
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ t, const float* __restrict__ x,
                                                               const double* __restrict__ x_stats,
                                                               const double* __restrict__ t_stats, int B, int ctot,
-                                                              int c0, int HW, float eps, int nrep, long long rs) {
+                                                              int c0, int HW, float eps, int nrep, long long rs, int early) {
   const int c = c0 + blockIdx.y, b = blockIdx.z;
   __shared__ float sc[4];
   __shared__ double sums[4];
+  const size_t base = ((size_t)b * ctot + c) * HW;
+  // HW is a multiple of 4 for every supported feature map (>= 8x8); vectorise when aligned.  The first element's
+  // loads do not depend on the statistics: issue them BEFORE the reduce -> fp64 -> LDS chain so that the two
+  // latencies overlap (this kernel runs 27 times per step on the critical stream and is pure latency)
+  const bool vec = (HW & 3) == 0;
+  const int i0 = blockIdx.x * 256 + threadIdx.x;
+  float4 tv0 = make_float4(0.f, 0.f, 0.f, 0.f), xv0 = tv0;
+  if (vec && early && i0 < HW / 4) {
+    tv0 = reinterpret_cast<const float4*>(t + base)[i0];
+    xv0 = reinterpret_cast<const float4*>(x + base)[i0];
+  }
   if (threadIdx.x < 64) {
     // 4 quantities x PDES_NREP(=16) replicas: one load per lane, then a 16-lane shuffle reduction
     const int q = threadIdx.x >> 4, r = threadIdx.x & 15;
@@ -29,25 +41,23 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double n = (double)B * HW;
-    const double m = sums[0] / n;
-    double var = sums[1] / n - m * m;
+    const double inv_n = 1.0 / ((double)B * HW);
+    const double m = sums[0] * inv_n;
+    double var = sums[1] * inv_n - m * m;
     var = var < 0.0 ? 0.0 : var;
     sc[0] = (float)m;
     sc[1] = (float)(1.0 / sqrt(var + (double)eps));
-    sc[2] = (float)(sums[2] / n);
-    sc[3] = (float)(sums[3] / n);
+    sc[2] = (float)(sums[2] * inv_n);
+    sc[3] = (float)(sums[3] * inv_n);
   }
   __syncthreads();
   const float mean = sc[0], invstd = sc[1], m1 = sc[2], m2 = sc[3];
-  const size_t base = ((size_t)b * ctot + c) * HW;
-  // HW is a multiple of 4 for every supported feature map (>= 8x8); vectorise when aligned
-  if ((HW & 3) == 0) {
+  if (vec) {
     float4* t4 = reinterpret_cast<float4*>(t + base);
     const float4* x4 = reinterpret_cast<const float4*>(x + base);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
-      float4 tv = t4[i];
-      const float4 xv = x4[i];
+    for (int i = i0; i < HW / 4; i += gridDim.x * 256) {
+      float4 tv = (early && i == i0) ? tv0 : t4[i];
+      const float4 xv = (early && i == i0) ? xv0 : x4[i];
       tv.x = invstd * (tv.x - m1 - (xv.x - mean) * invstd * m2);
       tv.y = invstd * (tv.y - m1 - (xv.y - mean) * invstd * m2);
       tv.z = invstd * (tv.z - m1 - (xv.z - mean) * invstd * m2);
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
       t4[i] = tv;
     }
   } else {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256)
+    for (int i = i0; i < HW; i += gridDim.x * 256)
       t[base + i] = invstd * (t[base + i] - m1 - (x[base + i] - mean) * invstd * m2);
   }
 }
@@ -133,8 +143,9 @@ extern "C" int pdes_bn_backward_finalize(float* t, const float* x, const double*
   if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   if (!aligned16(t) || !aligned16(x)) return PDES_EALIGN;
   dim3 grid(cdiv(cdiv(HW, 4), 256), c1 - c0, B), block(256);
+  const int early = !(getenv("PDES_FIN_EARLY") && getenv("PDES_FIN_EARLY")[0] == '0');
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, static_cast<hipStream_t>(stream), t, x, x_stats, t_stats,
-                     B, ctot, c0, HW, eps, nrep, rep_stride);
+                     B, ctot, c0, HW, eps, nrep, rep_stride, early);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

@@ -193,17 +193,19 @@ def test_mfma_kernels_match_direct_kernels(dev, monkeypatch, cfg):
     assert errs[0][0] < 1e-2, errs[:8]
 
 
-@pytest.mark.parametrize('knob', ['PDES_FUSE_FINALIZE', 'PDES_WGRAD_STREAM', 'PDES_MFMA_B3'])
+@pytest.mark.parametrize('knob', ['PDES_FUSE_FINALIZE', 'PDES_WGRAD_STREAM', 'PDES_MFMA_B3', 'PDES_MFMA_1X1',
+                                  'PDES_MFMA_1X1W'])
 def test_backward_variants_agree(dev, monkeypatch, knob):
     """finalize fused into the operand load vs the in-place kernel; weight gradients on a second stream vs one
-    stream; the 196->98 layer on the bf16 pipe (three-way split, fp32-accurate) vs the f32 pipe: same outputs and
-    gradients (fp64 atomics of the statistics are order dependent in the last bits only; two different fp32
+    stream; the 196->98 layer on the bf16 pipe (three-way split, fp32-accurate) vs the f32 pipe; the 1x1 layers
+    (forward + data gradient, weight gradient) on the register-operand kernels of conv_mfma_1x1.hip vs the LDS-tiled
+    generic ones: same outputs and gradients (fp64 atomics of the statistics are order dependent in the last bits only; two different fp32
     summation orders flip individual ReLU masks, hence the 1e-2 class bound on parameter gradients)"""
     monkeypatch.setenv(knob, '0')
     y0, l0, g0 = _run_default(dev, B=32)
     monkeypatch.setenv(knob, '1')
     y1, l1, g1 = _run_default(dev, B=32)
-    ytol = 2e-6 if knob == 'PDES_MFMA_B3' else 1e-6
+    ytol = 2e-6 if knob in ('PDES_MFMA_B3', 'PDES_MFMA_1X1') else 1e-6
     assert torch.equal(y0, y1) or rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < ytol
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)

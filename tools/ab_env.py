@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Same-process A/B of run-time knobs (the library reads its PDES_* environment variables on every call):
     python tools/ab_env.py PDES_MFMA_1X1 0 1 2 3        -> ms per training step for each value, interleaved rounds
+    python tools/ab_env.py PDES_MFMA_NG 1 2 -- PDES_FEW_R 2 4    several knobs, one after the other ('-' = unset)
 Different gpurun boxes differ by ~2 %, one process repeats to ~0.1 %, so knob decisions are made here."""
 import contextlib
 import io
@@ -14,7 +15,7 @@ from pde_surrogate_amd.train import MixedResidualTrainer
 from pde_surrogate_amd.utils.data import grf_kle_fields
 
 
-def main(name, values, rounds=3, steps=150, warm=20, B=32):
+def main(groups, rounds=3, steps=150, warm=20, B=32):
     dev = torch.device('cuda:0')
     torch.manual_seed(1)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -22,21 +23,34 @@ def main(name, values, rounds=3, steps=150, warm=20, B=32):
     tr = MixedResidualTrainer(model, B, 64, lr=1e-3, weight_bound=10.0, device=dev, use_graph=False)
     data = torch.from_numpy(grf_kle_fields(512, cache_dir='/tmp')).to(dev)
     batches = [data[i * B:(i + 1) * B].contiguous() for i in range(512 // B)]
-    res = {v: [] for v in values}
-    for r in range(rounds):
+    for name, values in groups:
+        res = {v: [] for v in values}
+        for r in range(rounds):
+            for v in values:
+                if v == '-':
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = v
+                for i in range(warm):
+                    tr.step(batches[i % len(batches)], 1e-4)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    tr.step(batches[i % len(batches)], 1e-4)
+                torch.cuda.synchronize()
+                res[v].append((time.perf_counter() - t0) / steps * 1e3)
+        os.environ.pop(name, None)
         for v in values:
-            os.environ[name] = v
-            for i in range(warm):
-                tr.step(batches[i % len(batches)], 1e-4)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                tr.step(batches[i % len(batches)], 1e-4)
-            torch.cuda.synchronize()
-            res[v].append((time.perf_counter() - t0) / steps * 1e3)
-    for v in values:
-        print(f'{name}={v}: ' + ' '.join(f'{t:.4f}' for t in res[v]) + f'  | min {min(res[v]):.4f} ms/step', flush=True)
+            print(f'{name}={v}: ' + ' '.join(f'{t:.4f}' for t in res[v]) + f'  | min {min(res[v]):.4f} ms/step', flush=True)
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2:])
+    groups, cur = [], []
+    for a in sys.argv[1:] + ['--']:
+        if a == '--':
+            if cur:
+                groups.append((cur[0], cur[1:]))
+            cur = []
+        else:
+            cur.append(a)
+    main(groups)
