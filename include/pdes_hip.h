@@ -237,6 +237,13 @@ int pdes_bn_param_grads(const pdes_bn_item* items, int n, int max_c, int nrep, l
 int pdes_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    const float* hyper, float grad_scale, long long n, void* stream);
 
+/* The same step with the 7 hyper-parameters read from HOST memory at call time and passed to the
+ * kernel by value: the eager training step needs no host->device copy of them (an asynchronous copy
+ * from a reused pinned buffer would race with the host running ahead of the stream).
+ * Returns PDES_EINVAL when a bias correction is not positive (step 0). */
+int pdes_adam_step_host(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                        const float* hyper_host, float grad_scale, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

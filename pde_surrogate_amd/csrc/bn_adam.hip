@@ -110,25 +110,38 @@ __global__ __launch_bounds__(256) void bn_param_grads_kernel(const pdes_bn_item*
   it.dbeta[c] += (float)rep_sum(it.bn_grad, 2 * c + 1, nrep, rs);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v,
-                                                   const float* __restrict__ hyper, float gscale, long long n) {
-  // torch.optim.Adam (non-amsgrad, non-maximize); the host computes the bias corrections in
-  // double exactly as torch does: bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step)
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
-  const float bc1 = hyper[5], bc2_sqrt = hyper[6];
-  const float step_size = lr / bc1;
+struct AdamHyper { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; };
+
+// torch.optim.Adam (non-amsgrad, non-maximize); the host computes the bias corrections in
+// double exactly as torch does: bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step)
+__device__ __forceinline__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                            float* __restrict__ v, const AdamHyper& h, float gscale, long long n) {
+  const float step_size = h.lr / h.bc1;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float gi = g[i] * gscale;
     const float pi = p[i];
-    if (wd != 0.f) gi += wd * pi;
-    const float mi = m[i] + (1.f - b1) * (gi - m[i]);          // lerp, as torch does
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    if (h.wd != 0.f) gi += h.wd * pi;
+    const float mi = m[i] + (1.f - h.b1) * (gi - m[i]);          // lerp, as torch does
+    const float vi = h.b2 * v[i] + (1.f - h.b2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float denom = sqrtf(vi) / h.bc2_sqrt + h.eps;
     p[i] = pi - step_size * (mi / denom);
   }
+}
+
+// hyper-parameters in device memory (a captured hipGraph replays with new values) ...
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ hyper, float gscale, long long n) {
+  const AdamHyper h = {hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
+  adam_update(p, g, m, v, h, gscale, n);
+}
+// ... or by value in the kernel arguments (eager steps: nothing to copy, nothing to race with)
+__global__ __launch_bounds__(256) void adam_kernel_v(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v, AdamHyper h,
+                                                     float gscale, long long n) {
+  adam_update(p, g, m, v, h, gscale, n);
 }
 
 }  // namespace pdes
@@ -199,6 +212,20 @@ extern "C" int pdes_adam_step(float* param, const float* grad, float* exp_avg, f
   gx = gx > 2048 ? 2048 : gx;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad,
                      exp_avg, exp_avg_sq, hyper, grad_scale, n);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_adam_step_host(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                   const float* hyper_host, float grad_scale, long long n, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper_host || n <= 0) return PDES_EINVAL;
+  const AdamHyper h = {hyper_host[0], hyper_host[1], hyper_host[2], hyper_host[3], hyper_host[4], hyper_host[5],
+                       hyper_host[6]};
+  if (!(h.bc1 > 0.f) || !(h.bc2_sqrt > 0.f)) return PDES_EINVAL;
+  long long gx = (n + 255) / 256;
+  gx = gx > 2048 ? 2048 : gx;
+  hipLaunchKernelGGL(adam_kernel_v, dim3((unsigned)gx), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad,
+                     exp_avg, exp_avg_sq, h, grad_scale, n);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

@@ -11,6 +11,7 @@ Adam -- without autograd, host synchronisation or per-parameter kernels.
     per-step ``loss.item()`` sync, :240, is not needed for its per-epoch mean);
   * the whole compute part of the step can be captured in a hipGraph (`use_graph=True`).
 """
+import ctypes
 import math
 import os
 
@@ -45,8 +46,9 @@ class MixedResidualTrainer:
         self.flat, self.gflat = model._flat, model._gscratch
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.hyper = torch.zeros(8, device=self.dev)
+        self.hyper = torch.zeros(8, device=self.dev)              # hipGraph mode: read by the captured Adam kernel
         self._hyper_host = torch.zeros(8, pin_memory=True)
+        self._hyper_args = (ctypes.c_float * 8)()                 # eager mode: passed to the kernel by value
         self.step_count = 0
         self.grad_y = torch.empty((batch_size, 3, imsize, imsize), device=self.dev)
         self.partials = torch.empty((batch_size, 4), device=self.dev)
@@ -55,6 +57,7 @@ class MixedResidualTrainer:
         self.n_accum = 0
         self.use_graph = use_graph
         self._graph = None
+        self._hyper_event = torch.cuda.Event() if use_graph else None
         self._L = _lib.lib()
 
     # ------------------------------------------------------------------------------------------
@@ -75,16 +78,22 @@ class MixedResidualTrainer:
     def _set_hyper(self, lr):
         self.step_count += 1
         b1, b2 = self.betas
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3], h[4] = lr, b1, b2, self.eps, self.wd
-        h[5] = 1.0 - b1 ** self.step_count
-        h[6] = math.sqrt(1.0 - b2 ** self.step_count)
-        self.hyper.copy_(h, non_blocking=True)
+        vals = (lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.step_count, math.sqrt(1.0 - b2 ** self.step_count))
+        if self.use_graph:
+            # the captured graph is followed by an Adam kernel that reads DEVICE memory.  The pinned source is
+            # reused every step, so step() waits (one event, graph path only) until the previous copy has read it
+            self._hyper_host[:7] = torch.tensor(vals, dtype=torch.float32)
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            self._hyper_event.record()
+        else:
+            self._hyper_args[:7] = vals          # by value in the kernel arguments: no copy, nothing to race with
 
     def step(self, x=None, lr=None):
         """one training step on minibatch `x` (device tensor (B,C,H,W); None = reuse x_static)."""
         if x is not None:
             self.x_static.copy_(x)
+        if self.use_graph and self.step_count:
+            self._hyper_event.synchronize()                       # previous step's hyper copy has read the pinned buffer
         self._set_hyper(self.lr if lr is None else lr)
         if self.use_graph:
             if self._graph is None:
@@ -95,9 +104,14 @@ class MixedResidualTrainer:
         self.n_accum += 1
         if self.world > 1:
             parallel.allreduce_sum_(self.gflat, self.pg)      # ONE flat RCCL all-reduce per step
-        rc = self._L.pdes_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
-                                    self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), 1.0 / self.world,
-                                    self.flat.numel(), _lib.stream_ptr())
+        if self.use_graph:
+            rc = self._L.pdes_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
+                                        self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), 1.0 / self.world,
+                                        self.flat.numel(), _lib.stream_ptr())
+        else:
+            rc = self._L.pdes_adam_step_host(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), self._hyper_args, 1.0 / self.world,
+                                             self.flat.numel(), _lib.stream_ptr())
         _lib.check(rc, 'pdes_adam_step')
 
     def _capture(self):

@@ -50,6 +50,33 @@ def test_adam_kernel_matches_torch_optim(dev):
     torch.testing.assert_close(p, ref.detach(), rtol=2e-6, atol=2e-7)
 
 
+def test_adam_by_value_equals_adam_from_device_memory(dev):
+    """pdes_adam_step_host (hyper-parameters read from host memory at call time, passed by value) == pdes_adam_step
+    (hyper-parameters in device memory), bit for bit; a non-positive bias correction is rejected"""
+    import ctypes
+    from pde_surrogate_amd import _lib
+    torch.manual_seed(0)
+    n = 70001
+    L = _lib.lib()
+    pa = torch.randn(n, device=dev)
+    pb = pa.clone()
+    ma, va, mb, vb = (torch.zeros(n, device=dev) for _ in range(4))
+    hv = (ctypes.c_float * 8)()
+    for step in range(1, 4):
+        g = torch.randn(n, device=dev)
+        vals = [1.5e-3 / step, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** step, (1 - 0.999 ** step) ** 0.5]
+        hd = torch.tensor(vals + [0.0], device=dev)
+        hv[:7] = vals
+        assert L.pdes_adam_step(pa.data_ptr(), g.data_ptr(), ma.data_ptr(), va.data_ptr(), hd.data_ptr(), 1.0, n,
+                                _lib.stream_ptr()) == 0
+        assert L.pdes_adam_step_host(pb.data_ptr(), g.data_ptr(), mb.data_ptr(), vb.data_ptr(), hv, 1.0, n,
+                                     _lib.stream_ptr()) == 0
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    hv[5] = 0.0
+    assert L.pdes_adam_step_host(pb.data_ptr(), g.data_ptr(), mb.data_ptr(), vb.data_ptr(), hv, 1.0, n,
+                                 _lib.stream_ptr()) == -1
+
+
 def test_fused_step_equals_reference_loop_body_and_graph_equals_eager(dev):
     from pde_surrogate_amd.models import darcy
     from pde_surrogate_amd.train import MixedResidualTrainer
