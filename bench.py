@@ -30,7 +30,7 @@ def loss_kernel_timing(dev, B, iters, warmup=10, burst=False):
     """HIP-event timing of pdes_darcy_loss (fwd+bwd, no finalize) on the stream it is launched on.
     Returns (average us per launch, GB/s[, burst GB/s]).  At B = 16384 the launches are NOT stationary: after an
     idle period the first ~3 launches run at ~6.0 TB/s, the power controller then pulls the chip down (to ~3.5 TB/s
-    for a few launches) and it settles at ~5 TB/s after ~50 launches (profiles/r01_g_loss_kernel_per_launch.csv), so
+    for a few launches) and it settles at ~5.6 TB/s after ~100 launches (profiles/r01_g_loss_kernel_per_launch.csv), so
     the sustained figure is measured after `warmup` back-to-back launches and the burst figure right after a pause."""
     from pde_surrogate_amd import _lib
     K = torch.exp(0.5 * torch.randn(B, 1, 64, 64, device=dev))
