@@ -240,9 +240,22 @@ int pdes_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 /* The same step with the 7 hyper-parameters read from HOST memory at call time and passed to the
  * kernel by value: the eager training step needs no host->device copy of them (an asynchronous copy
  * from a reused pinned buffer would race with the host running ahead of the stream).
+ * zero_grad != 0: the kernel also clears `grad` after reading it (optimizer.zero_grad() of the NEXT
+ * iteration, :225, without a separate fill launch).
  * Returns PDES_EINVAL when a bias correction is not positive (step 0). */
-int pdes_adam_step_host(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                        const float* hyper_host, float grad_scale, long long n, void* stream);
+int pdes_adam_step_host(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                        const float* hyper_host, float grad_scale, int zero_grad, long long n, void* stream);
+
+/* End of a training step in ONE launch: pdes_bn_param_grads, optionally pdes_bn_update_running
+ * (update_running != 0; same arithmetic), and -- when `partials` is given -- the reduction of the
+ * per-image loss partials of pdes_darcy_loss (called with loss_out = NULL) into terms[5] = {total,
+ * const, cont, dirichlet, neumann} (nullable) and terms_accum[5] += terms (fp64, nullable): the
+ * per-epoch loss sums of train_codec_mixed_residual.py:240 without a host sync or extra launches.
+ * The weights are those given to pdes_darcy_loss. */
+int pdes_step_tail(const pdes_bn_item* items, int n, int max_c, float momentum, int update_running,
+                   const float* partials, int B, int H, int W, float w_const, float w_cont, float w_dir,
+                   float w_neu, float* terms, double* terms_accum, int nrep, long long rep_stride,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -35,7 +35,9 @@ SIGNATURES = {
     'pdes_bn_update_running': [_c_p, _c_i, _c_i, _c_f, _c_i, ctypes.c_longlong, _c_p],
     'pdes_bn_param_grads': [_c_p, _c_i, _c_i, _c_i, ctypes.c_longlong, _c_p],
     'pdes_adam_step': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, ctypes.c_longlong, _c_p],
-    'pdes_adam_step_host': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, ctypes.c_longlong, _c_p],
+    'pdes_adam_step_host': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_i, ctypes.c_longlong, _c_p],
+    'pdes_step_tail': [_c_p, _c_i, _c_i, _c_f, _c_i, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_p, _c_p, _c_i,
+                       ctypes.c_longlong, _c_p],
 }
 
 _ERR = {-1: 'PDES_EINVAL (null pointer / non-positive size)',

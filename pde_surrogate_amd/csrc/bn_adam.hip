@@ -110,15 +110,72 @@ __global__ __launch_bounds__(256) void bn_param_grads_kernel(const pdes_bn_item*
   it.dbeta[c] += (float)rep_sum(it.bn_grad, 2 * c + 1, nrep, rs);
 }
 
+// End-of-step table kernel of the training loop: per BatchNorm layer the parameter gradients and (optionally) the
+// running statistics, plus -- in the extra block row -- the fixed-order fp64 reduction of the per-image loss partials
+// into terms[5] = {total, const, cont, dir, neu} and their per-epoch accumulator.  One launch instead of four small
+// ones (bn_update_running, darcy_loss_finalize, a tensor add, bn_param_grads) on the serial stream.
+struct LossTail { const float* partials; float* terms; double* accum; int B; double inv_n, inv_dir, inv_neu; float w[4]; };
+__global__ __launch_bounds__(256) void step_tail_kernel(const pdes_bn_item* __restrict__ items, int n_bn, float momentum,
+                                                        int update_running, LossTail lt, int nrep, long long rs) {
+  if ((int)blockIdx.y == n_bn) {
+    if (blockIdx.x != 0) return;
+    __shared__ double sh[4][4];
+    double acc[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < lt.B; b += 256) {
+      const float4 v = reinterpret_cast<const float4*>(lt.partials)[b];
+      acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sh[threadIdx.x >> 6][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
+      const double lc = t[0] * lt.inv_n, lcn = t[1] * lt.inv_n, ld = t[2] * lt.inv_dir, ln = t[3] * lt.inv_neu;
+      // the same fp32 values darcy_loss_finalize writes; the accumulator adds exactly those
+      const float o[5] = {(float)(lt.w[0] * lc + lt.w[1] * lcn + lt.w[2] * ld + lt.w[3] * ln), (float)lc, (float)lcn,
+                          (float)ld, (float)ln};
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        if (lt.terms) lt.terms[i] = o[i];
+        if (lt.accum) lt.accum[i] += (double)o[i];
+      }
+    }
+    return;
+  }
+  const pdes_bn_item it = items[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (update_running && c == 0 && it.num_batches_tracked) *it.num_batches_tracked += 1;
+  if (c >= it.C) return;
+  it.dgamma[c] += (float)rep_sum(it.bn_grad, 2 * c, nrep, rs);
+  it.dbeta[c] += (float)rep_sum(it.bn_grad, 2 * c + 1, nrep, rs);
+  if (update_running) {
+    const double n = (double)it.count;
+    const double m = rep_sum(it.x_stats, 2 * c, nrep, rs) / n;
+    double var = rep_sum(it.x_stats, 2 * c + 1, nrep, rs) / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const double unbiased = it.count > 1 ? var * n / (n - 1.0) : var;
+    it.run_mean[c] = (float)((1.0 - momentum) * it.run_mean[c] + momentum * m);
+    it.run_var[c] = (float)((1.0 - momentum) * it.run_var[c] + momentum * unbiased);
+  }
+}
+
 struct AdamHyper { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; };
 
 // torch.optim.Adam (non-amsgrad, non-maximize); the host computes the bias corrections in
 // double exactly as torch does: bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step)
-__device__ __forceinline__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool ZERO>
+__device__ __forceinline__ void adam_update(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                             float* __restrict__ v, const AdamHyper& h, float gscale, long long n) {
   const float step_size = h.lr / h.bc1;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float gi = g[i] * gscale;
+    if (ZERO) g[i] = 0.f;          // the next step accumulates into a clean buffer: no separate fill launch
     const float pi = p[i];
     if (h.wd != 0.f) gi += h.wd * pi;
     const float mi = m[i] + (1.f - h.b1) * (gi - m[i]);          // lerp, as torch does
@@ -135,13 +192,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ hyper, float gscale, long long n) {
   const AdamHyper h = {hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
-  adam_update(p, g, m, v, h, gscale, n);
+  adam_update<false>(p, const_cast<float*>(g), m, v, h, gscale, n);
 }
 // ... or by value in the kernel arguments (eager steps: nothing to copy, nothing to race with)
-__global__ __launch_bounds__(256) void adam_kernel_v(float* __restrict__ p, const float* __restrict__ g,
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_kernel_v(float* __restrict__ p, float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, AdamHyper h,
                                                      float gscale, long long n) {
-  adam_update(p, g, m, v, h, gscale, n);
+  adam_update<ZERO>(p, g, m, v, h, gscale, n);
 }
 
 }  // namespace pdes
@@ -216,16 +274,39 @@ extern "C" int pdes_adam_step(float* param, const float* grad, float* exp_avg, f
   return PDES_OK;
 }
 
-extern "C" int pdes_adam_step_host(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                   const float* hyper_host, float grad_scale, long long n, void* stream) {
+extern "C" int pdes_adam_step_host(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                   const float* hyper_host, float grad_scale, int zero_grad, long long n, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper_host || n <= 0) return PDES_EINVAL;
   const AdamHyper h = {hyper_host[0], hyper_host[1], hyper_host[2], hyper_host[3], hyper_host[4], hyper_host[5],
                        hyper_host[6]};
   if (!(h.bc1 > 0.f) || !(h.bc2_sqrt > 0.f)) return PDES_EINVAL;
   long long gx = (n + 255) / 256;
   gx = gx > 2048 ? 2048 : gx;
-  hipLaunchKernelGGL(adam_kernel_v, dim3((unsigned)gx), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad,
-                     exp_avg, exp_avg_sq, h, grad_scale, n);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (zero_grad)
+    hipLaunchKernelGGL(adam_kernel_v<true>, dim3((unsigned)gx), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, h,
+                       grad_scale, n);
+  else
+    hipLaunchKernelGGL(adam_kernel_v<false>, dim3((unsigned)gx), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, h,
+                       grad_scale, n);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_step_tail(const pdes_bn_item* items, int n, int max_c, float momentum, int update_running,
+                              const float* partials, int B, int H, int W, float w_const, float w_cont, float w_dir,
+                              float w_neu, float* terms, double* terms_accum, int nrep, long long rep_stride,
+                              void* stream) {
+  if (!items || n <= 0 || max_c <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
+  if (partials && (B <= 0 || H <= 0 || W <= 0 || !aligned16(partials))) return PDES_EINVAL;
+  LossTail lt;
+  lt.partials = partials; lt.terms = terms; lt.accum = terms_accum; lt.B = B;
+  lt.inv_n = partials ? 1.0 / ((double)B * H * W) : 0.0;
+  lt.inv_dir = partials ? 1.0 / ((double)B * H) : 0.0;
+  lt.inv_neu = partials ? 1.0 / (2.0 * B * W) : 0.0;
+  lt.w[0] = w_const; lt.w[1] = w_cont; lt.w[2] = w_dir; lt.w[3] = w_neu;
+  hipLaunchKernelGGL(step_tail_kernel, dim3(cdiv(max_c, 256), n + (partials ? 1 : 0)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, n, momentum, update_running, lt, nrep, rep_stride);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

@@ -159,12 +159,13 @@ extern "C" int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, v
   // with the separate kernel (x staged next to T costs the consumers more than 20 small launches), so it is opt-in.
   const bool fuse_on = getenv("PDES_FUSE_FINALIZE") && getenv("PDES_FUSE_FINALIZE")[0] == '1';
   const int fuse_maxc = getenv("PDES_FUSE_MAXC") ? atoi(getenv("PDES_FUSE_MAXC")) : 16;
+  const int fuse_maxhw = getenv("PDES_FUSE_MAXHW") ? atoi(getenv("PDES_FUSE_MAXHW")) : (1 << 30);   // only maps up to this many pixels
   std::vector<pdes_conv_desc> local(descs, descs + n);
   for (int i = 0; i < n; ++i) {
     pdes_conv_desc& d = local[i];
     d.g_fused = 0;
     if (!fuse_on || force_direct() || !d.fin_tstats || !d.fin_xstats || !d.out) continue;
-    if (d.Cout > fuse_maxc) continue;     // wide layers: staging x next to T costs the consumers more than the kernel saves
+    if (d.Cout > fuse_maxc || d.Hout * d.Wout > fuse_maxhw) continue;     // wide layers: staging x next to T costs the consumers more than the kernel saves
     if (d.g_ctot != d.out_ctot || d.g_coff != d.out_coff || d.nrep != PDES_NREP) continue;
     const bool w_ok = conv_backward_weight_mfma(d, st, true) == PDES_OK;
     const bool d_ok = !d.has_bn || conv_backward_data_up_mfma(d, st, true) == PDES_OK ||

@@ -672,4 +672,4 @@ extern "C" int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar,
   return PDES_OK;
 }
 
-extern "C" int pdes_abi_version(void) { return 11; }
+extern "C" int pdes_abi_version(void) { return 12; }

@@ -366,7 +366,9 @@ class _Engine:
         return self._side
 
     # -- launches -------------------------------------------------------------------------------
-    def forward(self, x, training):
+    def forward(self, x, training, defer_running=False):
+        """defer_running: the caller promises a backward(tail=...) for this forward, which updates the running
+        statistics in its end-of-step launch (they are read by nothing in between)"""
         L, st = _lib.lib(), _lib.stream_ptr()
         net = self.net
         if x.data_ptr() != self.X['in'].data_ptr():
@@ -379,14 +381,16 @@ class _Engine:
             self.arena.zero_()
         net._pack_weights()
         _lib.check(L.pdes_conv_forward(self.descs, len(self.descs), st), 'pdes_conv_forward')
-        if training:
+        if training and not defer_running:
             _lib.check(L.pdes_bn_update_running(self.bn_table.data_ptr(), self.n_bn, self.max_c,
                                                 ctypes.c_float(0.1), self.nrep, self.rep_stride, st),
                        'pdes_bn_update_running')
         return self.X['out']
 
-    def backward(self, grad_y, need_input_grad=False):
-        """parameter gradients are ACCUMULATED into net._gflat (zero it first for plain gradients)"""
+    def backward(self, grad_y, need_input_grad=False, tail=None):
+        """parameter gradients are ACCUMULATED into net._gflat (zero it first for plain gradients).
+        tail = (update_running, partials, B, H, W, w_const, w_cont, w_dir, w_neu, terms, terms_accum): finish with
+        pdes_step_tail (BatchNorm parameter gradients + running statistics + loss terms in one launch)"""
         L, st = _lib.lib(), _lib.stream_ptr()
         n = len(self.descs)
         if not hasattr(self, '_reduce_n'):
@@ -400,8 +404,14 @@ class _Engine:
             side = ctypes.c_void_p(self._side_stream().cuda_stream)
         rt = self._reduce_table.data_ptr() if self._reduce_n else None
         _lib.check(L.pdes_backward(self.descs, n, st, side, rt, self._reduce_index), 'pdes_backward')
-        _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, self.nrep, self.rep_stride,
-                                         st), 'pdes_bn_param_grads')
+        if tail is None:
+            _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, self.nrep,
+                                             self.rep_stride, st), 'pdes_bn_param_grads')
+        else:
+            upd, partials, B, H, W, w0, w1, w2, w3, terms, accum = tail
+            _lib.check(L.pdes_step_tail(self.bn_table.data_ptr(), self.n_bn, self.max_c, ctypes.c_float(0.1),
+                                        1 if upd else 0, _lib.ptr(partials), B, H, W, w0, w1, w2, w3, _lib.ptr(terms),
+                                        _lib.ptr(accum), self.nrep, self.rep_stride, st), 'pdes_step_tail')
 
 
 class _NetFn(torch.autograd.Function):

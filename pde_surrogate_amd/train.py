@@ -58,6 +58,7 @@ class MixedResidualTrainer:
         self.use_graph = use_graph
         self._graph = None
         self._hyper_event = torch.cuda.Event() if use_graph else None
+        self._grad_clean = False          # eager: True once the Adam kernel has cleared the gradient buffer
         self._L = _lib.lib()
 
     # ------------------------------------------------------------------------------------------
@@ -65,14 +66,17 @@ class MixedResidualTrainer:
         """forward + loss + backward on self.x_static -> gradients in self.gflat, terms in self.terms"""
         L, st = self._L, _lib.stream_ptr()
         m = self.model
-        y = self.eng.forward(self.x_static, True)
+        y = self.eng.forward(self.x_static, True, defer_running=True)
+        # loss_out = NULL: the per-image partials are reduced (and accumulated for the epoch mean) by the
+        # end-of-step launch of the backward, together with the BatchNorm bookkeeping
         rc = L.pdes_darcy_loss(self.x_static.data_ptr(), y.data_ptr(), self.grad_y.data_ptr(),
-                               self.partials.data_ptr(), self.terms.data_ptr(), self.B, self.n, self.n,
+                               self.partials.data_ptr(), None, self.B, self.n, self.n,
                                1.0, 1.0, self.wb, self.wb, 1 if self.nl else 0, self.nb1, self.nb2, st)
         _lib.check(rc, 'pdes_darcy_loss')
-        self.gflat.zero_()
-        self.eng.backward(self.grad_y)
-        self.terms_accum += self.terms
+        if not self._grad_clean:
+            self.gflat.zero_()
+        self.eng.backward(self.grad_y, tail=(True, self.partials, self.B, self.n, self.n, 1.0, 1.0, self.wb, self.wb,
+                                              self.terms, self.terms_accum))
         return m
 
     def _set_hyper(self, lr):
@@ -109,9 +113,11 @@ class MixedResidualTrainer:
                                         self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), 1.0 / self.world,
                                         self.flat.numel(), _lib.stream_ptr())
         else:
+            # the kernel clears the gradient buffer after reading it: the next step needs no fill launch
             rc = self._L.pdes_adam_step_host(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
-                                             self.exp_avg_sq.data_ptr(), self._hyper_args, 1.0 / self.world,
+                                             self.exp_avg_sq.data_ptr(), self._hyper_args, 1.0 / self.world, 1,
                                              self.flat.numel(), _lib.stream_ptr())
+            self._grad_clean = True
         _lib.check(rc, 'pdes_adam_step')
 
     def _capture(self):

@@ -69,11 +69,13 @@ def test_adam_by_value_equals_adam_from_device_memory(dev):
         hv[:7] = vals
         assert L.pdes_adam_step(pa.data_ptr(), g.data_ptr(), ma.data_ptr(), va.data_ptr(), hd.data_ptr(), 1.0, n,
                                 _lib.stream_ptr()) == 0
-        assert L.pdes_adam_step_host(pb.data_ptr(), g.data_ptr(), mb.data_ptr(), vb.data_ptr(), hv, 1.0, n,
+        g2 = g.clone()
+        assert L.pdes_adam_step_host(pb.data_ptr(), g2.data_ptr(), mb.data_ptr(), vb.data_ptr(), hv, 1.0, step % 2, n,
                                      _lib.stream_ptr()) == 0
+        assert torch.equal(g2, torch.zeros_like(g) if step % 2 else g)      # zero_grad clears, else untouched
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     hv[5] = 0.0
-    assert L.pdes_adam_step_host(pb.data_ptr(), g.data_ptr(), mb.data_ptr(), vb.data_ptr(), hv, 1.0, n,
+    assert L.pdes_adam_step_host(pb.data_ptr(), g.data_ptr(), mb.data_ptr(), vb.data_ptr(), hv, 1.0, 0, n,
                                  _lib.stream_ptr()) == -1
 
 
