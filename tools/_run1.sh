@@ -1,5 +1,4 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 500 python -m pytest tests/test_densed_gpu.py tests/test_trainer_gpu.py -x -q 2>&1 < /dev/null | tail -2 > gpurun_out/tests.log
-cat gpurun_out/tests.log
-timeout 200 python tools/ab_env.py PDES_PACK_BALANCED 0 1 2>&1 < /dev/null | grep "ms/step"
+timeout 200 python tools/ab_env.py PDES_EVENT_SCOPE system device 2>&1 < /dev/null | grep "ms/step"
+timeout 300 python -m pytest tests/test_densed_gpu.py tests/test_trainer_gpu.py -x -q 2>&1 < /dev/null | tail -2
