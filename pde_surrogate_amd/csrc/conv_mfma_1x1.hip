@@ -14,7 +14,7 @@
 //   * K is split over the KSPLIT waves of a workgroup that share a pixel group (the maps are small: 8192..32768
 //     pixels per minibatch, so N- and K-splits are what fills 1024 SIMDs); the partial sums meet in LDS and each
 //     wave finishes every KSPLIT-th N-tile (stores, BatchNorm statistics / BatchNorm-backward epilogue);
-//   * a workgroup is 8 waves = 8 / KSPLIT pixel groups; their per-channel statistics are combined in LDS before
+//   * a workgroup is 8 waves (4 when 8 would leave CUs idle) = NW / KSPLIT pixel groups; their per-channel statistics are combined in LDS before
 //     the fp64 atomics (measured: the atomics of one wave per 32 pixels cost 4 of the layer's 20 us).
 #include <stdlib.h>
 #include "pdes_common.h"

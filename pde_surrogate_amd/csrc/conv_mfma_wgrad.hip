@@ -592,13 +592,14 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   p->ngroups = (ntiles + p->ntw - 1) / p->ntw;
   p->gy = mtiles * p->ngroups;
   p->per = (long long)d.Cout * d.Cin * KK;
-  // pixel tiles per workgroup: as few as possible while (a) the grid has at most ~320 workgroups (PDES_WGRAD_WGS;
+  // pixel tiles per workgroup: as few as possible while (a) the grid has at most ~256 workgroups (PDES_WGRAD_WGS;
   // stand-alone the kernels are fastest with ~768, but they run beside the data-gradient chain on a second
   // stream and smaller grids leave it more of the chip: 2.203 / 2.182 / 2.179 / 2.177 / 2.204 ms per step at
-  // 768 / 512 / 384 / 256 / 128) and
+  // 768 / 512 / 384 / 256 / 128; with the final kernel set, separate processes on one box: 2.033 / 2.020 / 2.008 /
+  // 2.025 / 2.032 ms at 448 / 320 / 256 / 192 / 128) and
   // (b) the partial buffer fits the scratch
   p->tpw = p->tps;
-  static const int wg_target = getenv("PDES_WGRAD_WGS") ? atoi(getenv("PDES_WGRAD_WGS")) : 320;
+  static const int wg_target = getenv("PDES_WGRAD_WGS") ? atoi(getenv("PDES_WGRAD_WGS")) : 256;
   for (int cand = 1; cand <= p->tps; cand *= 2) {
     if (p->tps % cand) continue;
     const long long ns = (long long)d.B * (p->tps / cand);

@@ -362,6 +362,8 @@ class _Engine:
                 least = torch.cuda.Stream.priority_range()[0]
             except Exception:
                 least = 0
+            if os.environ.get('PDES_SIDE_PRIO') == 'default':      # A/B knob: default instead of least priority
+                least = 0
             self._side = torch.cuda.Stream(self.dev, priority=least)
         return self._side
 
