@@ -63,6 +63,42 @@ def sobel_grad_v(img, correct=True):
     return torch.cat([first, g[..., 1:-1, :], last], dim=-2)
 
 
+_SOBEL5 = np.array([[-5, -4, 0, 4, 5], [-8, -10, 0, 10, 8], [-10, -20, 0, 20, 10], [-8, -10, 0, 10, 8],
+                    [-5, -4, 0, 4, 5]], np.float64) / 240.0        # image_gradient.py:35-40 (d/dx; transpose = d/dy)
+
+
+def _sobel5(img, kern, scale, correct, axis):
+    """filter_size=5 (image_gradient.py:65-67, :82-84): replicate pad 2, 5x5 cross-correlation, x image size, and
+    the SAME 3-point boundary `modifier` as the 3x3 filter."""
+    H, W = img.shape[-2:]
+    q = img
+    for _ in range(2):
+        q = _rep_cols(_rep_rows(q))
+    g = torch.zeros_like(img)
+    for i in range(5):
+        for j in range(5):
+            if kern[i, j] != 0.0:
+                g = g + float(kern[i, j]) * q[..., i:i + H, j:j + W]
+    g = g * scale
+    if not correct:
+        return g
+    if axis == 'h':
+        first = 4.0 * g[..., :, 0:1] - g[..., :, 1:2]
+        last = 4.0 * g[..., :, -1:] - g[..., :, -2:-1]
+        return torch.cat([first, g[..., :, 1:-1], last], dim=-1)
+    first = 4.0 * g[..., 0:1, :] - g[..., 1:2, :]
+    last = 4.0 * g[..., -1:, :] - g[..., -2:-1, :]
+    return torch.cat([first, g[..., 1:-1, :], last], dim=-2)
+
+
+def sobel_grad_h5(img, correct=True):
+    return _sobel5(img, _SOBEL5, img.shape[-1], correct, 'h')
+
+
+def sobel_grad_v5(img, correct=True):
+    return _sobel5(img, _SOBEL5.T, img.shape[-2], correct, 'v')
+
+
 def constitutive(K, y, beta1=0.0, beta2=0.0, nonlinear=False):
     """mean[(sigma1 + K du/dx [+nl])^2 + (sigma2 + K du/dy [+nl])^2]; darcy.py:162-176 / :179-191."""
     u, s1, s2 = y[:, 0:1], y[:, 1:2], y[:, 2:3]

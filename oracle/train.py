@@ -69,5 +69,17 @@ class CpuTrainer:
         self.opt.step()
         return float(loss.detach()), lr, y.detach()
 
+    def step_mse(self, K, target, pct=None):
+        """train_codec_max_likelihood.py:197-211: the same loop body with F.mse_loss(output, target)."""
+        self.opt.zero_grad(set_to_none=True)
+        y = codec.densed_forward(self.sd, K, self.blocks, self.imsize, True, self.upsample)
+        loss = torch.nn.functional.mse_loss(y, target)
+        loss.backward()
+        lr = self.lr_max if pct is None else one_cycle_lr(pct, self.lr_max, self.lr_div, self.lr_pct)
+        for g in self.opt.param_groups:
+            g['lr'] = lr
+        self.opt.step()
+        return float(loss.detach()), lr
+
     def grads(self):
         return {k: self.sd[k].grad for k in self.keys}

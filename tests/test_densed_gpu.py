@@ -86,6 +86,68 @@ def test_g6_default_net(dev):
     assert rel_l2(gr['features.EncBlock1.denselayer1.norm1.bias'].grad.cpu().numpy(), g['grad_enc1_l1_bn_b']) < 1e-3
 
 
+def _default_net(dev):
+    from pde_surrogate_amd.models.codec import DenseED
+    g6 = golden('G6_densed_default.npz')
+    torch.manual_seed(1)
+    net = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
+    if _sha(net.state_dict()) != str(g6['sha256']):
+        pytest.skip('local torch RNG stream differs from the fixture generator')
+    return net.to(dev).train()
+
+
+def test_g11_headline_batch_every_gradient_tensor(dev):
+    """the HEADLINE configuration (default DenseED, B = 32, GRF-KLE512 fields) against the reference: output, the loss
+    terms and ALL 82 gradient tensors element by element (rel-L2 1e-3 each), on the automatically selected
+    matrix-core kernels -- the tile shapes / split-K plans / wave-group variants are chosen by batch size"""
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    g = golden('G11_densed_default_b32.npz')
+    net = _default_net(dev)
+    x = torch.from_numpy(g['x']).to(dev)
+    y = net(x)
+    yc = y.detach().cpu().numpy()
+    assert rel_l2(yc[0], g['y0']) < 1e-5
+    np.testing.assert_allclose(yc[:, :, ::8, ::8], g['y_slice'], rtol=1e-3, atol=1e-4)
+    loss, l_pde, l_dir, l_neu = darcy_mixed_residual_loss(x, y, 10.0)
+    ref = g['terms']
+    np.testing.assert_allclose([float(loss.detach()), float(l_pde), float(l_dir), float(l_neu)],
+                               [ref[0], ref[1] + ref[2], ref[3], ref[4]], rtol=1e-5)
+    loss.backward()
+    names = [str(s) for s in g['param_names']]
+    assert [k for k, _ in net.named_parameters()] == names
+    errs = sorted(((rel_l2(p.grad.cpu().numpy(), g['grad/' + k]), k) for k, p in net.named_parameters()), reverse=True)
+    print('G11 worst gradient tensors:', errs[:6])
+    assert errs[0][0] < 1e-3, errs[:8]
+
+
+def test_g12_teacher_forced_reference_steps(dev):
+    """steps 1..8 of the reference's Adam trajectory (G7), each restarted from the reference's OWN weights at that
+    step: loss terms to 1e-5 and every per-tensor gradient norm to 1e-3 (replaces the 15 % tail of the free-running
+    trajectory test, which pins nothing once fp32 chaos sets in)"""
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    g, g7 = golden('G12_teacher_forced.npz'), golden('G7_trajectory.npz')
+    net = _default_net(dev)
+    params = [p for _, p in net.named_parameters()]
+    assert [int(p.numel()) for p in params] == [int(v) for v in g['param_numel']]
+    for step in range(1, 9):
+        if step > 1:
+            flat, off = torch.from_numpy(g[f'w{step}']).to(dev), 0
+            with torch.no_grad():
+                for p in params:
+                    p.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+        net.zero_grad()
+        x = torch.from_numpy(g7['data'][g7['order'][step - 1]]).to(dev)
+        y = net(x)
+        loss, l_pde, l_dir, l_neu = darcy_mixed_residual_loss(x, y, 10.0)
+        ref = g[f'terms{step}']
+        np.testing.assert_allclose([float(loss.detach()), float(l_pde), float(l_dir), float(l_neu)],
+                                   [ref[0], ref[1] + ref[2], ref[3], ref[4]], rtol=1e-5, err_msg=f'step {step}')
+        loss.backward()
+        norms = np.array([float(p.grad.double().norm()) for p in params])
+        np.testing.assert_allclose(norms, g[f'gnorm{step}'], rtol=1e-3, err_msg=f'step {step}')
+
+
 def test_dropin_training_loop_matches_reference_first_steps(dev):
     """the reference's loop body (train_codec_mixed_residual.py:224-240) on the drop-in modules,
     with torch.optim.Adam -- step 1 is the parity check (G7), later steps the same descent."""
@@ -113,6 +175,8 @@ def test_dropin_training_loop_matches_reference_first_steps(dev):
         adjust_learning_rate(opt, lr)
         opt.step()
         assert abs(lr - g['lrs'][step - 1]) < 1e-12
+        # free-running fp32 Adam is chaotic (the CPU oracle with 1 vs 8 threads differs by 1e-4 at step 2): step 1 is
+        # the parity check here, steps 2..8 are pinned by the teacher-forced test above
         tol = {1: 1e-5, 2: 1e-3}.get(step, 0.15)
         assert abs(loss.item() - g['losses'][step - 1]) <= tol * g['losses'][step - 1], step
 

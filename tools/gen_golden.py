@@ -22,7 +22,9 @@ import torch
 sys.dont_write_bytecode = True
 REF = '/root/reference'
 sys.path.insert(0, REF)
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.append(ROOT)           # pde_surrogate_amd.utils.data (synthetic GRF generator) -- AFTER the reference on the path
+OUT = os.path.join(ROOT, 'tests', 'golden')
 
 from models.codec import DenseED, Decoder            # noqa: E402  (reference)
 from models import darcy as rdarcy                   # noqa: E402  (reference)
@@ -51,6 +53,122 @@ def ref_loss(K, y, sobel, wb, nonlinear=False, b1=0.0, b2=0.0):
     lt = rdarcy.conv_continuity_constraint(y, sobel)
     ld, ln = rdarcy.conv_boundary_condition(y)
     return lc + lt + (ld + ln) * wb, lc, lt, ld, ln
+
+
+def gen_round2():
+    """fixtures added in round 2; every section owns its rng so that G1..G10 stay bit-identical"""
+    sob = SobelFilter(64, correct=True)
+
+    # ---- G11: the HEADLINE configuration: default DenseED from manual_seed(1), B = 32 GRF-KLE512 fields (the build's
+    # synthetic generator; the fields are stored), reference forward + loss + backward, ALL 82 gradient tensors
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    xb = grf_kle_fields(32, seed=11, cache_dir='/tmp')
+    net.train()
+    xt = torch.from_numpy(xb)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob, 10.0)
+    terms[0].backward()
+    g11 = {'x': xb, 'y0': yo.detach().numpy()[0], 'y_slice': yo.detach().numpy()[:, :, ::8, ::8],
+           'terms': np.array([float(t) for t in terms], np.float64),
+           'param_names': np.array([k for k, _ in net.named_parameters()])}
+    for k, p in net.named_parameters():
+        g11['grad/' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G11_densed_default_b32.npz'), **g11)
+
+    # ---- G13: --upsample bilinear (reference codec.py:33-40, align_corners=True): tiny net with every tensor,
+    # default net (B = 4) with output, loss terms, every gradient norm and the tensors next to the upsampling layers
+    rng = np.random.default_rng(20190613)
+    torch.manual_seed(7)
+    net = quiet(DenseED, 1, 3, 16, [1, 1, 1], 4, 8, upsample='bilinear')
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if 'norm' in k and k.endswith('.weight'):
+                v.copy_(1 + 0.2 * torch.randn_like(v))
+            if k.endswith('.bias'):
+                v.copy_(0.1 * torch.randn_like(v))
+    sd0 = {k: v.clone().numpy() for k, v in net.state_dict().items()}
+    x = np.exp(0.5 * rng.standard_normal((4, 1, 16, 16))).astype(np.float32)
+    sob16 = SobelFilter(16, correct=True)
+    net.train()
+    xt = torch.from_numpy(x)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob16, 10.0)
+    terms[0].backward()
+    g13 = {'tiny/x': x, 'tiny/y': yo.detach().numpy(), 'tiny/terms': np.array([float(t) for t in terms], np.float64)}
+    for k, v in sd0.items():
+        g13['tiny/sd0/' + k] = v
+    for k, p in net.named_parameters():
+        g13['tiny/grad/' + k] = p.grad.numpy()
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48, upsample='bilinear')
+    xb = np.exp(0.5 * rng.standard_normal((4, 1, 64, 64))).astype(np.float32)
+    net.train()
+    xt = torch.from_numpy(xb)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob, 10.0)
+    terms[0].backward()
+    g13.update({'x': xb, 'y': yo.detach().numpy(), 'terms': np.array([float(t) for t in terms], np.float64),
+                'param_names': np.array([k for k, _ in net.named_parameters()]),
+                'grad_norms': np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])})
+    for k, p in net.named_parameters():
+        if k.startswith('features.TransUp1.') or (k.startswith('features.LastTransUp.') and 'conv1' not in k):
+            g13['grad/' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G13_bilinear.npz'), **g13)
+
+    # ---- G14: conv_continuity_constraint(use_tb=False) (darcy.py:224) value + gradient; 5x5 Sobel fields
+    rng = np.random.default_rng(20190614)
+    y = rng.standard_normal((2, 3, 64, 64)).astype(np.float32)
+    yt = torch.from_numpy(y).clone().requires_grad_(True)
+    lt = rdarcy.conv_continuity_constraint(yt, sob, use_tb=False)
+    lt.backward()
+    img = rng.standard_normal((2, 1, 64, 64)).astype(np.float32) * 3 + 1
+    t = torch.from_numpy(img)
+    np.savez_compressed(os.path.join(OUT, 'G14_no_tb_sobel5.npz'), y=y, cont_no_tb=np.array(float(lt)),
+                        cont_no_tb_grad=yt.grad.numpy(), img=img,
+                        gh5=sob.grad_h(t, filter_size=5).numpy(), gv5=sob.grad_v(t, filter_size=5).numpy())
+
+    # ---- G15: the data-driven harness train_codec_max_likelihood.py:197-211 (same DenseED, F.mse_loss):
+    # 3 Adam steps at bs = 8 from manual_seed(1), then the eval-mode test metrics of :166-190
+    import torch.nn.functional as F
+    rng = np.random.default_rng(20190615)
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.0)
+    sched = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)
+    data = np.exp(0.5 * rng.standard_normal((16, 1, 64, 64))).astype(np.float32)
+    target = rng.standard_normal((16, 3, 64, 64)).astype(np.float32)
+    losses, lrs, gn1 = [], [], None
+    net.train()
+    for step in range(1, 4):
+        idx = np.arange(8) + 8 * ((step - 1) % 2)
+        inp, tgt = torch.from_numpy(data[idx]), torch.from_numpy(target[idx])
+        net.zero_grad()
+        loss = F.mse_loss(net(inp), tgt)
+        loss.backward()
+        if step == 1:
+            gn1 = np.array([float(p.grad.double().norm()) for p in net.parameters()])
+            g_in = net.features.In_conv.weight.grad.numpy().copy()
+            g_last = net.features.LastTransUp.conv3.weight.grad.numpy().copy()
+        lr = sched.step(step / 40)
+        for g in opt.param_groups:
+            g['lr'] = lr
+        opt.step()
+        losses.append(float(loss))
+        lrs.append(lr)
+    net.eval()
+    with torch.no_grad():
+        o, t = net(torch.from_numpy(data)), torch.from_numpy(target)
+        mse_eval = float(F.mse_loss(o, t))
+        err2 = torch.sum((o - t) ** 2, [-1, -2])
+        rel = torch.sqrt(err2 / (t ** 2).sum([-1, -2])).mean(0).numpy()
+        yvar = ((target - target.mean(0, keepdims=True)) ** 2).sum(axis=(0, 2, 3))
+        r2 = 1 - err2.sum(0).numpy() / yvar
+    np.savez_compressed(os.path.join(OUT, 'G15_max_likelihood.npz'), data=data, target=target,
+                        losses=np.array(losses), lrs=np.array(lrs), grad_norms_step1=gn1, grad_In_conv_step1=g_in,
+                        grad_last_conv3_step1=g_last, mse_eval=np.array(mse_eval), nrmse_eval=rel, r2_eval=r2,
+                        y_variation=yvar, y_eval0=o.numpy()[0])
 
 
 def main():
@@ -164,6 +282,7 @@ def main():
     data = np.exp(0.5 * rng.standard_normal((16, 1, 64, 64))).astype(np.float32)
     order = np.array([[0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11, 12, 13, 14, 15]] * 4)
     total_steps, losses, lrs = 40, [], []
+    g12 = {}
     net.train()
     for step, idx in enumerate(order, 1):
         inp = torch.from_numpy(data[idx])
@@ -171,6 +290,12 @@ def main():
         outp = net(inp)
         terms = ref_loss(inp, outp, sob, 10.0)
         terms[0].backward()
+        # G12 (teacher forcing): the weights this step STARTED from (flat, named_parameters order), its four loss
+        # terms and every per-tensor gradient norm -- a test reloads the weights and must reproduce step `step`
+        if step > 1:
+            g12[f'w{step}'] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy().copy()
+        g12[f'terms{step}'] = np.array([float(t) for t in terms], np.float64)
+        g12[f'gnorm{step}'] = np.array([float(p.grad.double().norm()) for p in net.parameters()])
         lr = sched.step(step / total_steps)
         for g in opt.param_groups:
             g['lr'] = lr
@@ -181,6 +306,9 @@ def main():
                         total_steps=np.array(total_steps), losses=np.array(losses), lrs=np.array(lrs),
                         final_In_conv=net.features.In_conv.weight.detach().numpy(),
                         final_running_mean=net.features.LastTransUp.norm3.running_mean.numpy())
+    g12['param_names'] = np.array([k for k, _ in net.named_parameters()])
+    g12['param_numel'] = np.array([p.numel() for p in net.parameters()])
+    np.savez_compressed(os.path.join(OUT, 'G12_teacher_forced.npz'), **g12)
 
     # ---- G8: one-cycle LR values
     pcts = np.linspace(0, 1, 11)
@@ -215,6 +343,7 @@ def main():
                         param_names=np.array([k for k, _ in dec.named_parameters()]),
                         grad_norms=np.array([float(p.grad.double().norm()) for _, p in dec.named_parameters()]),
                         n_params=np.array(dec.model_size[0]), n_conv=np.array(dec.model_size[1]))
+    gen_round2()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
