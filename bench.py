@@ -37,10 +37,10 @@ def loss_kernel_timing(dev, B, iters, warmup=10, burst=False):
     y = torch.randn(B, 3, 64, 64, device=dev)
     g = torch.empty_like(y)
     part = torch.empty(B, 4, device=dev)
-    L, st = _lib.lib(), _lib.stream_ptr()
+    L, st, ctx = _lib.lib(), _lib.stream_ptr(), _lib.context(dev)
 
     def run():
-        rc = L.pdes_darcy_loss(K.data_ptr(), y.data_ptr(), g.data_ptr(), part.data_ptr(), None, B, 64, 64,
+        rc = L.pdes_darcy_loss(ctx, K.data_ptr(), y.data_ptr(), g.data_ptr(), part.data_ptr(), None, B, 64, 64,
                                1.0, 1.0, 10.0, 10.0, 0, 0.0, 0.0, st)
         assert rc == 0, rc
     gbs_burst = None

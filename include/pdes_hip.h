@@ -8,8 +8,15 @@
  *
  * Conventions (all entry points):
  *   - every pointer is DEVICE memory, fp32 unless stated, NCHW contiguous, 16-byte aligned;
- *   - the caller (PyTorch) owns every buffer including workspaces; the library never allocates,
- *     frees or retains a pointer; no global state;
+ *   - the caller (PyTorch) owns every buffer including workspaces; the library never allocates or
+ *     frees device memory and never retains a pointer;
+ *   - the ONLY state is the opaque `pdes_context` the caller creates and destroys: the run-time options
+ *     (kernel-selection knobs) and the order-only hipEvent_t objects pdes_backward uses to fork/join
+ *     its second stream, created WITH the context on the then-current device.  There is no process-global
+ *     or static state, and the library never reads the environment by itself (pdes_context_load_env does,
+ *     when the caller asks).  Entry points that consult options take the context as their first argument;
+ *     NULL = compiled-in defaults.  A context may be shared by threads that do not change its options
+ *     concurrently; use one context per device;
  *   - enqueue-only on `stream` (a hipStream_t passed as void*): no synchronisation, no hipMalloc,
  *     so every call is hipGraph-capturable and callable from the autograd backward thread;
  *   - returns 0 on success, <0 for an argument the library rejects (PDES_E*), >0 = hipError_t
@@ -26,6 +33,26 @@ extern "C" {
 #define PDES_EINVAL (-1) /* null pointer / non-positive size */
 #define PDES_ENOSUP (-2) /* shape or option not implemented */
 #define PDES_EALIGN (-3) /* pointer not 16-byte aligned */
+
+/* ---------------------------------------------------------------------------------------------
+ * Context: options + fork/join events (no reference counterpart -- the reference's knobs are Python
+ * arguments; these select among equivalent kernels and exist for A/B measurements and cross-checks).
+ *   pdes_context_create   n_events order-only events are created on the CURRENT device (pdes_backward with a
+ *                         second stream needs n_layers + 1); returns hipError_t > 0 on failure.
+ *   pdes_context_set_option  key = one of "PDES_CONV_IMPL" ("direct" | "auto"), "PDES_FUSE_FINALIZE",
+ *                         "PDES_FUSE_MAXC", "PDES_FUSE_MAXHW", "PDES_FIN_EARLY", "PDES_MFMA_NTW", "PDES_MFMA_MT",
+ *                         "PDES_MFMA_NG", "PDES_MFMA_1X1", "PDES_1X1_KSPLIT", "PDES_MFMA_1X1W", "PDES_1X1W_SPI",
+ *                         "PDES_MFMA_B3", "PDES_B3_MT", "PDES_FEW_R", "PDES_WGRAD_WGS", "PDES_LOSS_NT",
+ *                         "PDES_LOSS_DMA"; value = decimal string (NULL = default).  PDES_ENOSUP: unknown key.
+ *   pdes_context_load_env every key above that is set in the process environment, read ONCE, now.
+ *   pdes_context_device   the device the context's events belong to.
+ */
+typedef struct pdes_context pdes_context;
+int pdes_context_create(pdes_context** out, int n_events);
+int pdes_context_destroy(pdes_context* ctx);
+int pdes_context_set_option(pdes_context* ctx, const char* key, const char* value);
+int pdes_context_load_env(pdes_context* ctx);
+int pdes_context_device(const pdes_context* ctx);
 
 /* ABI version of this header; bumped on any signature change. */
 int pdes_abi_version(void);
@@ -49,7 +76,7 @@ int pdes_stat_replicas(void);
  *   nonlinear != 0: sigma + beta1*sqrt(K)*sigma^2 + beta2*K*sigma^3 constitutive law.
  *   H == W in {16, 32, 64}.
  */
-int pdes_darcy_loss(const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
+int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
                     int B, int H, int W, float w_const, float w_cont, float w_dir, float w_neu,
                     int nonlinear, float beta1, float beta2, void* stream);
 
@@ -135,22 +162,22 @@ typedef struct pdes_conv_desc {
  * out = conv(relu(bn(x))) for `n` descriptors in order; accumulates out_stats.
  * Replaces nn.BatchNorm2d + nn.ReLU + [UpsamplingNearest2d] + nn.Conv2d + torch.cat
  * (models/codec.py:43-75, :89-160, :163-188, :242-243). */
-int pdes_conv_forward(const pdes_conv_desc* descs, int n, void* stream);
+int pdes_conv_forward(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream);
 /* dw += sum_{b,p} g * relu(bn(x)) (autograd of F.conv2d wrt weight). */
-int pdes_conv_backward_weight(const pdes_conv_desc* descs, int n, void* stream);
+int pdes_conv_backward_weight(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream);
 /* T_in (+)= gamma * (conv^T(g)) * 1[bn(x) > 0]; also dgamma/dbeta and the finished channels'
  * {sum T, sum T xhat} (autograd of conv2d wrt input, ReLU, BatchNorm wrt gamma/beta). */
-int pdes_conv_backward_data(const pdes_conv_desc* descs, int n, void* stream);
+int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream);
 /* In place T -> dL/dx for channels [c0, c1) of a (B, ctot, H, W) buffer (BatchNorm backward wrt
  * its input, summed over every consumer BN). */
-int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
+int pdes_bn_backward_finalize(const pdes_context* ctx, float* t, const float* x, const double* x_stats, const double* t_stats,
                               int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
                               long long rep_stride, void* stream);
 
 /* Split plan of the matrix-core weight-gradient kernel for `d` (uses d->ws_bytes as the scratch
  * limit): number of pixel splits and floats of scratch it writes.  PDES_ENOSUP: this layer runs on
  * the generic kernel (fp32 atomics straight into dw, no scratch). */
-int pdes_conv_wgrad_plan(const pdes_conv_desc* d, int* nsplit, long long* floats);
+int pdes_conv_wgrad_plan(const pdes_context* ctx, const pdes_conv_desc* d, int* nsplit, long long* floats);
 typedef struct pdes_reduce_item { const float* part; float* dw; int n; int nsplit; } pdes_reduce_item;
 /* dw[i] += sum_s part[s][i] (fixed order) for every item; items: DEVICE array. */
 int pdes_wgrad_reduce_all(const pdes_reduce_item* items, int n, int max_n, void* stream);
@@ -162,14 +189,24 @@ int pdes_wgrad_reduce_all(const pdes_reduce_item* items, int n, int max_n, void*
  *   pdes_conv_backward_data(descs[i])     -- when has_bn
  * followed by the split-K reduce of the deferred weight-gradient partials (pdes_wgrad_reduce_all).
  * The weight gradients have no consumer before that reduce, so with a second stream they overlap
- * the finalize -> data-gradient dependency chain; they are released to it in batches of a few
- * layers (one event per batch) and each batch is reduced on that stream; the two streams are
- * joined before returning (everything is ordered on `stream` again).
+ * the finalize -> data-gradient dependency chain; each layer is released to it as soon as its
+ * output gradient exists (one event per layer) and the widest layers' partials are reduced on that stream as soon as
+ * they exist; the two streams are joined before returning (everything is ordered on `stream` again).
  * reduce_items: DEVICE table as for pdes_wgrad_reduce_all, in layer order; reduce_index: HOST
  * array, reduce_index[i] = table index of descs[i] or -1 (no deferred scratch).  Both may be NULL
- * (then the caller reduces). */
-int pdes_backward(const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
-                  const pdes_reduce_item* reduce_items, const int* reduce_index);
+ * (then the caller reduces).
+ * With a second stream the context must hold >= n + 1 events (PDES_EINVAL otherwise).
+ * hook (nullable): called ONCE, on the host, right after the early split-K reduce has been enqueued on
+ * `wgrad_stream`: the weight gradients `dw` of layers [first_layer, n) are final in stream order on
+ * `wgrad_stream` from that point.  The data-parallel trainer enqueues the all-reduce of that bucket there
+ * (RCCL over xGMI), so the exchange of ~3/4 of the gradient bytes overlaps the rest of the backward pass.
+ * A non-zero return aborts pdes_backward with that code.  Not called when nothing was reduced early. */
+typedef struct pdes_bucket_hook {
+  int (*fn)(void* user, int first_layer, void* wgrad_stream);
+  void* user;
+} pdes_bucket_hook;
+int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
+                  const pdes_reduce_item* reduce_items, const int* reduce_index, const pdes_bucket_hook* hook);
 
 /* Table-driven helpers: one launch for the whole network. */
 typedef struct pdes_pack_item {  /* one convolution's weights */

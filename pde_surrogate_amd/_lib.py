@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -15,16 +15,21 @@ _c_p = ctypes.c_void_p
 SIGNATURES = {
     'pdes_abi_version': [],
     'pdes_stat_replicas': [],
-    'pdes_darcy_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_p],
+    'pdes_context_create': [_c_p, _c_i],
+    'pdes_context_destroy': [_c_p],
+    'pdes_context_set_option': [_c_p, ctypes.c_char_p, ctypes.c_char_p],
+    'pdes_context_load_env': [_c_p],
+    'pdes_context_device': [_c_p],
+    'pdes_darcy_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_p],
     'pdes_sobel_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
     'pdes_sobel_grad_adjoint': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
-    'pdes_conv_forward': [_c_p, _c_i, _c_p],
-    'pdes_conv_backward_weight': [_c_p, _c_i, _c_p],
-    'pdes_conv_backward_data': [_c_p, _c_i, _c_p],
-    'pdes_backward': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p],
-    'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i,
+    'pdes_conv_forward': [_c_p, _c_p, _c_i, _c_p],
+    'pdes_conv_backward_weight': [_c_p, _c_p, _c_i, _c_p],
+    'pdes_conv_backward_data': [_c_p, _c_p, _c_i, _c_p],
+    'pdes_backward': [_c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p],
+    'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i,
                                   ctypes.c_longlong, _c_p],
-    'pdes_conv_wgrad_plan': [_c_p, _c_p, _c_p],
+    'pdes_conv_wgrad_plan': [_c_p, _c_p, _c_p, _c_p],
     'pdes_wgrad_reduce_all': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_weights': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_weights_mfma': [_c_p, _c_i, _c_i, _c_p],
@@ -70,6 +75,54 @@ def lib():
     return _lib
 
 
+# ---- contexts: the library's only state (options + fork/join events), one per device, owned here ------------
+N_EVENTS = 512                      # pdes_backward with a second stream needs n_layers + 1 (default net: 29)
+_contexts = {}                      # device index -> pdes_context*
+_overrides = {}                     # option key -> value, applied to every context (set_option)
+
+# signature of pdes_bucket_hook.fn (include/pdes_hip.h)
+BUCKET_FN = ctypes.CFUNCTYPE(_c_i, _c_p, _c_i, _c_p)
+
+
+class BucketHook(ctypes.Structure):
+    _fields_ = [('fn', BUCKET_FN), ('user', _c_p)]
+
+
+def context(device=None):
+    """the pdes_context of a device (created on first use, on that device; the process environment's PDES_* knobs
+    are read ONCE here, then `set_option` overrides apply)"""
+    import torch
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    ctx = _contexts.get(idx)
+    if ctx is None:
+        L = lib()
+        h = _c_p()
+        with torch.cuda.device(idx):
+            check(L.pdes_context_create(ctypes.byref(h), N_EVENTS), 'pdes_context_create')
+        check(L.pdes_context_load_env(h), 'pdes_context_load_env')
+        for k, v in _overrides.items():
+            check(L.pdes_context_set_option(h, k.encode(), None if v is None else str(v).encode()), f'option {k}')
+        ctx = _contexts[idx] = h
+    return ctx
+
+
+def set_option(key, value):
+    """override a kernel-selection knob (include/pdes_hip.h lists the keys) on every context of this process;
+    value None restores the compiled-in default"""
+    _overrides[key] = value
+    for h in _contexts.values():
+        check(lib().pdes_context_set_option(h, key.encode(), None if value is None else str(value).encode()),
+              f'option {key}')
+
+
+def destroy_contexts():
+    for h in _contexts.values():
+        lib().pdes_context_destroy(h)
+    _contexts.clear()
+
+
 def check(rc, what):
     if rc != 0:
         msg = _ERR.get(rc, f'hipError_t {rc}' if rc > 0 else f'error {rc}')
@@ -83,9 +136,31 @@ def ptr(t):
     return t.data_ptr()
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """the current HIP stream of `device` (default: the current device)"""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def device_guard(device):
+    """make `device` current for the launches inside (streams, events and kernels of a call all belong to the device of
+    its tensors); free when it already is"""
+    import torch
+    idx = torch.device(device).index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOGUARD
+    return torch.cuda.device(idx)
 
 
 def require_cuda(*tensors):

@@ -5,6 +5,7 @@
 // torch.optim.Adam as called in train_codec_mixed_residual.py:151-152,239.
 #include <stdlib.h>
 #include "pdes_common.h"
+#include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 #include "pack_kernels.h"
 
@@ -208,13 +209,14 @@ using namespace pdes;
 
 extern "C" int pdes_stat_replicas(void) { return PDES_NREP; }
 
-extern "C" int pdes_bn_backward_finalize(float* t, const float* x, const double* x_stats, const double* t_stats,
+extern "C" int pdes_bn_backward_finalize(const pdes_context* ctx, float* t, const float* x, const double* x_stats, const double* t_stats,
                                          int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
                                          long long rep_stride, void* stream) {
   if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   if (!aligned16(t) || !aligned16(x)) return PDES_EALIGN;
   dim3 grid(cdiv(cdiv(HW, 4), 256), c1 - c0, B), block(256);
-  const int early = !(getenv("PDES_FIN_EARLY") && getenv("PDES_FIN_EARLY")[0] == '0');
+  OptScope scope(ctx);
+  const int early = opt().fin_early != 0;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, static_cast<hipStream_t>(stream), t, x, x_stats, t_stats,
                      B, ctot, c0, HW, eps, nrep, rep_stride, early);
   PDES_LAUNCH_CHECK();

@@ -1,0 +1,93 @@
+// pdes_context: the only state the library keeps, owned by the caller (created / destroyed explicitly).
+#include <stdlib.h>
+#include <string.h>
+#include "pdes_common.h"
+#include "pdes_options.h"
+#include "../../include/pdes_hip.h"
+
+namespace pdes {
+
+static const Options kDefaults{};
+static thread_local const Options* tl_opt = nullptr;
+
+const Options& opt() { return tl_opt ? *tl_opt : kDefaults; }
+
+OptScope::OptScope(const void* ctx) : prev(tl_opt) {
+  tl_opt = ctx ? &static_cast<const Context*>(ctx)->opt : &kDefaults;
+}
+OptScope::~OptScope() { tl_opt = prev; }
+
+struct Knob { const char* name; int Options::*field; };
+static const Knob kKnobs[] = {
+    {"PDES_FUSE_FINALIZE", &Options::fuse_finalize}, {"PDES_FUSE_MAXC", &Options::fuse_maxc},
+    {"PDES_FUSE_MAXHW", &Options::fuse_maxhw},       {"PDES_FIN_EARLY", &Options::fin_early},
+    {"PDES_MFMA_NTW", &Options::mfma_ntw},           {"PDES_MFMA_MT", &Options::mfma_mt},
+    {"PDES_MFMA_NG", &Options::mfma_ng},             {"PDES_MFMA_1X1", &Options::mfma_1x1},
+    {"PDES_1X1_KSPLIT", &Options::k1_ksplit},        {"PDES_MFMA_1X1W", &Options::mfma_1x1w},
+    {"PDES_1X1W_SPI", &Options::w1x1_spi},           {"PDES_MFMA_B3", &Options::mfma_b3},
+    {"PDES_B3_MT", &Options::b3_mt},                 {"PDES_FEW_R", &Options::few_r},
+    {"PDES_WGRAD_WGS", &Options::wgrad_wgs},         {"PDES_LOSS_NT", &Options::loss_nt},
+    {"PDES_LOSS_DMA", &Options::loss_dma},           {"PDES_MIRROR", &Options::mirror},
+};
+
+static int set_knob(Options& o, const char* key, const char* value) {
+  if (!strcmp(key, "PDES_CONV_IMPL")) {             // "direct" | anything else = automatic
+    o.conv_direct = value && value[0] == 'd';
+    return PDES_OK;
+  }
+  for (const Knob& k : kKnobs)
+    if (!strcmp(key, k.name)) {
+      o.*(k.field) = value ? atoi(value) : kDefaults.*(k.field);
+      return PDES_OK;
+    }
+  return PDES_ENOSUP;
+}
+
+}  // namespace pdes
+
+using namespace pdes;
+
+extern "C" int pdes_context_create(pdes_context** out, int n_events) {
+  if (!out || n_events < 0 || n_events > 4096) return PDES_EINVAL;
+  Context* c = new (std::nothrow) Context();
+  if (!c) return (int)hipErrorOutOfMemory;
+  hipError_t he = hipGetDevice(&c->device);
+  for (int i = 0; i < n_events && he == hipSuccess; ++i) {
+    hipEvent_t e = nullptr;
+    he = hipEventCreateWithFlags(&e, hipEventDisableTiming);        // order-only events
+    if (he == hipSuccess) c->events.push_back(e);
+  }
+  if (he != hipSuccess) {
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    delete c;
+    return (int)he;
+  }
+  *out = reinterpret_cast<pdes_context*>(c);
+  return PDES_OK;
+}
+
+extern "C" int pdes_context_destroy(pdes_context* ctx) {
+  if (!ctx) return PDES_EINVAL;
+  Context* c = reinterpret_cast<Context*>(ctx);
+  for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+  delete c;
+  return PDES_OK;
+}
+
+extern "C" int pdes_context_set_option(pdes_context* ctx, const char* key, const char* value) {
+  if (!ctx || !key) return PDES_EINVAL;
+  return set_knob(reinterpret_cast<Context*>(ctx)->opt, key, value);
+}
+
+extern "C" int pdes_context_load_env(pdes_context* ctx) {
+  if (!ctx) return PDES_EINVAL;
+  Options& o = reinterpret_cast<Context*>(ctx)->opt;
+  if (const char* e = getenv("PDES_CONV_IMPL")) set_knob(o, "PDES_CONV_IMPL", e);
+  for (const Knob& k : kKnobs)
+    if (const char* e = getenv(k.name)) set_knob(o, k.name, e);
+  return PDES_OK;
+}
+
+extern "C" int pdes_context_device(const pdes_context* ctx) {
+  return ctx ? reinterpret_cast<const Context*>(ctx)->device : PDES_EINVAL;
+}

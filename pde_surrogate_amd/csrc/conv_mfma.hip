@@ -26,6 +26,7 @@
 // {sum T, sum T xhat}.
 #include <stdlib.h>
 #include "pdes_common.h"
+#include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 #include "bn_fused.h"
 #include "pack_kernels.h"
@@ -568,10 +569,6 @@ static bool mfma_shape_ok(const pdes_conv_desc& d, bool bwd, int* W, int* H) {
   return *H % (8 / twg) == 0;
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 
 template <int KS, int S, int MODE, int KM>
 static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st, bool dry = false) {
@@ -593,7 +590,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     if (tiles8 < 256 && mt4_ok) mt = 4;
   } else {
     wk = 1;
-    const bool ntw2_ok = KS != 5 && kpad > 16 && nt_total > 4 && env_int("PDES_MFMA_NTW", 2) != 1;
+    const bool ntw2_ok = KS != 5 && kpad > 16 && nt_total > 4 && opt().mfma_ntw != 1;
     const int cand[4][2] = {{8, 2}, {8, 1}, {4, 2}, {4, 1}};
     long long best = -1;
     mt = 8; ntw = 1;
@@ -606,7 +603,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     }
     gz = (nt_total + 4 * ntw - 1) / (4 * ntw);
   }
-  { const int e = env_int("PDES_MFMA_MT", 0); if ((e == 8 || e == 4) && (e == 8 || mt4_ok)) mt = e; }
+  { const int e = opt().mfma_mt; if ((e == 8 || e == 4) && (e == 8 || mt4_ok)) mt = e; }
   const int th = mt / twg;
   if (H % th) return PDES_ENOSUP;
   dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
@@ -617,7 +614,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (twg == TWG_ && mt == MT_ && wk == WK_ && ntw == NTW_) {                                                 \
     using G = TileGeo<KS, TWG_, MT_, S>;                                                                      \
     const size_t cf_f = (bwd && !fused) ? 0 : 4 * (size_t)kpad;                                              \
-    const int ng = (WK_ == 4 && !bwd && S == 1 && nchunk >= 3 && env_int("PDES_MFMA_NG", 2) == 2) ? 2 : 1;  \
+    const int ng = (WK_ == 4 && !bwd && S == 1 && nchunk >= 3 && opt().mfma_ng == 2) ? 2 : 1;  \
     size_t fl = cf_f + (size_t)ng * 2 * G::KC * G::CS;                                                        \
     const size_t red = cf_f + (size_t)4 * ng * MT_ * 4 * 64 + 256;                                            \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \

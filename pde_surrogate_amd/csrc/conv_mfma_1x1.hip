@@ -18,6 +18,7 @@
 //     the fp64 atomics (measured: the atomics of one wave per 32 pixels cost 4 of the layer's 20 us).
 #include <stdlib.h>
 #include "pdes_common.h"
+#include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 
 namespace pdes {
@@ -363,8 +364,7 @@ __global__ __launch_bounds__(64 * KSW, 2) void conv1x1_wgrad_kernel(pdes_conv_de
 // PDES_MFMA_1X1: 0 = off (conv_mfma.hip serves the 1x1 layers), 1 = forward and data gradient (default),
 // 2 = forward only, 3 = data gradient only
 static bool p1_enabled(bool bwd) {
-  const char* e = getenv("PDES_MFMA_1X1");
-  const int m = e ? atoi(e) : 1;
+  const int m = opt().mfma_1x1;
   return m == 1 || (m == 2 && !bwd) || (m == 3 && bwd);
 }
 
@@ -386,7 +386,7 @@ static int launch_p1(const pdes_conv_desc& d, const float* wm, hipStream_t st) {
   const long long groups = (long long)d.B * (d.Hin * d.Win / 32);
   // K-split: enough waves for 1024 SIMDs, but at least four K-steps per wave
   int ksplit = (groups * nz * 2 >= 1024 || kC < 64) ? 2 : 4;
-  { const char* e = getenv("PDES_1X1_KSPLIT"); if (e && (atoi(e) == 2 || atoi(e) == 4)) ksplit = atoi(e); }
+  if (opt().k1_ksplit == 2 || opt().k1_ksplit == 4) ksplit = opt().k1_ksplit;
   // 8 waves per workgroup (more pixel groups share one set of statistics atomics) unless that leaves CUs idle
   const int nw = ((groups + 8 / ksplit - 1) / (8 / ksplit)) * nz >= 256 ? 8 : 4;
   const int gp = nw / ksplit, nown = (ntw + ksplit - 1) / ksplit;
@@ -422,7 +422,7 @@ int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry) {
 // weight gradient into the split-K partial buffer d.ws, spi splits per image (the plan of conv_mfma_wgrad.hip);
 // PDES_ENOSUP leaves the layer to the generic kernel
 int conv_backward_weight_1x1(const pdes_conv_desc& d, int spi, hipStream_t st) {
-  { const char* e = getenv("PDES_MFMA_1X1W"); if (e && e[0] == '0') return PDES_ENOSUP; }
+  if (!opt().mfma_1x1w) return PDES_ENOSUP;
   if (!p1_shape_ok(d, false) || !d.ws || d.eval_mode || d.g_fused || spi < 1) return PDES_ENOSUP;
   const int mtiles = (d.Cout + 15) / 16, ntiles = (d.Cin + 15) / 16, HW = d.Hin * d.Win;
   if ((long long)d.B * spi * d.Cout * d.Cin * 4 > d.ws_bytes) return PDES_ENOSUP;

@@ -19,6 +19,7 @@
 // Reference: models/codec.py:163-175 (LastTransUp.conv1, 196 -> 98 channels at 32 x 32) and its autograd.
 #include <stdlib.h>
 #include "pdes_common.h"
+#include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 #include "pack_kernels.h"
 
@@ -317,8 +318,7 @@ __global__ __launch_bounds__(256) void pack_b3_kernel(const pdes_b3_pack_item* _
 
 // ------------------------------------------------------------------------------- host dispatch
 static bool b3_enabled() {
-  const char* e = getenv("PDES_MFMA_B3");
-  return !(e && e[0] == '0');
+  return opt().mfma_b3 != 0;
 }
 
 // the layers this kernel takes: 3x3, stride 1, no upsampling, wide on both sides of the contraction
@@ -341,7 +341,7 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
   // 8 M-tiles per workgroup (82 KB of LDS: one workgroup per CU) or 4 (52 KB: two to three per CU, whose staging
   // and matrix phases overlap)
   int mt = 4;
-  { const char* e = getenv("PDES_B3_MT"); if (e && atoi(e) == 8) mt = 8; }
+  if (opt().b3_mt == 8) mt = 8;
   if (H % (mt / twg)) mt = 8;
   dim3 grid((W / (16 * twg)) * (H / (mt / twg)), d.B, (nt_total + 7) / 8), block(256);
   const size_t cf = bwd ? 0 : 16 * (size_t)kpad;

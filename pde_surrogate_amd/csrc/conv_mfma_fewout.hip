@@ -14,6 +14,7 @@
 // register pipeline of conv_mfma.hip.
 #include <stdlib.h>
 #include "pdes_common.h"
+#include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 
 namespace pdes {
@@ -191,7 +192,7 @@ int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st) {
   if (d.out_stats || d.Hin != d.Hout || d.Win != d.Wout || d.nrep != PDES_NREP || !d.w) return PDES_ENOSUP;
   if (!(d.Win == 64 || d.Win == 32 || d.Win == 16) || d.Hin % 2) return PDES_ENOSUP;
   const int kpad = (d.Cin + 15) & ~15;
-  const int R = (getenv("PDES_FEW_R") && atoi(getenv("PDES_FEW_R")) == 4 && d.Hin % 4 == 0) ? 4 : 2;
+  const int R = (opt().few_r == 4 && d.Hin % 4 == 0) ? 4 : 2;
   dim3 grid(d.Hin / R, d.B), block(256);
 #define PDES_FEW_LAUNCH(NMT_, R_)                                                                    \
   do {                                                                                                \

@@ -12,6 +12,7 @@
 // the 16 channels x 2 pixels of a ds_read_b32 lane group hit 32 distinct banks.
 #include <stdlib.h>
 #include "pdes_common.h"
+#include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 #include "bn_fused.h"
 
@@ -599,7 +600,7 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   // 2.025 / 2.032 ms at 448 / 320 / 256 / 192 / 128) and
   // (b) the partial buffer fits the scratch
   p->tpw = p->tps;
-  static const int wg_target = getenv("PDES_WGRAD_WGS") ? atoi(getenv("PDES_WGRAD_WGS")) : 256;
+  const int wg_target = opt().wgrad_wgs;
   for (int cand = 1; cand <= p->tps; cand *= 2) {
     if (p->tps % cand) continue;
     const long long ns = (long long)d.B * (p->tps / cand);
@@ -611,7 +612,7 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   // for the 144->72 layer, but no gain inside the step (2.0375 vs 2.0389 ms, three same-box runs each: the bigger
   // grid takes more of the chip from the data-gradient chain), so one split per image stays the default
   if (d.ksize == 1 && d.stride == 1 && !d.upsample && d.Hout * d.Wout >= 1024 && p->tps % 4 == 0 &&
-      getenv("PDES_1X1W_SPI") && atoi(getenv("PDES_1X1W_SPI")) == 4 &&
+      opt().w1x1_spi == 4 &&
       (long long)d.B * 4 * p->per * 4 <= d.ws_bytes)
     p->tpw = p->tps / 4;
   p->nsplit = d.B * (p->tps / p->tpw);
@@ -747,10 +748,11 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry)
 
 using namespace pdes;
 
-extern "C" int pdes_conv_wgrad_plan(const pdes_conv_desc* d, int* nsplit, long long* floats) {
+extern "C" int pdes_conv_wgrad_plan(const pdes_context* ctx, const pdes_conv_desc* d, int* nsplit, long long* floats) {
   if (!d || !nsplit || !floats) return PDES_EINVAL;
+  OptScope scope(ctx);
   WgradPlan pl;
-  { const char* e = getenv("PDES_CONV_IMPL"); if (e && e[0] == 'd') return PDES_ENOSUP; }   // VALU kernels forced: no partials
+  if (opt().conv_direct) return PDES_ENOSUP;   // VALU kernels forced: no partials
   if (!wgrad_shape_ok(*d) || !wgrad_plan(*d, &pl)) return PDES_ENOSUP;
   *nsplit = pl.nsplit;
   *floats = (long long)pl.nsplit * pl.per;

@@ -26,6 +26,8 @@
 // the per-image partials in fp64 in a fixed order (deterministic, no float atomics).
 #include <stdlib.h>
 #include "pdes_common.h"
+#include "pdes_options.h"
+#include "../../include/pdes_hip.h"
 
 namespace pdes {
 
@@ -600,7 +602,7 @@ static int launch_loss(const float* K, const float* y, float* gy, float* partial
 
 using namespace pdes;
 
-extern "C" int pdes_darcy_loss(const float* K, const float* y, float* grad_y, float* partials,
+extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
                                float* loss_out, int B, int H, int W, float w_const, float w_cont,
                                float w_dir, float w_neu, int nonlinear, float beta1, float beta2,
                                void* stream) {
@@ -618,13 +620,13 @@ extern "C" int pdes_darcy_loss(const float* K, const float* y, float* grad_y, fl
   p.beta2 = beta2;
   // streaming accesses once the 7 planes/sample no longer fit the 256 MiB Infinity Cache; at training
   // batch sizes y was just produced and grad_y is consumed next, so those stay cacheable
-  { const char* e = getenv("PDES_LOSS_NT"); p.nt = e ? atoi(e) : ((long long)B * H * W * 28 > (200ll << 20)); }
+  OptScope scope(ctx);
+  p.nt = opt().loss_nt >= 0 ? opt().loss_nt : ((long long)B * H * W * 28 > (200ll << 20));
   // PDES_LOSS_DMA=1: persistent workgroups + asynchronous global->LDS copies (n = 64, with gradients).  Off by
   // default: measured 5.0-5.1 TB/s at B = 16384 against 5.1-5.6 TB/s for the register-staged kernel on the same
   // box (it is steadier, and faster at B = 2048: 4.7-4.9 vs 4.0-4.9 TB/s) -- with 16 waves per CU the stencil
   // arithmetic and LDS traffic of one image take about as long as its HBM traffic.
-  { const char* e = getenv("PDES_LOSS_DMA");
-    const bool dma = e ? atoi(e) != 0 : false;
+  { const bool dma = opt().loss_dma != 0;
     if (dma && H == 64 && grad_y) {
       const int nwg = B < 256 ? B : 256;
       const size_t lds = 0;      // static LDS: two 64 KiB image buffers
@@ -672,4 +674,4 @@ extern "C" int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar,
   return PDES_OK;
 }
 
-extern "C" int pdes_abi_version(void) { return 12; }
+extern "C" int pdes_abi_version(void) { return 13; }

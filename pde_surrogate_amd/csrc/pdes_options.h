@@ -1,0 +1,47 @@
+// Run-time knobs of the library and the opaque context that carries them (include/pdes_hip.h: pdes_context).
+// Nothing in the library reads the environment on its own: pdes_context_load_env() does, once, when the caller
+// asks for it; every other read goes through opt(), which resolves to the options of the context the running
+// entry point was called with (or to the compiled-in defaults for a NULL context).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace pdes {
+
+struct Options {
+  int conv_direct = 0;          // PDES_CONV_IMPL=direct : generic VALU kernels for every convolution (cross-check)
+  int fuse_finalize = 0;        // PDES_FUSE_FINALIZE    : BatchNorm-backward finalize on operand load (opt-in, slower)
+  int fuse_maxc = 16;           // PDES_FUSE_MAXC
+  int fuse_maxhw = 1 << 30;     // PDES_FUSE_MAXHW
+  int fin_early = 1;            // PDES_FIN_EARLY        : finalize kernel issues its T/x loads before the statistics chain
+  int mfma_ntw = 2;             // PDES_MFMA_NTW
+  int mfma_mt = 0;              // PDES_MFMA_MT          : 0 = automatic
+  int mfma_ng = 2;              // PDES_MFMA_NG
+  int mfma_1x1 = 1;             // PDES_MFMA_1X1         : 0 off, 1 forward + data gradient, 2 forward, 3 data gradient
+  int k1_ksplit = 0;            // PDES_1X1_KSPLIT       : 0 = automatic, 2, 4
+  int mfma_1x1w = 1;            // PDES_MFMA_1X1W
+  int w1x1_spi = 0;             // PDES_1X1W_SPI         : 4 = four splits per image
+  int mfma_b3 = 1;              // PDES_MFMA_B3          : bf16 x3 split kernel for the wide 3x3 layer
+  int b3_mt = 4;                // PDES_B3_MT
+  int few_r = 2;                // PDES_FEW_R
+  int wgrad_wgs = 256;          // PDES_WGRAD_WGS        : workgroup target of the split-K weight-gradient plan
+  int loss_nt = -1;             // PDES_LOSS_NT          : -1 = by working-set size
+  int loss_dma = 0;             // PDES_LOSS_DMA
+  int mirror = 1;               // PDES_MIRROR           : reserved for the dense-block "mirror" data gradient
+};
+
+struct Context {
+  Options opt;
+  int device = 0;
+  std::vector<hipEvent_t> events;     // fork/join events of pdes_backward, created with the context on `device`
+};
+
+const Options& opt();                 // options in force on this thread (defaults outside an entry point)
+
+struct OptScope {                     // RAII: an entry point installs its context's options for its duration
+  const Options* prev;
+  explicit OptScope(const void* ctx);
+  ~OptScope();
+};
+
+}  // namespace pdes

@@ -209,6 +209,9 @@ class _Engine:
         self.net, self.B = net, B
         dev = net._flat.device
         self.dev = dev
+        self.ctx = _lib.context(dev)           # options + fork/join events of this device (include/pdes_hip.h)
+        self.busy = False                      # leased to an autograd forward whose backward has not run yet
+        self.reserved = False                  # owned by a MixedResidualTrainer: never leased
         specs, bufs = net._specs, net._bufs
 
         def size_of(scale, base):
@@ -330,7 +333,7 @@ class _Engine:
             d = self.descs[i]
             d.ws_bytes = 1 << 40                       # plan without a scratch limit
             ns, fl = _I(0), ctypes.c_longlong(0)
-            rc = L.pdes_conv_wgrad_plan(ctypes.byref(d), ctypes.byref(ns), ctypes.byref(fl))
+            rc = L.pdes_conv_wgrad_plan(self.ctx, ctypes.byref(d), ctypes.byref(ns), ctypes.byref(fl))
             if rc != 0:                                # generic kernel: atomics into dw, shared scratch unused
                 d.ws, d.ws_bytes, d.ws_defer = self.net._ws.data_ptr(), self.net._ws.numel() * 4, 0
                 continue
@@ -355,17 +358,17 @@ class _Engine:
             self._reduce_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
 
     def _side_stream(self):
-        """second HIP stream for the weight gradients, at the LOWEST queue priority: free workgroup slots go to
-        the finalize -> data-gradient chain on the main stream first, the weight gradients fill what is left"""
-        if not hasattr(self, '_side'):
+        """second HIP stream for the weight gradients (one per network and device), at the LOWEST queue priority: free
+        workgroup slots go to the finalize -> data-gradient chain on the main stream first, the weight gradients fill
+        what is left"""
+        side = self.net._side_streams.get(self.dev)
+        if side is None:
             try:
                 least = torch.cuda.Stream.priority_range()[0]
             except Exception:
                 least = 0
-            if os.environ.get('PDES_SIDE_PRIO') == 'default':      # A/B knob: default instead of least priority
-                least = 0
-            self._side = torch.cuda.Stream(self.dev, priority=least)
-        return self._side
+            side = self.net._side_streams[self.dev] = torch.cuda.Stream(self.dev, priority=least)
+        return side
 
     # -- launches -------------------------------------------------------------------------------
     def forward(self, x, training, defer_running=False):
@@ -382,17 +385,19 @@ class _Engine:
         if training:
             self.arena.zero_()
         net._pack_weights()
-        _lib.check(L.pdes_conv_forward(self.descs, len(self.descs), st), 'pdes_conv_forward')
+        _lib.check(L.pdes_conv_forward(self.ctx, self.descs, len(self.descs), st), 'pdes_conv_forward')
         if training and not defer_running:
             _lib.check(L.pdes_bn_update_running(self.bn_table.data_ptr(), self.n_bn, self.max_c,
                                                 ctypes.c_float(0.1), self.nrep, self.rep_stride, st),
                        'pdes_bn_update_running')
         return self.X['out']
 
-    def backward(self, grad_y, need_input_grad=False, tail=None):
+    def backward(self, grad_y, need_input_grad=False, tail=None, bucket_hook=None):
         """parameter gradients are ACCUMULATED into net._gflat (zero it first for plain gradients).
         tail = (update_running, partials, B, H, W, w_const, w_cont, w_dir, w_neu, terms, terms_accum): finish with
-        pdes_step_tail (BatchNorm parameter gradients + running statistics + loss terms in one launch)"""
+        pdes_step_tail (BatchNorm parameter gradients + running statistics + loss terms in one launch).
+        bucket_hook: _lib.BucketHook called by pdes_backward once the widest layers' weight gradients are final on
+        the weight-gradient stream (data-parallel bucket, train.py)"""
         L, st = _lib.lib(), _lib.stream_ptr()
         n = len(self.descs)
         if not hasattr(self, '_reduce_n'):
@@ -402,10 +407,11 @@ class _Engine:
         # reduce at the end), so pdes_backward runs them on a second HIP stream.  Not under hipGraph
         # capture: the runtime serialises forked graph branches with heavier barriers than it saves.
         side = None
-        if os.environ.get('PDES_WGRAD_STREAM', '1') != '0' and not torch.cuda.is_current_stream_capturing():
+        if self.net.wgrad_stream and not torch.cuda.is_current_stream_capturing():
             side = ctypes.c_void_p(self._side_stream().cuda_stream)
         rt = self._reduce_table.data_ptr() if self._reduce_n else None
-        _lib.check(L.pdes_backward(self.descs, n, st, side, rt, self._reduce_index), 'pdes_backward')
+        hook = ctypes.byref(bucket_hook) if (bucket_hook is not None and side is not None) else None
+        _lib.check(L.pdes_backward(self.ctx, self.descs, n, st, side, rt, self._reduce_index, hook), 'pdes_backward')
         if tail is None:
             _lib.check(L.pdes_bn_param_grads(self.bn_table.data_ptr(), self.n_bn, self.max_c, self.nrep,
                                              self.rep_stride, st), 'pdes_bn_param_grads')
@@ -416,31 +422,65 @@ class _Engine:
                                         _lib.ptr(accum), self.nrep, self.rep_stride, st), 'pdes_step_tail')
 
 
+class _Lease:
+    """an engine held by one autograd forward until its backward has run -- or until autograd drops the graph
+    (the lease is garbage collected with the function's ctx)"""
+
+    def __init__(self, eng):
+        self.eng = eng
+        eng.busy = True
+
+    def release(self):
+        if self.eng is not None:
+            self.eng.busy = False
+            self.eng = None
+
+    __del__ = release
+
+
 class _NetFn(torch.autograd.Function):
+    """forward/backward of the whole network as ONE autograd node.  The node owns an engine (activations, BatchNorm
+    batch statistics, gradient accumulators) from its forward to its backward, so several forwards may be outstanding
+    -- `(loss(model(x1)) + loss(model(x2))).backward()`, or an eval forward between a forward and its backward --
+    exactly as with the reference's nn.Module."""
+
     @staticmethod
-    def forward(ctx, x, net, *params):
-        eng = net._engine(x)
+    def forward(ctx, x, net, grad_on, *params):
+        eng = net._acquire(x)
         ctx.net, ctx.eng = net, eng
-        ctx.n_params = len(params)
-        y = eng.forward(x, net.training)
         ctx.trained = net.training
-        return y.clone()      # engine buffers are reused by the next call
+        ctx.pver = sum(p._version for p in params)
+        with _lib.device_guard(x.device):
+            y = eng.forward(x, net.training)
+            y = y.clone()      # the engine's output buffer is reused by its next forward
+        # the engine stays leased only when a backward can follow
+        # (grad mode is always off inside Function.forward: the caller's mode comes in as `grad_on`)
+        ctx.lease = _Lease(eng) if (grad_on and any(p.requires_grad for p in params)) else None
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        net, eng = ctx.net, ctx.eng
+        net, eng, lease = ctx.net, ctx.eng, ctx.lease
         if not ctx.trained:
             raise RuntimeError('backward through an eval-mode forward is not implemented (BatchNorm in eval mode '
                                'is only used under torch.no_grad() by the reference)')
-        net._gscratch.zero_()
-        eng.backward(gy.contiguous())
-        # hand autograd views of ONE fresh copy (it may keep them as .grad; the scratch is reused)
-        fresh = net._gscratch.clone()
-        grads, off = [], 0
-        for p in net._params:
-            grads.append(fresh[off:off + p.numel()].view(p.shape))
-            off += p.numel()
-        return (None, None) + tuple(grads)
+        if lease is None or lease.eng is not eng:
+            raise RuntimeError('backward through this forward a second time: its activations have been released '
+                               '(retain_graph is not supported by the HIP DenseED)')
+        if sum(p._version for p in net._params) != ctx.pver:
+            lease.release()
+            raise RuntimeError('a parameter of the network was modified in place between forward and backward '
+                               '(the packed weight images no longer match the activations)')
+        with _lib.device_guard(gy.device):
+            net._pack_weights()       # another forward may have re-packed; the live weights are unchanged (checked above)
+            net._gscratch.zero_()
+            net._grad_dirty = True    # a fused trainer sharing this buffer must clear it before its next step
+            eng.backward(gy.contiguous())
+            # hand autograd views of ONE fresh copy (it may keep them as .grad; the scratch is reused)
+            fresh = net._gscratch.clone()
+        lease.release()
+        grads = [fresh[off:off + p.numel()].view(p.shape) for p, off in zip(net._params, net._offsets)]
+        return (None, None, None) + tuple(grads)
 
 
 class _HipNet(nn.Module):
@@ -459,24 +499,42 @@ class _HipNet(nn.Module):
         _build_modules(self.features, specs)
         self._flat = None
         self._engines = {}
+        self._side_streams = {}
+        self._grad_dirty = False
+        # weight gradients on a second HIP stream beside the finalize -> data-gradient chain (PDES_WGRAD_STREAM=0 in
+        # the environment at construction, or this attribute, selects the single-stream form)
+        self.wgrad_stream = os.environ.get('PDES_WGRAD_STREAM', '1') != '0'
 
     # -- flat parameter / gradient storage -------------------------------------------------------
     def _flatten(self, device):
-        """move every parameter into one flat fp32 buffer on `device` and re-point .data at views"""
+        """move every parameter into one flat fp32 buffer on `device` and re-point .data at views.
+        Layout: [every BatchNorm weight/bias | the convolution weights in layer order].  Backward finishes the
+        convolution weights of the LAST layers first and the BatchNorm gradients last (pdes_step_tail), so the tail of
+        the gradient buffer is final early: the data-parallel trainer all-reduces it as its first bucket while the
+        rest of the backward pass still runs (train.py)."""
         named = list(self.named_parameters())
         total = sum(p.numel() for _, p in named)
         flat = torch.empty(total, device=device, dtype=torch.float32)
         gflat = torch.zeros(total, device=device, dtype=torch.float32)
         self._grad_view = {}
-        views, off = [], 0
-        for name, p in named:
+        conv_names = {'features.' + sp.conv + '.weight' for sp in self._specs}
+        order = [i for i, (nm, _) in enumerate(named) if nm not in conv_names] + \
+                [i for i, (nm, _) in enumerate(named) if nm in conv_names]
+        offsets, off = [0] * len(named), 0
+        for i in order:
+            offsets[i] = off
+            off += named[i][1].numel()
+        views = []
+        for (name, p), off in zip(named, offsets):
             n = p.numel()
             flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = flat[off:off + n].view(p.shape)
             key = name[len('features.'):]
             self._grad_view[key] = gflat[off:off + n].view(p.shape)
             views.append(self._grad_view[key])
-            off += n
+        self._offsets = offsets
+        # gradient-buffer offset of each layer's convolution weight (ascending in layer order)
+        self._conv_off = [offsets[[nm for nm, _ in named].index('features.' + sp.conv + '.weight')] for sp in self._specs]
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.running_mean.data = m.running_mean.data.to(device).contiguous()
@@ -576,22 +634,40 @@ class _HipNet(nn.Module):
     def _is_flat(self, device):
         if self._flat is None or self._flat.device != device:
             return False
-        off = 0
         base = self._flat.data_ptr()
-        for p in self._params:
+        for p, off in zip(self._params, self._offsets):
             if p.data_ptr() != base + 4 * off:
                 return False
-            off += p.numel()
         return True
 
-    def _engine(self, x):
+    MAX_OUTSTANDING = 8      # engines per (batch, size): forwards whose backward has not run yet
+
+    def _pool(self, x):
         if not self._is_flat(x.device):
             self._flatten(x.device)
         key = (x.shape[0], x.shape[2], x.shape[3])
-        eng = self._engines.get(key)
-        if eng is None:
+        pool = self._engines.get(key)
+        if pool is None:
+            with _lib.device_guard(x.device):
+                pool = self._engines[key] = [_Engine(self, *key)]
+        return key, pool
+
+    def _engine(self, x):
+        """the primary engine of this (batch, size) -- the one a MixedResidualTrainer drives directly"""
+        return self._pool(x)[1][0]
+
+    def _acquire(self, x):
+        """an engine no outstanding autograd forward (and no trainer) owns; a new one when all are taken"""
+        key, pool = self._pool(x)
+        for eng in pool:
+            if not eng.busy and not eng.reserved:
+                return eng
+        if len(pool) >= self.MAX_OUTSTANDING:
+            raise RuntimeError(f'{len(pool)} forward passes of shape {key} are waiting for their backward: call '
+                               'backward() (or drop the outputs / use torch.no_grad()) before running more')
+        with _lib.device_guard(x.device):
             eng = _Engine(self, *key)
-            self._engines[key] = eng
+        pool.append(eng)
         return eng
 
     def forward(self, x):
@@ -602,7 +678,7 @@ class _HipNet(nn.Module):
             raise RuntimeError('the HIP kernels compute in fp32: pass an fp32 input')
         x = x.contiguous()
         self._engine(x)   # flattens parameters before autograd sees them
-        return _NetFn.apply(x, self, *self._params)
+        return _NetFn.apply(x, self, torch.is_grad_enabled(), *self._params)
 
     def forward_test(self, x):
         print('input: {}'.format(x.data.size()))

@@ -41,9 +41,13 @@ class MixedResidualTrainer:
         model.to(self.dev)
         probe = torch.zeros((batch_size, cin, imsize, imsize), device=self.dev)
         self.eng = model._engine(probe)                   # flattens parameters, allocates buffers
+        self.eng.reserved = True                          # autograd forwards of the same model get other engines
+        self.ctx = self.eng.ctx
         self.x_static = self.eng.X['in']                  # minibatches are gathered straight into it
         self.x_static.zero_()
         self.flat, self.gflat = model._flat, model._gscratch
+        if self.world > 1 or process_group is not None:
+            parallel.broadcast_parameters(self.flat, process_group)      # seeds already agree; belt and braces
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.hyper = torch.zeros(8, device=self.dev)              # hipGraph mode: read by the captured Adam kernel
@@ -60,23 +64,55 @@ class MixedResidualTrainer:
         self._hyper_event = torch.cuda.Event() if use_graph else None
         self._grad_clean = False          # eager: True once the Adam kernel has cleared the gradient buffer
         self._L = _lib.lib()
+        # data parallel: the gradient buffer is exchanged in two buckets.  Bucket A = the convolution weights of the
+        # last layers (the tail of the buffer, ~3/4 of the bytes), all-reduced from the weight-gradient stream as soon
+        # as pdes_backward has reduced their split-K partials -- it overlaps the rest of the backward pass; bucket B =
+        # everything before it, after the end-of-step launch.
+        self._bucket_work, self._bucket_off = None, 0
+        self._hook = None
+        self.overlap_allreduce = os.environ.get('PDES_DP_OVERLAP', '1') != '0'
+        if self.world > 1 or process_group is not None:
+            self._hook_fn = _lib.BUCKET_FN(self._on_bucket)          # keep the callback object alive
+            self._hook = _lib.BucketHook(self._hook_fn, None)
+
+    def _on_bucket(self, _user, first_layer, _stream):
+        """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
+        try:
+            off = self.model._conv_off[first_layer]
+            with torch.cuda.stream(self.eng._side_stream()):
+                self._bucket_work = torch.distributed.all_reduce(self.gflat[off:], op=torch.distributed.ReduceOp.SUM,
+                                                                 group=self.pg, async_op=True)
+            self._bucket_off = off
+            return 0
+        except Exception as e:                                  # never let an exception cross the C ABI
+            self._hook_error = e
+            return -1
 
     # ------------------------------------------------------------------------------------------
     def _compute(self):
         """forward + loss + backward on self.x_static -> gradients in self.gflat, terms in self.terms"""
         L, st = self._L, _lib.stream_ptr()
         m = self.model
+        assert m._flat is self.flat, 'the model was re-flattened (moved to another device?) after the trainer was built'
         y = self.eng.forward(self.x_static, True, defer_running=True)
         # loss_out = NULL: the per-image partials are reduced (and accumulated for the epoch mean) by the
         # end-of-step launch of the backward, together with the BatchNorm bookkeeping
-        rc = L.pdes_darcy_loss(self.x_static.data_ptr(), y.data_ptr(), self.grad_y.data_ptr(),
+        rc = L.pdes_darcy_loss(self.ctx, self.x_static.data_ptr(), y.data_ptr(), self.grad_y.data_ptr(),
                                self.partials.data_ptr(), None, self.B, self.n, self.n,
                                1.0, 1.0, self.wb, self.wb, 1 if self.nl else 0, self.nb1, self.nb2, st)
         _lib.check(rc, 'pdes_darcy_loss')
-        if not self._grad_clean:
+        if not self._grad_clean or m._grad_dirty:      # an autograd backward of the same model shares this buffer
             self.gflat.zero_()
-        self.eng.backward(self.grad_y, tail=(True, self.partials, self.B, self.n, self.n, 1.0, 1.0, self.wb, self.wb,
-                                              self.terms, self.terms_accum))
+            m._grad_dirty = False
+        hook = self._hook if (self.overlap_allreduce and not self.use_graph) else None
+        self._hook_error = None
+        try:
+            self.eng.backward(self.grad_y, tail=(True, self.partials, self.B, self.n, self.n, 1.0, 1.0, self.wb,
+                                                  self.wb, self.terms, self.terms_accum), bucket_hook=hook)
+        except RuntimeError:
+            if self._hook_error is not None:                  # the all-reduce of bucket A failed inside the callback
+                raise self._hook_error
+            raise
         return m
 
     def _set_hyper(self, lr):
@@ -94,6 +130,10 @@ class MixedResidualTrainer:
 
     def step(self, x=None, lr=None):
         """one training step on minibatch `x` (device tensor (B,C,H,W); None = reuse x_static)."""
+        with _lib.device_guard(self.dev):
+            self._step(x, lr)
+
+    def _step(self, x, lr):
         if x is not None:
             self.x_static.copy_(x)
         if self.use_graph and self.step_count:
@@ -106,8 +146,15 @@ class MixedResidualTrainer:
         else:
             self._compute()
         self.n_accum += 1
-        if self.world > 1:
-            parallel.allreduce_sum_(self.gflat, self.pg)      # ONE flat RCCL all-reduce per step
+        if self._hook is not None:                            # data parallel (a group of ONE rank still runs the path)
+            work, off = self._bucket_work, self._bucket_off
+            self._bucket_work = None
+            if work is not None:                              # bucket A is in flight since the middle of the backward pass
+                if off:
+                    torch.distributed.all_reduce(self.gflat[:off], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                work.wait()                                   # the main stream waits for bucket A
+            else:
+                torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         if self.use_graph:
             rc = self._L.pdes_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
                                         self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), 1.0 / self.world,

@@ -115,9 +115,22 @@ def test_g11_headline_batch_every_gradient_tensor(dev):
     loss.backward()
     names = [str(s) for s in g['param_names']]
     assert [k for k, _ in net.named_parameters()] == names
-    errs = sorted(((rel_l2(p.grad.cpu().numpy(), g['grad/' + k]), k) for k, p in net.named_parameters()), reverse=True)
+    grads = {k: p.grad.cpu().numpy() for k, p in net.named_parameters()}
+    # tolerance 1e-3 per tensor.  The reference's OWN fp32 rounding error against the fp64 oracle is
+    # stored per tensor (`ref_fp32_vs_fp64_floor`, tools/gen_golden.py): three BatchNorm-bias gradients (sums with
+    # heavy cancellation) sit at 0.4e-3 .. 1.6e-3 there, so for tensors with a floor above 3e-4 the bound is
+    # 1e-3 + floor, and the HIP gradient (fp64 accumulators) must ALSO be within 1e-3 of the stored fp64 gradient
+    floor = dict(zip(names, g['ref_fp32_vs_fp64_floor']))
+    errs = sorted(((rel_l2(grads[k], g['grad/' + k]), k) for k in names), reverse=True)
     print('G11 worst gradient tensors:', errs[:6])
-    assert errs[0][0] < 1e-3, errs[:8]
+    for e, k in errs:
+        assert e < 1e-3 + (floor[k] if floor[k] > 3e-4 else 0.0), (k, e, floor[k])
+    n64 = 0
+    for k in g.files:
+        if k.startswith('grad64/'):
+            n64 += 1
+            assert rel_l2(grads[k[7:]], g[k]) < 1e-3, k
+    assert n64 >= 1
 
 
 def test_g12_teacher_forced_reference_steps(dev):
@@ -240,13 +253,13 @@ def _run_default(dev, B=4, seed=5, imsize=64, blocks=(6, 8, 6)):
 
 @pytest.mark.parametrize('cfg', [dict(B=4), dict(B=32), dict(B=1), dict(B=8, imsize=32, blocks=(3, 4, 3)),
                                  dict(B=3, imsize=64, blocks=(2, 3, 2))])
-def test_mfma_kernels_match_direct_kernels(dev, monkeypatch, cfg):
+def test_mfma_kernels_match_direct_kernels(dev, option, cfg):
     """matrix-core implicit-GEMM convolutions vs the VALU reference kernels, same weights/inputs.
     The configurations walk different tile shapes, split plans, pipelined / single-chunk variants, the
     sub-pixel and few-output kernels at 64 and 32 pixels, and 8x8 maps that stay on the VALU kernels."""
-    monkeypatch.setenv('PDES_CONV_IMPL', 'direct')
+    option('PDES_CONV_IMPL', 'direct')
     y0, l0, g0 = _run_default(dev, **cfg)
-    monkeypatch.setenv('PDES_CONV_IMPL', 'auto')
+    option('PDES_CONV_IMPL', 'auto')
     y1, l1, g1 = _run_default(dev, **cfg)
     assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
     assert abs(l1 - l0) < 1e-5 * abs(l0)
@@ -259,15 +272,17 @@ def test_mfma_kernels_match_direct_kernels(dev, monkeypatch, cfg):
 
 @pytest.mark.parametrize('knob', ['PDES_FUSE_FINALIZE', 'PDES_WGRAD_STREAM', 'PDES_MFMA_B3', 'PDES_MFMA_1X1',
                                   'PDES_MFMA_1X1W'])
-def test_backward_variants_agree(dev, monkeypatch, knob):
+def test_backward_variants_agree(dev, monkeypatch, option, knob):
     """finalize fused into the operand load vs the in-place kernel; weight gradients on a second stream vs one
     stream; the 196->98 layer on the bf16 pipe (three-way split, fp32-accurate) vs the f32 pipe; the 1x1 layers
     (forward + data gradient, weight gradient) on the register-operand kernels of conv_mfma_1x1.hip vs the LDS-tiled
     generic ones: same outputs and gradients (fp64 atomics of the statistics are order dependent in the last bits only; two different fp32
     summation orders flip individual ReLU masks, hence the 1e-2 class bound on parameter gradients)"""
-    monkeypatch.setenv(knob, '0')
+    # PDES_WGRAD_STREAM is read by the model at construction; the others are options of the library's context
+    setk = (lambda v: monkeypatch.setenv(knob, v)) if knob == 'PDES_WGRAD_STREAM' else (lambda v: option(knob, v))
+    setk('0')
     y0, l0, g0 = _run_default(dev, B=32)
-    monkeypatch.setenv(knob, '1')
+    setk('1')
     y1, l1, g1 = _run_default(dev, B=32)
     ytol = 2e-6 if knob in ('PDES_MFMA_B3', 'PDES_MFMA_1X1') else 1e-6
     assert torch.equal(y0, y1) or rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < ytol

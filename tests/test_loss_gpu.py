@@ -140,7 +140,7 @@ def test_fused_loss_vs_oracle(dev, n, B, nl):
 
 
 @pytest.mark.parametrize('nl', [False, True])
-def test_lds_dma_variant_equals_default_kernel(dev, nl, monkeypatch):
+def test_lds_dma_variant_equals_default_kernel(dev, nl, option):
     """PDES_LOSS_DMA=1 (persistent workgroups, global_load_lds double buffering) against the default kernel:
     B = 300 > 256 workgroups, so some workgroups walk two images and exercise the counted vmcnt waits"""
     from pde_surrogate_amd.models.darcy import darcy_loss_launch
@@ -149,9 +149,9 @@ def test_lds_dma_variant_equals_default_kernel(dev, nl, monkeypatch):
     K = torch.exp(0.5 * torch.randn(B, 1, n, n, device=dev))
     y = torch.randn(B, 3, n, n, device=dev)
     args = ((1, 1, 10, 10), True, nl, 0.1 if nl else 0.0, 0.1 if nl else 0.0)
-    monkeypatch.setenv('PDES_LOSS_DMA', '0')
+    option('PDES_LOSS_DMA', '0')
     terms0, gy0 = darcy_loss_launch(K, y, *args)
-    monkeypatch.setenv('PDES_LOSS_DMA', '1')
+    option('PDES_LOSS_DMA', '1')
     terms1, gy1 = darcy_loss_launch(K, y, *args)
     # same formulas per strip; the two kernels are compiled separately (fma contraction differs in the last bit)
     assert rel_l2(gy1.cpu().numpy(), gy0.cpu().numpy()) < 1e-6

@@ -104,7 +104,7 @@ def test_fused_step_equals_reference_loop_body_and_graph_equals_eager(dev):
         means = tr.epoch_means()
         assert abs(means[0] - g['losses'][0]) < 1e-5 * g['losses'][0]          # step-1 loss == reference (G7)
         assert abs(means[0] - loss.item()) < 1e-5 * loss.item()
-        finals[tag] = tr.flat.clone()
+        finals[tag] = torch.cat([p.detach().reshape(-1) for p in net.parameters()])   # (tr.flat has its own layout)
         bn = net.features.LastTransUp.norm3
         assert int(bn.num_batches_tracked) == 1                                 # graph warm-up left no trace
     flat_a = torch.cat([p.detach().reshape(-1) for p in net_a.parameters()])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Same-process A/B of run-time knobs (the library reads its PDES_* environment variables on every call):
+"""Same-process A/B of run-time knobs (options of the library's context, pdes_context_set_option):
     python tools/ab_env.py PDES_MFMA_1X1 0 1 2 3        -> ms per training step for each value, interleaved rounds
     python tools/ab_env.py PDES_MFMA_NG 1 2 -- PDES_FEW_R 2 4    several knobs, one after the other ('-' = unset)
 Different gpurun boxes differ by ~2 %, one process repeats to ~0.1 %, so knob decisions are made here."""
@@ -10,6 +10,7 @@ import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from pde_surrogate_amd import _lib
 from pde_surrogate_amd.models.codec import DenseED
 from pde_surrogate_amd.train import MixedResidualTrainer
 from pde_surrogate_amd.utils.data import grf_kle_fields
@@ -27,10 +28,9 @@ def main(groups, rounds=3, steps=150, warm=20, B=32):
         res = {v: [] for v in values}
         for r in range(rounds):
             for v in values:
-                if v == '-':
-                    os.environ.pop(name, None)
-                else:
-                    os.environ[name] = v
+                _lib.set_option(name, None if v == '-' else v)
+                if hasattr(tr.eng, '_reduce_n'):
+                    del tr.eng._reduce_n              # re-plan the split-K scratch under the new options
                 for i in range(warm):
                     tr.step(batches[i % len(batches)], 1e-4)
                 torch.cuda.synchronize()
@@ -39,7 +39,7 @@ def main(groups, rounds=3, steps=150, warm=20, B=32):
                     tr.step(batches[i % len(batches)], 1e-4)
                 torch.cuda.synchronize()
                 res[v].append((time.perf_counter() - t0) / steps * 1e3)
-        os.environ.pop(name, None)
+        _lib.set_option(name, None)
         for v in values:
             print(f'{name}={v}: ' + ' '.join(f'{t:.4f}' for t in res[v]) + f'  | min {min(res[v]):.4f} ms/step', flush=True)
 

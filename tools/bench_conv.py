@@ -47,9 +47,9 @@ def main(B=32, only=None):
             d.g_fused = 1          # time the finalize-on-load variants (values are meaningless here, timing is not)
         ref = ctypes.byref(d)
         fl = 2.0 * s.cout * s.cin * s.k * s.k * d.Hout * d.Wout * B
-        t_f = timeit(lambda: L.pdes_conv_forward(ref, 1, st))
-        t_w = timeit(lambda: L.pdes_conv_backward_weight(ref, 1, st))
-        t_d = timeit(lambda: L.pdes_conv_backward_data(ref, 1, st)) if s.norm is not None else 0.0
+        t_f = timeit(lambda: L.pdes_conv_forward(eng.ctx, ref, 1, st))
+        t_w = timeit(lambda: L.pdes_conv_backward_weight(eng.ctx, ref, 1, st))
+        t_d = timeit(lambda: L.pdes_conv_backward_data(eng.ctx, ref, 1, st)) if s.norm is not None else 0.0
         tot[0] += t_f; tot[1] += t_w; tot[2] += t_d
         print(f'{i:2d} {s.conv:34s} {s.cin:3d}->{s.cout:3d} k{s.k} s{s.stride} up{s.up} {d.Hout:2d}x{d.Wout:2d} '
               f'fwd {t_f:7.1f}us {fl / t_f / 1e6:6.1f}TF | wgrad {t_w:7.1f}us {fl / t_w / 1e6:6.1f}TF | '

@@ -19,7 +19,7 @@ def time_loss(B, n=64, iters=50, bwd=True):
     L = _lib.lib()
     st = _lib.stream_ptr()
     def run():
-        rc = L.pdes_darcy_loss(K.data_ptr(), y.data_ptr(), g.data_ptr() if bwd else None, part.data_ptr(), None,
+        rc = L.pdes_darcy_loss(_lib.context(dev), K.data_ptr(), y.data_ptr(), g.data_ptr() if bwd else None, part.data_ptr(), None,
                                B, n, n, 1.0, 1.0, 10.0, 10.0, 0, 0.0, 0.0, st)
         assert rc == 0, rc
     for _ in range(5):

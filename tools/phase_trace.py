@@ -27,10 +27,10 @@ def main(layers, B=32):
         ref = ctypes.byref(d)
         for name, fn in (('fwd', L.pdes_conv_forward), ('dgrad', L.pdes_conv_backward_data)):
             for _ in range(3):
-                fn(ref, 1, st)
+                fn(eng.ctx, ref, 1, st)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); fn(ref, 1, st); e1.record()
+            e0.record(); fn(eng.ctx, ref, 1, st); e1.record()
             torch.cuda.synchronize()
             L.pdes_debug_trace(buf)
             t = list(buf)
