@@ -294,6 +294,27 @@ int pdes_step_tail(const pdes_bn_item* items, int n, int max_c, float momentum, 
                    float w_neu, float* terms, double* terms_accum, int nrep, long long rep_stride,
                    void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Test-time metrics and the data-driven (maximum-likelihood) loss: the steps either side of the hot loop.
+ *
+ * pdes_test_metrics: per (image, channel) {sum_hw (output-target)^2, sum_hw target^2} -> per_image (B, C, 2), and,
+ * when `accum` is given (2C+1 doubles, zeroed by the caller before the first batch),
+ *   accum[c] += sum_b sqrt(err2/t2), accum[C+c] += sum_b err2, accum[2C] += B   (fixed order: deterministic).
+ * After the last batch: relative-l2 (NRMSE) = accum[c] / accum[2C]; R^2 = 1 - accum[C+c] / y_variation[c].
+ * Replaces train_codec_mixed_residual.py:180-183 (err2_sum, relative_l2, err2 per batch) and :196-197 (the
+ * torch.cat(...).mean(0) / .sum(0) at the end) without per-batch host syncs; C <= 64.
+ */
+int pdes_test_metrics(const float* output, const float* target, float* per_image, double* accum, int B, int C,
+                      int HW, void* stream);
+
+/* loss = mean((output - target)^2) over n elements and, when grad_out is given, grad_out = 2 (output - target) / n.
+ * partials: workspace of pdes_mse_partials(n) doubles (per-block sums, reduced in a fixed order: deterministic).
+ * loss_out (1 float, nullable) and loss_accum (1 double, += loss, nullable) are written by a one-block finalize.
+ * Replaces F.mse_loss + loss.backward() wrt output, train_codec_max_likelihood.py:170,203-204. */
+int pdes_mse_partials(long long n);
+int pdes_mse_loss(const float* output, const float* target, float* grad_out, double* partials, float* loss_out,
+                  double* loss_accum, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,26 @@ def broadcast_parameters(flat, group=None, src=0):
     return flat
 
 
+def broadcast_buffers(model, group=None, src=0):
+    """BatchNorm running statistics / num_batches_tracked of rank `src` to everyone (after loading a checkpoint;
+    during training they stay rank-local and rank 0's are what a checkpoint stores)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        for b in model.buffers():
+            dist.broadcast(b, src=src, group=group)
+    return model
+
+
+def mean_over_ranks(values, group=None):
+    """list of python floats -> their mean over the ranks (one small all-reduce; identity without a group).
+    Used once per epoch for the logged loss terms: every rank holds the mean over ITS shards."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return list(values)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return (t / dist.get_world_size(group)).cpu().tolist()
+
+
 def adam_reference_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
                     weight_decay=0.0, grad_scale=1.0):
     """torch restatement of the flat HIP Adam kernel (`pdes_adam_step`): used by the CPU tests of the

@@ -95,25 +95,29 @@ class MixedResidualTrainer:
         m = self.model
         assert m._flat is self.flat, 'the model was re-flattened (moved to another device?) after the trainer was built'
         y = self.eng.forward(self.x_static, True, defer_running=True)
-        # loss_out = NULL: the per-image partials are reduced (and accumulated for the epoch mean) by the
-        # end-of-step launch of the backward, together with the BatchNorm bookkeeping
-        rc = L.pdes_darcy_loss(self.ctx, self.x_static.data_ptr(), y.data_ptr(), self.grad_y.data_ptr(),
-                               self.partials.data_ptr(), None, self.B, self.n, self.n,
-                               1.0, 1.0, self.wb, self.wb, 1 if self.nl else 0, self.nb1, self.nb2, st)
-        _lib.check(rc, 'pdes_darcy_loss')
+        tail = self._loss(y, st)
         if not self._grad_clean or m._grad_dirty:      # an autograd backward of the same model shares this buffer
             self.gflat.zero_()
             m._grad_dirty = False
         hook = self._hook if (self.overlap_allreduce and not self.use_graph) else None
         self._hook_error = None
         try:
-            self.eng.backward(self.grad_y, tail=(True, self.partials, self.B, self.n, self.n, 1.0, 1.0, self.wb,
-                                                  self.wb, self.terms, self.terms_accum), bucket_hook=hook)
+            self.eng.backward(self.grad_y, tail=tail, bucket_hook=hook)
         except RuntimeError:
             if self._hook_error is not None:                  # the all-reduce of bucket A failed inside the callback
                 raise self._hook_error
             raise
         return m
+
+    def _loss(self, y, st):
+        """loss + dL/dy of the network output `y` into self.grad_y; returns the `tail` of Engine.backward"""
+        # loss_out = NULL: the per-image partials are reduced (and accumulated for the epoch mean) by the
+        # end-of-step launch of the backward, together with the BatchNorm bookkeeping
+        rc = self._L.pdes_darcy_loss(self.ctx, self.x_static.data_ptr(), y.data_ptr(), self.grad_y.data_ptr(),
+                                     self.partials.data_ptr(), None, self.B, self.n, self.n,
+                                     1.0, 1.0, self.wb, self.wb, 1 if self.nl else 0, self.nb1, self.nb2, st)
+        _lib.check(rc, 'pdes_darcy_loss')
+        return (True, self.partials, self.B, self.n, self.n, 1.0, 1.0, self.wb, self.wb, self.terms, self.terms_accum)
 
     def _set_hyper(self, lr):
         self.step_count += 1
@@ -197,3 +201,28 @@ class MixedResidualTrainer:
         self.terms_accum.zero_()
         self.n_accum = 0
         return t
+
+
+class MaxLikelihoodTrainer(MixedResidualTrainer):
+    """The data-driven loop body of train_codec_max_likelihood.py:197-211 (same DenseED, F.mse_loss against FEniCS
+    targets) on the same fused step: only the loss launch differs (pdes_mse_loss instead of pdes_darcy_loss)."""
+
+    def __init__(self, model, batch_size, imsize=64, out_channels=3, **kw):
+        super().__init__(model, batch_size, imsize, **kw)
+        self.target_static = torch.zeros((batch_size, out_channels, imsize, imsize), device=self.dev)
+        n = self.target_static.numel()
+        self._mse_partials = torch.empty(self._L.pdes_mse_partials(n), device=self.dev, dtype=torch.float64)
+
+    def _loss(self, y, st):
+        # the finalize launch adds the batch loss to terms_accum[0] (epoch mean, one host sync per epoch)
+        rc = self._L.pdes_mse_loss(y.data_ptr(), self.target_static.data_ptr(), self.grad_y.data_ptr(),
+                                   self._mse_partials.data_ptr(), self.terms.data_ptr(), self.terms_accum.data_ptr(),
+                                   y.numel(), st)
+        _lib.check(rc, 'pdes_mse_loss')
+        return (True, None, self.B, self.n, self.n, 0.0, 0.0, 0.0, 0.0, None, None)
+
+    def step(self, x=None, target=None, lr=None):
+        """one step on (input, target); None = reuse the static buffers"""
+        if target is not None:
+            self.target_static.copy_(target)
+        super().step(x, lr)

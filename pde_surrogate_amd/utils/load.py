@@ -6,6 +6,7 @@ the (non-redistributed) datasets.
 `h5py` is optional: it is only imported when an .hdf5 file is actually opened; `.npz` files with the
 same two arrays are accepted too."""
 import json
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -19,7 +20,10 @@ def load_args(run_dir):
 
 
 def read_arrays(path, ndata, only_input=True):
-    """(x, y or None) from an .hdf5 / .npz file holding `input` and `output`."""
+    """(x, y or None) from an .hdf5 / .npz file holding `input` and `output`.  When the .hdf5 file named by the
+    reference's path convention is absent but an .npz with the same stem exists, that one is read."""
+    if not os.path.exists(path) and os.path.exists(os.path.splitext(path)[0] + '.npz'):
+        path = os.path.splitext(path)[0] + '.npz'
     if path.endswith('.npz'):
         with np.load(path) as f:
             x = f['input'][:ndata]

@@ -36,10 +36,41 @@ def test_parser_flags_defaults_and_run_dir(tmp_path, capsys):
                            '--batch-size', '8', '--blocks', '343'])
     assert a2.run_dir.startswith(f'{tmp_path}/codec/mixed_residual/debug/channelized_ntrain512')
     assert a2.blocks == [3, 4, 3]                      # reference quirk: type=list splits characters
-    with pytest.raises(AssertionError):
+    with pytest.raises(SystemExit):
         t.Parser().parse(['--exp-dir', str(tmp_path), '--ntrain', '100', '--batch-size', '32'])
     with pytest.raises(SystemExit):
         t.Parser().parse(['--exp-dir', str(tmp_path), '--upsample', 'cubic'])
+
+
+def test_parser_rejects_what_the_hip_path_cannot_run_before_creating_directories(tmp_path):
+    """--imsize 65 used to fail with PDES_ENOSUP after the run directory existed; the global batch must
+    divide the dataset under torchrun; only rank 0 writes"""
+    import train_codec_mixed_residual as t
+    with pytest.raises(SystemExit, match='imsize'):
+        t.Parser().parse(['--exp-dir', str(tmp_path / 'a'), '--imsize', '65'])
+    assert not (tmp_path / 'a').exists()
+    with pytest.raises(SystemExit, match='global batch'):
+        t.Parser().parse(['--exp-dir', str(tmp_path / 'b'), '--ntrain', '4096', '--batch-size', '32'], rank=0, world=3)
+    assert not (tmp_path / 'b').exists()
+    args = t.Parser().parse(['--exp-dir', str(tmp_path / 'c'), '--ntrain', '8192', '--batch-size', '32'], rank=1, world=8)
+    assert not os.path.exists(args.run_dir)                 # rank 1 creates nothing and writes no args.txt
+    args = t.Parser().parse(['--exp-dir', str(tmp_path / 'c'), '--ntrain', '8192', '--batch-size', '32'], rank=0, world=8)
+    assert os.path.exists(args.run_dir + '/args.txt')
+
+
+def test_max_likelihood_parser_matches_reference_defaults(tmp_path):
+    """train_codec_max_likelihood.py:25-56 of the reference: the same flags minus --weight-bound, its own defaults"""
+    import train_codec_max_likelihood as m
+    args = m.Parser().parse(['--exp-dir', str(tmp_path)])
+    want = dict(REFERENCE_DEFAULTS, exp_name='codec/max_likelihood', epochs=200, ckpt_freq=50)
+    want.pop('weight_bound')
+    for k, v in want.items():
+        if k != 'exp_dir':
+            assert getattr(args, k) == v, k
+    assert not hasattr(args, 'weight_bound')
+    assert args.run_dir == f'{tmp_path}/codec/max_likelihood/grf_kle512_ntrain4096_run1_bs32_lr0.001_epochs200'
+    with pytest.raises(SystemExit, match='targets'):
+        m.Parser().parse(['--exp-dir', str(tmp_path), '--synthetic'])
 
 
 def test_dataset_paths_match_reference_layout():

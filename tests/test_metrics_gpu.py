@@ -1,0 +1,182 @@
+"""GPU tests of the steps either side of the hot loop: test-time NRMSE / R^2 on the device, the
+MSE loss kernel, the data-driven harness (train_codec_max_likelihood.py) and the CLI's test() WITH targets."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def test_metrics_kernel_matches_reference_g9_and_g15(dev):
+    """the reference's test() arithmetic (train_codec_mixed_residual.py:180-197) on its own fixtures, accumulated over
+    several batches on the device"""
+    from pde_surrogate_amd.metrics import TestMetrics
+    g = golden('G9_metrics.npz')
+    m = TestMetrics(3, dev)
+    pred, tgt = torch.from_numpy(g['pred']).to(dev), torch.from_numpy(g['target']).to(dev)
+    for lo, hi in ((0, 2), (2, 6)):                          # ragged batches
+        m.update(pred[lo:hi].contiguous(), tgt[lo:hi].contiguous())
+    nrmse, r2 = m.result(g['y_variation'])
+    np.testing.assert_allclose(nrmse, g['nrmse'], rtol=1e-5)
+    np.testing.assert_allclose(r2, g['r2'], rtol=1e-5)
+    g = golden('G15_max_likelihood.npz')                      # 64x64 fields, the reference network's eval output
+    m = TestMetrics(3, dev)
+    o, t = torch.from_numpy(g['y_eval']).to(dev), torch.from_numpy(g['target']).to(dev)
+    for lo in (0, 8):
+        m.update(o[lo:lo + 8].contiguous(), t[lo:lo + 8].contiguous())
+    nrmse, r2 = m.result(g['y_variation'])
+    np.testing.assert_allclose(nrmse, g['nrmse_eval'], rtol=1e-5)
+    np.testing.assert_allclose(r2, g['r2_eval'], rtol=1e-5)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.update(o.cpu(), t.cpu())
+
+
+def test_mse_loss_kernel_value_gradient_and_fixture(dev):
+    from pde_surrogate_amd.metrics import mse_launch, mse_loss
+    g = golden('G15_max_likelihood.npz')
+    o, t = torch.from_numpy(g['y_eval']).to(dev), torch.from_numpy(g['target']).to(dev)
+    np.testing.assert_allclose(float(mse_loss(o, t)), float(g['mse_eval']), rtol=1e-5)
+    torch.manual_seed(0)
+    for shape in ((3, 3, 64, 64), (5, 1, 7, 9), (1, 1, 1, 1), (300, 3, 64, 64)):   # ragged sizes, tail, many blocks
+        a = torch.randn(shape, device=dev, requires_grad=True)
+        b = torch.randn(shape, device=dev)
+        loss = mse_loss(a, b)
+        (3.0 * loss).backward()
+        ref = torch.nn.functional.mse_loss(a.detach().double(), b.double())
+        np.testing.assert_allclose(float(loss.detach()), float(ref), rtol=1e-6)
+        want = 3.0 * 2.0 * (a.detach() - b) / a.numel()
+        assert rel_l2(a.grad.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    acc = torch.zeros(1, device=dev, dtype=torch.float64)
+    mse_launch(o, t, False, acc)
+    mse_launch(o, t, False, acc)
+    np.testing.assert_allclose(float(acc[0]), 2 * float(g['mse_eval']), rtol=1e-5)
+
+
+def test_g15_max_likelihood_fused_and_dropin_steps(dev):
+    """train_codec_max_likelihood.py:197-211 against the reference's 3-step trajectory: fused trainer and the drop-in
+    loop body (step 1: loss 1e-5, every gradient norm 1e-3; steps 2-3: the same descent)"""
+    from pde_surrogate_amd.metrics import mse_loss
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MaxLikelihoodTrainer
+    from pde_surrogate_amd.utils.practices import OneCycleScheduler, adjust_learning_rate
+    g, g6 = golden('G15_max_likelihood.npz'), golden('G6_densed_default.npz')
+    data, target = torch.from_numpy(g['data']).to(dev), torch.from_numpy(g['target']).to(dev)
+
+    def net():
+        import hashlib
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            n = DenseED(1, 3, 64, [6, 8, 6])
+        h = hashlib.sha256()
+        for k, v in n.state_dict().items():
+            h.update(k.encode())
+            h.update(v.numpy().tobytes())
+        if h.hexdigest() != str(g6['sha256']):
+            pytest.skip('local torch RNG stream differs from the fixture generator')
+        return n.to(dev).train()
+
+    sched = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)
+    # drop-in loop body
+    m = net()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for step in range(1, 4):
+        idx = torch.arange(8, device=dev) + 8 * ((step - 1) % 2)
+        m.zero_grad()
+        loss = mse_loss(m(data[idx]), target[idx])
+        loss.backward()
+        if step == 1:
+            norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+            np.testing.assert_allclose(norms, g['grad_norms_step1'], rtol=1e-3)
+            assert rel_l2(m.features.In_conv.weight.grad.cpu().numpy(), g['grad_In_conv_step1']) < 1e-3
+            assert rel_l2(m.features.LastTransUp.conv3.weight.grad.cpu().numpy(), g['grad_last_conv3_step1']) < 1e-3
+        lr = sched.step(step / 40)
+        assert abs(lr - g['lrs'][step - 1]) < 1e-12
+        adjust_learning_rate(opt, lr)
+        opt.step()
+        tol = {1: 1e-5, 2: 1e-3}.get(step, 0.05)
+        assert abs(loss.item() - g['losses'][step - 1]) <= tol * g['losses'][step - 1], step
+    # fused trainer
+    tr = MaxLikelihoodTrainer(net(), 8, 64, lr=1e-3, device=dev)
+    for step in range(1, 4):
+        idx = torch.arange(8, device=dev) + 8 * ((step - 1) % 2)
+        tr.step(data[idx], target[idx], sched.step(step / 40))
+        loss = tr.epoch_means()[0]
+        tol = {1: 1e-5, 2: 1e-3}.get(step, 0.05)
+        assert abs(loss - g['losses'][step - 1]) <= tol * g['losses'][step - 1], step
+
+
+def _write_npz_datasets(root, ntrain, ntest, seed=5):
+    """datasets in the reference's directory layout, as .npz (`input`, `output`): synthetic channelized inputs and
+    smooth made-up targets (FEniCS outputs are not available here; the metric arithmetic does not care)"""
+    from pde_surrogate_amd.utils.data import channelized_fields
+    d = root / '64x64'
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(seed)
+    for name, n, s in (('channel_ng64_n4096_train', ntrain, 1), ('channel_ng64_n512_test', ntest, 2)):
+        x = channelized_fields(n, 64, seed=seed + s)
+        u = np.broadcast_to(1 - np.linspace(0, 1, 64)[None, None, :], (n, 64, 64)) + 0.1 * rng.standard_normal((n, 1, 1))
+        y = np.stack([u, x[:, 0] * 0.1, 0.05 * rng.standard_normal((n, 64, 64))], 1)
+        np.savez(d / (name + '.npz'), input=x, output=y.astype(np.float32))
+
+
+def test_cli_test_pass_with_targets_reports_reference_metrics(dev, tmp_path, monkeypatch):
+    """the mixed-residual CLI reading datasets WITH targets (.npz with the reference's stem): nrmse_test / r2_test of
+    the run equal the reference formulas (oracle restatement) applied to the checkpointed model's eval output"""
+    import train_codec_mixed_residual as t
+    from oracle import train as otrain
+    from pde_surrogate_amd.models.codec import DenseED
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    _write_npz_datasets(tmp_path / 'data', 32, 16)
+    argv = ['--exp-dir', str(tmp_path), '--data-dir', str(tmp_path / 'data'), '--data', 'channelized', '--ntrain', '32',
+            '--ntest', '16', '--batch-size', '8', '--test-batch-size', '8', '--epochs', '2', '--ckpt-freq', '2',
+            '--cuda', '0', '--blocks', '111', '--growth-rate', '8', '--init-features', '16', '--plot-freq', '2']
+    with contextlib.redirect_stdout(io.StringIO()):
+        t.main(argv)
+    run = tmp_path / 'codec/mixed_residual/channelized_ntrain32_run1_bs8_lr0.001_epochs2'
+    nrmse, r2 = np.loadtxt(run / 'training/nrmse_test.txt'), np.loadtxt(run / 'training/r2_test.txt')
+    assert nrmse.shape == (2, 3) and r2.shape == (2, 3) and np.isfinite(nrmse).all() and np.isfinite(r2).all()
+    assert (run / 'training/predictions/pred_epoch2_0.png').exists()
+    with np.load(tmp_path / 'data/64x64/channel_ng64_n512_test.npz') as f:
+        x, y = f['input'][:16], f['output'][:16]
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DenseED(1, 3, 64, [1, 1, 1], growth_rate=8, init_features=16)
+    net.load_state_dict(torch.load(run / 'checkpoints/model_epoch2.pth', map_location='cpu'))
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        out = net(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want_nrmse, want_r2 = otrain.test_metrics(out, y, otrain.y_variation(y))
+    np.testing.assert_allclose(nrmse[-1], want_nrmse, rtol=1e-4)
+    np.testing.assert_allclose(r2[-1], want_r2, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('mode', ['fused', 'dropin'])
+def test_max_likelihood_cli_end_to_end(dev, tmp_path, monkeypatch, mode):
+    import train_codec_max_likelihood as m
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    _write_npz_datasets(tmp_path / 'data', 32, 16)
+    argv = ['--exp-dir', str(tmp_path), '--data-dir', str(tmp_path / 'data'), '--data', 'channelized', '--ntrain', '32',
+            '--ntest', '16', '--batch-size', '8', '--test-batch-size', '8', '--epochs', '3', '--ckpt-freq', '3',
+            '--cuda', '0', '--blocks', '111', '--growth-rate', '8', '--init-features', '16', '--mode', mode]
+    with contextlib.redirect_stdout(io.StringIO()):
+        logger = m.main(argv)
+    run = tmp_path / 'codec/max_likelihood/channelized_ntrain32_run1_bs8_lr0.001_epochs3'
+    for f in ('args.txt', 'checkpoints/model_epoch3.pth', 'training/loss_train.txt', 'training/loss_test.txt',
+              'training/nrmse_test.txt', 'training/r2_test.txt'):
+        assert os.path.exists(run / f), f
+    lt = np.loadtxt(run / 'training/loss_train.txt')
+    assert lt.shape == (3,) and lt[-1] < lt[0]
+    assert np.isfinite(np.loadtxt(run / 'training/r2_test.txt')).all()
+    a = json.load(open(run / 'args.txt'))
+    assert a['n_params'] > 0 and a['n_layers'] == 11

@@ -184,7 +184,7 @@ def gen_round2():
     np.savez_compressed(os.path.join(OUT, 'G15_max_likelihood.npz'), data=data, target=target,
                         losses=np.array(losses), lrs=np.array(lrs), grad_norms_step1=gn1, grad_In_conv_step1=g_in,
                         grad_last_conv3_step1=g_last, mse_eval=np.array(mse_eval), nrmse_eval=rel, r2_eval=r2,
-                        y_variation=yvar, y_eval0=o.numpy()[0])
+                        y_variation=yvar, y_eval=o.numpy())
 
 
 def main():

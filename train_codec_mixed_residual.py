@@ -35,6 +35,7 @@ from pde_surrogate_amd.models.darcy import conv_boundary_condition as boundary_c
 from pde_surrogate_amd.models.darcy import conv_constitutive_constraint as constitutive_constraint
 from pde_surrogate_amd.models.darcy import conv_continuity_constraint as continuity_constraint
 from pde_surrogate_amd.models.darcy import darcy_loss_launch
+from pde_surrogate_amd.metrics import TestMetrics
 from pde_surrogate_amd.train import MixedResidualTrainer
 from pde_surrogate_amd.utils.image_gradient import SobelFilter
 from pde_surrogate_amd.utils.load import DeviceLoader, load_data, read_arrays, y_variation
@@ -60,10 +61,31 @@ _REFERENCE_FLAGS = [
 ]
 
 
+SUPPORTED_IMSIZES = (16, 32, 64)       # the fused Sobel + residual kernels (csrc/darcy_loss.hip) are built for these
+
+
+def validate_args(args, world):
+    """reject what the HIP path cannot run BEFORE any directory is created (clear message instead of a late
+    PDES_ENOSUP): image sizes of the loss kernels, divisibility of the dataset by the GLOBAL batch"""
+    if args.imsize not in SUPPORTED_IMSIZES:
+        raise SystemExit(f'--imsize {args.imsize}: the HIP Sobel/Darcy-residual kernels support square fields of '
+                         f'{SUPPORTED_IMSIZES} pixels (the reference default is 64)')
+    if not (0.0 <= args.drop_rate < 1.0):
+        raise SystemExit(f'--drop-rate {args.drop_rate} must be in [0, 1)')
+    gb = args.batch_size * world
+    if args.ntrain % gb:
+        raise SystemExit(f'--ntrain {args.ntrain} is not a multiple of the global batch {args.batch_size} x {world} ranks')
+    if args.ntest % args.test_batch_size:
+        raise SystemExit(f'--ntest {args.ntest} is not a multiple of --test-batch-size {args.test_batch_size}')
+
+
 class Parser(argparse.ArgumentParser):
+    description = 'Learning surrogate with mixed residual norm loss (MI355X HIP build)'
+    flags = _REFERENCE_FLAGS
+
     def __init__(self):
-        super().__init__(description='Learning surrogate with mixed residual norm loss (MI355X HIP build)')
-        for flag, typ, default, choices in _REFERENCE_FLAGS:
+        super().__init__(description=self.description)
+        for flag, typ, default, choices in self.flags:
             kw = {'type': typ, 'default': default}
             if choices is not None:
                 kw['choices'] = choices
@@ -79,30 +101,33 @@ class Parser(argparse.ArgumentParser):
         self.add_argument('--synthetic', action='store_true', default=False,
                           help='generate inputs instead of reading HDF5 files')
 
-    def parse(self, argv=None):
+    def parse(self, argv=None, rank=0, world=1):
+        """rank / world: under torchrun every rank parses, only rank 0 creates directories, prints and writes args.txt"""
         args = self.parse_args(argv)
         if args.blocks and isinstance(args.blocks[0], str):       # reference quirk: type=list splits a CLI string
             args.blocks = [int(c) for c in args.blocks if c.isdigit()]
+        validate_args(args, world)
 
         hparams = f'{args.data}_ntrain{args.ntrain}_run{args.run}_bs{args.batch_size}_lr{args.lr}_epochs{args.epochs}'
         if args.debug:
             hparams = 'debug/' + hparams
         args.run_dir = args.exp_dir + '/' + args.exp_name + '/' + hparams
         args.ckpt_dir = args.run_dir + '/checkpoints'
-        mkdirs(args.run_dir, args.ckpt_dir)
+        if rank == 0:
+            mkdirs(args.run_dir, args.ckpt_dir)
 
         assert args.ntrain % args.batch_size == 0 and args.ntest % args.test_batch_size == 0
 
         if args.seed is None:
             args.seed = random.randint(1, 10000)
-        print("Random Seed: ", args.seed)
         random.seed(args.seed)
         torch.manual_seed(args.seed)
-
-        print('Arguments:')
-        pprint(vars(args))
-        with open(args.run_dir + "/args.txt", 'w') as args_file:
-            json.dump(vars(args), args_file, indent=4)
+        if rank == 0:
+            print("Random Seed: ", args.seed)
+            print('Arguments:')
+            pprint(vars(args))
+            with open(args.run_dir + "/args.txt", 'w') as args_file:
+                json.dump(vars(args), args_file, indent=4)
         return args
 
 
@@ -120,8 +145,8 @@ def dataset_files(args):
     return train, test
 
 
-def make_arrays(args):
-    """(x_train, x_test, y_test or None)"""
+def make_arrays(args, only_input=True):
+    """(x_train, x_test, y_test or None[, y_train when only_input is False])"""
     if args.synthetic:
         from pde_surrogate_amd.utils.data import channelized_fields, grf_kle_fields
         if args.data == 'grf_kle512':
@@ -130,6 +155,11 @@ def make_arrays(args):
             x = channelized_fields(args.ntrain + args.ntest, args.imsize)
         return x[:args.ntrain], x[args.ntrain:], None
     train_file, test_file = dataset_files(args)
+    if only_input is False:
+        x_train, y_train = read_arrays(train_file, args.ntrain, only_input=False)
+        x_test, y_test = read_arrays(test_file, args.ntest, only_input=False)
+        return (np.asarray(x_train, np.float32), np.asarray(x_test, np.float32), np.asarray(y_test, np.float32),
+                np.asarray(y_train, np.float32))
     x_train, _ = read_arrays(train_file, args.ntrain, only_input=True)
     x_test, y_test = read_arrays(test_file, args.ntest, only_input=False)
     return np.asarray(x_train, np.float32), np.asarray(x_test, np.float32), np.asarray(y_test, np.float32)
@@ -137,16 +167,20 @@ def make_arrays(args):
 
 def main(argv=None):
     rank, local_rank, world = parallel.init_from_env()
-    args = Parser().parse(argv)
+    args = Parser().parse(argv, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('this build runs on an MI355X (ROCm) only -- there is no CPU fallback for the HIP kernels')
     device = torch.device('cuda', local_rank if world > 1 else args.cuda % torch.cuda.device_count())
     torch.cuda.set_device(device)
     is_main = rank == 0
+    say = print if is_main else (lambda *a, **k: None)
 
     args.train_dir = args.run_dir + '/training'
     args.pred_dir = args.train_dir + '/predictions'
-    mkdirs(args.train_dir, args.pred_dir)
+    if is_main:
+        mkdirs(args.train_dir, args.pred_dir)
+    if world > 1:
+        torch.distributed.barrier()          # the run directory exists before any rank goes on
 
     model = DenseED(in_channels=1, out_channels=3, imsize=args.imsize, blocks=args.blocks,
                     growth_rate=args.growth_rate, init_features=args.init_features,
@@ -156,14 +190,14 @@ def main(argv=None):
     if args.ckpt_epoch is not None:
         ckpt_file = args.run_dir + f'/checkpoints/model_epoch{args.ckpt_epoch}.pth'
         model.load_state_dict(torch.load(ckpt_file, map_location='cpu'))
-        print(f'Loaded ckpt: {ckpt_file}')
-        print(f'Resume training from epoch {args.ckpt_epoch + 1} to {args.epochs}')
+        say(f'Loaded ckpt: {ckpt_file}')
+        say(f'Resume training from epoch {args.ckpt_epoch + 1} to {args.epochs}')
     model = model.to(device)
 
     x_train, x_test, y_test = make_arrays(args)
     have_targets = y_test is not None
     y_test_variation = y_variation(y_test) if have_targets else np.full(3, np.nan)
-    print(f'Test output variation per channel: {y_test_variation}')
+    say(f'Test output variation per channel: {y_test_variation}')
     train_loader = DeviceLoader(torch.from_numpy(x_train), batch_size=args.batch_size, device=device,
                                 seed=args.seed, rank=rank, world_size=world)
     test_tensors = [torch.from_numpy(x_test)] + ([torch.from_numpy(y_test)] if have_targets else [])
@@ -175,6 +209,7 @@ def main(argv=None):
         trainer = MixedResidualTrainer(model, args.batch_size, args.imsize, lr=args.lr, weight_decay=args.weight_decay,
                                        weight_bound=args.weight_bound, device=device, use_graph=args.graph)
         parallel.broadcast_parameters(trainer.flat)
+        parallel.broadcast_buffers(model)         # BatchNorm running statistics of a resumed checkpoint
     else:
         if world > 1:
             raise SystemExit('--mode dropin is the single-GPU reference loop; use --mode fused with torchrun')
@@ -182,22 +217,23 @@ def main(argv=None):
 
     logger = {'loss_train': [], 'loss_test': [], 'r2_test': [], 'nrmse_test': []}
 
+    metrics = TestMetrics(3, device) if have_targets else None
+
     def test(epoch, loss_train):
         model.eval()
-        loss_test, relative_l2, err2 = 0., [], []
+        loss_accum = torch.zeros(5, device=device, dtype=torch.float64)
+        if metrics is not None:
+            metrics.reset()
         nb = 0
         for batch in test_loader:
             input = batch[0]
             output = model(input)
             terms, _ = darcy_loss_launch(input, output, (1.0, 1.0, args.weight_bound, args.weight_bound), False)
-            t = terms.cpu().tolist()
-            loss_test += t[0]
+            loss_accum += terms            # device accumulation: the test pass syncs once, below
             nb += 1
             if have_targets:
                 target = batch[1]
-                err2_sum = torch.sum((output - target) ** 2, [-1, -2])
-                relative_l2.append(torch.sqrt(err2_sum / (target ** 2).sum([-1, -2])))
-                err2.append(err2_sum)
+                metrics.update(output, target)       # err2_sum / relative_l2 of the reference (:180-183), on device
                 if (epoch % args.plot_freq == 0 or epoch == args.epochs) and nb == len(test_loader) and is_main:
                     n_samples = 6 if epoch == args.epochs else 2
                     idx = torch.randperm(input.size(0))[:n_samples]
@@ -205,27 +241,26 @@ def main(argv=None):
                     for i in range(n_samples):
                         print('epoch {}: plotting prediction {}'.format(epoch, i))
                         plot_prediction_det(args.pred_dir, st[i], so[i], epoch, i, plot_fn=args.plot_fn)
-        loss_test /= nb
+        t = terms.cpu().tolist()               # last batch's terms, printed like the reference (:199-200)
+        loss_test = float(loss_accum[0]) / nb
         if have_targets:
-            rel = to_numpy(torch.cat(relative_l2, 0).mean(0))
-            r2_score = 1 - to_numpy(torch.cat(err2, 0).sum(0)) / y_test_variation
+            rel, r2_score = metrics.result(y_test_variation)
         else:
             rel, r2_score = np.full(3, np.nan), np.full(3, np.nan)
-        if is_main:
-            print(f"Epoch: {epoch}, test r2-score:  {r2_score}")
-            print(f"Epoch: {epoch}, test relative-l2:  {rel}")
-            print(f'Epoch {epoch}: test loss: {loss_test:.6f}, loss_pde: {t[1] + t[2]:.6f}, '
-                  f'dirichlet {t[3]:.6f}, nuemann {t[4]:.6f}')
+        say(f"Epoch: {epoch}, test r2-score:  {r2_score}")
+        say(f"Epoch: {epoch}, test relative-l2:  {rel}")
+        say(f'Epoch {epoch}: test loss: {loss_test:.6f}, loss_pde: {t[1] + t[2]:.6f}, '
+            f'dirichlet {t[3]:.6f}, nuemann {t[4]:.6f}')
         if epoch % args.log_freq == 0:
             logger['loss_test'].append(loss_test)
             logger['r2_test'].append(r2_score)
             logger['nrmse_test'].append(rel)
 
-    print('Start training...................................................')
+    say('Start training...................................................')
     start_epoch = 1 if args.ckpt_epoch is None else args.ckpt_epoch + 1
     tic = time.time()
     total_steps = args.epochs * len(train_loader)
-    print(f'total steps: {total_steps}')
+    say(f'total steps: {total_steps}')
     train_seconds = 0.0
     for epoch in range(start_epoch, args.epochs + 1):
         model.train()
@@ -236,7 +271,9 @@ def main(argv=None):
                 step = (epoch - 1) * len(train_loader) + batch_idx
                 lr = scheduler.step(step / total_steps)
                 trainer.step(input, lr)
-            loss_train, l_const, l_cont, loss_dirichlet, loss_neumann = trainer.epoch_means()   # the only host sync
+            # the only host sync of the epoch; under torchrun the five terms are averaged over the ranks (each rank
+            # accumulated the means of its own shards)
+            loss_train, l_const, l_cont, loss_dirichlet, loss_neumann = parallel.mean_over_ranks(trainer.epoch_means())
             loss_pde = l_const + l_cont
         else:
             loss_train = 0.
@@ -268,7 +305,7 @@ def main(argv=None):
             test(epoch, loss_train)
 
     tic2 = time.time()
-    print(f'Finished training {args.epochs} epochs with {args.ntrain} data using {(tic2 - tic) / 60:.2f} mins')
+    say(f'Finished training {args.epochs} epochs with {args.ntrain} data using {(tic2 - tic) / 60:.2f} mins')
     if is_main:
         save_stats(args.train_dir, logger, 'loss_train', 'loss_test', 'nrmse_test', 'r2_test')
         args.training_time = tic2 - tic
