@@ -69,24 +69,126 @@ def loss_kernel_timing(dev, B, iters, warmup=10, burst=False):
     return (us, gbs, gbs_burst) if burst else (us, gbs)
 
 
-def cpu_baseline(bs, steps=8):
-    """the CPU oracle (port of the reference's PyTorch-CPU path) on this box's host cores"""
-    from oracle import codec as oc, train as ot
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(bs, steps=10, warm=2):
+    """the CPU oracle (port of the reference's PyTorch-CPU path) on this box's host cores (2 warm-up +
+    >= 10 timed full steps at bs = 32, plus the loss-only forward + backward rate)"""
+    from oracle import codec as oc, darcy as od, train as ot
     from pde_surrogate_amd.utils.data import grf_kle_fields
-    import io
-    import contextlib
     torch.manual_seed(1)
     sd = oc.densed_init(1, 3, [6, 8, 6], 16, 48)
     tr = ot.CpuTrainer(sd, [6, 8, 6])
-    x = torch.from_numpy(grf_kle_fields(bs, seed=7))
-    tr.step(x)                                  # warm-up
+    x = torch.from_numpy(grf_kle_fields(bs, seed=7, cache_dir='/tmp'))
+    for _ in range(warm):
+        tr.step(x)
     t0 = time.time()
     for _ in range(steps):
         tr.step(x)
     dt = time.time() - t0
+    # loss only: Sobel + residual + boundary forward and its backward wrt the network output
+    y = torch.randn(bs, 3, 64, 64)
+    n_loss = 50
+    for i in range(2 + n_loss):
+        if i == 2:
+            t1 = time.time()
+        yy = y.clone().requires_grad_(True)
+        od.mixed_residual_loss(x, yy, 10.0)[0].backward()
+    dl = time.time() - t1
     return {'value': round(bs * steps / dt, 2), 'unit': 'samples/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'sample': f'{steps} full training steps (fwd+loss+bwd+Adam) at bs={bs}, '
-            f'PyTorch-CPU fp32 oracle, after 1 warm-up step'}
+            'kind': 'port', 'cpu_model': cpu_model(),
+            'loss_only_samples_per_s': round(bs * n_loss / dl, 1),
+            'sample': f'{steps} full training steps (fwd+loss+bwd+Adam) at bs={bs} after {warm} warm-up steps, and '
+                      f'{n_loss} loss-only fwd+bwd passes at bs={bs}; PyTorch-CPU fp32 oracle (port of the reference path)'}
+
+
+def conv1x1_timing(dev, B, iters=200):
+    """the 1x1 channel-halving layers (north_star: MFMA utilisation of the 1x1 path): live HIP-event timing of the
+    forward kernel of TransDown1.conv1 (144 -> 72 at 32x32) and TransUp1.conv1 (200 -> 100 at 16x16) on their own
+    descriptors, utilisation = 2*Cout*Cin*H*W*B / t / 157.3 TF (dense f32 MFMA peak of MI355X)"""
+    import contextlib
+    import ctypes
+    import io
+    from pde_surrogate_amd import _lib
+    from pde_surrogate_amd.models.codec import DenseED
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DenseED(1, 3, 64, [6, 8, 6]).to(dev).train()
+    x = torch.exp(0.5 * torch.randn(B, 1, 64, 64, device=dev))
+    with torch.no_grad():
+        net(x)
+    eng = net._engine(x)
+    L, st = _lib.lib(), _lib.stream_ptr()
+    out = []
+    for i, s in enumerate(net._specs):
+        if s.k != 1:
+            continue
+        ref = ctypes.byref(eng.descs[i])
+        for _ in range(20):
+            L.pdes_conv_forward(eng.ctx, ref, 1, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            L.pdes_conv_forward(eng.ctx, ref, 1, st)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        d = eng.descs[i]
+        flop = 2.0 * s.cout * s.cin * d.Hout * d.Wout * B
+        out.append({'layer': s.conv, 'gemm': f'M={s.cout} K={s.cin} N={d.Hout * d.Wout}x{B}', 'us_per_launch': round(us, 2),
+                    'achieved': round(flop / us / 1e6, 2), 'frac': round(flop / us / 1e6 / 157.3, 4)})
+    return out
+
+
+def rendezvous(gpus):
+    """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, one process per GPU, backend
+    nccl (= RCCL over xGMI) -- gloo only when there is no GPU at all (CPU test of this function).  Returns
+    (rank, local_rank, world, device)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != gpus:
+        raise SystemExit(f'--gpus {gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run '
+                         f'--nproc-per-node {gpus} bench.py --gpus {gpus}')
+    have_gpu = torch.cuda.is_available()
+    dev = torch.device('cuda', local) if have_gpu else torch.device('cpu')
+    if have_gpu:
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f'LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible')
+        torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if have_gpu:
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    return rank, local, world, dev
+
+
+def allreduce_timing(trainer, iters=50):
+    """stand-alone cost of the gradient exchange (both buckets back to back, nothing to overlap with): what the step
+    would pay for the all-reduce if it were NOT hidden under the backward pass"""
+    g = torch.zeros_like(trainer.gflat)
+    for _ in range(5):
+        torch.distributed.all_reduce(g)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.distributed.all_reduce(g)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
 
 
 def main():
@@ -101,19 +203,24 @@ def main():
                          'gradients on a second HIP stream, which measured faster than one serial graph)')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='initialise the process group (gloo when there is no GPU), count the ranks with one '
+                         'all-reduce, print it and exit: exercises the launch contract without touching a kernel')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
+    rank, local, world, dev = rendezvous(args.gpus)
+    if args.rendezvous_only:
+        t = torch.ones(1, device=dev if dev.type == 'cuda' else 'cpu')
+        if world > 1:
+            torch.distributed.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'rendezvous': 'ok', 'ranks': int(t.item()), 'world_size': world,
+                              'backend': torch.distributed.get_backend() if world > 1 else None}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    if dev.type != 'cuda':
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from pde_surrogate_amd.models.codec import DenseED
     from pde_surrogate_amd.train import MixedResidualTrainer
@@ -165,14 +272,17 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     means = trainer.epoch_means()
+    ar_us = allreduce_timing(trainer) if world > 1 else None
 
     if rank == 0:
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_loss_kernel_pmc.json')
-        if os.path.exists(pmc):                              # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            with open(pmc) as f:
-                pj = json.load(f)
-            traffic, traffic_src = pj['hbm_bytes_per_launch'], 'profiles/r01_loss_kernel_pmc.json (B=16384)'
+        for name in ('r02_loss_kernel_pmc.json', 'r01_loss_kernel_pmc.json'):
+            pmc = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(pmc):                          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                with open(pmc) as f:
+                    pj = json.load(f)
+                traffic, traffic_src = pj['hbm_bytes_per_launch'], f'profiles/{name} (B=16384)'
+                break
         us32, gb32 = loss_kernel_timing(dev, B, 200)
         usL, gbL, gbBurst = loss_kernel_timing(dev, 16384, 100, warmup=100, burst=True)
         out = {
@@ -184,6 +294,15 @@ def main():
             'config': {'workload': 'configs[1]: GRF KLE512 64x64, ntrain=%d, bs=%d per GPU, DenseED blocks [6,8,6] '
                                    'growth 16 init 48 (740,091 params), fp32, Adam + one-cycle LR' % (args.ntrain, B),
                        'global_batch': GB, 'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph), 'wgrad_stream': not args.graph,
+                       'ranks': torch.distributed.get_world_size() if world > 1 else 1,
+                       'collective': None if world == 1 else {
+                           'backend': 'nccl (RCCL over xGMI)', 'bytes_per_step': int(trainer.gflat.numel()) * 4,
+                           'buckets': 2 if trainer.overlap_allreduce and not args.graph else 1,
+                           'overlapped_with_backward': bool(trainer.overlap_allreduce and not args.graph),
+                           'allreduce_us_standalone': round(ar_us, 1),
+                           'note': 'bucket A (conv weights of the last layers, ~3/4 of the bytes) is all-reduced from the '
+                                   'weight-gradient stream inside pdes_backward; allreduce_us_standalone is the exchange '
+                                   'timed alone after the run (what the step would pay without the overlap)'},
                        'arithmetic': 'fp32 end to end; convolutions on v_mfma_f32_16x16x4_f32, except the 196->98 3x3 layer '
                                      '(forward + data gradient): both operands split into three bf16 terms, six cross '
                                      'products accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (24-bit significand '
@@ -201,6 +320,11 @@ def main():
                                            'frac': round(gb32 / HBM_PEAK_GBPS, 4),
                                            'note': 'cache-resident / launch-bound at the training batch size'}},
         }
+        if world == 1:
+            out['roofline_1x1'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'kernel': 'conv1x1_mfma_kernel (forward)',
+                                   'layers': conv1x1_timing(dev, B),
+                                   'note': 'the 1x1 channel-halving layers, HIP-event timed stand-alone at the training '
+                                           'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(B)
         print(json.dumps(out), flush=True)

@@ -91,3 +91,50 @@ def test_device_loader_shards_partition_epoch():
         assert len(dl) == 4
         got.append(torch.cat([b[0].flatten() for b in dl]))
     assert sorted(torch.cat(got).tolist()) == list(range(32))
+
+
+def test_bench_launch_contract_rendezvous_world2_gloo():
+    """bench.py under the driver's launch contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment,
+    --gpus N == WORLD_SIZE), up to the first CUDA call: two processes rendezvous (gloo here, nccl = RCCL on a GPU box),
+    count themselves with one all-reduce, rank 0 prints one JSON line; a mismatching --gpus is refused"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE='2')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rendezvous-only'],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line == {'rendezvous': 'ok', 'ranks': 2, 'world_size': 2, 'backend': 'gloo'}
+    assert 'rendezvous' not in outs[1][0]                         # only rank 0 prints the JSON line (gloo itself logs)
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rendezvous-only'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'WORLD_SIZE=1' in (p.stderr + p.stdout)
+
+
+def test_mean_over_ranks_and_buffer_broadcast_world2_gloo():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_mean, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1] == [1.5, 15.0]
+
+
+def _worker_mean(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend='gloo')
+    out[rank] = parallel.mean_over_ranks([1.0 + rank, 10.0 * (1 + rank)])
+    bn = torch.nn.BatchNorm2d(3)
+    bn.running_mean.fill_(float(rank + 1))
+    parallel.broadcast_buffers(bn)
+    assert float(bn.running_mean[0]) == 1.0
+    dist.barrier()
+    dist.destroy_process_group()
