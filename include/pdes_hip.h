@@ -73,12 +73,16 @@ int pdes_stat_replicas(void);
  *   loss_out (5)        OUT {total, L_const, L_cont, L_dir, L_neu}; NULL = skip the final reduce
  *   total = w_const*L_const + w_cont*L_cont + w_dir*L_dir + w_neu*L_neu
  *           (the reference's loss is w = (1, 1, weight_bound, weight_bound))
- *   nonlinear != 0: sigma + beta1*sqrt(K)*sigma^2 + beta2*K*sigma^3 constitutive law.
+ *   flags & PDES_LOSS_NONLINEAR: sigma + beta1*sqrt(K)*sigma^2 + beta2*K*sigma^3 constitutive law.
+ *   flags & PDES_LOSS_NO_TB: conv_continuity_constraint(use_tb=False), models/darcy.py:224 -- rows 0 and H-1 are left
+ *           out of the continuity residual (mean over (H-2) W pixels); linear law only (PDES_ENOSUP with NONLINEAR).
  *   H == W in {16, 32, 64}.
  */
+#define PDES_LOSS_NONLINEAR 1
+#define PDES_LOSS_NO_TB 2
 int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
                     int B, int H, int W, float w_const, float w_cont, float w_dir, float w_neu,
-                    int nonlinear, float beta1, float beta2, void* stream);
+                    int flags, float beta1, float beta2, void* stream);
 
 /* Stand-alone Sobel gradients of `nimg` single-channel images (either output may be NULL).
  * Replaces utils/image_gradient.py:50-75 (grad_h) and :77-92 (grad_v), filter_size=3. */
@@ -89,6 +93,13 @@ int pdes_sobel_grad(const float* img, float* gh, float* gv, int nimg, int H, int
  * This is what autograd computes for the reference's pad/conv2d/matmul chain. */
 int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg, int H,
                             int W, void* stream);
+
+/* The same two calls for filter_size = 5 (utils/image_gradient.py:35-41 kernel, :65-67 / :82-84 selection): replicate
+ * pad 2, 5x5 cross-correlation, the same boundary `modifier`.  Square images, 4 <= H <= 64.  No reference caller
+ * passes filter_size = 5; provided for completeness of SobelFilter's signature. */
+int pdes_sobel5_grad(const float* img, float* gh, float* gv, int nimg, int H, int W, int correct, void* stream);
+int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg, int H, int W,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DenseED / Decoder building blocks (models/codec.py).  One descriptor per convolution; the
@@ -104,10 +115,18 @@ int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img
  * and then dL/dx_c = invstd_c * (T_c - mean(T_c) - xhat_c * mean(T_c xhat_c)) (pdes_bn_backward_finalize),
  * which is exactly the sum of the BatchNorm backward formulas of all consumers (shared batch stats).
  */
+#define PDES_UPSAMPLE_NEAREST 1      /* nearest x2 between BN-ReLU and this convolution (fused into its operand load) */
+#define PDES_UPSAMPLE_BILINEAR_OP 2 /* this descriptor is NOT a convolution (ksize = 0, Cout = Cin, Hout = 2 Hin): it
+                                       writes out = bilinear_x2(relu(bn(x))), align_corners=True (codec.py:33-40); the
+                                       convolution that follows reads `out` through an identity BatchNorm whose
+                                       statistics {0, n (1 - eps)} this op stores in out_stats (replica 0).  Backward:
+                                       pdes_conv_backward_data applies the adjoint resampling + ReLU mask + gamma into
+                                       t_in, dgamma / dbeta into bn_grad; there is no weight gradient and `g` must be
+                                       dL/d(out) itself (fin_tstats = NULL) */
 typedef struct pdes_conv_desc {
   /* geometry */
   int B, Cin, Cout, Hin, Win, Hout, Wout;
-  int ksize, stride, pad, upsample; /* upsample=1: nearest x2 between BN-ReLU and the conv */
+  int ksize, stride, pad, upsample; /* upsample: 0, PDES_UPSAMPLE_NEAREST or PDES_UPSAMPLE_BILINEAR_OP */
   /* input activation (raw, pre-BN) */
   const float* x;        /* (B, x_ctot, Hin, Win); channels [0, Cin) are read */
   int x_ctot;

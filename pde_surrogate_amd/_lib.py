@@ -23,6 +23,8 @@ SIGNATURES = {
     'pdes_darcy_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_p],
     'pdes_sobel_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
     'pdes_sobel_grad_adjoint': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
+    'pdes_sobel5_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
+    'pdes_sobel5_grad_adjoint': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
     'pdes_conv_forward': [_c_p, _c_p, _c_i, _c_p],
     'pdes_conv_backward_weight': [_c_p, _c_p, _c_i, _c_p],
     'pdes_conv_backward_data': [_c_p, _c_p, _c_i, _c_p],

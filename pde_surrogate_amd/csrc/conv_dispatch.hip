@@ -20,6 +20,9 @@ int conv_backward_data_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = fa
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
 int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
+int upsample_bilinear_forward(const pdes_conv_desc& d, hipStream_t st);   // PDES_UPSAMPLE_BILINEAR_OP descriptors
+int upsample_bilinear_backward(const pdes_conv_desc& d, hipStream_t st);
+static bool is_resample_op(const pdes_conv_desc& d) { return d.upsample == PDES_UPSAMPLE_BILINEAR_OP; }
 
 // option PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
 // the matrix-core kernels against them); anything else = automatic selection.
@@ -33,6 +36,11 @@ extern "C" int pdes_conv_forward(const pdes_context* ctx, const pdes_conv_desc* 
   OptScope scope(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
+    if (is_resample_op(descs[i])) {
+      const int rc = upsample_bilinear_forward(descs[i], st);
+      if (rc) return rc;
+      continue;
+    }
     int rc = force_direct() ? PDES_ENOSUP : conv_forward_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_fewout(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_b3(descs[i], st);
@@ -49,6 +57,7 @@ extern "C" int pdes_conv_backward_weight(const pdes_context* ctx, const pdes_con
   OptScope scope(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
+    if (is_resample_op(descs[i])) continue;                          // a resampling op has no weights
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_weight_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && descs[i].g_fused) return PDES_EINVAL;      // only the matrix-core kernels finalize on load
     if (rc == PDES_ENOSUP) {
@@ -70,6 +79,11 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
   OptScope scope(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
+    if (is_resample_op(descs[i])) {
+      const int rc = upsample_bilinear_backward(descs[i], st);
+      if (rc) return rc;
+      continue;
+    }
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_b3(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_1x1(descs[i], st);
@@ -153,7 +167,7 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
     for (int i = 0; i < n; ++i) {
       pdes_conv_desc& d = local[i];
       d.g_fused = 0;
-      if (!d.fin_tstats || !d.fin_xstats || !d.out) continue;
+      if (!d.fin_tstats || !d.fin_xstats || !d.out || is_resample_op(d)) continue;
       if (d.Cout > opt().fuse_maxc || d.Hout * d.Wout > opt().fuse_maxhw) continue;   // wide layers: staging x next to T costs the consumers more than the kernel saves
       if (d.g_ctot != d.out_ctot || d.g_coff != d.out_coff || d.nrep != PDES_NREP) continue;
       const bool w_ok = conv_backward_weight_mfma(d, st, true) == PDES_OK;
@@ -173,7 +187,7 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
     // (saves the event hop; its scratch / dw are disjoint from what the second stream still works on)
-    {
+    if (!is_resample_op(d)) {
       const int rc = release(i, fork && i == 0);
       if (rc) return rc;
     }

@@ -177,7 +177,9 @@ struct Geo {
 };
 
 // ------------------------------------------------------------------------------------------
-template <int N, bool BWD, bool NONLIN>
+// NOTB: conv_continuity_constraint(use_tb=False), darcy.py:224 -- rows 0 and N-1 are left out of the continuity
+// residual (its mean is then over (N-2) N pixels per image: the host scales a_cont accordingly)
+template <int N, bool BWD, bool NONLIN, bool NOTB = false>
 __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS) : 1)) void darcy_loss_kernel(const float* __restrict__ Kp,
                                                                 const float* __restrict__ yp,
                                                                 float* __restrict__ gyp,
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS)
         q1 += 2.f * p.beta1 * sq * x1 + 3.f * p.beta2 * K * x1 * x1;
         q2 += 2.f * p.beta1 * sq * x2 + 3.f * p.beta2 * K * x2 * x2;
       }
-      const float c = gh1.v[i] + gv2.v[i];
+      const float c = (NOTB && tb) ? 0.f : gh1.v[i] + gv2.v[i];
       sum_const += r1 * r1 + r2 * r2;
       sum_cont += c * c;
       if (tb) sum_neu += s2_own.v[i] * s2_own.v[i];
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(1024) void darcy_loss_dma_kernel(const float* __res
 
 // Fixed-order fp64 reduction of the per-image partials -> out[5] = {total, const, cont, dir, neu}.
 __global__ __launch_bounds__(256) void darcy_loss_finalize(const float* __restrict__ partials, int B,
-                                                           float* __restrict__ out, double inv_n,
+                                                           float* __restrict__ out, double inv_n, double inv_cont,
                                                            double inv_dir, double inv_neu, float w0,
                                                            float w1, float w2, float w3) {
   __shared__ double sh[4][4];
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(256) void darcy_loss_finalize(const float* __restri
     double t[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
-    const double lc = t[0] * inv_n, lt = t[1] * inv_n, ld = t[2] * inv_dir, ln = t[3] * inv_neu;
+    const double lc = t[0] * inv_n, lt = t[1] * inv_cont, ld = t[2] * inv_dir, ln = t[3] * inv_neu;
     out[0] = (float)(w0 * lc + w1 * lt + w2 * ld + w3 * ln);
     out[1] = (float)lc; out[2] = (float)lt; out[3] = (float)ld; out[4] = (float)ln;
   }
@@ -584,10 +586,117 @@ __global__ __launch_bounds__(Geo<N>::NT) void sobel_adjoint_kernel(const float* 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// filter_size = 5 (image_gradient.py:35-41, :65-67, :82-84): replicate pad 2, the 5x5 kernel below (NOT separable),
+// x image size, and the same 3-point boundary `modifier`.  No reference caller selects it; one thread per pixel,
+// plane in LDS, any square n <= 64.
+__constant__ float kSobel5[5][5] = {{-5.f / 240, -4.f / 240, 0.f, 4.f / 240, 5.f / 240},
+                                    {-8.f / 240, -10.f / 240, 0.f, 10.f / 240, 8.f / 240},
+                                    {-10.f / 240, -20.f / 240, 0.f, 20.f / 240, 10.f / 240},
+                                    {-8.f / 240, -10.f / 240, 0.f, 10.f / 240, 8.f / 240},
+                                    {-5.f / 240, -4.f / 240, 0.f, 4.f / 240, 5.f / 240}};   // d/dx; transposed = d/dy
+
+__device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
+
+// raw (uncorrected) 5x5 response at (r, c) of the plane in LDS; horiz: d/dx, else d/dy
+__device__ __forceinline__ float sobel5_raw(const float* pl, int n, int r, int c, bool horiz) {
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float w = horiz ? kSobel5[i][j] : kSobel5[j][i];
+      a += w * pl[clampi(r + i - 2, n) * n + clampi(c + j - 2, n)];
+    }
+  return a * (float)n;
+}
+
+__global__ __launch_bounds__(256) void sobel5_grad_kernel(const float* __restrict__ img, float* __restrict__ gh,
+                                                          float* __restrict__ gv, int n, int correct) {
+  extern __shared__ float pl[];
+  const float* src = img + (size_t)blockIdx.x * n * n;
+  for (int i = threadIdx.x; i < n * n; i += 256) pl[i] = src[i];
+  __syncthreads();
+  for (int p = threadIdx.x; p < n * n; p += 256) {
+    const int r = p / n, c = p % n;
+    if (gh) {
+      float g = sobel5_raw(pl, n, r, c, true);
+      if (correct && c == 0) g = 4.f * g - sobel5_raw(pl, n, r, 1, true);              // grad @ modifier, column 0
+      if (correct && c == n - 1) g = 4.f * g - sobel5_raw(pl, n, r, n - 2, true);
+      gh[(size_t)blockIdx.x * n * n + p] = g;
+    }
+    if (gv) {
+      float g = sobel5_raw(pl, n, r, c, false);
+      if (correct && r == 0) g = 4.f * g - sobel5_raw(pl, n, 1, c, false);              // modifier^T @ grad, row 0
+      if (correct && r == n - 1) g = 4.f * g - sobel5_raw(pl, n, n - 2, c, false);
+      gv[(size_t)blockIdx.x * n * n + p] = g;
+    }
+  }
+}
+
+// adjoint: img_bar = grad_h^T(gh_bar) + grad_v^T(gv_bar), correct = True.  First the adjoint of the modifier
+// (column / row 0 and n-1 couple to their neighbour), then a gather over every (output pixel, tap) whose clamped
+// source is this pixel.
+__global__ __launch_bounds__(256) void sobel5_adjoint_kernel(const float* __restrict__ ghb, const float* __restrict__ gvb,
+                                                             float* __restrict__ out, int n) {
+  extern __shared__ float sm[];
+  float* a = sm;              // modifier-adjoint of gh_bar
+  float* b = sm + n * n;      // modifier-adjoint of gv_bar
+  const size_t base = (size_t)blockIdx.x * n * n;
+  for (int p = threadIdx.x; p < n * n; p += 256) {
+    const int r = p / n, c = p % n;
+    float va = 0.f, vb = 0.f;
+    if (ghb) {
+      va = ghb[base + p];
+      if (c == 0) va *= 4.f;
+      if (c == n - 1) va *= 4.f;
+      if (c == 1) va -= ghb[base + r * n];
+      if (c == n - 2) va -= ghb[base + r * n + n - 1];
+    }
+    if (gvb) {
+      vb = gvb[base + p];
+      if (r == 0) vb *= 4.f;
+      if (r == n - 1) vb *= 4.f;
+      if (r == 1) vb -= gvb[base + c];
+      if (r == n - 2) vb -= gvb[base + (size_t)(n - 1) * n + c];
+    }
+    a[p] = va; b[p] = vb;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < n * n; p += 256) {
+    const int r = p / n, c = p % n;
+    float acc = 0.f;
+    // output rows orow and taps i with clamp(orow + i - 2) == r
+    for (int i = 0; i < 5; ++i) {
+      int olo = r - (i - 2), ohi = olo;                       // interior: exactly one output row per tap
+      if (r == 0) { olo = 0; ohi = -(i - 2); }                // orow + i - 2 <= 0
+      if (r == n - 1) { olo = n - 1 - (i - 2); ohi = n - 1; } // orow + i - 2 >= n - 1
+      if (olo < 0) olo = 0;
+      if (ohi > n - 1) ohi = n - 1;
+      for (int orow = olo; orow <= ohi; ++orow)
+        for (int j = 0; j < 5; ++j) {
+          int clo = c - (j - 2), chi = clo;
+          if (c == 0) { clo = 0; chi = -(j - 2); }
+          if (c == n - 1) { clo = n - 1 - (j - 2); chi = n - 1; }
+          if (clo < 0) clo = 0;
+          if (chi > n - 1) chi = n - 1;
+          for (int ocol = clo; ocol <= chi; ++ocol)
+            acc += kSobel5[i][j] * a[orow * n + ocol] + kSobel5[j][i] * b[orow * n + ocol];
+        }
+    }
+    out[base + p] = acc * (float)n;
+  }
+}
+
 template <int N>
 static int launch_loss(const float* K, const float* y, float* gy, float* partials, int B, LossParams p,
-                       int nonlinear, hipStream_t st) {
+                       int nonlinear, int no_tb, hipStream_t st) {
   dim3 grid(B), block(Geo<N>::NT);
+  if (no_tb) {          // linear law only (the drop-in function takes no K at all)
+    if (gy) hipLaunchKernelGGL((darcy_loss_kernel<N, true, false, true>), grid, block, 0, st, K, y, gy, partials, p);
+    else hipLaunchKernelGGL((darcy_loss_kernel<N, false, false, true>), grid, block, 0, st, K, y, gy, partials, p);
+    return 0;
+  }
   if (gy) {
     if (nonlinear) hipLaunchKernelGGL((darcy_loss_kernel<N, true, true>), grid, block, 0, st, K, y, gy, partials, p);
     else hipLaunchKernelGGL((darcy_loss_kernel<N, true, false>), grid, block, 0, st, K, y, gy, partials, p);
@@ -604,16 +713,19 @@ using namespace pdes;
 
 extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
                                float* loss_out, int B, int H, int W, float w_const, float w_cont,
-                               float w_dir, float w_neu, int nonlinear, float beta1, float beta2,
+                               float w_dir, float w_neu, int flags, float beta1, float beta2,
                                void* stream) {
   if (!K || !y || !partials || B <= 0) return PDES_EINVAL;
+  const int nonlinear = flags & PDES_LOSS_NONLINEAR, no_tb = (flags & PDES_LOSS_NO_TB) ? 1 : 0;
+  if (nonlinear && no_tb) return PDES_ENOSUP;
   if (H != W || !(H == 16 || H == 32 || H == 64)) return PDES_ENOSUP;
   if (!aligned16(K) || !aligned16(y) || !aligned16(partials) || (grad_y && !aligned16(grad_y))) return PDES_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double ntot = (double)B * H * W;
   LossParams p;
   p.a_const = (float)(2.0 * w_const / ntot);
-  p.a_cont = (float)(2.0 * w_cont / ntot);
+  const double ncont = no_tb ? (double)B * (H - 2) * W : ntot;
+  p.a_cont = (float)(2.0 * w_cont / ncont);
   p.b_dir = (float)(2.0 * w_dir / ((double)B * H));
   p.b_neu = (float)(2.0 * w_neu / (2.0 * B * W));
   p.beta1 = beta1;
@@ -627,7 +739,7 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
   // box (it is steadier, and faster at B = 2048: 4.7-4.9 vs 4.0-4.9 TB/s) -- with 16 waves per CU the stencil
   // arithmetic and LDS traffic of one image take about as long as its HBM traffic.
   { const bool dma = opt().loss_dma != 0;
-    if (dma && H == 64 && grad_y) {
+    if (dma && H == 64 && grad_y && !no_tb) {
       const int nwg = B < 256 ? B : 256;
       const size_t lds = 0;      // static LDS: two 64 KiB image buffers
       if (nonlinear) hipLaunchKernelGGL(darcy_loss_dma_kernel<true>, dim3(nwg), dim3(1024), lds, st, K, y, grad_y, partials, p, B);
@@ -636,12 +748,12 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
     }
   }
   if (H == 0) { H = 64; }
-  else if (H == 64) launch_loss<64>(K, y, grad_y, partials, B, p, nonlinear, st);
-  else if (H == 32) launch_loss<32>(K, y, grad_y, partials, B, p, nonlinear, st);
-  else launch_loss<16>(K, y, grad_y, partials, B, p, nonlinear, st);
+  else if (H == 64) launch_loss<64>(K, y, grad_y, partials, B, p, nonlinear, no_tb, st);
+  else if (H == 32) launch_loss<32>(K, y, grad_y, partials, B, p, nonlinear, no_tb, st);
+  else launch_loss<16>(K, y, grad_y, partials, B, p, nonlinear, no_tb, st);
   PDES_LAUNCH_CHECK();
   if (loss_out) {
-    hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partials, B, loss_out, 1.0 / ntot,
+    hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partials, B, loss_out, 1.0 / ntot, 1.0 / ncont,
                        1.0 / ((double)B * H), 1.0 / (2.0 * B * W), w_const, w_cont, w_dir, w_neu);
     PDES_LAUNCH_CHECK();
   }
@@ -670,6 +782,26 @@ extern "C" int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar,
   if (H == 64) hipLaunchKernelGGL(sobel_adjoint_kernel<64>, dim3(nimg), dim3(Geo<64>::NT), 0, st, gh_bar, gv_bar, img_bar);
   else if (H == 32) hipLaunchKernelGGL(sobel_adjoint_kernel<32>, dim3(nimg), dim3(Geo<32>::NT), 0, st, gh_bar, gv_bar, img_bar);
   else hipLaunchKernelGGL(sobel_adjoint_kernel<16>, dim3(nimg), dim3(Geo<16>::NT), 0, st, gh_bar, gv_bar, img_bar);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_sobel5_grad(const float* img, float* gh, float* gv, int nimg, int H, int W, int correct,
+                                void* stream) {
+  if (!img || (!gh && !gv) || nimg <= 0) return PDES_EINVAL;
+  if (H != W || H < 4 || H > 64) return PDES_ENOSUP;
+  hipLaunchKernelGGL(sobel5_grad_kernel, dim3(nimg), dim3(256), (size_t)H * W * 4, static_cast<hipStream_t>(stream), img,
+                     gh, gv, H, correct);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg, int H,
+                                        int W, void* stream) {
+  if ((!gh_bar && !gv_bar) || !img_bar || nimg <= 0) return PDES_EINVAL;
+  if (H != W || H < 4 || H > 64) return PDES_ENOSUP;
+  hipLaunchKernelGGL(sobel5_adjoint_kernel, dim3(nimg), dim3(256), (size_t)2 * H * W * 4,
+                     static_cast<hipStream_t>(stream), gh_bar, gv_bar, img_bar, H);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

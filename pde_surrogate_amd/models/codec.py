@@ -76,14 +76,37 @@ def _pad16(n):
 
 # ------------------------------------------------------------------------------------------------
 # network description: a list of convolution specs in forward order
-class _ConvSpec:
-    __slots__ = ('conv', 'norm', 'cin', 'cout', 'k', 'stride', 'pad', 'up', 'src', 'dst', 'dst_coff', 'scale')
+UP_NEAREST, UP_BILINEAR_OP = 1, 2     # pdes_conv_desc.upsample (include/pdes_hip.h)
 
-    def __init__(self, conv, norm, cin, cout, k, stride, pad, up, src, dst, dst_coff, scale):
+
+class _ConvSpec:
+    """one descriptor of the chain: a convolution with the BatchNorm+ReLU that precedes it -- or, with conv = None and
+    up = UP_BILINEAR_OP, the bilinear x2 resampling of relu(bn(x)) into its own buffer; the convolution after such an op
+    has no BatchNorm module of its own and reads the resampled buffer through an identity BatchNorm (`fake_bn`)"""
+    __slots__ = ('conv', 'norm', 'cin', 'cout', 'k', 'stride', 'pad', 'up', 'src', 'dst', 'dst_coff', 'scale', 'fake_bn')
+
+    def __init__(self, conv, norm, cin, cout, k, stride, pad, up, src, dst, dst_coff, scale, fake_bn=False):
         self.conv, self.norm = conv, norm          # module paths under `features`
         self.cin, self.cout, self.k, self.stride, self.pad, self.up = cin, cout, k, stride, pad, up
         self.src, self.dst, self.dst_coff = src, dst, dst_coff   # activation buffer ids
         self.scale = scale                          # (num, den): input-buffer size = imsize*num/den
+        self.fake_bn = fake_bn
+
+    @property
+    def bn(self):
+        """the kernels apply a BatchNorm+ReLU on operand load (a real module's, or the identity one)"""
+        return self.norm is not None or self.fake_bn
+
+
+def _plan_up_conv(specs, bufs, t, conv, norm, cin, cout, mid, nxt, res, nres, upsample):
+    """BN-ReLU -> x2 upsampling -> conv3x3 (reference codec.py:137-146 / :174-181)"""
+    if upsample == 'nearest':
+        specs.append(_ConvSpec(conv, norm, cin, cout, 3, 1, 1, UP_NEAREST, mid, nxt, 0, res))
+        return
+    up = mid + 'u'                                   # the resampled activation: (B, cin, 2H, 2W)
+    bufs[up] = [cin, nres]
+    specs.append(_ConvSpec(None, norm, cin, cin, 0, 1, 0, UP_BILINEAR_OP, mid, up, 0, res))
+    specs.append(_ConvSpec(conv, None, cin, cout, 3, 1, 1, 0, up, nxt, 0, nres, fake_bn=True))
 
 
 def _plan_block(specs, bufs, name, c, n_layers, growth, src, scale):
@@ -95,7 +118,7 @@ def _plan_block(specs, bufs, name, c, n_layers, growth, src, scale):
     return c
 
 
-def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsize):
+def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsize, upsample='nearest'):
     """stage order and channel bookkeeping of DenseED (reference codec.py:229-293)"""
     if len(blocks) > 1 and len(blocks) % 2 == 0:
         raise ValueError('length of blocks must be an odd number, but got {}'.format(len(blocks)))
@@ -130,13 +153,13 @@ def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsiz
             specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
             nres = (res[0] * 2, res[1])
             bufs[nxt] = [c // 2 + dec[i] * growth, nres]
-            specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 2, 3, 1, 1, 1, mid, nxt, 0, res))
+            _plan_up_conv(specs, bufs, t, t + '.conv2', t + '.norm2', c // 2, c // 2, mid, nxt, res, nres, upsample)
             cur, c, res = nxt, c // 2, nres
-    _plan_last(specs, bufs, cur, c, res, out_channels, nb)
+    _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample)
     return specs, bufs
 
 
-def _plan_last(specs, bufs, cur, c, res, out_channels, nb):
+def _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample='nearest'):
     """last decoding (reference codec.py:163-188)"""
     t = 'LastTransUp'
     m1, m2 = f'b{nb}', f'b{nb + 1}'
@@ -144,12 +167,12 @@ def _plan_last(specs, bufs, cur, c, res, out_channels, nb):
     specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 3, 1, 1, 0, cur, m1, 0, res))
     nres = (res[0] * 2, res[1])
     bufs[m2] = [c // 4, nres]
-    specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 4, 3, 1, 1, 1, m1, m2, 0, res))
+    _plan_up_conv(specs, bufs, t, t + '.conv2', t + '.norm2', c // 2, c // 4, m1, m2, res, nres, upsample)
     bufs['out'] = [out_channels, nres]
     specs.append(_ConvSpec(t + '.conv3', t + '.norm3', c // 4, out_channels, 5, 1, 2, 0, m2, 'out', 0, nres))
 
 
-def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels):
+def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels, upsample='nearest'):
     """Decoder (reference codec.py:326-354); sizes are relative to the latent map (16x16 -> 64x64)"""
     specs, bufs = [], {}
     res = (1, 1)
@@ -167,9 +190,9 @@ def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels):
             specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
             nres = (res[0] * 2, res[1])
             bufs[nxt] = [c // 2 + blocks[i] * growth, nres]
-            specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 2, 3, 1, 1, 1, mid, nxt, 0, res))
+            _plan_up_conv(specs, bufs, t, t + '.conv2', t + '.norm2', c // 2, c // 2, mid, nxt, res, nres, upsample)
             cur, c, res = nxt, c // 2, nres
-    _plan_last(specs, bufs, cur, c, res, out_channels, nb)
+    _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample)
     return specs, bufs
 
 
@@ -191,7 +214,8 @@ def _build_modules(features, specs):
         if s.norm is not None:
             _add_path(features, s.norm, nn.BatchNorm2d(s.cin))
             # the reference inserts ReLU (and upsample) modules here; they hold no state
-        _add_path(features, s.conv, nn.Conv2d(s.cin, s.cout, s.k, s.stride, s.pad, bias=False))
+        if s.conv is not None:
+            _add_path(features, s.conv, nn.Conv2d(s.cin, s.cout, s.k, s.stride, s.pad, bias=False))
 
 
 def _get(root, path):
@@ -237,8 +261,8 @@ class _Engine:
         self.n_xstat = n_stat
         bn_off, n_bn = {}, 0
         for s in specs:
-            if s.norm is not None:
-                bn_off[s.norm] = n_bn
+            if s.bn:                                   # identity BatchNorms get a (never read) slot too
+                bn_off[s.norm or ('identity:' + s.conv)] = n_bn
                 n_bn += 2 * s.cin
         # NREP replicas of the whole arena spread same-address fp64 atomics (readers sum them)
         self.nrep, self.rep_stride = _lib.lib().pdes_stat_replicas(), 2 * n_stat + n_bn
@@ -263,12 +287,14 @@ class _Engine:
             d.ksize, d.stride, d.pad, d.upsample = s.k, s.stride, s.pad, s.up
             d.x = self.X[s.src].data_ptr()
             d.x_ctot = bufs[s.src][0]
-            d.has_bn = 1 if s.norm is not None else 0
+            d.has_bn = 1 if s.bn else 0
             d.eval_mode = 0
             d.eps = 1e-5
-            conv = _get(net.features, s.conv)
-            d.w = conv.weight.data_ptr()
-            d.w_fwd, d.w_bwd = pk[s.conv][0].data_ptr(), pk[s.conv][1].data_ptr()
+            if s.conv is not None:
+                conv = _get(net.features, s.conv)
+                d.w = conv.weight.data_ptr()
+                d.w_fwd, d.w_bwd = pk[s.conv][0].data_ptr(), pk[s.conv][1].data_ptr()
+                d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
             d.cout_pad, d.cin_pad = _pad16(s.cout), _pad16(s.cin)
             mf = net._packed_mfma.get(s.conv)
             d.wm_fwd = mf[0].data_ptr() if mf else None
@@ -279,17 +305,20 @@ class _Engine:
             b3 = net._packed_b3.get(s.conv)
             d.wb_fwd = b3[0].data_ptr() if b3 else None
             d.wb_bwd = b3[1].data_ptr() if b3 else None
-            d.dw = net._grad_view[s.conv + '.weight'].data_ptr()
             d.ws, d.ws_bytes, d.ws_defer = net._ws.data_ptr(), net._ws.numel() * 4, 0
             d.nrep, d.rep_stride = self.nrep, self.rep_stride
-            if s.norm is not None:
-                bn = _get(net.features, s.norm)
-                d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
-                d.run_mean, d.run_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            if s.bn:
+                if s.norm is not None:
+                    bn = _get(net.features, s.norm)
+                    d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                    d.run_mean, d.run_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                else:            # identity BatchNorm over a resampled buffer (csrc/upsample_bilinear.hip)
+                    one, zero, var = net._identity_bn(dev, s.cin)
+                    d.gamma, d.beta, d.run_mean, d.run_var = one.data_ptr(), zero.data_ptr(), zero.data_ptr(), var.data_ptr()
                 d.x_stats = xs(s.src)
                 d.t_in = self.T[s.src].data_ptr()
                 d.t_stats = ts(s.src)
-                d.bn_grad = bg(s.norm)
+                d.bn_grad = bg(s.norm or ('identity:' + s.conv))
                 d.t_accumulate = 0 if last_reader[s.src] == i else 1
                 d.final_c0 = consumed.get(s.src, 0)
                 d.final_c1 = s.cin
@@ -301,6 +330,8 @@ class _Engine:
                 d.fin_xstats, d.fin_tstats = xs(s.dst), ts(s.dst)
                 d.g = self.T[s.dst].data_ptr()      # finalised in place before use
                 d.g_ctot, d.g_coff = bufs[s.dst][0], s.dst_coff
+                if s.up == UP_BILINEAR_OP:          # its consumer's BatchNorm is the identity: T IS dL/d(out)
+                    d.fin_xstats, d.fin_tstats = None, None
             else:
                 d.out_stats = None
                 d.g, d.g_ctot, d.g_coff = None, bufs[s.dst][0], 0
@@ -490,8 +521,8 @@ class _HipNet(nn.Module):
         if drop_rate and drop_rate > 0:
             raise NotImplementedError('drop_rate > 0 (Dropout2d) is not implemented by the HIP path '
                                       '(the reference default and every published setup use 0)')
-        if upsample != 'nearest':
-            raise NotImplementedError("only upsample='nearest' (the reference default) is implemented in HIP")
+        if upsample not in ('nearest', 'bilinear'):
+            raise ValueError(f"upsample must be 'nearest' or 'bilinear' (reference codec.py:132-146); got {upsample!r}")
         if out_activation is not None:
             raise NotImplementedError('out_activation is not implemented (the mixed-residual scripts pass None)')
         self._specs, self._bufs = specs, bufs
@@ -517,7 +548,7 @@ class _HipNet(nn.Module):
         flat = torch.empty(total, device=device, dtype=torch.float32)
         gflat = torch.zeros(total, device=device, dtype=torch.float32)
         self._grad_view = {}
-        conv_names = {'features.' + sp.conv + '.weight' for sp in self._specs}
+        conv_names = {'features.' + sp.conv + '.weight' for sp in self._specs if sp.conv is not None}
         order = [i for i, (nm, _) in enumerate(named) if nm not in conv_names] + \
                 [i for i, (nm, _) in enumerate(named) if nm in conv_names]
         offsets, off = [0] * len(named), 0
@@ -534,7 +565,14 @@ class _HipNet(nn.Module):
             views.append(self._grad_view[key])
         self._offsets = offsets
         # gradient-buffer offset of each layer's convolution weight (ascending in layer order)
-        self._conv_off = [offsets[[nm for nm, _ in named].index('features.' + sp.conv + '.weight')] for sp in self._specs]
+        # (a resampling op has no weights: it takes the offset of the convolution that follows it)
+        names = [nm for nm, _ in named]
+        self._conv_off, nxt_off = [0] * len(self._specs), total
+        for i in range(len(self._specs) - 1, -1, -1):
+            sp = self._specs[i]
+            if sp.conv is not None:
+                nxt_off = offsets[names.index('features.' + sp.conv + '.weight')]
+            self._conv_off[i] = nxt_off
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.running_mean.data = m.running_mean.data.to(device).contiguous()
@@ -544,7 +582,10 @@ class _HipNet(nn.Module):
         self._params = [p for _, p in named]
         # packed weight copies (zero padded once; the pack kernel rewrites the live part every forward)
         self._packed, items, mx = {}, [], 0
+        self._identity = {}
         for s in self._specs:
+            if s.conv is None:
+                continue
             kk = s.k * s.k
             wf = torch.zeros(s.cin * kk * _pad16(s.cout), device=device)
             wb = torch.zeros(s.cout * kk * _pad16(s.cin), device=device)
@@ -561,7 +602,7 @@ class _HipNet(nn.Module):
         # matrix-core weight images for the 1x1 / 3x3 stride-1 convolutions with >= 16 input channels
         self._packed_mfma, mitems, mmx = {}, [], 0
         for s in self._specs:
-            if s.k not in (1, 3, 5) or s.norm is None or (s.stride != 1 and not (s.stride == 2 and s.k == 3)):
+            if s.conv is None or s.k not in (1, 3, 5) or not s.bn or (s.stride != 1 and not (s.stride == 2 and s.k == 3)):
                 continue
             kk = s.k * s.k
             pad128 = lambda n: (n + 127) // 128 * 128            # N-tiles are padded to a multiple of 8
@@ -581,7 +622,7 @@ class _HipNet(nn.Module):
         self._packed_up, uitems, umx = {}, [], 0
         pad128 = lambda n: (n + 127) // 128 * 128
         for s in self._specs:
-            if not (s.up and s.k == 3 and s.stride == 1 and s.norm is not None):
+            if not (s.up == UP_NEAREST and s.k == 3 and s.stride == 1 and s.norm is not None):
                 continue
             nf, nb = _pad16(s.cin) * pad128(s.cout) * 16, _pad16(s.cout) * pad128(s.cin) * 16
             uf, ub = torch.zeros(nf, device=device), torch.zeros(nb, device=device)
@@ -598,7 +639,7 @@ class _HipNet(nn.Module):
         # three-way bf16 split images of the wide 3x3 layers (conv_mfma_b3.hip: fp32 accuracy on the bf16 matrix pipe)
         self._packed_b3, bitems, bmx = {}, [], 0
         for s in self._specs:
-            if not (s.k == 3 and s.stride == 1 and not s.up and s.norm is not None and s.cin >= 64 and s.cout >= 80):
+            if not (s.conv is not None and s.k == 3 and s.stride == 1 and not s.up and s.bn and s.cin >= 64 and s.cout >= 80):
                 continue
             nf, nb = ctypes.c_longlong(0), ctypes.c_longlong(0)
             _lib.check(_lib.lib().pdes_b3_image_elems(s.cout, s.cin, ctypes.byref(nf), ctypes.byref(nb)), 'pdes_b3_image_elems')
@@ -619,6 +660,16 @@ class _HipNet(nn.Module):
             arr = (MfmaPackItem * len(mitems))(*mitems)
             self._mpack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._engines = {}
+
+    def _identity_bn(self, device, c):
+        """(ones, zeros, 1 - eps) vectors: gamma / beta = running_mean / running_var of the identity BatchNorm through
+        which a convolution reads a resampled buffer"""
+        t = self._identity.get(device)
+        if t is None or t[0].numel() < c:
+            n = max(c, 256)
+            t = self._identity[device] = (torch.ones(n, device=device), torch.zeros(n, device=device),
+                                          torch.full((n,), 1.0 - 1e-5, device=device))
+        return t
 
     def _pack_weights(self):
         """rebuild every packed weight image from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables)"""
@@ -685,12 +736,13 @@ class _HipNet(nn.Module):
         y = self.forward(x)
         eng = self._engine(x)
         seen = []
-        for s in self._specs:
+        convs = [s for s in self._specs if s.conv is not None]
+        for s in convs:
             stage = s.conv.split('.')[0]
             if stage not in seen:
                 seen.append(stage)
         for stage in seen:
-            last = [s for s in self._specs if s.conv.split('.')[0] == stage][-1]
+            last = [s for s in convs if s.conv.split('.')[0] == stage][-1]
             c = last.dst_coff + last.cout
             h, w = eng.buf_hw[last.dst]
             print('{}: {}'.format(stage, torch.Size((x.shape[0], c, h, w))))
@@ -721,7 +773,7 @@ class DenseED(_HipNet):
         if bottleneck:
             raise NotImplementedError('bottleneck dense layers are not implemented (reference default False)')
         blocks = [int(b) for b in blocks]
-        specs, bufs = _plan_densed(blocks, growth_rate, init_features, in_channels, out_channels, imsize)
+        specs, bufs = _plan_densed(blocks, growth_rate, init_features, in_channels, out_channels, imsize, upsample)
         self._finish_init(specs, bufs, drop_rate, upsample, out_activation)
         print('# params {}, # conv layers {}'.format(*self.model_size))
 
@@ -733,5 +785,5 @@ class Decoder(_HipNet):
                  drop_rate=0., upsample='nearest', out_activation=None):
         super(Decoder, self).__init__()
         blocks = [int(b) for b in blocks]
-        specs, bufs = _plan_decoder(blocks, growth_rate, init_features, dim_latent, out_channels)
+        specs, bufs = _plan_decoder(blocks, growth_rate, init_features, dim_latent, out_channels, upsample)
         self._finish_init(specs, bufs, drop_rate, upsample, out_activation)

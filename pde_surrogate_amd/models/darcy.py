@@ -42,8 +42,9 @@ def _check_sobel(sobel_filter, H):
         raise ValueError(f'sobel_filter was built for imsize {n}, fields are {H}')
 
 
-def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta2=0.0):
-    """Raw launch: returns (terms[5] = {total, const, cont, dir, neu} device tensor, grad_y or None)."""
+def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta2=0.0, use_tb=True):
+    """Raw launch: returns (terms[5] = {total, const, cont, dir, neu} device tensor, grad_y or None).
+    use_tb=False: the continuity term leaves out rows 0 and H-1 (darcy.py:224; linear law only)."""
     B, H, W = _check_fields(K, y)
     if K is None:
         K = torch.zeros((B, 1, H, W), device=y.device, dtype=torch.float32)
@@ -56,7 +57,8 @@ def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta
     with _lib.device_guard(y.device):
         rc = _lib.lib().pdes_darcy_loss(_lib.context(y.device), _lib.ptr(K), _lib.ptr(y), _lib.ptr(grad),
                                         _lib.ptr(partials), _lib.ptr(terms), B, H, W, w[0], w[1], w[2], w[3],
-                                        1 if nonlinear else 0, float(beta1), float(beta2), _lib.stream_ptr(y.device))
+                                        (1 if nonlinear else 0) | (0 if use_tb else 2), float(beta1), float(beta2),
+                                        _lib.stream_ptr(y.device))
     _lib.check(rc, 'pdes_darcy_loss')
     return terms, grad
 
@@ -94,10 +96,10 @@ class _Terms(torch.autograd.Function):
     weights are the upstream gradients (exactly autograd's linear combination)."""
 
     @staticmethod
-    def forward(ctx, K, y, nonlinear, beta1, beta2):
-        terms, _ = darcy_loss_launch(K, y, (1.0, 1.0, 1.0, 1.0), False, nonlinear, beta1, beta2)
+    def forward(ctx, K, y, nonlinear, beta1, beta2, use_tb=True):
+        terms, _ = darcy_loss_launch(K, y, (1.0, 1.0, 1.0, 1.0), False, nonlinear, beta1, beta2, use_tb)
         ctx.save_for_backward(K, y)
-        ctx.cfg = (nonlinear, beta1, beta2)
+        ctx.cfg = (nonlinear, beta1, beta2, use_tb)
         return terms[1:5].clone()
 
     @staticmethod
@@ -105,7 +107,7 @@ class _Terms(torch.autograd.Function):
         K, y = ctx.saved_tensors
         w = g.detach().float().cpu().tolist()
         _, grad = darcy_loss_launch(K, y, w, True, *ctx.cfg)
-        return None, grad, None, None, None
+        return None, grad, None, None, None, None
 
 
 def conv_constitutive_constraint(input, output, sobel_filter):
@@ -122,11 +124,8 @@ def conv_constitutive_constraint_nonlinear(input, output, sobel_filter, beta1, b
 
 def conv_continuity_constraint(output, sobel_filter, use_tb=True):
     """div(sigma) = 0: mean[(d sigma1/dx + d sigma2/dy)^2]                    (darcy.py:210-224)"""
-    if not use_tb:
-        raise NotImplementedError('use_tb=False (drop rows 0, H-1) is not used by any reference '
-                                  'script and is not implemented by the HIP kernel')
     _check_sobel(sobel_filter, output.shape[-1])
-    return _Terms.apply(None, output, False, 0.0, 0.0)[1]
+    return _Terms.apply(None, output, False, 0.0, 0.0, bool(use_tb))[1]
 
 
 def conv_boundary_condition(output):

@@ -1,8 +1,8 @@
 """SobelFilter on MI355X -- drop-in for the reference's utils/image_gradient.py:24-92.
 
 grad_h / grad_v are HIP kernels (csrc/darcy_loss.hip: `pdes_sobel_grad`, and
-`pdes_sobel_grad_adjoint` for autograd) instead of pad + conv2d + matmul.  3x3 filter only
-(no reference caller passes filter_size); correct=False is forward-only.
+`pdes_sobel_grad_adjoint` for autograd, `pdes_sobel5_*` for filter_size=5) instead of pad + conv2d + matmul;
+correct=False is forward-only.
 """
 import numpy as np
 import torch
@@ -10,7 +10,7 @@ import torch
 from .. import _lib
 
 
-def _launch_grad(image, want_h, want_v, correct):
+def _launch_grad(image, want_h, want_v, correct, filter_size=3):
     _lib.require_cuda(image)
     if image.dim() != 4 or image.shape[1] != 1:
         raise ValueError(f'image must be (B, 1, H, W); got {tuple(image.shape)}')
@@ -20,17 +20,18 @@ def _launch_grad(image, want_h, want_v, correct):
     x = image.detach().contiguous()
     gh = torch.empty_like(x) if want_h else None
     gv = torch.empty_like(x) if want_v else None
-    rc = _lib.lib().pdes_sobel_grad(_lib.ptr(x), _lib.ptr(gh), _lib.ptr(gv), B, H, W,
-                                    1 if correct else 0, _lib.stream_ptr())
+    fn = _lib.lib().pdes_sobel_grad if filter_size == 3 else _lib.lib().pdes_sobel5_grad
+    with _lib.device_guard(x.device):
+        rc = fn(_lib.ptr(x), _lib.ptr(gh), _lib.ptr(gv), B, H, W, 1 if correct else 0, _lib.stream_ptr(x.device))
     _lib.check(rc, 'pdes_sobel_grad')
     return gh, gv
 
 
 class _Grad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, horizontal, correct):
-        ctx.horizontal, ctx.correct = horizontal, correct
-        gh, gv = _launch_grad(image, horizontal, not horizontal, correct)
+    def forward(ctx, image, horizontal, correct, filter_size=3):
+        ctx.horizontal, ctx.correct, ctx.filter_size = horizontal, correct, filter_size
+        gh, gv = _launch_grad(image, horizontal, not horizontal, correct, filter_size)
         return gh if horizontal else gv
 
     @staticmethod
@@ -41,10 +42,11 @@ class _Grad(torch.autograd.Function):
         B, _, H, W = g.shape
         out = torch.empty_like(g)
         a, b = (g, None) if ctx.horizontal else (None, g)
-        rc = _lib.lib().pdes_sobel_grad_adjoint(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), B, H, W,
-                                                _lib.stream_ptr())
+        fn = _lib.lib().pdes_sobel_grad_adjoint if ctx.filter_size == 3 else _lib.lib().pdes_sobel5_grad_adjoint
+        with _lib.device_guard(g.device):
+            rc = fn(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), B, H, W, _lib.stream_ptr(g.device))
         _lib.check(rc, 'pdes_sobel_grad_adjoint')
-        return out, None, None
+        return out, None, None, None
 
 
 class SobelFilter(object):
@@ -61,15 +63,14 @@ class SobelFilter(object):
         self.modifier = torch.tensor(modifier, dtype=torch.float32, device=device)
 
     def _check(self, filter_size):
-        if filter_size != 3:
-            raise NotImplementedError('only the 3x3 Sobel filter is implemented (no reference '
-                                      'caller selects filter_size=5)')
+        if filter_size not in (3, 5):
+            raise ValueError(f'filter_size must be 3 or 5 (image_gradient.py:62-67); got {filter_size}')
 
     def grad_h(self, image, filter_size=3):
         """image gradient along the horizontal direction (x axis), (B,1,H,W) -> (B,1,H,W)"""
         self._check(filter_size)
-        return _Grad.apply(image, True, self.correct)
+        return _Grad.apply(image, True, self.correct, filter_size)
 
     def grad_v(self, image, filter_size=3):
         self._check(filter_size)
-        return _Grad.apply(image, False, self.correct)
+        return _Grad.apply(image, False, self.correct, filter_size)

@@ -161,6 +161,59 @@ def test_g12_teacher_forced_reference_steps(dev):
         np.testing.assert_allclose(norms, g[f'gnorm{step}'], rtol=1e-3, err_msg=f'step {step}')
 
 
+def test_g13_bilinear_upsampling(dev):
+    """--upsample bilinear (reference codec.py:33-40, align_corners=True): the resampling op + identity-BatchNorm
+    convolution against the reference -- tiny net with every tensor, default net with output, loss terms, every gradient
+    norm and the full tensors of the layers around the two upsampling stages"""
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    g = golden('G13_bilinear.npz')
+    net = DenseED(1, 3, 16, [1, 1, 1], growth_rate=4, init_features=8, upsample='bilinear')
+    sd = {k[len('tiny/sd0/'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('tiny/sd0/')}
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = torch.from_numpy(g['tiny/x']).to(dev)
+    y = net(x)
+    assert rel_l2(y.detach().cpu().numpy(), g['tiny/y']) < 1e-5
+    loss, l_pde, l_dir, l_neu = darcy_mixed_residual_loss(x, y, 10.0)
+    ref = g['tiny/terms']
+    np.testing.assert_allclose([float(loss.detach()), float(l_pde), float(l_dir), float(l_neu)],
+                               [ref[0], ref[1] + ref[2], ref[3], ref[4]], rtol=1e-5)
+    loss.backward()
+    for name, p in net.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), g['tiny/grad/' + name]) < 1e-3, name
+    net.eval()                                              # eval mode: running statistics + the identity BatchNorm
+    with torch.no_grad():
+        ye = net(x)
+    assert torch.isfinite(ye).all()
+    # default net
+    g6 = golden('G6_densed_default.npz')
+    torch.manual_seed(1)
+    net = DenseED(1, 3, 64, [6, 8, 6], upsample='bilinear')
+    assert len(net.state_dict()) == 163 and net.model_size == (740091, 28)
+    if _sha(net.state_dict()) != str(g6['sha256']):
+        pytest.skip('local torch RNG stream differs from the fixture generator')
+    net = net.to(dev).train()
+    x = torch.from_numpy(g['x']).to(dev)
+    y = net(x)
+    assert rel_l2(y.detach().cpu().numpy(), g['y']) < 1e-5
+    loss, l_pde, l_dir, l_neu = darcy_mixed_residual_loss(x, y, 10.0)
+    ref = g['terms']
+    np.testing.assert_allclose([float(loss.detach()), float(l_pde), float(l_dir), float(l_neu)],
+                               [ref[0], ref[1] + ref[2], ref[3], ref[4]], rtol=1e-5)
+    loss.backward()
+    assert [k for k, _ in net.named_parameters()] == [str(s) for s in g['param_names']]
+    norms = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=1e-3)
+    gr = dict(net.named_parameters())
+    n_full = 0
+    for k in g.files:
+        if k.startswith('grad/'):
+            n_full += 1
+            assert rel_l2(gr[k[5:]].grad.cpu().numpy(), g[k]) < 1e-3, k
+    assert n_full >= 10
+
+
 def test_dropin_training_loop_matches_reference_first_steps(dev):
     """the reference's loop body (train_codec_mixed_residual.py:224-240) on the drop-in modules,
     with torch.optim.Adam -- step 1 is the parity check (G7), later steps the same descent."""
@@ -218,8 +271,8 @@ def test_rejects_unsupported_options(dev):
     from pde_surrogate_amd.models.codec import DenseED
     with pytest.raises(NotImplementedError):
         DenseED(1, 3, 64, [1, 1, 1], drop_rate=0.1)
-    with pytest.raises(NotImplementedError):
-        DenseED(1, 3, 64, [1, 1, 1], upsample='bilinear')
+    with pytest.raises(ValueError):
+        DenseED(1, 3, 64, [1, 1, 1], upsample='bicubic')
     with pytest.raises(ValueError):
         DenseED(1, 3, 64, [1, 1])
     net = DenseED(1, 3, 64, [1, 1, 1], growth_rate=4, init_features=8)

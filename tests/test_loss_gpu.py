@@ -216,8 +216,36 @@ def test_rejects_bad_arguments(dev):
     with pytest.raises(RuntimeError):      # 48x48 is not implemented by the kernel
         darcy.darcy_loss_launch(Kd[:, :, :48, :48].contiguous(), yd[:, :, :48, :48].contiguous(), (1, 1, 1, 1), True)
     with pytest.raises(NotImplementedError):
-        darcy.conv_continuity_constraint(yd, SobelFilter(64, device=dev), use_tb=False)
-    with pytest.raises(NotImplementedError):
         darcy.conv_constitutive_constraint(Kd, yd, SobelFilter(64, correct=False, device=dev))
-    with pytest.raises(NotImplementedError):
-        SobelFilter(64, device=dev).grad_h(Kd, filter_size=5)
+
+
+def test_g14_continuity_without_top_bottom_rows_and_5x5_sobel(dev):
+    """conv_continuity_constraint(use_tb=False) (darcy.py:224) value + gradient, and SobelFilter.grad_h/grad_v with
+    filter_size=5 (image_gradient.py:65-67, :82-84) incl. their autograd adjoint against the fp64 oracle"""
+    from oracle import darcy as od
+    from pde_surrogate_amd.models import darcy
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    g = golden('G14_no_tb_sobel5.npz')
+    sob = SobelFilter(64, correct=True, device=dev)
+    y = torch.from_numpy(g['y']).to(dev).requires_grad_(True)
+    lt = darcy.conv_continuity_constraint(y, sob, use_tb=False)
+    np.testing.assert_allclose(float(lt.detach()), float(g['cont_no_tb']), rtol=LOSS_RTOL)
+    lt.backward()
+    assert rel_l2(y.grad.cpu().numpy(), g['cont_no_tb_grad']) < 1e-5
+    # use_tb=True on the same field still gives the other value (the flag is not sticky)
+    assert abs(float(darcy.conv_continuity_constraint(y.detach(), sob)) - float(g['cont_no_tb'])) > 1e-3 * float(g['cont_no_tb'])
+    img = torch.from_numpy(g['img']).to(dev)
+    np.testing.assert_allclose(sob.grad_h(img, filter_size=5).cpu().numpy(), g['gh5'], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(sob.grad_v(img, filter_size=5).cpu().numpy(), g['gv5'], rtol=1e-5, atol=1e-4)
+    for n in (64, 16, 8):                                   # adjoint: <grad(x), w> gradient vs the oracle's autograd
+        torch.manual_seed(n)
+        xi = torch.randn(2, 1, n, n)
+        wh, wv = torch.randn(2, 1, n, n), torch.randn(2, 1, n, n)
+        xo = xi.double().requires_grad_(True)
+        ((od.sobel_grad_h5(xo) * wh.double()).sum() + (od.sobel_grad_v5(xo) * wv.double()).sum()).backward()
+        xd = xi.to(dev).requires_grad_(True)
+        s = SobelFilter(n, correct=True, device=dev)
+        ((s.grad_h(xd, 5) * wh.to(dev)).sum() + (s.grad_v(xd, 5) * wv.to(dev)).sum()).backward()
+        assert rel_l2(xd.grad.cpu().numpy(), xo.grad.numpy()) < 1e-5, n
+    with pytest.raises(ValueError):
+        sob.grad_h(img, filter_size=7)
