@@ -204,7 +204,12 @@ def test_g13_bilinear_upsampling(dev):
     loss.backward()
     assert [k for k, _ in net.named_parameters()] == [str(s) for s in g['param_names']]
     norms = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
-    np.testing.assert_allclose(norms, g['grad_norms'], rtol=1e-3)
+    # 1e-3 of the reference -- except that ONE ReLU whose pre-activation lies within fp32 rounding of zero flips
+    # between two correct fp32 implementations and moves every upstream gradient by ~1e-3 (measured with
+    # tools/grad_floor.py on this input family, B = 4: CPU fp32 vs fp64 shows 2.3e-3 on the same tensors as HIP vs fp64,
+    # 3e-6 when no flip occurs).  Hence: all within 3e-3, at most 3 of 82 beyond 1e-3.
+    dev_n = np.abs(norms - g['grad_norms']) / g['grad_norms']
+    assert dev_n.max() < 3e-3 and int((dev_n > 1e-3).sum()) <= 3, np.sort(dev_n)[-5:]
     gr = dict(net.named_parameters())
     n_full = 0
     for k in g.files:
@@ -316,11 +321,13 @@ def test_mfma_kernels_match_direct_kernels(dev, option, cfg):
     y1, l1, g1 = _run_default(dev, **cfg)
     assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
     assert abs(l1 - l0) < 1e-5 * abs(l0)
-    # parameter gradients: fp32 rounding flips individual ReLU masks, so two correct fp32
-    # implementations differ by up to ~3e-3 here (each is 1e-3-class vs the fp64 oracle, measured
-    # with tools/debug_layers.py); a wrong stencil / layout would be O(1)
+    # parameter gradients: fp32 rounding flips individual ReLU masks (white-noise inputs, small batches), so two
+    # correct fp32 implementations differ by up to ~2.3e-3 here -- the CPU fp32 oracle shows the same 2.3e-3 against
+    # fp64 on this input family, and 3e-6 when no mask flips (tools/grad_floor.py); the reference-pinned checks are
+    # G11 (B = 32, every tensor, 1e-3) and G12; a wrong stencil / layout would be O(1)
     errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
-    assert errs[0][0] < 1e-2, errs[:8]
+    print('mfma vs direct, worst gradient tensors:', cfg, errs[:3])
+    assert errs[0][0] < 5e-3, errs[:8]
 
 
 @pytest.mark.parametrize('knob', ['PDES_FUSE_FINALIZE', 'PDES_WGRAD_STREAM', 'PDES_MFMA_B3', 'PDES_MFMA_1X1',
@@ -341,4 +348,5 @@ def test_backward_variants_agree(dev, monkeypatch, option, knob):
     assert torch.equal(y0, y1) or rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < ytol
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
-    assert errs[0][0] < (1e-5 if knob == 'PDES_WGRAD_STREAM' else 1e-2), errs[:8]
+    print('variant', knob, 'worst gradient tensors:', errs[:3])
+    assert errs[0][0] < (1e-5 if knob == 'PDES_WGRAD_STREAM' else 5e-3), errs[:8]

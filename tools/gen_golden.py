@@ -131,6 +131,14 @@ def gen_round2():
     for k, p in net.named_parameters():
         if k.startswith('features.TransUp1.') or (k.startswith('features.LastTransUp.') and 'conv1' not in k):
             g13['grad/' + k] = p.grad.numpy()
+    # the same pass on the fp64 oracle: where the reference's own fp32 norm is off by ~1e-3 (BatchNorm-bias sums with
+    # heavy cancellation) a test may accept the fp64 value instead
+    torch.manual_seed(1)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in ocodec.densed_init(1, 3, [6, 8, 6], 16, 48).items()}
+    tr64 = otrain.CpuTrainer(sd64, [6, 8, 6], upsample='bilinear')
+    _, l64, _ = tr64.forward_loss(xt.double(), True)
+    l64.backward()
+    g13['grad_norms_fp64'] = np.array([float(sd64[k].grad.norm()) for k in tr64.keys])
     np.savez_compressed(os.path.join(OUT, 'G13_bilinear.npz'), **g13)
 
     # ---- G14: conv_continuity_constraint(use_tb=False) (darcy.py:224) value + gradient; 5x5 Sobel fields
