@@ -301,7 +301,10 @@ def _run_default(dev, B=4, seed=5, imsize=64, blocks=(6, 8, 6)):
             if 'norm' in k and k.endswith('.bias'):
                 v.copy_(0.1 * torch.randn_like(v))
     net = net.to(dev).train()
-    x = torch.exp(0.5 * torch.randn(B, 1, imsize, imsize)).to(dev)
+    # smooth GRF-KLE fields (the benchmark's input family): on white-noise inputs isolated ReLU flips between two
+    # correct fp32 implementations dominate the comparison (5e-3 .. 7e-3 on this net, tools/grad_floor.py)
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    x = torch.from_numpy(grf_kle_fields(B, imsize, n_kle=64, seed=100 + seed, cache_dir='/tmp')).to(dev)
     y = net(x)
     loss, *_ = darcy_mixed_residual_loss(x, y, 10.0)
     loss.backward()
@@ -327,7 +330,8 @@ def test_mfma_kernels_match_direct_kernels(dev, option, cfg):
     # G11 (B = 32, every tensor, 1e-3) and G12; a wrong stencil / layout would be O(1)
     errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
     print('mfma vs direct, worst gradient tensors:', cfg, errs[:3])
-    assert errs[0][0] < 5e-3, errs[:8]
+    # measured on MI355X: <= 5e-4 for B >= 3, 9e-4 at B = 1 (one sample: a single mask flip weighs the most)
+    assert errs[0][0] < (2e-3 if cfg.get('B') == 1 else 1e-3), errs[:8]
 
 
 @pytest.mark.parametrize('knob', ['PDES_FUSE_FINALIZE', 'PDES_WGRAD_STREAM', 'PDES_MFMA_B3', 'PDES_MFMA_1X1',
@@ -337,7 +341,7 @@ def test_backward_variants_agree(dev, monkeypatch, option, knob):
     stream; the 196->98 layer on the bf16 pipe (three-way split, fp32-accurate) vs the f32 pipe; the 1x1 layers
     (forward + data gradient, weight gradient) on the register-operand kernels of conv_mfma_1x1.hip vs the LDS-tiled
     generic ones: same outputs and gradients (fp64 atomics of the statistics are order dependent in the last bits only; two different fp32
-    summation orders flip individual ReLU masks, hence the 1e-2 class bound on parameter gradients)"""
+    summation orders can flip an individual ReLU mask, hence 1e-3 and not 1e-6 on the parameter gradients)"""
     # PDES_WGRAD_STREAM is read by the model at construction; the others are options of the library's context
     setk = (lambda v: monkeypatch.setenv(knob, v)) if knob == 'PDES_WGRAD_STREAM' else (lambda v: option(knob, v))
     setk('0')
@@ -349,4 +353,4 @@ def test_backward_variants_agree(dev, monkeypatch, option, knob):
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
     print('variant', knob, 'worst gradient tensors:', errs[:3])
-    assert errs[0][0] < (1e-5 if knob == 'PDES_WGRAD_STREAM' else 5e-3), errs[:8]
+    assert errs[0][0] < (1e-5 if knob == 'PDES_WGRAD_STREAM' else 1e-3), errs[:8]      # measured: <= 1.7e-4
