@@ -9,9 +9,16 @@ drop-in for the reference's solve_conv_mixed_residual.py (same flags; config 5 o
 kernel, the network forward/backward from the HIP convolution kernels; torch.optim.LBFGS drives the
 closure on the host exactly as in the reference (lr 0.5, max_iter 20, history 50).
 
+  --mode fused  (default)  the closure is pde_surrogate_amd.solver.ResidualClosure: forward + loss + backward through
+                           the C ABI, captured in ONE hipGraph (B = 1 is pure launch latency); --no-graph replays the
+                           same launches eagerly;
+  --mode dropin            the reference's closure verbatim on the drop-in modules (autograd).
+
 The reference validates the nonlinear case against a FEniCS solve (utils/fenics.py); dolfin is not
-available here, so this script reports the residual loss only (parity unpinned for that
-comparison).  Inputs: an HDF5/.npz file with `input` (and optionally `output`), or --synthetic.
+available here (parity unpinned for that comparison); tests/test_solver_gpu.py compares the fields this
+script produces with the build's own independent fp64 finite-volume Newton solution (oracle/fd_newton.py, test
+infrastructure): a self-consistency check, not FEniCS parity.
+Inputs: an HDF5/.npz file with `input` (and optionally `output`), or --synthetic.
 """
 import argparse
 import os
@@ -23,6 +30,7 @@ import torch
 
 from pde_surrogate_amd.models.codec import Decoder
 from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+from pde_surrogate_amd.solver import ResidualClosure
 from pde_surrogate_amd.utils.load import read_arrays
 from pde_surrogate_amd.utils.misc import mkdirs, to_numpy
 from pde_surrogate_amd.utils.plot import plot_prediction_det, save_stats
@@ -48,6 +56,8 @@ def build_parser():
     p.add_argument('--animate', action='store_true')
     p.add_argument('-v', '--verbose', action='store_true')
     p.add_argument('--synthetic', action='store_true', help='generate the permeability field instead of reading HDF5')
+    p.add_argument('--mode', type=str, default='fused', choices=['fused', 'dropin'], help='closure (module docstring)')
+    p.add_argument('--no-graph', action='store_true', help='fused mode: eager launches instead of one hipGraph replay')
     return p
 
 
@@ -98,9 +108,22 @@ def main(argv=None):
     b1, b2 = (args.alpha1, args.alpha2) if args.nonlinear else (0.0, 0.0)
     logger = {'loss': []}
     n_closure = [0]
+    fused = None
+    if args.mode == 'fused':
+        model.train()
+        fused = ResidualClosure(model, fixed_latent, perm_tensor, args.weight_bound, args.nonlinear, b1, b2,
+                                use_graph=not args.no_graph)
 
     def train(epoch):
         model.train()
+
+        def fused_closure():
+            loss = fused()
+            n_closure[0] += 1
+            if args.verbose:
+                t = fused.terms.tolist()
+                print(f'epoch {epoch}: loss {t[0]:6f}, energy {t[1] + t[2]:.6f}, diri {t[3]:.6f}, neum {t[4]:.6f}')
+            return loss
 
         def closure():
             optimizer.zero_grad()
@@ -114,7 +137,7 @@ def main(argv=None):
                       f'diri {l_dir.item():.6f}, neum {l_neu.item():.6f}')
             return loss
 
-        loss = optimizer.step(closure)
+        loss = optimizer.step(fused_closure if fused is not None else closure)
         value = loss.item() if not isinstance(loss, float) else loss
         logger['loss'].append(value)
         print(f'epoch {epoch}: loss {value:.6f}')
