@@ -149,6 +149,59 @@ def conv1x1_timing(dev, B, iters=200):
     return out
 
 
+def config5_timing(dev, n=300):
+    """config 5 of BASELINE.json (single-instance nonlinear solver: Decoder [8,6] + mixed residual at B = 1, the closure of
+    solve_conv_mixed_residual.py:131-149 there): closure evaluations per second -- forward + fused nonlinear loss + backward
+    + the loss value read back on the host (what L-BFGS needs per evaluation) -- as one hipGraph replay, as the same
+    launches issued eagerly, and through autograd on the drop-in modules; plus whole L-BFGS epochs (torch.optim.LBFGS,
+    max_iter 20, history 50: its host-side two-loop recursion dominates)"""
+    import contextlib
+    import io
+    from pde_surrogate_amd.models.codec import Decoder
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    from pde_surrogate_amd.solver import ResidualClosure
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    K = torch.from_numpy(grf_kle_fields(9, n_kle=512, cache_dir='/tmp')[[8]]).to(dev)
+    torch.manual_seed(0)
+    z = (torch.randn(1, 1, 16, 16) * 0.5).to(dev)
+    out = {'workload': 'Decoder(1, 3, blocks [8, 6]) 16x16 latent -> 64x64, nonlinear Darcy alpha1 = alpha2 = 0.1, B = 1'}
+
+    def rate(fn, k):
+        for _ in range(10):
+            float(fn())
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            float(fn())
+        return k / (time.perf_counter() - t0)
+    for tag, graph in (('hipgraph', True), ('eager', False)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = Decoder(1, 3, [8, 6]).to(dev).train()
+        clo = ResidualClosure(net, z, K, 10.0, True, 0.1, 0.1, use_graph=graph)
+        out[f'closure_evals_per_s_{tag}'] = round(rate(clo, n), 1)
+        if graph:
+            opt = torch.optim.LBFGS(net.parameters(), lr=0.5, max_iter=20, history_size=50)
+            n0 = clo.n_calls
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                opt.step(clo)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            out['lbfgs_epochs_per_s'] = round(5 / dt, 2)
+            out['lbfgs_closure_evals_per_s'] = round((clo.n_calls - n0) / dt, 1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Decoder(1, 3, [8, 6]).to(dev).train()
+
+    def autograd_closure():
+        net.zero_grad()
+        loss = darcy_mixed_residual_loss(K, net(z), 10.0, True, 0.1, 0.1)[0]
+        loss.backward()
+        return loss
+    out['closure_evals_per_s_autograd_dropin'] = round(rate(autograd_closure, n // 3), 1)
+    return out
+
+
 def rendezvous(gpus):
     """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, one process per GPU, backend
     nccl (= RCCL over xGMI) -- gloo only when there is no GPU at all (CPU test of this function).  Returns
@@ -325,6 +378,8 @@ def main():
                                    'layers': conv1x1_timing(dev, B),
                                    'note': 'the 1x1 channel-halving layers, HIP-event timed stand-alone at the training '
                                            'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}
+        if world == 1:
+            out['config5_solver'] = config5_timing(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(B)
         print(json.dumps(out), flush=True)
