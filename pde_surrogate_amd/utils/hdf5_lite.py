@@ -1,0 +1,492 @@
+"""Minimal pure-Python HDF5 reader (and a matching minimal writer) for the dataset wire format of the reference.
+
+The reference reads its datasets with h5py (utils/load.py:18-22: `f['input'][:ndata]`, `f['output'][:ndata]`;
+solve_conv_mixed_residual.py:103-105: `f['input'][()]`).  h5py is not part of this image, so `read_arrays`
+(utils/load.py here) falls back to this module when `import h5py` fails.  Scope = what h5py / the HDF5 library write
+for `create_dataset(name, data=ndarray[, chunks=..., compression='gzip', shuffle=True])` in a file's root group or
+sub-groups:
+  * superblock versions 0-3, with or without a user block (base address);
+  * old-style groups (symbol-table message -> B-tree v1 + local heap + SNOD nodes) and new-style groups with COMPACT
+    link storage (link messages in the object header); dense link storage (fractal heap) is not implemented;
+  * object headers version 1 and 2, continuation blocks;
+  * dataspace v1/v2 (simple), datatype classes fixed-point and floating-point (little or big endian);
+  * data layout: compact, contiguous, chunked with a B-tree v1 chunk index (layout message v1-v3) or a single chunk /
+    implicit index (v4); filters deflate (1), shuffle (2), fletcher32 (3).
+Anything else raises NotImplementedError naming the construct -- never a silent wrong read.
+
+The on-disk structures follow the public "HDF5 File Format Specification Version 3.0"; this is the build's own
+restatement (the reference contains no HDF5 code).  Validated in tests/test_hdf5_lite_cpu.py against a file written by
+the HDF5 library itself that ships with scipy (MATLAB 7.3 test file) and by round trips through `write_hdf5` below,
+which emits the oldest layout (superblock v0, symbol-table root group, contiguous or chunked+deflate datasets).
+"""
+import struct
+import zlib
+
+import numpy as np
+
+SIG = b'\x89HDF\r\n\x1a\n'
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class _Buf:
+    def __init__(self, data, so=8, sl=8, base=0):
+        self.d, self.so, self.sl, self.base = data, so, sl, base
+
+    def u(self, off, n):
+        return int.from_bytes(self.d[off:off + n], 'little')
+
+    def addr(self, off):                      # file address field -> absolute offset (None when undefined)
+        v = self.u(off, self.so)
+        return None if v == (1 << (8 * self.so)) - 1 else v + self.base
+
+    def length(self, off):
+        return self.u(off, self.sl)
+
+
+class Dataset:
+    def __init__(self, f, shape, dtype, layout, filters):
+        self._f, self.shape, self.dtype, self._layout, self._filters = f, tuple(shape), np.dtype(dtype), layout, filters
+
+    def __len__(self):
+        return self.shape[0]
+
+    def _read_all(self):
+        b, kind = self._f._b, self._layout[0]
+        n = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        if kind == 'compact':
+            raw = self._layout[1]
+            return np.frombuffer(raw, self.dtype, n).reshape(self.shape).copy()
+        if kind == 'contiguous':
+            addr = self._layout[1]
+            if addr is None:
+                return np.zeros(self.shape, self.dtype)
+            return np.frombuffer(b.d, self.dtype, n, addr).reshape(self.shape).copy()
+        _, addr, cdims, index = self._layout
+        out = np.zeros(self.shape, self.dtype)
+        if addr is None:
+            return out
+        for offs, caddr, csize, mask in self._f._chunks(addr, len(self.shape), cdims, index, self.dtype.itemsize):
+            raw = bytes(b.d[caddr:caddr + csize])
+            for i, (fid, cd) in reversed(list(enumerate(self._filters))):
+                if mask & (1 << i):
+                    continue
+                if fid == 1:
+                    raw = zlib.decompress(raw)
+                elif fid == 2:
+                    es = cd[0] if cd else self.dtype.itemsize
+                    raw = np.frombuffer(raw, np.uint8).reshape(es, -1).T.tobytes()
+                elif fid == 3:
+                    raw = raw[:-4]
+                else:
+                    raise NotImplementedError(f'HDF5 filter id {fid}')
+            chunk = np.frombuffer(raw, self.dtype, int(np.prod(cdims))).reshape(cdims)
+            sl_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, self.shape))
+            sl_in = tuple(slice(0, s.stop - s.start) for s in sl_out)
+            out[sl_out] = chunk[sl_in]
+        return out
+
+    def __getitem__(self, key):
+        """numpy semantics on the fully materialised array (datasets of this path are a few hundred MB at most)"""
+        a = self._read_all()
+        return a if (key is Ellipsis or key == ()) else a[key]
+
+
+class File:
+    """read-only `h5py.File` look-alike: context manager, `f['name']` -> Dataset / sub-group, `keys()`"""
+
+    def __init__(self, path, mode='r'):
+        if mode != 'r':
+            raise ValueError('hdf5_lite.File is read-only')
+        with open(path, 'rb') as fh:
+            data = fh.read()
+        off = 0
+        while data[off:off + 8] != SIG:           # the superblock sits at 0, 512, 1024, ... (user block)
+            off = 512 if off == 0 else off * 2
+            if off >= len(data):
+                raise OSError(f'{path}: not an HDF5 file (no signature)')
+        ver = data[off + 8]
+        if ver in (0, 1):
+            so, sl = data[off + 13], data[off + 14]
+            p = off + 24 + (4 if ver == 1 else 0)
+            b = _Buf(data, so, sl, 0)
+            b.base = b.u(p, so)
+            ste = p + 4 * so                                    # root group symbol table entry
+            self._b = b
+            self._root = b.addr(ste + so)
+        elif ver in (2, 3):
+            so, sl = data[off + 9], data[off + 10]
+            b = _Buf(data, so, sl, 0)
+            b.base = b.u(off + 12, so)
+            self._b = b
+            self._root = b.addr(off + 12 + 3 * so)
+        else:
+            raise NotImplementedError(f'HDF5 superblock version {ver}')
+        self._links = self._group_links(self._root)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def close(self):
+        pass
+
+    def keys(self):
+        return list(self._links)
+
+    def __contains__(self, name):
+        return name in self._links
+
+    def __getitem__(self, name):
+        links, obj = self._links, None
+        for part in [p for p in name.split('/') if p]:
+            if part not in links:
+                raise KeyError(name)
+            obj = self._object(links[part])
+            links = obj if isinstance(obj, dict) else {}
+        return _Group(self, obj) if isinstance(obj, dict) else obj
+
+    # ---- object headers ------------------------------------------------------------------------------------------
+    def _messages(self, addr):
+        b = self._b
+        d = b.d
+        msgs = []
+        if d[addr:addr + 4] == b'OHDR':                       # version 2
+            flags = d[addr + 5]
+            p = addr + 6 + (16 if flags & 0x20 else 0) + (4 if flags & 0x10 else 0)
+            nsz = 1 << (flags & 3)
+            size = b.u(p, nsz)
+            p += nsz
+            blocks = [(p, p + size)]
+            while blocks:
+                p, end = blocks.pop(0)
+                while p + 4 <= end:
+                    mtype, msize, mflags = d[p], b.u(p + 1, 2), d[p + 3]
+                    p += 4 + (2 if flags & 0x04 else 0)
+                    body = p
+                    p += msize
+                    if mtype == 0x10:
+                        ca, cl = b.addr(body), b.length(body + b.so)
+                        blocks.append((ca + 4, ca + cl - 4))     # "OCHK" ... checksum
+                    elif mtype != 0:
+                        msgs.append((mtype, body, msize))
+            return msgs
+        if d[addr] != 1:
+            raise NotImplementedError(f'HDF5 object header version {d[addr]}')
+        nmsg, hsize = b.u(addr + 2, 2), b.u(addr + 8, 4)
+        blocks = [(addr + 16, addr + 16 + hsize)]
+        while blocks and len(msgs) < nmsg + 64:
+            p, end = blocks.pop(0)
+            while p + 8 <= end:
+                mtype, msize = b.u(p, 2), b.u(p + 2, 2)
+                body = p + 8
+                p = body + msize
+                if mtype == 0x10:
+                    blocks.append((b.addr(body), b.addr(body) + b.length(body + b.so)))
+                elif mtype != 0:
+                    msgs.append((mtype, body, msize))
+        return msgs
+
+    def _group_links(self, addr):
+        b = self._b
+        links = {}
+        for mtype, body, msize in self._messages(addr):
+            if mtype == 0x11:                                  # symbol table: B-tree v1 + local heap
+                heap = b.addr(body + b.so)
+                if b.d[heap:heap + 4] != b'HEAP':
+                    raise OSError('HDF5: bad local heap')
+                hdata = b.addr(heap + 8 + 2 * b.sl)
+                self._walk_group_btree(b.addr(body), hdata, links)
+            elif mtype == 0x06:                                # link message (compact new-style group)
+                flags = b.d[body + 1]
+                p = body + 2
+                ltype = 0
+                if flags & 0x08:
+                    ltype = b.d[p]; p += 1
+                if flags & 0x04:
+                    p += 8
+                if flags & 0x10:
+                    p += 1
+                nsz = 1 << (flags & 3)
+                nlen = b.u(p, nsz); p += nsz
+                name = bytes(b.d[p:p + nlen]).decode(); p += nlen
+                if ltype != 0:
+                    continue                                   # soft / external links are not followed
+                links[name] = b.addr(p)
+            elif mtype == 0x02:                                # link info: dense storage?
+                flags = b.d[body + 1]
+                p = body + 2 + (8 if flags & 1 else 0)
+                if b.addr(p) is not None:
+                    raise NotImplementedError('HDF5 groups with dense link storage (fractal heap) are not implemented')
+        return links
+
+    def _walk_group_btree(self, addr, hdata, links):
+        b = self._b
+        if addr is None:
+            return
+        if b.d[addr:addr + 4] == b'SNOD':
+            n = b.u(addr + 6, 2)
+            p = addr + 8
+            for _ in range(n):
+                noff, oaddr = b.u(p, b.so), b.addr(p + b.so)
+                end = b.d.index(b'\0', hdata + noff)
+                links[bytes(b.d[hdata + noff:end]).decode()] = oaddr
+                p += 2 * b.so + 24
+            return
+        if b.d[addr:addr + 4] != b'TREE':
+            raise OSError('HDF5: bad group B-tree node')
+        n = b.u(addr + 6, 2)
+        p = addr + 8 + 2 * b.so + b.sl                          # skip the first key
+        for _ in range(n):
+            self._walk_group_btree(b.addr(p), hdata, links)
+            p += b.so + b.sl
+
+    def _chunks(self, addr, rank, cdims, index, esize):
+        """yield (offsets, address, stored size, filter mask) of every chunk"""
+        b = self._b
+        if index == 'single':
+            yield (0,) * rank, addr[0], addr[1], addr[2]
+            return
+        if index == 'implicit':
+            raise NotImplementedError('HDF5 implicit chunk index')
+        if b.d[addr:addr + 4] != b'TREE':
+            raise OSError('HDF5: bad chunk B-tree node')
+        level, n = b.d[addr + 5], b.u(addr + 6, 2)
+        p = addr + 8 + 2 * b.so
+        ksz = 8 + 8 * (rank + 1)
+        for _ in range(n):
+            csize, mask = b.u(p, 4), b.u(p + 4, 4)
+            offs = tuple(b.u(p + 8 + 8 * i, 8) for i in range(rank))
+            child = b.addr(p + ksz)
+            if level == 0:
+                yield offs, child, csize, mask
+            else:
+                yield from self._chunks(child, rank, cdims, index, esize)
+            p += ksz + b.so
+
+    def _object(self, addr):
+        b = self._b
+        shape = dtype = layout = None
+        filters = []
+        is_group = False
+        for mtype, body, msize in self._messages(addr):
+            if mtype in (0x11, 0x02, 0x06):
+                is_group = True
+            elif mtype == 0x01:                                # dataspace
+                ver, rank = b.d[body], b.d[body + 1]
+                p = body + (8 if ver == 1 else 4)
+                shape = tuple(b.length(p + i * b.sl) for i in range(rank))
+            elif mtype == 0x03:                                # datatype
+                cls, bits0, size = b.d[body] & 0x0F, b.d[body + 1], b.u(body + 4, 4)
+                order = '>' if bits0 & 1 else '<'
+                if cls == 1:
+                    dtype = np.dtype(f'{order}f{size}')
+                elif cls == 0:
+                    dtype = np.dtype(f'{order}{"i" if bits0 & 0x08 else "u"}{size}')
+                else:
+                    raise NotImplementedError(f'HDF5 datatype class {cls}')
+            elif mtype == 0x08:                                # data layout
+                ver = b.d[body]
+                if ver in (1, 2):
+                    rank, cls = b.d[body + 1], b.d[body + 2]
+                    p = body + 8
+                    a = None
+                    if cls != 0:
+                        a = b.addr(p); p += b.so
+                    dims = [b.u(p + 4 * i, 4) for i in range(rank)]
+                    p += 4 * rank
+                    if cls == 0:
+                        layout = ('compact', bytes(b.d[p + 4:p + 4 + b.u(p, 4)]))
+                    elif cls == 1:
+                        layout = ('contiguous', a)
+                    else:
+                        layout = ('chunked', a, tuple(dims[:-1]), 'btree1')
+                elif ver == 3:
+                    cls = b.d[body + 1]
+                    if cls == 0:
+                        layout = ('compact', bytes(b.d[body + 4:body + 4 + b.u(body + 2, 2)]))
+                    elif cls == 1:
+                        layout = ('contiguous', b.addr(body + 2))
+                    else:
+                        rank = b.d[body + 2]
+                        a = b.addr(body + 3)
+                        dims = [b.u(body + 3 + b.so + 4 * i, 4) for i in range(rank)]
+                        layout = ('chunked', a, tuple(dims[:-1]), 'btree1')
+                elif ver == 4:
+                    cls = b.d[body + 1]
+                    if cls == 0:
+                        layout = ('compact', bytes(b.d[body + 4:body + 4 + b.u(body + 2, 2)]))
+                    elif cls == 1:
+                        layout = ('contiguous', b.addr(body + 2))
+                    elif cls == 2:
+                        flags, rank, dsz = b.d[body + 2], b.d[body + 3], b.d[body + 4]
+                        dims = [b.u(body + 5 + dsz * i, dsz) for i in range(rank)]
+                        p = body + 5 + dsz * rank
+                        itype = b.d[p]; p += 1
+                        if itype == 1:                           # single chunk
+                            csize, mask = None, 0
+                            if flags & 2:
+                                csize, mask = b.length(p), b.u(p + b.sl, 4); p += b.sl + 4
+                            layout = ('chunked', (b.addr(p), csize, mask), tuple(dims[:-1]), 'single')
+                        else:
+                            raise NotImplementedError(f'HDF5 v4 chunk index type {itype} (only a single chunk is implemented)')
+                    else:
+                        raise NotImplementedError('HDF5 virtual datasets')
+                else:
+                    raise NotImplementedError(f'HDF5 data layout message version {ver}')
+            elif mtype == 0x0B:                                # filter pipeline
+                ver, nf = b.d[body], b.d[body + 1]
+                p = body + (8 if ver == 1 else 2)
+                for _ in range(nf):
+                    fid = b.u(p, 2); p += 2
+                    nlen = 0
+                    if ver == 1 or fid >= 256:
+                        nlen = b.u(p, 2); p += 2
+                    p += 2                                       # flags
+                    ncd = b.u(p, 2); p += 2
+                    p += (nlen + 7) // 8 * 8 if ver == 1 else nlen
+                    cd = [b.u(p + 4 * i, 4) for i in range(ncd)]
+                    p += 4 * ncd + (4 if ver == 1 and ncd % 2 else 0)
+                    filters.append((fid, cd))
+        if shape is not None and dtype is not None and layout is not None:
+            if layout[0] == 'chunked' and layout[3] == 'single' and layout[1][1] is None:
+                a = layout[1]
+                layout = ('chunked', (a[0], int(np.prod(layout[2])) * np.dtype(dtype).itemsize, 0), layout[2], 'single')
+            return Dataset(self, shape, dtype, layout, filters)
+        if is_group:
+            return self._group_links(addr)
+        raise NotImplementedError('HDF5 object that is neither a simple dataset nor a group')
+
+
+class _Group:
+    def __init__(self, f, links):
+        self._f, self._links = f, links
+
+    def keys(self):
+        return list(self._links)
+
+    def __getitem__(self, name):
+        obj = self._f._object(self._links[name])
+        return _Group(self._f, obj) if isinstance(obj, dict) else obj
+
+
+# ------------------------------------------------------------------------------------------------------------ writer
+def write_hdf5(path, arrays, chunks=None, compression=None, user_block=0):
+    """write {name: ndarray} as datasets of the root group in the OLDEST on-disk layout (superblock v0, symbol-table
+    group, object headers v1, contiguous data -- or chunked + deflate when `chunks` (dict name -> chunk shape) and
+    compression='gzip' are given).  Used to produce datasets in the reference's wire format without h5py (tests,
+    tools); float32/float64/int32/int64, little endian."""
+    so = sl = 8
+    names = sorted(arrays)                                       # SNOD entries must be sorted by name
+    if len(names) > 8:
+        raise NotImplementedError('write_hdf5: at most 8 datasets (one symbol-table node)')
+    out = bytearray()
+
+    def align(n=8):
+        while len(out) % n:
+            out.append(0)
+
+    def pack_addr(v):
+        return struct.pack('<Q', UNDEF if v is None else v)
+
+    out += b'\0' * (96)                                          # superblock v0 placeholder (56 + 40-byte root entry)
+    # local heap with the link names
+    heap_data = bytearray(b'\0' * 8)
+    name_off = {}
+    for nm in names:
+        name_off[nm] = len(heap_data)
+        heap_data += nm.encode() + b'\0'
+        while len(heap_data) % 8:
+            heap_data.append(0)
+    heap_size = max(len(heap_data) + 16, 88)
+    heap_data += b'\0' * (heap_size - len(heap_data))
+    free_off = heap_size - 16
+    heap_data[free_off:free_off + 16] = struct.pack('<QQ', 1, 16)    # one free block: next = 1 (none), size 16
+    align()
+    heap_addr = len(out)
+    out += b'HEAP' + bytes([0, 0, 0, 0]) + struct.pack('<QQ', heap_size, free_off) + pack_addr(heap_addr + 32) + bytes(heap_data)
+
+    # dataset payloads + object headers
+    obj_addr = {}
+    for nm in names:
+        a = np.ascontiguousarray(arrays[nm])
+        if a.dtype.byteorder == '>':
+            a = a.astype(a.dtype.newbyteorder('<'))
+        kind, size = a.dtype.kind, a.dtype.itemsize
+        if kind == 'f':                                          # IEEE little endian
+            props = {4: struct.pack('<HHBBBBI', 0, 32, 23, 8, 0, 23, 127), 8: struct.pack('<HHBBBBI', 0, 64, 52, 11, 0, 52, 1023)}[size]
+            dt = bytes([0x11, 0x20, 31 if size == 4 else 63, 0]) + struct.pack('<I', size) + props
+        elif kind in 'iu':
+            dt = bytes([0x10, 0x08 if kind == 'i' else 0x00, 0, 0]) + struct.pack('<I', size) + struct.pack('<HH', 0, 8 * size)
+        else:
+            raise NotImplementedError(f'write_hdf5: dtype {a.dtype}')
+        ds = bytes([1, a.ndim, 0, 0, 0, 0, 0, 0]) + b''.join(struct.pack('<Q', s) for s in a.shape)
+        msgs = [(0x01, ds), (0x03, dt)]
+        cshape = (chunks or {}).get(nm)
+        if cshape is None:
+            align()
+            data_addr = len(out)
+            out += a.tobytes()
+            msgs.append((0x08, bytes([3, 1]) + pack_addr(data_addr) + struct.pack('<Q', a.nbytes)))
+        else:
+            cshape = tuple(cshape)
+            grid = [range(0, s, c) for s, c in zip(a.shape, cshape)]
+            entries = []
+            for offs in np.ndindex(*[len(g) for g in grid]):
+                o = tuple(g[i] for g, i in zip(grid, offs))
+                blk = np.zeros(cshape, a.dtype)
+                sl_ = tuple(slice(oo, min(oo + c, s)) for oo, c, s in zip(o, cshape, a.shape))
+                blk[tuple(slice(0, s.stop - s.start) for s in sl_)] = a[sl_]
+                raw = blk.tobytes()
+                if compression == 'gzip':
+                    raw = zlib.compress(raw, 4)
+                align()
+                entries.append((o, len(out), len(raw)))
+                out += raw
+            if len(entries) > 64:
+                raise NotImplementedError('write_hdf5: more than 64 chunks (one B-tree leaf)')
+            align()
+            bt = len(out)
+            node = bytearray(b'TREE' + bytes([1, 0]) + struct.pack('<H', len(entries)) + pack_addr(None) + pack_addr(None))
+            for o, ca, cs in entries:
+                node += struct.pack('<II', cs, 0) + b''.join(struct.pack('<Q', v) for v in o) + struct.pack('<Q', 0) + pack_addr(ca)
+            node += struct.pack('<II', 0, 0) + b''.join(struct.pack('<Q', s) for s in a.shape) + struct.pack('<Q', 0)   # final key
+            out += node
+            if compression == 'gzip':
+                msgs.append((0x0B, bytes([1, 1, 0, 0, 0, 0, 0, 0]) + struct.pack('<HHHH', 1, 0, 1, 1) + struct.pack('<I', 4) + b'\0' * 4))
+            lay = bytes([3, 2, a.ndim + 1]) + pack_addr(bt) + b''.join(struct.pack('<I', c) for c in cshape) + struct.pack('<I', size)
+            msgs.append((0x08, lay))
+        body = bytearray()
+        for t, m in msgs:
+            pad = (-len(m)) % 8
+            body += struct.pack('<HHB3x', t, len(m) + pad, 0) + m + b'\0' * pad
+        align()
+        obj_addr[nm] = len(out)
+        out += struct.pack('<BBHII4x', 1, 0, len(msgs), 1, len(body)) + body
+
+    # symbol table node + B-tree + root group object header
+    align()
+    snod = len(out)
+    out += b'SNOD' + bytes([1, 0]) + struct.pack('<H', len(names))
+    for nm in names:
+        out += struct.pack('<Q', name_off[nm]) + pack_addr(obj_addr[nm]) + struct.pack('<II', 0, 0) + b'\0' * 16
+    out += b'\0' * (40 * (8 - len(names)))                          # a node has room for 2K = 8 entries (K = 4)
+    align()
+    btree = len(out)
+    out += b'TREE' + bytes([0, 0]) + struct.pack('<H', 1) + pack_addr(None) + pack_addr(None)
+    out += struct.pack('<Q', 0) + pack_addr(snod) + struct.pack('<Q', name_off[names[-1]])
+    out += b'\0' * (2 * 8 * 16)                                     # unused key/child slots of the node (2K = 32 entries)
+    align()
+    root = len(out)
+    stab = pack_addr(btree) + pack_addr(heap_addr)
+    out += struct.pack('<BBHII4x', 1, 0, 1, 1, 8 + len(stab)) + struct.pack('<HHB3x', 0x11, len(stab), 0) + stab
+    eof = len(out)
+    sb = SIG + bytes([0, 0, 0, 0, 0, so, sl, 0]) + struct.pack('<HHI', 4, 16, 0)
+    sb += pack_addr(0) + pack_addr(None) + pack_addr(eof) + pack_addr(None)
+    sb += struct.pack('<Q', 0) + pack_addr(root) + struct.pack('<II', 1, 0) + pack_addr(btree) + pack_addr(heap_addr)
+    out[:len(sb)] = sb
+    with open(path, 'wb') as fh:
+        if user_block:
+            raise NotImplementedError('write_hdf5: user blocks')
+        fh.write(bytes(out))

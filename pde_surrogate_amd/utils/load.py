@@ -3,8 +3,9 @@
 plus the device-resident loader the fused trainer uses and a synthetic source for machines without
 the (non-redistributed) datasets.
 
-`h5py` is optional: it is only imported when an .hdf5 file is actually opened; `.npz` files with the
-same two arrays are accepted too."""
+`h5py` is optional: it is only imported when an .hdf5 file is actually opened, and when it is not installed the
+files are read by utils/hdf5_lite.py (pure Python: superblock v0-v3, contiguous / chunked + deflate datasets);
+`.npz` files with the same two arrays are accepted too."""
 import json
 import os
 from argparse import Namespace
@@ -31,8 +32,8 @@ def read_arrays(path, ndata, only_input=True):
         return x, y
     try:
         import h5py
-    except ImportError as e:                                    # pragma: no cover
-        raise RuntimeError(f'h5py is needed to read {path} (or convert the dataset to .npz)') from e
+    except ImportError:
+        from . import hdf5_lite as h5py          # the build's own reader of the subset of HDF5 the datasets use
     with h5py.File(path, 'r') as f:
         x = f['input'][:ndata]
         y = None if only_input else f['output'][:ndata]

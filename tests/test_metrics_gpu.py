@@ -117,9 +117,12 @@ def test_g15_max_likelihood_fused_and_dropin_steps(dev):
         assert abs(loss - g['losses'][step - 1]) <= tol * g['losses'][step - 1], step
 
 
-def _write_npz_datasets(root, ntrain, ntest, seed=5):
-    """datasets in the reference's directory layout, as .npz (`input`, `output`): synthetic channelized inputs and
-    smooth made-up targets (FEniCS outputs are not available here; the metric arithmetic does not care)"""
+def _write_npz_datasets(root, ntrain, ntest, seed=5, fmt='npz'):
+    """datasets in the reference's directory layout and names -- as .hdf5 (the reference's wire format, utils/load.py:
+    18-22: datasets `input` and `output`; written by hdf5_lite.write_hdf5, read back by the loader's HDF5 branch) or as
+    .npz with the same stem: synthetic channelized inputs and smooth made-up targets (FEniCS outputs are not available
+    here; the metric arithmetic does not care)"""
+    from pde_surrogate_amd.utils.hdf5_lite import write_hdf5
     from pde_surrogate_amd.utils.data import channelized_fields
     d = root / '64x64'
     d.mkdir(parents=True)
@@ -128,7 +131,11 @@ def _write_npz_datasets(root, ntrain, ntest, seed=5):
         x = channelized_fields(n, 64, seed=seed + s)
         u = np.broadcast_to(1 - np.linspace(0, 1, 64)[None, None, :], (n, 64, 64)) + 0.1 * rng.standard_normal((n, 1, 1))
         y = np.stack([u, x[:, 0] * 0.1, 0.05 * rng.standard_normal((n, 64, 64))], 1)
-        np.savez(d / (name + '.npz'), input=x, output=y.astype(np.float32))
+        if fmt == 'npz':
+            np.savez(d / (name + '.npz'), input=x, output=y.astype(np.float32))
+        else:
+            write_hdf5(str(d / (name + '.hdf5')), {'input': x, 'output': y.astype(np.float32)},
+                       chunks={'input': (8, 1, 64, 64), 'output': (8, 3, 64, 64)}, compression='gzip')
 
 
 def test_cli_test_pass_with_targets_reports_reference_metrics(dev, tmp_path, monkeypatch):
@@ -138,7 +145,7 @@ def test_cli_test_pass_with_targets_reports_reference_metrics(dev, tmp_path, mon
     from oracle import train as otrain
     from pde_surrogate_amd.models.codec import DenseED
     monkeypatch.setenv('WORLD_SIZE', '1')
-    _write_npz_datasets(tmp_path / 'data', 32, 16)
+    _write_npz_datasets(tmp_path / 'data', 32, 16, fmt='hdf5')          # the HDF5 branch of the loader runs here
     argv = ['--exp-dir', str(tmp_path), '--data-dir', str(tmp_path / 'data'), '--data', 'channelized', '--ntrain', '32',
             '--ntest', '16', '--batch-size', '8', '--test-batch-size', '8', '--epochs', '2', '--ckpt-freq', '2',
             '--cuda', '0', '--blocks', '111', '--growth-rate', '8', '--init-features', '16', '--plot-freq', '2']
@@ -148,8 +155,8 @@ def test_cli_test_pass_with_targets_reports_reference_metrics(dev, tmp_path, mon
     nrmse, r2 = np.loadtxt(run / 'training/nrmse_test.txt'), np.loadtxt(run / 'training/r2_test.txt')
     assert nrmse.shape == (2, 3) and r2.shape == (2, 3) and np.isfinite(nrmse).all() and np.isfinite(r2).all()
     assert (run / 'training/predictions/pred_epoch2_0.png').exists()
-    with np.load(tmp_path / 'data/64x64/channel_ng64_n512_test.npz') as f:
-        x, y = f['input'][:16], f['output'][:16]
+    from pde_surrogate_amd.utils.load import read_arrays
+    x, y = read_arrays(str(tmp_path / 'data/64x64/channel_ng64_n512_test.hdf5'), 16, only_input=False)
     with contextlib.redirect_stdout(io.StringIO()):
         net = DenseED(1, 3, 64, [1, 1, 1], growth_rate=8, init_features=16)
     net.load_state_dict(torch.load(run / 'checkpoints/model_epoch2.pth', map_location='cpu'))
@@ -165,7 +172,7 @@ def test_cli_test_pass_with_targets_reports_reference_metrics(dev, tmp_path, mon
 def test_max_likelihood_cli_end_to_end(dev, tmp_path, monkeypatch, mode):
     import train_codec_max_likelihood as m
     monkeypatch.setenv('WORLD_SIZE', '1')
-    _write_npz_datasets(tmp_path / 'data', 32, 16)
+    _write_npz_datasets(tmp_path / 'data', 32, 16, fmt='hdf5' if mode == 'fused' else 'npz')
     argv = ['--exp-dir', str(tmp_path), '--data-dir', str(tmp_path / 'data'), '--data', 'channelized', '--ntrain', '32',
             '--ntest', '16', '--batch-size', '8', '--test-batch-size', '8', '--epochs', '3', '--ckpt-freq', '3',
             '--cuda', '0', '--blocks', '111', '--growth-rate', '8', '--init-features', '16', '--mode', mode]
