@@ -180,16 +180,19 @@ def config5_timing(dev, n=300):
         clo = ResidualClosure(net, z, K, 10.0, True, 0.1, 0.1, use_graph=graph)
         out[f'closure_evals_per_s_{tag}'] = round(rate(clo, n), 1)
         if graph:
-            opt = torch.optim.LBFGS(net.parameters(), lr=0.5, max_iter=20, history_size=50)
-            n0 = clo.n_calls
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(5):
-                opt.step(clo)
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-            out['lbfgs_epochs_per_s'] = round(5 / dt, 2)
-            out['lbfgs_closure_evals_per_s'] = round((clo.n_calls - n0) / dt, 1)
+            from pde_surrogate_amd.lbfgs import FlatLBFGS
+            for name, opt, k in (('torch_optim_lbfgs', torch.optim.LBFGS(net.parameters(), lr=0.5, max_iter=20, history_size=50), 4),
+                                 ('flat_lbfgs', FlatLBFGS(net._flat, net._gscratch, lr=0.5, max_iter=20, history_size=50), 12)):
+                opt.step(clo)                                 # warm-up epoch
+                n0 = clo.n_calls
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    opt.step(clo)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+                out[f'{name}_epochs_per_s'] = round(k / dt, 2)
+                out[f'{name}_closure_evals_per_s'] = round((clo.n_calls - n0) / dt, 1)
     with contextlib.redirect_stdout(io.StringIO()):
         net = Decoder(1, 3, [8, 6]).to(dev).train()
 
