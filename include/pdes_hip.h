@@ -334,6 +334,14 @@ int pdes_mse_partials(long long n);
 int pdes_mse_loss(const float* output, const float* target, float* grad_out, double* partials, float* loss_out,
                   double* loss_accum, long long n, void* stream);
 
+/* Inner products of the L-BFGS curvature history against up to four vectors, in one bandwidth-bound pass:
+ *   partials[s][r][j] = sum over slice s of k of W[r][k] * V[j][k]     (fp64; the caller sums the nsplit slices)
+ * W: (rows, ld) row-major with ld >= n a multiple of 4, V: (nv, n) row-major, nv <= 4; rows of both 16-byte aligned.
+ * Used by pde_surrogate_amd/lbfgs.py, which restates the two-loop recursion of torch.optim.LBFGS (the optimiser of
+ * solve_conv_mixed_residual.py:124) on the Gram matrix of the history. */
+int pdes_multi_dot(const float* W, long long ld, int rows, const float* V, int nv, long long n, double* partials,
+                   int nsplit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ SIGNATURES = {
     'pdes_test_metrics': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
     'pdes_mse_partials': [ctypes.c_longlong],
     'pdes_mse_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_p],
+    'pdes_multi_dot': [_c_p, ctypes.c_longlong, _c_i, _c_p, _c_i, ctypes.c_longlong, _c_p, _c_i, _c_p],
     'pdes_step_tail': [_c_p, _c_i, _c_i, _c_f, _c_i, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_p, _c_p, _c_i,
                        ctypes.c_longlong, _c_p],
 }

@@ -147,3 +147,59 @@ extern "C" int pdes_test_metrics(const float* output, const float* target, float
   }
   return PDES_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Inner products of the L-BFGS curvature history (config 5: the two-loop recursion of torch.optim.LBFGS,
+// reference solve_conv_mixed_residual.py:124, restated on Gram matrices in pde_surrogate_amd/lbfgs.py):
+//   out[s][r][j] = sum over the s-th slice of k of W[r][k] * V[j][k],   r < rows (<= 2 m + 1), j < nv (<= 4)
+// W is (rows, ld) row-major, V is (nv, n): one bandwidth-bound pass over the history (rows * n * 4 bytes) instead of a
+// GEMM with a 101 x 3 output tile and K = n (one workgroup in a BLAS library).  Per-slice fp64 partials are summed by
+// the caller in a fixed order (deterministic).
+namespace pdes {
+template <int NV>
+__global__ __launch_bounds__(256) void multi_dot_kernel(const float* __restrict__ W, long long ld, const float* __restrict__ V,
+                                                        long long n, double* __restrict__ out, int rows) {
+  __shared__ double sm[4];
+  const int r = blockIdx.y, s = blockIdx.x, ns = gridDim.x;
+  const long long n4 = n >> 2;
+  const long long lo = n4 * s / ns, hi = n4 * (s + 1) / ns;
+  const float4* w4 = reinterpret_cast<const float4*>(W + (long long)r * ld);
+  float acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float4 a = w4[i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const float4 b = reinterpret_cast<const float4*>(V + (long long)j * n)[i];
+      acc[j] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+  }
+  if (s == ns - 1 && threadIdx.x < (n & 3)) {               // tail elements
+    const long long i = (n4 << 2) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += W[(long long)r * ld + i] * V[(long long)j * n + i];
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const double t = block_sum((double)acc[j], sm);
+    if (threadIdx.x == 0) out[((long long)s * rows + r) * NV + j] = t;
+  }
+}
+}  // namespace pdes
+
+extern "C" int pdes_multi_dot(const float* W, long long ld, int rows, const float* V, int nv, long long n,
+                              double* partials, int nsplit, void* stream) {
+  if (!W || !V || !partials || rows <= 0 || nv < 1 || nv > 4 || n <= 0 || nsplit <= 0 || ld < n) return PDES_EINVAL;
+  if (!aligned16(W) || !aligned16(V) || (ld & 3) || ((n & 3) && nv > 1)) return PDES_EALIGN;   // rows of W and V 16-byte aligned
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(nsplit, rows), block(256);
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(multi_dot_kernel<1>, grid, block, 0, st, W, ld, V, n, partials, rows); break;
+    case 2: hipLaunchKernelGGL(multi_dot_kernel<2>, grid, block, 0, st, W, ld, V, n, partials, rows); break;
+    case 3: hipLaunchKernelGGL(multi_dot_kernel<3>, grid, block, 0, st, W, ld, V, n, partials, rows); break;
+    default: hipLaunchKernelGGL(multi_dot_kernel<4>, grid, block, 0, st, W, ld, V, n, partials, rows); break;
+  }
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}

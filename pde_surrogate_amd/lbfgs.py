@@ -32,8 +32,16 @@ class FlatLBFGS:
         self.tol_grad, self.tol_change, self.m = float(tolerance_grad), float(tolerance_change), int(history_size)
         n, m = flat_param.numel(), self.m
         kw = dict(device=flat_param.device, dtype=flat_param.dtype)
-        self.W = torch.zeros((2 * m + 1, n), **kw)          # rows [0, m): s_i, [m, 2m): y_i (ring slots), 2m: g
-        self.V = torch.zeros((n, 3), **kw)                  # columns s_new, y_new, g of the one GEMM per iteration
+        self.ld = (n + 3) // 4 * 4                          # rows 16-byte aligned for the HIP inner-product kernel
+        self.W = torch.zeros((2 * m + 1, self.ld), **kw)[:, :n]   # rows [0, m): s_i, [m, 2m): y_i (ring slots), 2m: g
+        self.V = torch.zeros((3, self.ld), **kw)[:, :n]     # rows s_new, y_new, g: the three vectors of the one pass
+        self.on_gpu = flat_param.is_cuda
+        if self.on_gpu:
+            if flat_param.dtype != torch.float32:
+                raise RuntimeError('FlatLBFGS on the GPU works on fp32 buffers (the HIP inner-product kernel)')
+            self.nsplit = 16
+            self._partials = torch.zeros((self.nsplit, 2 * m + 1, 3), device=flat_param.device, dtype=torch.float64)
+            self._pv = torch.zeros((self.nsplit, 3, 3), device=flat_param.device, dtype=torch.float64)
         self.d = torch.zeros(n, **kw)
         self.prev_g = torch.zeros(n, **kw)
         self.slots = []                                     # ring slots in age order (oldest first)
@@ -41,6 +49,23 @@ class FlatLBFGS:
         self.H_diag, self.t = 1.0, None
         self.n_iter_total, self.func_evals, self.prev_loss = 0, 0, None
         self.state = {}
+
+    def _products(self):
+        """(2m+1+3, 3) fp64 host array: rows of W and the three rows of V against the three rows of V -- ONE read"""
+        m = self.m
+        if not self.on_gpu:
+            return torch.cat([self.W @ self.V.t(), self.V @ self.V.t()], 0).double().cpu().numpy()
+        from . import _lib
+        L, st = _lib.lib(), _lib.stream_ptr(self.x.device)
+        with _lib.device_guard(self.x.device):
+            p = self._partials
+            rc = L.pdes_multi_dot(self.W.data_ptr(), self.ld, 2 * m + 1, self.V.data_ptr(), 3, self.ld, p.data_ptr(),
+                                  self.nsplit, st)
+            _lib.check(rc, 'pdes_multi_dot')
+            rc = L.pdes_multi_dot(self.V.data_ptr(), self.ld, 3, self.V.data_ptr(), 3, self.ld,
+                                  self._pv.data_ptr(), self.nsplit, st)
+            _lib.check(rc, 'pdes_multi_dot')
+        return torch.cat([p[:, :2 * m + 1].sum(0), self._pv.sum(0)], 0).cpu().numpy()
 
     # -- host side: the two-loop recursion on coefficient vectors ------------------------------------------------------
     def _direction_coef(self):
@@ -85,10 +110,10 @@ class FlatLBFGS:
             else:
                 # candidate pair (y, s) and every inner product with the history in one pass over W
                 V = self.V
-                torch.mul(self.d, self.t, out=V[:, 0])                 # s = d * t
-                torch.sub(self.g, self.prev_g, out=V[:, 1])            # y = g - prev_g
-                V[:, 2].copy_(self.g)
-                P = torch.cat([W @ V, V.t() @ V], 0).double().cpu().numpy()   # (2m+1+3, 3): the one host read
+                torch.mul(self.d, self.t, out=V[0])                    # s = d * t
+                torch.sub(self.g, self.prev_g, out=V[1])               # y = g - prev_g
+                V[2].copy_(self.g)
+                P = self._products()                                   # (2m+1+3, 3): the one host read
                 ys, yy = P[2 * m + 1 + 1, 0], P[2 * m + 1 + 1, 1]
                 if ys > 1e-10:
                     if len(self.slots) == m:
@@ -96,8 +121,8 @@ class FlatLBFGS:
                     else:
                         k = len(self.slots)
                     self.slots.append(k)
-                    W[k].copy_(V[:, 0])
-                    W[m + k].copy_(V[:, 1])
+                    W[k].copy_(V[0])
+                    W[m + k].copy_(V[1])
                     # Gram rows / columns of the new s and y against everything currently stored
                     G[k, :], G[:, k] = P[:2 * m + 1, 0], P[:2 * m + 1, 0]
                     G[m + k, :], G[:, m + k] = P[:2 * m + 1, 1], P[:2 * m + 1, 1]
