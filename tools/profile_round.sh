@@ -1,0 +1,58 @@
+#!/bin/bash
+# rocprofv3 evidence of one round, run ON THE GPU BOX from the repo root:
+#   gpurun -- 'bash tools/profile_round.sh r02_b'
+# writes summaries under gpurun_out/<tag>/ (copy the ones to be judged into profiles/).  Counter passes (--pmc) run
+# separately from the kernel-trace/stats pass, each with --kernel-trace only (MI355X_MICROARCH.md).
+TAG=${1:-r02}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+db() { find $1 -name "*.db" | head -1; }
+
+# (A) the bench command: kernel trace + stats, step timeline, loss-kernel launches
+rocprofv3 --kernel-trace --stats --output-format rocpd -d $OUT/bench -o bench -- \
+    python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+D=$(db $OUT/bench)
+python $ROOT/tools/rocprof_summary.py $D > $OUT/kernel_stats.csv
+python $ROOT/tools/timeline.py $D > $OUT/step_timeline.txt
+python $ROOT/tools/rocprof_summary.py $D --by-grid darcy_loss > $OUT/loss_kernel_by_batch.csv
+python $ROOT/tools/rocprof_summary.py $D --per-launch darcy_loss 8388608 > $OUT/loss_kernel_per_launch.csv
+python - $OUT/loss_kernel_per_launch.csv > $OUT/loss_kernel_sustained.csv <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+last = rows[-100:]                      # bench.py: 1 + 3 burst + 100 warm-up launches, then the 100 timed ones
+d = [float(r['duration_us']) for r in last]
+avg = sum(d) / len(d)
+b = 114688 * 16384
+print(f'# darcy_loss_kernel<64,true,false>, B = 16384: the LAST 100 of {len(rows)} dispatches of `bench.py` (the HIP-event timed ones, after 100+ back-to-back warm-up launches)')
+print(f'# avg_us,{avg:.3f},min_us,{min(d):.3f},max_us,{max(d):.3f},algorithmic_bytes,{b},GBps,{b / avg / 1e3:.1f},frac_of_8TBps,{b / avg / 1e3 / 8000:.4f}')
+print('launch,start_us,duration_us')
+for r in last:
+    print(f"{r['launch']},{r['start_us']},{r['duration_us']}")
+PY
+
+# (B) HBM traffic of the loss kernel (B = 16384): FETCH_SIZE and WRITE_SIZE in separate passes
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format rocpd -d $OUT/pmc_loss_$C -o p -- python $ROOT/tools/bench_loss.py pmc > /dev/null 2>&1
+  echo "== $C (loss kernel, B = 16384)" >> $OUT/pmc_loss.txt
+  python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_loss_$C) >> $OUT/pmc_loss.txt
+done
+
+# (C) HBM traffic of the dense-block data-gradient kernels (layers 24 = 180->16 at 32x32, 16 = 184->16 at 16x16, 6 = 128->16
+#     at 32x32) and of the 1x1 layers (7, 17): the read-modify-write of the accumulator T
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format rocpd -d $OUT/pmc_conv_$C -o p -- python $ROOT/tools/bench_conv.py 6,7,16,17,24 > $OUT/bench_conv_pmc_run.log 2>&1
+  echo "== $C (tools/bench_conv.py 6,7,16,17,24)" >> $OUT/pmc_conv.txt
+  python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_conv_$C) >> $OUT/pmc_conv.txt
+done
+
+# (D) matrix-pipe occupancy of the 1x1 kernels and the dense layers
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format rocpd -d $OUT/pmc_mfma -o p -- python $ROOT/tools/bench_conv.py 6,7,16,17,24,25 > /dev/null 2>&1
+python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_mfma) > $OUT/pmc_mfma.txt
+
+# (E) per-layer stand-alone timings (HIP events)
+python $ROOT/tools/bench_conv.py > $OUT/per_layer_conv_microbench.log 2>&1
+rm -rf $OUT/bench $OUT/pmc_loss_* $OUT/pmc_conv_* $OUT/pmc_mfma       # the databases stay on the box
+ls -la $OUT
