@@ -42,10 +42,13 @@ done
 
 # (C) HBM traffic of the dense-block data-gradient kernels (layers 24 = 180->16 at 32x32, 16 = 184->16 at 16x16, 6 = 128->16
 #     at 32x32) and of the 1x1 layers (7, 17): the read-modify-write of the accumulator T
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format rocpd -d $OUT/pmc_conv_$C -o p -- python $ROOT/tools/bench_conv.py 6,7,16,17,24 > $OUT/bench_conv_pmc_run.log 2>&1
-  echo "== $C (tools/bench_conv.py 6,7,16,17,24)" >> $OUT/pmc_conv.txt
-  python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_conv_$C) >> $OUT/pmc_conv.txt
+#     one layer per process: the kernel template names do not tell layers of one shape class apart
+for LAYER in 24 16 7 17; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format rocpd -d $OUT/pmc_conv_${LAYER}_$C -o p -- python $ROOT/tools/bench_conv.py $LAYER > $OUT/bench_conv_pmc_run.log 2>&1
+    echo "== $C layer $LAYER (tools/bench_conv.py $LAYER)" >> $OUT/pmc_conv.txt
+    python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_conv_${LAYER}_$C) | grep -A1 -E "1, 1, 1, 1, 0, false, false|1x1_mfma_kernel<[0-9, ]*1>|finalize" >> $OUT/pmc_conv.txt
+  done
 done
 
 # (D) matrix-pipe occupancy of the 1x1 kernels and the dense layers
