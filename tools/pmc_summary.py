@@ -25,7 +25,7 @@ def main(path):
             continue
         print(k[:110])
         for n, vs in sorted(agg[k].items()):
-            print(f'    {n:32s} mean {sum(vs) / len(vs):16.1f}  n={len(vs)}')
+            print(f'    {n:32s} mean {sum(vs) / len(vs):16.1f}  median {sorted(vs)[len(vs) // 2]:16.1f}  n={len(vs)}')
 
 
 if __name__ == '__main__':
