@@ -123,10 +123,16 @@ int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* im
                                        pdes_conv_backward_data applies the adjoint resampling + ReLU mask + gamma into
                                        t_in, dgamma / dbeta into bn_grad; there is no weight gradient and `g` must be
                                        dL/d(out) itself (fin_tstats = NULL) */
+#define PDES_OP_CHANNEL_MASK 3       /* this descriptor is NOT a convolution (ksize = 0, Cout = Cin, same map size): nn.Dropout2d
+                                       after the previous descriptor's convolution (codec.py:70-71, :111-120, :134-150,
+                                       :172-173).  out[b, out_coff + c] *= w[b * Cout + c] in place (`w` = B x Cout floats, 0
+                                       or 1/(1-p), drawn by the caller), out_stats accumulated here (the convolution before it
+                                       passes out_stats = NULL); backward: g[b, g_coff + c] *= w[b * Cout + c] in place, after
+                                       the finalize of these channels, which is carried by THIS descriptor's fin_* */
 typedef struct pdes_conv_desc {
   /* geometry */
   int B, Cin, Cout, Hin, Win, Hout, Wout;
-  int ksize, stride, pad, upsample; /* upsample: 0, PDES_UPSAMPLE_NEAREST or PDES_UPSAMPLE_BILINEAR_OP */
+  int ksize, stride, pad, upsample; /* upsample: 0, PDES_UPSAMPLE_NEAREST, or an op: PDES_UPSAMPLE_BILINEAR_OP / PDES_OP_CHANNEL_MASK */
   /* input activation (raw, pre-BN) */
   const float* x;        /* (B, x_ctot, Hin, Win); channels [0, Cin) are read */
   int x_ctot;

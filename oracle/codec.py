@@ -32,47 +32,58 @@ def _up(x, upsample):
     return F.interpolate(x, scale_factor=2.0, mode='bilinear', align_corners=True)
 
 
-def _dense_block(sd, name, x, n_layers, training):
+def _drop(y, masks, training):
+    """nn.Dropout2d after a convolution (codec.py:70-71, :111-120, :134-150, :172-173): `masks` is an iterator of
+    (B, C) arrays holding 0 or 1/(1-p), consumed in the reference's call order; None = drop_rate 0"""
+    if masks is None or not training:
+        return y
+    m = torch.as_tensor(next(masks), dtype=y.dtype)
+    return y * m[:, :, None, None]
+
+
+def _dense_block(sd, name, x, n_layers, training, masks=None):
     for j in range(1, n_layers + 1):
         p = f'{name}.denselayer{j}'
         z = _bn_relu(sd, p + '.norm1', x, training)
-        x = torch.cat([x, F.conv2d(z, sd[p + '.conv1.weight'], padding=1)], 1)
+        x = torch.cat([x, _drop(F.conv2d(z, sd[p + '.conv1.weight'], padding=1), masks, training)], 1)
     return x
 
 
-def _transition(sd, name, x, down, training, upsample):
+def _transition(sd, name, x, down, training, upsample, masks=None):
     z = _bn_relu(sd, name + '.norm1', x, training)
-    x = F.conv2d(z, sd[name + '.conv1.weight'])
+    x = _drop(F.conv2d(z, sd[name + '.conv1.weight']), masks, training)
     z = _bn_relu(sd, name + '.norm2', x, training)
     if down:
-        return F.conv2d(z, sd[name + '.conv2.weight'], stride=2, padding=1)
-    return F.conv2d(_up(z, upsample), sd[name + '.conv2.weight'], padding=1)
+        return _drop(F.conv2d(z, sd[name + '.conv2.weight'], stride=2, padding=1), masks, training)
+    return _drop(F.conv2d(_up(z, upsample), sd[name + '.conv2.weight'], padding=1), masks, training)
 
 
-def _last(sd, name, x, training, upsample):
+def _last(sd, name, x, training, upsample, masks=None):
     z = _bn_relu(sd, name + '.norm1', x, training)
-    x = F.conv2d(z, sd[name + '.conv1.weight'], padding=1)
+    x = _drop(F.conv2d(z, sd[name + '.conv1.weight'], padding=1), masks, training)
     z = _bn_relu(sd, name + '.norm2', x, training)
     x = F.conv2d(_up(z, upsample), sd[name + '.conv2.weight'], padding=1)
     z = _bn_relu(sd, name + '.norm3', x, training)
     return F.conv2d(z, sd[name + '.conv3.weight'], padding=2)
 
 
-def densed_forward(sd, x, blocks, imsize=64, training=True, upsample='nearest'):
+def densed_forward(sd, x, blocks, imsize=64, training=True, upsample='nearest', dropout_masks=None):
     """DenseED.forward (codec.py:295-296). `sd` maps 'features.*' keys to tensors; running
-    statistics in `sd` are updated in place when training (like nn.BatchNorm2d)."""
+    statistics in `sd` are updated in place when training (like nn.BatchNorm2d).  dropout_masks: list of (B, C) channel
+    masks (0 or 1/(1-p)) in the reference's Dropout2d call order (drop_rate > 0), None otherwise."""
+    masks = iter(dropout_masks) if dropout_masks is not None else None
     f = 'features.'
     enc, dec = blocks[:len(blocks) // 2], blocks[len(blocks) // 2:]
     pad = 3 if imsize % 2 == 0 else 2
     x = F.conv2d(x, sd[f + 'In_conv.weight'], stride=2, padding=pad)
     for i, n in enumerate(enc, 1):
-        x = _dense_block(sd, f'{f}EncBlock{i}', x, n, training)
-        x = _transition(sd, f'{f}TransDown{i}', x, True, training, upsample)
+        x = _dense_block(sd, f'{f}EncBlock{i}', x, n, training, masks)
+        x = _transition(sd, f'{f}TransDown{i}', x, True, training, upsample, masks)
     for i, n in enumerate(dec, 1):
-        x = _dense_block(sd, f'{f}DecBlock{i}', x, n, training)
+        x = _dense_block(sd, f'{f}DecBlock{i}', x, n, training, masks)
         if i < len(dec):
-            x = _transition(sd, f'{f}TransUp{i}', x, False, training, upsample)
-    return _last(sd, f + 'LastTransUp', x, training, upsample)
+            x = _transition(sd, f'{f}TransUp{i}', x, False, training, upsample, masks)
+    return _last(sd, f + 'LastTransUp', x, training, upsample, masks)
 
 
 def decoder_forward(sd, z, blocks, training=True, upsample='nearest'):

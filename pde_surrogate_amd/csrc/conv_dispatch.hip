@@ -22,7 +22,16 @@ int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st);            // 1x1
 int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int upsample_bilinear_forward(const pdes_conv_desc& d, hipStream_t st);   // PDES_UPSAMPLE_BILINEAR_OP descriptors
 int upsample_bilinear_backward(const pdes_conv_desc& d, hipStream_t st);
-static bool is_resample_op(const pdes_conv_desc& d) { return d.upsample == PDES_UPSAMPLE_BILINEAR_OP; }
+int channel_mask_forward(const pdes_conv_desc& d, hipStream_t st);        // PDES_OP_CHANNEL_MASK descriptors (Dropout2d)
+int channel_mask_backward(const pdes_conv_desc& d, hipStream_t st);
+// descriptors that are not convolutions: no weights, their own forward / backward kernels
+static bool is_resample_op(const pdes_conv_desc& d) { return d.upsample == PDES_UPSAMPLE_BILINEAR_OP || d.upsample == PDES_OP_CHANNEL_MASK; }
+static int op_forward(const pdes_conv_desc& d, hipStream_t st) {
+  return d.upsample == PDES_OP_CHANNEL_MASK ? channel_mask_forward(d, st) : upsample_bilinear_forward(d, st);
+}
+static int op_backward(const pdes_conv_desc& d, hipStream_t st) {
+  return d.upsample == PDES_OP_CHANNEL_MASK ? channel_mask_backward(d, st) : upsample_bilinear_backward(d, st);
+}
 
 // option PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
 // the matrix-core kernels against them); anything else = automatic selection.
@@ -37,7 +46,7 @@ extern "C" int pdes_conv_forward(const pdes_context* ctx, const pdes_conv_desc* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
     if (is_resample_op(descs[i])) {
-      const int rc = upsample_bilinear_forward(descs[i], st);
+      const int rc = op_forward(descs[i], st);
       if (rc) return rc;
       continue;
     }
@@ -80,7 +89,7 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
     if (is_resample_op(descs[i])) {
-      const int rc = upsample_bilinear_backward(descs[i], st);
+      const int rc = op_backward(descs[i], st);
       if (rc) return rc;
       continue;
     }
@@ -191,7 +200,7 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
       const int rc = release(i, fork && i == 0);
       if (rc) return rc;
     }
-    if (d.has_bn) {
+    if (d.has_bn || is_resample_op(d)) {
       const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
       if (rc) return rc;
     }

@@ -159,3 +159,64 @@ int upsample_bilinear_backward(const pdes_conv_desc& d, hipStream_t st) {
 }
 
 }  // namespace pdes
+
+// ------------------------------------------------------------------------------------------------------------------
+// `--drop-rate > 0`: nn.Dropout2d after a convolution (reference codec.py:70-71 dense layer, :111-120 / :134-150
+// transitions, :172-173 last decoding): whole channels of a sample are zeroed, the rest scaled by 1/(1-p).
+// PDES_OP_CHANNEL_MASK descriptor: out[b, out_coff + c] *= mask[b, c] IN PLACE (mask = `w`, B x Cout floats holding 0 or
+// 1/(1-p), drawn by the caller), accumulating the batch statistics of the masked channels (the convolution before it
+// runs with out_stats = NULL).  Backward (pdes_conv_backward_data): g[b, g_coff + c] *= mask[b, c] in place -- the
+// BatchNorm-backward finalize of these channels belongs to THIS descriptor (fin_*), the convolution's is NULL.
+namespace pdes {
+
+// grid (ceil(HW / 1024), C, B), 256 threads x float4
+__global__ __launch_bounds__(256) void channel_mask_kernel(float* __restrict__ buf, int ctot, int coff, int HW,
+                                                           const float* __restrict__ mask, int C, double* __restrict__ stats,
+                                                           int nrep, long long rep_stride) {
+  __shared__ double red[4][2];
+  const int c = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const float m = mask[b * C + c];
+  float4* p = reinterpret_cast<float4*>(buf + ((size_t)b * ctot + coff + c) * HW);
+  const int i = blockIdx.x * 256 + tid;
+  float s = 0.f, q = 0.f;
+  if (i < HW / 4) {
+    float4 v = p[i];
+    v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+    p[i] = v;
+    s = (v.x + v.y) + (v.z + v.w);
+    q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (!stats) return;
+  const float ws = wave_sum(s), wq = wave_sum(q);
+  if ((tid & 63) == 0) { red[tid >> 6][0] = ws; red[tid >> 6][1] = wq; }
+  __syncthreads();
+  if (tid < 2) {
+    const double t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    atomicAdd(&stats[(long long)rep_of_block(nrep) * rep_stride + 2 * (coff + c) + tid], t);
+  }
+}
+
+static bool mask_desc_ok(const pdes_conv_desc& d) {
+  return d.upsample == PDES_OP_CHANNEL_MASK && d.ksize == 0 && d.Cin == d.Cout && d.Hout == d.Hin && d.Wout == d.Win &&
+         d.w && (d.Hout * d.Wout) % 4 == 0 && d.nrep == PDES_NREP;
+}
+
+int channel_mask_forward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!mask_desc_ok(d) || !d.out || !aligned16(d.out)) return PDES_EINVAL;
+  const int HW = d.Hout * d.Wout;
+  hipLaunchKernelGGL(channel_mask_kernel, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, d.out, d.out_ctot,
+                     d.out_coff, HW, d.w, d.Cout, d.out_stats, d.nrep, d.rep_stride);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int channel_mask_backward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!mask_desc_ok(d) || !d.g || !aligned16(d.g)) return PDES_EINVAL;
+  const int HW = d.Hout * d.Wout;
+  hipLaunchKernelGGL(channel_mask_kernel, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, const_cast<float*>(d.g),
+                     d.g_ctot, d.g_coff, HW, d.w, d.Cout, (double*)nullptr, d.nrep, d.rep_stride);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+}  // namespace pdes

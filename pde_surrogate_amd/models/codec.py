@@ -76,7 +76,7 @@ def _pad16(n):
 
 # ------------------------------------------------------------------------------------------------
 # network description: a list of convolution specs in forward order
-UP_NEAREST, UP_BILINEAR_OP = 1, 2     # pdes_conv_desc.upsample (include/pdes_hip.h)
+UP_NEAREST, UP_BILINEAR_OP, OP_CHANNEL_MASK = 1, 2, 3     # pdes_conv_desc.upsample (include/pdes_hip.h)
 
 
 class _ConvSpec:
@@ -98,6 +98,14 @@ class _ConvSpec:
         return self.norm is not None or self.fake_bn
 
 
+def _plan_dropout(specs, bufs, drop):
+    """nn.Dropout2d after the convolution just planned (reference codec.py:70-71, :111-120, :134-150, :172-173): a
+    channel-mask op in place on the channels that convolution wrote"""
+    if drop:
+        s = specs[-1]
+        specs.append(_ConvSpec(None, None, s.cout, s.cout, 0, 1, 0, OP_CHANNEL_MASK, s.dst, s.dst, s.dst_coff, bufs[s.dst][1]))
+
+
 def _plan_up_conv(specs, bufs, t, conv, norm, cin, cout, mid, nxt, res, nres, upsample):
     """BN-ReLU -> x2 upsampling -> conv3x3 (reference codec.py:137-146 / :174-181)"""
     if upsample == 'nearest':
@@ -109,16 +117,17 @@ def _plan_up_conv(specs, bufs, t, conv, norm, cin, cout, mid, nxt, res, nres, up
     specs.append(_ConvSpec(conv, None, cin, cout, 3, 1, 1, 0, up, nxt, 0, nres, fake_bn=True))
 
 
-def _plan_block(specs, bufs, name, c, n_layers, growth, src, scale):
+def _plan_block(specs, bufs, name, c, n_layers, growth, src, scale, drop=False):
     """dense block: buffer `src` has room for all channels; layer j reads [0,c) writes [c,c+g)"""
     for j in range(1, n_layers + 1):
         p = f'{name}.denselayer{j}'
         specs.append(_ConvSpec(p + '.conv1', p + '.norm1', c, growth, 3, 1, 1, 0, src, src, c, scale))
+        _plan_dropout(specs, bufs, drop)
         c += growth
     return c
 
 
-def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsize, upsample='nearest'):
+def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsize, upsample='nearest', drop=False):
     """stage order and channel bookkeeping of DenseED (reference codec.py:229-293)"""
     if len(blocks) > 1 and len(blocks) % 2 == 0:
         raise ValueError('length of blocks must be an odd number, but got {}'.format(len(blocks)))
@@ -132,39 +141,44 @@ def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsiz
     specs.append(_ConvSpec('In_conv', None, in_channels, init_features, 7, 2, pad, 0, 'in', cur, 0, (1, 1)))
     nb = 1
     for i, n in enumerate(enc, 1):
-        c = _plan_block(specs, bufs, f'EncBlock{i}', c, n, growth, cur, res)
+        c = _plan_block(specs, bufs, f'EncBlock{i}', c, n, growth, cur, res, drop)
         t = f'TransDown{i}'
         mid, nxt = f'b{nb}', f'b{nb + 1}'
         nb += 2
         bufs[mid] = [c // 2, res]
         specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
+        _plan_dropout(specs, bufs, drop)
         nres = (res[0], res[1] * 2)
         following = enc[i] if i < len(enc) else dec[0]
         bufs[nxt] = [c // 2 + following * growth, nres]
         specs.append(_ConvSpec(t + '.conv2', t + '.norm2', c // 2, c // 2, 3, 2, 1, 0, mid, nxt, 0, res))
+        _plan_dropout(specs, bufs, drop)
         cur, c, res = nxt, c // 2, nres
     for i, n in enumerate(dec, 1):
-        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res)
+        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res, drop)
         if i < len(dec):
             t = f'TransUp{i}'
             mid, nxt = f'b{nb}', f'b{nb + 1}'
             nb += 2
             bufs[mid] = [c // 2, res]
             specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
+            _plan_dropout(specs, bufs, drop)
             nres = (res[0] * 2, res[1])
             bufs[nxt] = [c // 2 + dec[i] * growth, nres]
             _plan_up_conv(specs, bufs, t, t + '.conv2', t + '.norm2', c // 2, c // 2, mid, nxt, res, nres, upsample)
+            _plan_dropout(specs, bufs, drop)
             cur, c, res = nxt, c // 2, nres
-    _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample)
+    _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample, drop)
     return specs, bufs
 
 
-def _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample='nearest'):
+def _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample='nearest', drop=False):
     """last decoding (reference codec.py:163-188)"""
     t = 'LastTransUp'
     m1, m2 = f'b{nb}', f'b{nb + 1}'
     bufs[m1] = [c // 2, res]
     specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 3, 1, 1, 0, cur, m1, 0, res))
+    _plan_dropout(specs, bufs, drop)                  # (the reference drops only after conv1 here, codec.py:172-173)
     nres = (res[0] * 2, res[1])
     bufs[m2] = [c // 4, nres]
     _plan_up_conv(specs, bufs, t, t + '.conv2', t + '.norm2', c // 2, c // 4, m1, m2, res, nres, upsample)
@@ -172,7 +186,7 @@ def _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample='nearest'):
     specs.append(_ConvSpec(t + '.conv3', t + '.norm3', c // 4, out_channels, 5, 1, 2, 0, m2, 'out', 0, nres))
 
 
-def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels, upsample='nearest'):
+def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels, upsample='nearest', drop=False):
     """Decoder (reference codec.py:326-354); sizes are relative to the latent map (16x16 -> 64x64)"""
     specs, bufs = [], {}
     res = (1, 1)
@@ -181,18 +195,20 @@ def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels, upsam
     bufs[cur] = [c + blocks[0] * growth, res]
     specs.append(_ConvSpec('conv0', None, dim_latent, init_features, 3, 1, 1, 0, 'in', cur, 0, res))
     for i, n in enumerate(blocks, 1):
-        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res)
+        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res, drop)
         if i < len(blocks):
             t = f'TransUp{i}'
             mid, nxt = f'b{nb}', f'b{nb + 1}'
             nb += 2
             bufs[mid] = [c // 2, res]
             specs.append(_ConvSpec(t + '.conv1', t + '.norm1', c, c // 2, 1, 1, 0, 0, cur, mid, 0, res))
+            _plan_dropout(specs, bufs, drop)
             nres = (res[0] * 2, res[1])
             bufs[nxt] = [c // 2 + blocks[i] * growth, nres]
             _plan_up_conv(specs, bufs, t, t + '.conv2', t + '.norm2', c // 2, c // 2, mid, nxt, res, nres, upsample)
+            _plan_dropout(specs, bufs, drop)
             cur, c, res = nxt, c // 2, nres
-    _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample)
+    _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample, drop)
     return specs, bufs
 
 
@@ -272,6 +288,14 @@ class _Engine:
         ts = lambda k: a0 + 8 * (n_stat + self.stat_off[k])
         bg = lambda nm: a0 + 8 * (2 * n_stat + bn_off[nm])
 
+        # Dropout2d channel masks: one flat buffer for every mask op (B x C each), and ones for eval mode
+        self.mask_off, n_mask = {}, 0
+        for i, s in enumerate(specs):
+            if s.up == OP_CHANNEL_MASK:
+                self.mask_off[i] = n_mask
+                n_mask += B * s.cout
+        self.drop_masks = torch.ones(max(n_mask, 1), device=dev)
+        self.drop_ones = torch.ones(max(n_mask, 1), device=dev)
         n = len(specs)
         self.descs = (ConvDesc * n)()
         last_reader = {}
@@ -325,6 +349,8 @@ class _Engine:
                 consumed[s.src] = max(consumed.get(s.src, 0), s.cin)
             d.out = self.X[s.dst].data_ptr()
             d.out_ctot, d.out_coff = bufs[s.dst][0], s.dst_coff
+            if s.up == OP_CHANNEL_MASK:
+                d.w = self.drop_masks.data_ptr() + 4 * self.mask_off[i]
             if s.dst != 'out':
                 d.out_stats = xs(s.dst)
                 d.fin_xstats, d.fin_tstats = xs(s.dst), ts(s.dst)
@@ -332,6 +358,10 @@ class _Engine:
                 d.g_ctot, d.g_coff = bufs[s.dst][0], s.dst_coff
                 if s.up == UP_BILINEAR_OP:          # its consumer's BatchNorm is the identity: T IS dL/d(out)
                     d.fin_xstats, d.fin_tstats = None, None
+                if i + 1 < n and specs[i + 1].up == OP_CHANNEL_MASK:
+                    # a Dropout2d op follows: IT accumulates the statistics of these channels and carries their
+                    # BatchNorm-backward finalize; this convolution's `g` is then already dL/d(its own output)
+                    d.out_stats, d.fin_xstats, d.fin_tstats = None, None, None
             else:
                 d.out_stats = None
                 d.g, d.g_ctot, d.g_coff = None, bufs[s.dst][0], 0
@@ -413,6 +443,19 @@ class _Engine:
         for d, os_ in zip(self.descs, self._out_stats):
             d.eval_mode = ev
             d.out_stats = os_ if training else None     # eval: running statistics, nothing accumulated
+        if self.mask_off:
+            # nn.Dropout2d: a fresh Bernoulli(1 - p) channel mask scaled by 1/(1-p) per training forward; identity in eval
+            src = self.drop_masks if training else self.drop_ones
+            for i, off in self.mask_off.items():
+                self.descs[i].w = src.data_ptr() + 4 * off
+            if training:
+                p = net.drop_rate
+                inject = getattr(net, '_dropout_inject', None)      # tests: masks given in the reference's call order
+                if inject is not None:
+                    flat = torch.cat([torch.as_tensor(m, dtype=torch.float32).reshape(-1) for m in inject])
+                    self.drop_masks.copy_(flat.to(self.dev))
+                else:
+                    self.drop_masks.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
         if training:
             self.arena.zero_()
         net._pack_weights()
@@ -518,9 +561,9 @@ class _HipNet(nn.Module):
     """shared machinery of DenseED and Decoder"""
 
     def _finish_init(self, specs, bufs, drop_rate, upsample, out_activation):
-        if drop_rate and drop_rate > 0:
-            raise NotImplementedError('drop_rate > 0 (Dropout2d) is not implemented by the HIP path '
-                                      '(the reference default and every published setup use 0)')
+        if not (0.0 <= float(drop_rate) < 1.0):
+            raise ValueError(f'drop_rate must be in [0, 1); got {drop_rate}')
+        self.drop_rate = float(drop_rate)
         if upsample not in ('nearest', 'bilinear'):
             raise ValueError(f"upsample must be 'nearest' or 'bilinear' (reference codec.py:132-146); got {upsample!r}")
         if out_activation is not None:
@@ -773,7 +816,10 @@ class DenseED(_HipNet):
         if bottleneck:
             raise NotImplementedError('bottleneck dense layers are not implemented (reference default False)')
         blocks = [int(b) for b in blocks]
-        specs, bufs = _plan_densed(blocks, growth_rate, init_features, in_channels, out_channels, imsize, upsample)
+        if upsample not in ('nearest', 'bilinear'):
+            raise ValueError(f"upsample must be 'nearest' or 'bilinear' (reference codec.py:132-146); got {upsample!r}")
+        specs, bufs = _plan_densed(blocks, growth_rate, init_features, in_channels, out_channels, imsize, upsample,
+                                   drop=bool(drop_rate and drop_rate > 0))
         self._finish_init(specs, bufs, drop_rate, upsample, out_activation)
         print('# params {}, # conv layers {}'.format(*self.model_size))
 
@@ -785,5 +831,8 @@ class Decoder(_HipNet):
                  drop_rate=0., upsample='nearest', out_activation=None):
         super(Decoder, self).__init__()
         blocks = [int(b) for b in blocks]
-        specs, bufs = _plan_decoder(blocks, growth_rate, init_features, dim_latent, out_channels, upsample)
+        if upsample not in ('nearest', 'bilinear'):
+            raise ValueError(f"upsample must be 'nearest' or 'bilinear' (reference codec.py:344-347); got {upsample!r}")
+        specs, bufs = _plan_decoder(blocks, growth_rate, init_features, dim_latent, out_channels, upsample,
+                                    drop=bool(drop_rate and drop_rate > 0))
         self._finish_init(specs, bufs, drop_rate, upsample, out_activation)

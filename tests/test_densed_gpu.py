@@ -219,6 +219,57 @@ def test_g13_bilinear_upsampling(dev):
     assert n_full >= 10
 
 
+def test_g16_dropout(dev):
+    """--drop-rate > 0 (nn.Dropout2d after the convolutions, reference codec.py:70-71, :111-120, :134-150, :172-173):
+    with the reference's channel masks injected -- output, loss terms, every gradient tensor, running statistics; eval
+    mode ignores the masks; and the masks the engine draws itself are Bernoulli(1 - p) / (1 - p) per (sample, channel)"""
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    g = golden('G16_dropout.npz')
+    p = float(g['p'])
+    net = DenseED(1, 3, 16, [2, 2, 2], growth_rate=4, init_features=8, drop_rate=p)
+    net.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd0/')})
+    net = net.to(dev).train()
+    net._dropout_inject = [g[f'mask{i}'] for i in range(int(g['n_masks']))]
+    x = torch.from_numpy(g['x']).to(dev)
+    y = net(x)
+    assert rel_l2(y.detach().cpu().numpy(), g['y']) < 1e-5
+    loss, l_pde, l_dir, l_neu = darcy_mixed_residual_loss(x, y, 10.0)
+    ref = g['terms']
+    np.testing.assert_allclose([float(loss.detach()), float(l_pde), float(l_dir), float(l_neu)],
+                               [ref[0], ref[1] + ref[2], ref[3], ref[4]], rtol=1e-5)
+    loss.backward()
+    for name, q in net.named_parameters():
+        assert rel_l2(q.grad.cpu().numpy(), g['grad/' + name]) < 1e-3, name
+    sd1 = net.state_dict()
+    for k in g.files:
+        if k.startswith('sd1/'):
+            np.testing.assert_allclose(sd1[k[4:]].cpu().numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        ye = net(x)
+    assert rel_l2(ye.cpu().numpy(), g['y_eval']) < 1e-5
+    # the engine's own masks
+    net._dropout_inject = None
+    net.train()
+    big = DenseED(1, 3, 64, [3, 3, 3], growth_rate=16, init_features=48, drop_rate=0.3).to(dev).train()
+    xb = torch.exp(0.5 * torch.randn(16, 1, 64, 64, device=dev))
+    y1 = big(xb)
+    eng = big._engines[(16, 64, 64)][0]
+    m = eng.drop_masks
+    vals = torch.unique(m)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.7) < 1e-6
+    assert abs(float((m == 0).float().mean()) - 0.3) < 0.05
+    y2 = big(xb)
+    assert not torch.equal(y1, y2)                                   # a fresh mask per forward
+    big.eval()
+    with torch.no_grad():
+        assert torch.equal(big(xb), big(xb))                          # deterministic without dropout
+    big.train()
+    darcy_mixed_residual_loss(xb, big(xb), 10.0)[0].backward()
+    assert all(torch.isfinite(q.grad).all() for q in big.parameters())
+
+
 def test_dropin_training_loop_matches_reference_first_steps(dev):
     """the reference's loop body (train_codec_mixed_residual.py:224-240) on the drop-in modules,
     with torch.optim.Adam -- step 1 is the parity check (G7), later steps the same descent."""
@@ -274,8 +325,8 @@ def test_g10_decoder_nonlinear(dev):
 
 def test_rejects_unsupported_options(dev):
     from pde_surrogate_amd.models.codec import DenseED
-    with pytest.raises(NotImplementedError):
-        DenseED(1, 3, 64, [1, 1, 1], drop_rate=0.1)
+    with pytest.raises(ValueError):
+        DenseED(1, 3, 64, [1, 1, 1], drop_rate=1.0)
     with pytest.raises(ValueError):
         DenseED(1, 3, 64, [1, 1, 1], upsample='bicubic')
     with pytest.raises(ValueError):

@@ -281,3 +281,27 @@ def test_g15_max_likelihood_loop_and_eval_metrics():
     # eval-mode metrics from the reference's weights are chaotic after 3 Adam steps; the metric FORMULAS are pinned
     # on the stored eval output instead (mse, nrmse, r2 of test())
     np.testing.assert_allclose(train.y_variation(g['target']), g['y_variation'], rtol=1e-6)
+
+
+def test_g16_dropout_positions_and_scaling():
+    """--drop-rate > 0: the reference with injected channel masks (tools/gen_golden.py gen_dropout)"""
+    g = golden('G16_dropout.npz')
+    sd = {k[4:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith('sd0/')}
+    masks = [g[f'mask{i}'] for i in range(int(g['n_masks']))]
+    keys = codec.param_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    x = torch.from_numpy(g['x'])
+    y = codec.densed_forward(sd, x, [2, 2, 2], 16, True, dropout_masks=masks)
+    assert rel_l2(y.detach().numpy(), g['y']) < 1e-5
+    t = darcy.mixed_residual_loss(x, y, 10.0)
+    np.testing.assert_allclose([float(v.detach()) for v in t], g['terms'], rtol=1e-5)
+    t[0].backward()
+    for k in keys:
+        assert rel_l2(sd[k].grad.numpy(), g['grad/' + k]) < 1e-3, k
+    for k in g.files:
+        if k.startswith('sd1/'):
+            np.testing.assert_allclose(sd[k[4:]].detach().numpy(), g[k], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        ye = codec.densed_forward(sd, x, [2, 2, 2], 16, False, dropout_masks=masks)      # eval: masks ignored
+    assert rel_l2(ye.numpy(), g['y_eval']) < 1e-5

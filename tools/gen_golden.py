@@ -195,6 +195,62 @@ def gen_round2():
                         y_variation=yvar, y_eval=o.numpy())
 
 
+def gen_dropout():
+    """G16: --drop-rate > 0 (nn.Dropout2d after the convolution of every dense layer, after both convolutions of a
+    transition and after the first convolution of the last decoding: reference codec.py:70-71, :111-120, :134-150,
+    :172-173).  The channel masks are drawn here with numpy and INJECTED into the reference through
+    torch.nn.functional.dropout2d (what nn.Dropout2d.forward calls), so the fixture pins WHERE the reference applies
+    dropout and its 1/(1-p) scaling, independent of any RNG stream: masks (in call order), output, loss terms, all
+    gradients, running statistics after the step, and the eval-mode output (dropout inactive)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(20190616)
+    p = 0.25
+    torch.manual_seed(7)
+    net = quiet(DenseED, 1, 3, 16, [2, 2, 2], 4, 8, drop_rate=p)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if 'norm' in k and k.endswith('.weight'):
+                v.copy_(1 + 0.2 * torch.randn_like(v))
+            if k.endswith('.bias'):
+                v.copy_(0.1 * torch.randn_like(v))
+    sd0 = {k: v.clone().numpy() for k, v in net.state_dict().items()}
+    x = np.exp(0.5 * rng.standard_normal((4, 1, 16, 16))).astype(np.float32)
+    masks = []
+    orig = F.dropout2d
+
+    def injected(input, p=0.5, training=True, inplace=False):
+        if not training:
+            return input
+        m = (rng.uniform(size=input.shape[:2]) >= p).astype(np.float32) / (1.0 - p)
+        masks.append(m)
+        return input * torch.from_numpy(m)[:, :, None, None]
+    F.dropout2d = injected
+    try:
+        sob16 = SobelFilter(16, correct=True)
+        net.train()
+        xt = torch.from_numpy(x)
+        yo = net(xt)
+        terms = ref_loss(xt, yo, sob16, 10.0)
+        terms[0].backward()
+        g = {'x': x, 'p': np.array(p), 'y': yo.detach().numpy(), 'terms': np.array([float(t) for t in terms], np.float64),
+             'n_masks': np.array(len(masks))}
+        for i, m in enumerate(masks):
+            g[f'mask{i}'] = m
+        for k, v in sd0.items():
+            g['sd0/' + k] = v
+        for k, q in net.named_parameters():
+            g['grad/' + k] = q.grad.numpy()
+        for k, v in net.state_dict().items():
+            if 'running' in k:
+                g['sd1/' + k] = v.numpy()
+        net.eval()
+        with torch.no_grad():
+            g['y_eval'] = net(xt).numpy()
+    finally:
+        F.dropout2d = orig
+    np.savez_compressed(os.path.join(OUT, 'G16_dropout.npz'), **g)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -368,6 +424,7 @@ def main():
                         grad_norms=np.array([float(p.grad.double().norm()) for _, p in dec.named_parameters()]),
                         n_params=np.array(dec.model_size[0]), n_conv=np.array(dec.model_size[1]))
     gen_round2()
+    gen_dropout()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
