@@ -45,7 +45,12 @@ def _dense_block(sd, name, x, n_layers, training, masks=None):
     for j in range(1, n_layers + 1):
         p = f'{name}.denselayer{j}'
         z = _bn_relu(sd, p + '.norm1', x, training)
-        x = torch.cat([x, _drop(F.conv2d(z, sd[p + '.conv1.weight'], padding=1), masks, training)], 1)
+        if (p + '.conv2.weight') in sd:        # bottleneck layer (codec.py:55-62): 1x1 reduction, then norm2 + 3x3
+            z = _bn_relu(sd, p + '.norm2', F.conv2d(z, sd[p + '.conv1.weight']), training)
+            y = F.conv2d(z, sd[p + '.conv2.weight'], padding=1)
+        else:
+            y = F.conv2d(z, sd[p + '.conv1.weight'], padding=1)
+        x = torch.cat([x, _drop(y, masks, training)], 1)
     return x
 
 

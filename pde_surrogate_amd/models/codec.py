@@ -117,17 +117,26 @@ def _plan_up_conv(specs, bufs, t, conv, norm, cin, cout, mid, nxt, res, nres, up
     specs.append(_ConvSpec(conv, None, cin, cout, 3, 1, 1, 0, up, nxt, 0, nres, fake_bn=True))
 
 
-def _plan_block(specs, bufs, name, c, n_layers, growth, src, scale, drop=False):
-    """dense block: buffer `src` has room for all channels; layer j reads [0,c) writes [c,c+g)"""
+def _plan_block(specs, bufs, name, c, n_layers, growth, src, scale, drop=False, bottleneck=False, bn_size=8):
+    """dense block: buffer `src` has room for all channels; layer j reads [0,c) writes [c,c+g).
+    bottleneck (reference codec.py:55-62): layers with more than bn_size * growth inputs first reduce to
+    bn_size * growth channels with a 1x1 convolution (norm1/conv1) into a buffer of their own, then norm2/conv2 3x3"""
     for j in range(1, n_layers + 1):
         p = f'{name}.denselayer{j}'
-        specs.append(_ConvSpec(p + '.conv1', p + '.norm1', c, growth, 3, 1, 1, 0, src, src, c, scale))
+        if bottleneck and c > bn_size * growth:
+            mid = f'{src}_{name}_bk{j}'
+            bufs[mid] = [bn_size * growth, scale]
+            specs.append(_ConvSpec(p + '.conv1', p + '.norm1', c, bn_size * growth, 1, 1, 0, 0, src, mid, 0, scale))
+            specs.append(_ConvSpec(p + '.conv2', p + '.norm2', bn_size * growth, growth, 3, 1, 1, 0, mid, src, c, scale))
+        else:
+            specs.append(_ConvSpec(p + '.conv1', p + '.norm1', c, growth, 3, 1, 1, 0, src, src, c, scale))
         _plan_dropout(specs, bufs, drop)
         c += growth
     return c
 
 
-def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsize, upsample='nearest', drop=False):
+def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsize, upsample='nearest', drop=False,
+                 bottleneck=False, bn_size=8):
     """stage order and channel bookkeeping of DenseED (reference codec.py:229-293)"""
     if len(blocks) > 1 and len(blocks) % 2 == 0:
         raise ValueError('length of blocks must be an odd number, but got {}'.format(len(blocks)))
@@ -141,7 +150,7 @@ def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsiz
     specs.append(_ConvSpec('In_conv', None, in_channels, init_features, 7, 2, pad, 0, 'in', cur, 0, (1, 1)))
     nb = 1
     for i, n in enumerate(enc, 1):
-        c = _plan_block(specs, bufs, f'EncBlock{i}', c, n, growth, cur, res, drop)
+        c = _plan_block(specs, bufs, f'EncBlock{i}', c, n, growth, cur, res, drop, bottleneck, bn_size)
         t = f'TransDown{i}'
         mid, nxt = f'b{nb}', f'b{nb + 1}'
         nb += 2
@@ -155,7 +164,7 @@ def _plan_densed(blocks, growth, init_features, in_channels, out_channels, imsiz
         _plan_dropout(specs, bufs, drop)
         cur, c, res = nxt, c // 2, nres
     for i, n in enumerate(dec, 1):
-        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res, drop)
+        c = _plan_block(specs, bufs, f'DecBlock{i}', c, n, growth, cur, res, drop, bottleneck, bn_size)
         if i < len(dec):
             t = f'TransUp{i}'
             mid, nxt = f'b{nb}', f'b{nb + 1}'
@@ -210,6 +219,21 @@ def _plan_decoder(blocks, growth, init_features, dim_latent, out_channels, upsam
             cur, c, res = nxt, c // 2, nres
     _plan_last(specs, bufs, cur, c, res, out_channels, nb, upsample, drop)
     return specs, bufs
+
+
+def activation(name):
+    """reference codec.py:191-203"""
+    if name in ['tanh', 'Tanh']:
+        return nn.Tanh()
+    if name in ['relu', 'ReLU']:
+        return nn.ReLU(inplace=False)      # (not in place: the input is the output of a custom autograd node)
+    if name in ['lrelu', 'LReLU']:
+        return nn.LeakyReLU(inplace=False)
+    if name in ['sigmoid', 'Sigmoid']:
+        return nn.Sigmoid()
+    if name in ['softplus', 'Softplus']:
+        return nn.Softplus(beta=4)
+    raise ValueError('Unknown activation function')
 
 
 def _add_path(root, path, module):
@@ -566,11 +590,15 @@ class _HipNet(nn.Module):
         self.drop_rate = float(drop_rate)
         if upsample not in ('nearest', 'bilinear'):
             raise ValueError(f"upsample must be 'nearest' or 'bilinear' (reference codec.py:132-146); got {upsample!r}")
-        if out_activation is not None:
-            raise NotImplementedError('out_activation is not implemented (the mixed-residual scripts pass None)')
         self._specs, self._bufs = specs, bufs
         self.features = nn.Sequential()
         _build_modules(self.features, specs)
+        # optional output activation (reference codec.py:289-290, :355-356; every script passes None): a stateless
+        # elementwise module applied to the network output by torch, registered under the reference's module name
+        self._out_act = None
+        if out_activation is not None:
+            self._out_act = activation(out_activation)
+            self.features.add_module(out_activation, self._out_act)
         self._flat = None
         self._engines = {}
         self._side_streams = {}
@@ -772,7 +800,8 @@ class _HipNet(nn.Module):
             raise RuntimeError('the HIP kernels compute in fp32: pass an fp32 input')
         x = x.contiguous()
         self._engine(x)   # flattens parameters before autograd sees them
-        return _NetFn.apply(x, self, torch.is_grad_enabled(), *self._params)
+        y = _NetFn.apply(x, self, torch.is_grad_enabled(), *self._params)
+        return y if self._out_act is None else self._out_act(y)
 
     def forward_test(self, x):
         print('input: {}'.format(x.data.size()))
@@ -809,17 +838,14 @@ class DenseED(_HipNet):
                  out_activation=None, upsample='nearest'):
         """Dense Convolutional Encoder-Decoder Network (reference codec.py:210-293).
 
-        Args are the reference's.  `bn_size` is unused there too; `bottleneck=True` for dense
-        layers, dropout, bilinear upsampling and output activations are not implemented in HIP.
+        Args are the reference's (`bn_size` only matters with `bottleneck=True`, as there).
         """
         super(DenseED, self).__init__()
-        if bottleneck:
-            raise NotImplementedError('bottleneck dense layers are not implemented (reference default False)')
         blocks = [int(b) for b in blocks]
         if upsample not in ('nearest', 'bilinear'):
             raise ValueError(f"upsample must be 'nearest' or 'bilinear' (reference codec.py:132-146); got {upsample!r}")
         specs, bufs = _plan_densed(blocks, growth_rate, init_features, in_channels, out_channels, imsize, upsample,
-                                   drop=bool(drop_rate and drop_rate > 0))
+                                   drop=bool(drop_rate and drop_rate > 0), bottleneck=bool(bottleneck), bn_size=bn_size)
         self._finish_init(specs, bufs, drop_rate, upsample, out_activation)
         print('# params {}, # conv layers {}'.format(*self.model_size))
 

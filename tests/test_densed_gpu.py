@@ -219,6 +219,48 @@ def test_g13_bilinear_upsampling(dev):
     assert n_full >= 10
 
 
+def test_out_activation(dev):
+    """DenseED(out_activation=...) (reference codec.py:289-290): same network, activation applied to its output"""
+    from pde_surrogate_amd.models.codec import DenseED
+    x = torch.exp(0.5 * torch.randn(2, 1, 64, 64, device=dev))
+    torch.manual_seed(2)
+    a = DenseED(1, 3, 64, [1, 1, 1], growth_rate=8, init_features=16).to(dev).train()
+    torch.manual_seed(2)
+    b = DenseED(1, 3, 64, [1, 1, 1], growth_rate=8, init_features=16, out_activation='softplus').to(dev).train()
+    assert list(a.state_dict()) == list(b.state_dict()) and 'softplus' in dict(b.features.named_children())
+    ya, yb = a(x), b(x)
+    assert torch.allclose(yb, torch.nn.functional.softplus(ya, beta=4), rtol=1e-6, atol=1e-6)
+    (yb ** 2).mean().backward()
+    (torch.nn.functional.softplus(ya, beta=4) ** 2).mean().backward()
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_l2(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 1e-5, k
+    with pytest.raises(ValueError, match='Unknown activation'):
+        DenseED(1, 3, 64, [1, 1, 1], out_activation='gelu')
+
+
+def test_g17_bottleneck_dense_layers(dev):
+    """DenseED(bottleneck=True) (reference codec.py:55-62) against the reference: same state_dict keys, every tensor"""
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    g = golden('G17_bottleneck.npz')
+    net = DenseED(1, 3, 16, [3, 3, 3], growth_rate=4, init_features=8, bn_size=2, bottleneck=True)
+    assert net.model_size == (int(g['n_params']), int(g['n_conv']))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd0/')}
+    assert list(net.state_dict()) == list(sd)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = torch.from_numpy(g['x']).to(dev)
+    y = net(x)
+    assert rel_l2(y.detach().cpu().numpy(), g['y']) < 1e-5
+    loss, l_pde, l_dir, l_neu = darcy_mixed_residual_loss(x, y, 10.0)
+    ref = g['terms']
+    np.testing.assert_allclose([float(loss.detach()), float(l_pde), float(l_dir), float(l_neu)],
+                               [ref[0], ref[1] + ref[2], ref[3], ref[4]], rtol=1e-5)
+    loss.backward()
+    for name, q in net.named_parameters():
+        assert rel_l2(q.grad.cpu().numpy(), g['grad/' + name]) < 1e-3, name
+
+
 def test_g16_dropout(dev):
     """--drop-rate > 0 (nn.Dropout2d after the convolutions, reference codec.py:70-71, :111-120, :134-150, :172-173):
     with the reference's channel masks injected -- output, loss terms, every gradient tensor, running statistics; eval

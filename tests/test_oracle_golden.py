@@ -305,3 +305,16 @@ def test_g16_dropout_positions_and_scaling():
     with torch.no_grad():
         ye = codec.densed_forward(sd, x, [2, 2, 2], 16, False, dropout_masks=masks)      # eval: masks ignored
     assert rel_l2(ye.numpy(), g['y_eval']) < 1e-5
+
+
+def test_g17_bottleneck_dense_layers():
+    g = golden('G17_bottleneck.npz')
+    sd = {k[4:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith('sd0/')}
+    assert 'features.EncBlock1.denselayer2.conv2.weight' in sd and 'features.EncBlock1.denselayer1.conv2.weight' not in sd
+    tr = train.CpuTrainer(sd, [3, 3, 3], imsize=16)
+    y, loss, parts = tr.forward_loss(torch.from_numpy(g['x']), True)
+    assert rel_l2(y.detach().numpy(), g['y']) < 1e-5
+    np.testing.assert_allclose([float(loss.detach())] + [float(p.detach()) for p in parts], g['terms'], rtol=1e-5)
+    loss.backward()
+    for k in tr.keys:
+        assert rel_l2(sd[k].grad.numpy(), g['grad/' + k]) < 1e-3, k

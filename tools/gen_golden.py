@@ -251,6 +251,35 @@ def gen_dropout():
     np.savez_compressed(os.path.join(OUT, 'G16_dropout.npz'), **g)
 
 
+def gen_bottleneck():
+    """G17: DenseED(bottleneck=True, bn_size=2) (codec.py:55-62: dense layers with more than bn_size * growth_rate
+    inputs get norm1 / conv1 1x1 -> bn_size * growth_rate, norm2 / conv2 3x3): every tensor of a tiny net"""
+    rng = np.random.default_rng(20190617)
+    torch.manual_seed(7)
+    net = quiet(DenseED, 1, 3, 16, [3, 3, 3], 4, 8, bn_size=2, bottleneck=True)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if 'norm' in k and k.endswith('.weight'):
+                v.copy_(1 + 0.2 * torch.randn_like(v))
+            if k.endswith('.bias'):
+                v.copy_(0.1 * torch.randn_like(v))
+    sd0 = {k: v.clone().numpy() for k, v in net.state_dict().items()}
+    x = np.exp(0.5 * rng.standard_normal((4, 1, 16, 16))).astype(np.float32)
+    sob16 = SobelFilter(16, correct=True)
+    net.train()
+    xt = torch.from_numpy(x)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob16, 10.0)
+    terms[0].backward()
+    g = {'x': x, 'y': yo.detach().numpy(), 'terms': np.array([float(t) for t in terms], np.float64),
+         'n_params': np.array(net.model_size[0]), 'n_conv': np.array(net.model_size[1])}
+    for k, v in sd0.items():
+        g['sd0/' + k] = v
+    for k, q in net.named_parameters():
+        g['grad/' + k] = q.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G17_bottleneck.npz'), **g)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -425,6 +454,7 @@ def main():
                         n_params=np.array(dec.model_size[0]), n_conv=np.array(dec.model_size[1]))
     gen_round2()
     gen_dropout()
+    gen_bottleneck()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
