@@ -4,6 +4,7 @@
 // for normalisation, unbiased var into running_var, momentum 0.1, eps 1e-5);
 // torch.optim.Adam as called in train_codec_mixed_residual.py:151-152,239.
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "pdes_common.h"
 #include "pdes_options.h"
 #include "../../include/pdes_hip.h"
@@ -209,18 +210,35 @@ using namespace pdes;
 
 extern "C" int pdes_stat_replicas(void) { return PDES_NREP; }
 
-extern "C" int pdes_bn_backward_finalize(const pdes_context* ctx, float* t, const float* x, const double* x_stats, const double* t_stats,
-                                         int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
-                                         long long rep_stride, void* stream) {
+namespace pdes {
+// `done` (nullable): an event that completes WITH this kernel -- it rides on the dispatch packet's own completion signal
+// (hipExtLaunchKernelGGL stop event) instead of a barrier packet behind it.  pdes_backward forks its weight-gradient
+// stream from it: measured with tools/proto/event_gap.hip, hipEventRecord costs the NEXT kernel of the recording
+// stream 3-5 us (27 times per step on the finalize -> data-gradient chain), the completion-signal form costs nothing.
+int bn_backward_finalize_launch(const pdes_context* ctx, float* t, const float* x, const double* x_stats,
+                                const double* t_stats, int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
+                                long long rep_stride, hipStream_t st, hipEvent_t done) {
   if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   if (!aligned16(t) || !aligned16(x)) return PDES_EALIGN;
   dim3 grid(cdiv(cdiv(HW, 4), 256), c1 - c0, B), block(256);
   OptScope scope(ctx);
   const int early = opt().fin_early != 0;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, static_cast<hipStream_t>(stream), t, x, x_stats, t_stats,
-                     B, ctot, c0, HW, eps, nrep, rep_stride, early);
+  if (done)
+    hipExtLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, st, nullptr, done, 0, t, x, x_stats, t_stats, B, ctot,
+                          c0, HW, eps, nrep, rep_stride, early);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, st, t, x, x_stats, t_stats, B, ctot, c0, HW, eps, nrep,
+                       rep_stride, early);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
+}
+}  // namespace pdes
+
+extern "C" int pdes_bn_backward_finalize(const pdes_context* ctx, float* t, const float* x, const double* x_stats, const double* t_stats,
+                                         int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
+                                         long long rep_stride, void* stream) {
+  return bn_backward_finalize_launch(ctx, t, x, x_stats, t_stats, B, ctot, c0, c1, HW, eps, nrep, rep_stride,
+                                     static_cast<hipStream_t>(stream), nullptr);
 }
 
 extern "C" int pdes_pack_weights(const pdes_pack_item* items, int n, int max_elems, void* stream) {

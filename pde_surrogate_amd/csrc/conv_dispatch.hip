@@ -25,6 +25,9 @@ int upsample_bilinear_backward(const pdes_conv_desc& d, hipStream_t st);
 int channel_mask_forward(const pdes_conv_desc& d, hipStream_t st);        // PDES_OP_CHANNEL_MASK descriptors (Dropout2d)
 int channel_mask_backward(const pdes_conv_desc& d, hipStream_t st);
 // descriptors that are not convolutions: no weights, their own forward / backward kernels
+int bn_backward_finalize_launch(const pdes_context* ctx, float* t, const float* x, const double* x_stats,
+                                const double* t_stats, int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
+                                long long rep_stride, hipStream_t st, hipEvent_t done);
 static bool is_resample_op(const pdes_conv_desc& d) { return d.upsample == PDES_UPSAMPLE_BILINEAR_OP || d.upsample == PDES_OP_CHANNEL_MASK; }
 static int op_forward(const pdes_conv_desc& d, hipStream_t st) {
   return d.upsample == PDES_OP_CHANNEL_MASK ? channel_mask_forward(d, st) : upsample_bilinear_forward(d, st);
@@ -129,10 +132,15 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
       if (reduce_index[i] >= 0) { per_total += per_of(i); ++n_items; }
   size_t nev = 0;
   // layers are released in the order n-1 .. 0, so the enqueued ones always form the suffix [i, n)
-  auto release = [&](int i, bool on_main) -> int {
+  // `signalled`: the fork event already completes with the finalize kernel just launched (its completion signal)
+  auto release = [&](int i, bool on_main, hipEvent_t signalled) -> int {
     if (fork && !on_main) {
-      hipEvent_t e = cx->events[nev++];
-      hipError_t he = hipEventRecord(e, st);
+      hipEvent_t e = signalled;
+      hipError_t he = hipSuccess;
+      if (!e) {
+        e = cx->events[nev++];
+        he = hipEventRecord(e, st);
+      }
       if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
       if (he != hipSuccess) return (int)he;
     }
@@ -187,17 +195,23 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
     descs = local.data();
   }
 
+  const bool use_signal = opt().fork_signal != 0;
   for (int i = n - 1; i >= 0; --i) {
     const pdes_conv_desc& d = descs[i];
+    hipEvent_t signalled = nullptr;
     if (d.fin_tstats && !d.g_fused) {
-      int rc = pdes_bn_backward_finalize(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B, d.g_ctot,
-                                         d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep, d.rep_stride, st);
+      // this layer's weight gradient is released by the completion of ITS finalize kernel: the fork event rides on
+      // that kernel's completion signal, no barrier packet sits between the finalize and the data gradient
+      if (fork && use_signal && i != 0 && !is_resample_op(d)) signalled = cx->events[nev++];
+      int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
+                                           d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
+                                           d.rep_stride, st, signalled);
       if (rc) return rc;
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
     // (saves the event hop; its scratch / dw are disjoint from what the second stream still works on)
     if (!is_resample_op(d)) {
-      const int rc = release(i, fork && i == 0);
+      const int rc = release(i, fork && i == 0, signalled);
       if (rc) return rc;
     }
     if (d.has_bn || is_resample_op(d)) {

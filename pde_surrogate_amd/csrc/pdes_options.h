@@ -27,7 +27,7 @@ struct Options {
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS        : workgroup target of the split-K weight-gradient plan
   int loss_nt = -1;             // PDES_LOSS_NT          : -1 = by working-set size
   int loss_dma = 0;             // PDES_LOSS_DMA
-  int mirror = 1;               // PDES_MIRROR           : reserved for the dense-block "mirror" data gradient
+  int fork_signal = 1;          // PDES_FORK_SIGNAL      : fork events ride on the finalize kernel's completion signal (0: hipEventRecord)
 };
 
 struct Context {
