@@ -259,6 +259,9 @@ def main():
                          'gradients on a second HIP stream, which measured faster than one serial graph)')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the roofline_1x1 and config5_solver legs (profiling runs: only the training step and the '
+                         'loss-kernel roofline launches)')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='initialise the process group (gloo when there is no GPU), count the ranks with one '
                          'all-reduce, print it and exit: exercises the launch contract without touching a kernel')
@@ -376,12 +379,12 @@ def main():
                                            'frac': round(gb32 / HBM_PEAK_GBPS, 4),
                                            'note': 'cache-resident / launch-bound at the training batch size'}},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out['roofline_1x1'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'kernel': 'conv1x1_mfma_kernel (forward)',
                                    'layers': conv1x1_timing(dev, B),
                                    'note': 'the 1x1 channel-halving layers, HIP-event timed stand-alone at the training '
                                            'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out['config5_solver'] = config5_timing(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(B)

@@ -13,7 +13,7 @@ db() { find $1 -name "*.db" | head -1; }
 
 # (A) the bench command: kernel trace + stats, step timeline, loss-kernel launches
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $OUT/bench -o bench -- \
-    python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+    python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/bench.err
 D=$(db $OUT/bench)
 python $ROOT/tools/rocprof_summary.py $D > $OUT/kernel_stats.csv
 python $ROOT/tools/timeline.py $D > $OUT/step_timeline.txt
