@@ -18,6 +18,9 @@
 
 namespace pdes {
 int conv_backward_weight_1x1(const pdes_conv_desc& d, int splits_per_image, hipStream_t st);   // conv_mfma_1x1.hip
+bool wgrad_b3_applies(const pdes_conv_desc& d);                                                  // conv_mfma_wgrad_b3.hip
+int wgrad_b3_splits(const pdes_conv_desc& d);
+int conv_backward_weight_b3(const pdes_conv_desc& d, hipStream_t st);
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -593,6 +596,11 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   p->ngroups = (ntiles + p->ntw - 1) / p->ntw;
   p->gy = mtiles * p->ngroups;
   p->per = (long long)d.Cout * d.Cin * KK;
+  if (wgrad_b3_applies(d)) {                             // bf16 x3 kernel for the wide layers: its own split count
+    p->nsplit = wgrad_b3_splits(d);
+    p->tpw = p->tps;
+    if ((long long)p->nsplit * p->per * 4 <= d.ws_bytes) return true;
+  }
   // pixel tiles per workgroup: as few as possible while (a) the grid has at most ~256 workgroups (PDES_WGRAD_WGS;
   // stand-alone the kernels are fastest with ~768, but they run beside the data-gradient chain on a second
   // stream and smaller grids leave it more of the chip: 2.203 / 2.182 / 2.179 / 2.177 / 2.204 ms per step at
@@ -737,6 +745,15 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry)
       }
       if (rc != PDES_ENOSUP) return rc;
     }
+  }
+  if (wgrad_b3_applies(d)) {
+    WgradPlan pl;
+    const int rc = conv_backward_weight_b3(d, st);
+    if (rc == PDES_OK && !d.ws_defer && wgrad_plan(d, &pl)) {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)pl.per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)pl.per, pl.nsplit);
+      PDES_LAUNCH_CHECK();
+    }
+    if (rc != PDES_ENOSUP) return rc;
   }
   if (d.upsample) return launch_wgrad_up(d, st);
   if (d.stride == 2) return launch_wgrad<3, 2>(d, st);

@@ -1,0 +1,242 @@
+// Weight gradient of the WIDE 3x3 stride-1 convolutions on the bf16 matrix pipe with fp32 accuracy (three-way bf16
+// split of both operands, six cross products -- see conv_mfma_b3.hip for the arithmetic and its adversarial test):
+//     dW[co][ci][ky][kx] = sum_{b, y, x} g[b][co][y][x] * z[b][ci][y + ky - 1][x + kx - 1],   z = relu(bn(x))
+// (autograd of F.conv2d wrt its weight, reference models/codec.py:169-170 LastTransUp.conv1: 196 -> 98 at 32 x 32 --
+// with 160 us the largest single kernel of the step on the f32 pipe).
+//
+// GEMM roles per v_mfma_f32_16x16x32_bf16: M = 16 input channels (A = z), N = 16 output channels (B = g),
+// K = 32 consecutive pixels = ONE ROW of a 32-wide map.  Both operands are pixel-contiguous in NCHW, so a lane's
+// 8 k-elements are 8 consecutive pixels of one channel: the LDS images are [plane hi|mid|lo][row][channel][32 px]
+// bf16 and a fragment is one aligned ds_read_b128 per lane (a wave reads one contiguous KiB, conflict free).
+// The kx shift of z would misalign those reads, so z is kept in THREE column-shifted copies (z[x-1], z[x], z[x+1],
+// zero beyond the row), built at staging time from the neighbour lanes' packed words; the ky shift is a row of the
+// 3-slot ring the workgroup slides down the image.  g needs no shift: its three planes of one row are loaded into
+// registers once per row and reused by all 9 taps.
+// Workgroup = 256 threads = 4 waves: ONE 16-channel M-tile, ALL N-tiles (wave w owns tiles w and w + 4), a run of rows
+// of one image; per row 9 taps x 2 tiles x 6 = 108 MFMAs per wave against 27 + 6 fragment reads.  71 KB of LDS: two
+// workgroups per CU.  The (co, ci, tap) block of partial sums goes through LDS to the split-K scratch in runs of
+// 16 x 9 contiguous floats; the fixed-order reduce is the one of conv_mfma_wgrad.hip (deterministic).
+#include "pdes_common.h"
+#include "pdes_options.h"
+#include "../../include/pdes_hip.h"
+#include "pack_kernels.h"
+
+namespace pdes {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+namespace wb3 {
+constexpr int W = 32;                      // map width = pixels per k-step
+constexpr int ZROW = 16 * W;               // bf16 elements of one ring slot (16 channels x 32 pixels)
+constexpr int ZPLANE = 3 * ZROW;           // 3 ring slots
+constexpr int ZCOPY = 3 * ZPLANE;          // 3 planes
+constexpr int ZSIZE = 3 * ZCOPY;           // 3 column-shifted copies: 13,824 elements = 27,648 B
+}  // namespace wb3
+
+// grid: (B * H / rows, M-tiles); dynamic LDS: Z + G[2][3][nco][32] (bf16), reused for the [nco][16][9] fp32 epilogue
+__global__ __launch_bounds__(256, 2) void conv_wgrad_b3_kernel(pdes_conv_desc d, float* __restrict__ part, int rows) {
+  using namespace wb3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_wb3[];
+  unsigned short* Z = reinterpret_cast<unsigned short*>(smem_wb3);            // [kx][plane][slot][16][32]
+  unsigned short* G = Z + ZSIZE;                                              // [buf][plane][nco][32]
+  __shared__ float cf[16][3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = d.Hout, HW = H * W;
+  const int ntiles = (d.Cout + 15) >> 4, nco = ntiles * 16;
+  const int hs_n = H / rows;
+  const int b = blockIdx.x / hs_n, y0 = (blockIdx.x % hs_n) * rows;
+  const int ci0 = blockIdx.y * 16;
+  const long long per = (long long)d.Cout * d.Cin * 9;
+
+  if (tid < 16) {                         // BatchNorm coefficients of this workgroup's 16 input channels
+    const int c = ci0 + tid;
+    float m = 0.f, s = 0.f, bt = 0.f;
+    if (c < d.Cin) {
+      double mean, invstd;
+      if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
+      else {
+        const double n = (double)d.B * HW;
+        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
+        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        invstd = 1.0 / sqrt(var + (double)d.eps);
+      }
+      m = (float)mean; s = d.gamma[c] * (float)invstd; bt = d.beta[c];
+    }
+    cf[tid][0] = m; cf[tid][1] = s; cf[tid][2] = bt;
+  }
+
+  const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HW;
+  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HW;
+  const int crem = d.Cin - ci0;
+  // staging roles: threads 0..127 own one float4 of the z row (channel zc, columns 4 zj ..); everyone owns up to four
+  // float4 of the g row (channel e >> 3, columns 4 (e & 7) ..)
+  const bool zt = tid < 128;
+  const int zc = (tid >> 3) & 15, zj = tid & 7;
+  const int ng4 = nco * 8;
+  struct Stage { float4 z; float4 g[4]; };
+  Stage s;
+  // raw loads only (clamped addresses): validity is applied at commit, nothing consumes a load right after its issue
+  auto issue = [&](int y, Stage& st) __attribute__((always_inline)) {
+    const int zr = min(max(y + 1, 0), H - 1), gr = min(max(y, 0), H - 1);
+    st.z = *reinterpret_cast<const float4*>(xb + (size_t)min(zc, crem - 1) * HW + zr * W + 4 * zj);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = min(tid + 256 * i, ng4 - 1);
+      const int co = min(e >> 3, d.Cout - 1);
+      st.g[i] = *reinterpret_cast<const float4*>(gb + (size_t)co * HW + gr * W + 4 * (e & 7));
+    }
+  };
+  auto commit = [&](int y, const Stage& st) __attribute__((always_inline)) {
+    if (zt) {                              // z row y + 1 -> ring slot, three column-shifted copies
+      const int row = y + 1;
+      const bool ok = row >= 0 && row < H && zc < crem;
+      const float mean = cf[zc][0], sc = cf[zc][1], bt = cf[zc][2];
+      float v[4] = {st.z.x, st.z.y, st.z.z, st.z.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = ok ? fmaxf(0.f, (v[i] - mean) * sc + bt) : 0.f;
+      u32 w0[3], w1[3];
+      split3_pair(v[0], v[1], w0[0], w0[1], w0[2]);        // w?[plane]: pixels (0,1) and (2,3) of this quad
+      split3_pair(v[2], v[3], w1[0], w1[1], w1[2]);
+      const int slot = (row + 3) % 3;
+      unsigned short* zp = Z + slot * ZROW + zc * W + 4 * zj;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        u32 prev1 = __shfl_up(w1[p], 1, 64), next0 = __shfl_down(w0[p], 1, 64);
+        if (zj == 0) prev1 = 0u;           // zero padding left of column 0 / right of column 31
+        if (zj == 7) next0 = 0u;
+        const u32 mid = (w0[p] >> 16) | (w1[p] << 16);     // pixels (1,2)
+        unsigned short* q = zp + p * ZPLANE;
+        *reinterpret_cast<uint2*>(q) = make_uint2((prev1 >> 16) | (w0[p] << 16), mid);              // kx = 0: z[x - 1]
+        *reinterpret_cast<uint2*>(q + ZCOPY) = make_uint2(w0[p], w1[p]);                             // kx = 1: z[x]
+        *reinterpret_cast<uint2*>(q + 2 * ZCOPY) = make_uint2(mid, (w1[p] >> 16) | (next0 << 16));  // kx = 2: z[x + 1]
+      }
+    }
+    unsigned short* gbuf = G + (y & 1) * 3 * nco * W;      // g row y -> buffer y & 1
+    const bool rok = y >= 0 && y < H;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      if (e < ng4) {
+        const int co = e >> 3;
+        const bool ok = rok && co < d.Cout;
+        u32 a[3], c2[3];
+        split3_pair(ok ? st.g[i].x : 0.f, ok ? st.g[i].y : 0.f, a[0], a[1], a[2]);
+        split3_pair(ok ? st.g[i].z : 0.f, ok ? st.g[i].w : 0.f, c2[0], c2[1], c2[2]);
+        unsigned short* q = gbuf + co * W + 4 * (e & 7);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(q + p * nco * W) = make_uint2(a[p], c2[p]);
+      }
+    }
+  };
+
+  v4f acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[t][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();                          // coefficients visible
+  issue(y0 - 2, s); commit(y0 - 2, s);      // z row y0 - 1
+  issue(y0 - 1, s); commit(y0 - 1, s);      // z row y0
+  issue(y0, s);
+  const int frag = (lane & 15) * W + 8 * (lane >> 4);      // a lane's 8 pixels inside a [16][32] tile
+  const int ylast = y0 + rows - 1;
+  for (int y = y0; y <= ylast; ++y) {
+    __syncthreads();                        // the fragment reads of row y - 1 are done: its oldest slot may be overwritten
+    commit(y, s);                           // z row y + 1, g row y
+    __syncthreads();
+    issue(min(y + 1, ylast), s);            // in flight during the matrix work below
+    const unsigned short* gbuf = G + (y & 1) * 3 * nco * W;
+    v8bf bh[2], bm[2], bl[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int tile = min(wave + 4 * nt, ntiles - 1);
+      const unsigned short* q = gbuf + tile * 16 * W + frag;
+      bh[nt] = *reinterpret_cast<const v8bf*>(q);
+      bm[nt] = *reinterpret_cast<const v8bf*>(q + nco * W);
+      bl[nt] = *reinterpret_cast<const v8bf*>(q + 2 * nco * W);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int slot = (y + ky + 2) % 3;    // row y - 1 + ky
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const unsigned short* zp = Z + kx * ZCOPY + slot * ZROW + frag;
+        const v8bf ah = *reinterpret_cast<const v8bf*>(zp);
+        const v8bf am = *reinterpret_cast<const v8bf*>(zp + ZPLANE);
+        const v8bf al = *reinterpret_cast<const v8bf*>(zp + 2 * ZPLANE);
+        const int t = ky * 3 + kx;
+        // six cross terms, smallest first; the two N-tiles alternate so that consecutive MFMAs are independent
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[t][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: accumulator tile = D[ci = (lane >> 4) * 4 + r][co = lane & 15]; through LDS as [co][ci][tap]
+  __syncthreads();
+  float* outl = reinterpret_cast<float*>(smem_wb3);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int tile = wave + 4 * nt;
+    if (tile < ntiles) {
+      const int co = tile * 16 + (lane & 15);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outl[(co * 16 + (lane >> 4) * 4 + r) * 9 + t] = acc[t][nt][r];
+    }
+  }
+  __syncthreads();
+  float* pb = part + (size_t)blockIdx.x * per;
+  const int run = min(16, crem) * 9;                       // contiguous floats per output channel
+  for (int e = tid; e < d.Cout * run; e += 256) {
+    const int co = e / run, k = e - co * run;
+    pb[((size_t)co * d.Cin + ci0) * 9 + k] = outl[co * 144 + k];
+  }
+}
+
+// ------------------------------------------------------------------------------- host side
+bool wgrad_b3_applies(const pdes_conv_desc& d) {
+  if (!opt().mfma_b3w || d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.upsample || !d.has_bn || d.g_fused) return false;
+  if (d.Win != wb3::W || d.Wout != wb3::W || d.Hin != d.Hout || d.nrep != PDES_NREP) return false;
+  return d.Cin >= 64 && d.Cout >= 32 && d.Cout <= 128;
+}
+
+// rows per workgroup: the whole image (one split per sample) unless that leaves most of the chip idle
+int wgrad_b3_splits(const pdes_conv_desc& d) {
+  const int mtiles = (d.Cin + 15) / 16;
+  int hs = 1;
+  while (d.B * hs * mtiles < 384 && hs * 2 <= d.Hout / 8 && d.Hout % (hs * 2) == 0) hs *= 2;
+  return d.B * hs;
+}
+
+int conv_backward_weight_b3(const pdes_conv_desc& d, hipStream_t st) {
+  if (!wgrad_b3_applies(d) || !d.ws) return PDES_ENOSUP;
+  const int nsplit = wgrad_b3_splits(d), rows = d.Hout / (nsplit / d.B);
+  const long long per = (long long)d.Cout * d.Cin * 9;
+  if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
+  const int ntiles = (d.Cout + 15) / 16, nco = ntiles * 16;
+  size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)2 * 3 * nco * wb3::W * 2;
+  const size_t epi = (size_t)nco * 144 * sizeof(float);
+  if (epi > lds) lds = epi;
+  dim3 grid(nsplit, (d.Cin + 15) / 16), block(256);
+  hipLaunchKernelGGL(conv_wgrad_b3_kernel, grid, block, lds, st, d, d.ws, rows);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+}  // namespace pdes
