@@ -335,13 +335,13 @@ def main():
 
     if rank == 0:
         traffic, traffic_src = None, None
-        for name in ('r02_loss_kernel_pmc.json', 'r01_loss_kernel_pmc.json'):
-            pmc = os.path.join(ROOT, 'profiles', name)
-            if os.path.exists(pmc):                          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                with open(pmc) as f:
-                    pj = json.load(f)
-                traffic, traffic_src = pj['hbm_bytes_per_launch'], f'profiles/{name} (B=16384)'
-                break
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_loss_kernel_pmc.json')))
+        if pmcs:                                             # the latest rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            with open(pmcs[-1]) as f:
+                pj = json.load(f)
+            traffic = pj['hbm_bytes_per_launch']
+            traffic_src = f'profiles/{os.path.basename(pmcs[-1])} (B=16384, separate --pmc passes, FETCH_SIZE doubled: gfx950)'
         us32, gb32 = loss_kernel_timing(dev, B, 200)
         usL, gbL, gbBurst = loss_kernel_timing(dev, 16384, 100, warmup=100, burst=True)
         out = {
