@@ -163,3 +163,76 @@ def test_data_parallel_branch_on_one_rank(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _dp2_worker(rank, world, port, out):
+    """one of TWO ranks sharing the one GPU of the test box, rendezvous over gloo (RCCL refuses two ranks on one
+    device; gloo moves CUDA tensors through the host): the trainer's world-size-2 branch with real shards"""
+    import torch.distributed as dist
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DenseED(1, 3, 64, [2, 2, 2], growth_rate=8, init_features=16).to(dev).train()
+    data = torch.from_numpy(grf_kle_fields(16, n_kle=64, cache_dir='/tmp')).to(dev)
+    tr = MixedResidualTrainer(net, 4, 64, lr=1e-3, device=dev)
+    assert tr.world == 2 and tr._hook is not None
+    for step in range(3):
+        lo = step * 8 + rank * 4                          # contiguous split of the global batch of 8
+        tr.step(data[lo:lo + 4], 1e-3)
+    torch.cuda.synchronize()
+    out[rank] = (torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), tr.epoch_means())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_equals_mean_of_shard_gradients(dev):
+    """world size 2 for real: both ranks end every step with IDENTICAL parameters, and they equal a single-process
+    emulation that averages the two shards' gradients (rank-local BatchNorm) before one Adam step -- the definition of
+    data-parallel parity of SURVEY 8(e)"""
+    import socket
+    import torch.multiprocessing as mp
+    from pde_surrogate_amd import parallel
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_dp2_worker, args=(2, port, out), nprocs=2, join=True)
+    p0, p1 = out[0][0], out[1][0]
+    assert torch.equal(p0, p1)                                        # same reduced gradient, same Adam step
+    # emulation: two shard trainers that never step, gradients averaged by hand
+    data = torch.from_numpy(grf_kle_fields(16, n_kle=64, cache_dir='/tmp')).to(dev)
+    nets = []
+    for r in range(2):
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            nets.append(DenseED(1, 3, 64, [2, 2, 2], growth_rate=8, init_features=16).to(dev).train())
+    trs = [MixedResidualTrainer(n, 4, 64, lr=1e-3, device=dev) for n in nets]
+    m = torch.zeros_like(trs[0].flat)
+    v = torch.zeros_like(trs[0].flat)
+    for step in range(3):
+        g = []
+        for r in range(2):
+            lo = step * 8 + r * 4
+            trs[r].x_static.copy_(data[lo:lo + 4])
+            trs[r].gflat.zero_()
+            trs[r]._grad_clean = False
+            trs[r]._compute()
+            g.append(trs[r].gflat.clone())
+        gsum = g[0] + g[1]
+        for r in range(2):                                              # both "ranks" apply the same averaged step
+            parallel.adam_reference_(trs[r].flat, gsum, m.clone() if r else m, v.clone() if r else v, step + 1, 1e-3,
+                                     grad_scale=0.5)
+    want = torch.cat([p.detach().reshape(-1) for p in nets[0].parameters()]).cpu()
+    assert rel_l2(p0.numpy(), want.numpy()) < 1e-5
+    # the logged loss of a rank is the mean over ITS shards
+    assert out[0][1][0] != out[1][1][0]
