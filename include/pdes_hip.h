@@ -222,7 +222,7 @@ int pdes_wgrad_reduce_all(const pdes_reduce_item* items, int n, int max_n, void*
  * reduce_items: DEVICE table as for pdes_wgrad_reduce_all, in layer order; reduce_index: HOST
  * array, reduce_index[i] = table index of descs[i] or -1 (no deferred scratch).  Both may be NULL
  * (then the caller reduces).
- * With a second stream the context must hold >= n + 1 events (PDES_EINVAL otherwise).
+ * With a second stream the context must hold >= n + 4 events (PDES_EINVAL otherwise).
  * hook (nullable): called ONCE, on the host, right after the early split-K reduce has been enqueued on
  * `wgrad_stream`: the weight gradients `dw` of layers [first_layer, n) are final in stream order on
  * `wgrad_stream` from that point.  The data-parallel trainer enqueues the all-reduce of that bucket there
@@ -234,6 +234,12 @@ typedef struct pdes_bucket_hook {
 } pdes_bucket_hook;
 int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
                   const pdes_reduce_item* reduce_items, const int* reduce_index, const pdes_bucket_hook* hook);
+/* The same with an optional SECOND weight-gradient stream (`wgrad_stream_b`, NULL = pdes_backward): the weight
+ * gradients of successive layers are independent, odd layers are enqueued on it; it is joined into `wgrad_stream`
+ * before every split-K reduce and at the end.  The context must hold >= n + 4 events. */
+int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
+                   void* wgrad_stream_b, const pdes_reduce_item* reduce_items, const int* reduce_index,
+                   const pdes_bucket_hook* hook);
 
 /* Table-driven helpers: one launch for the whole network. */
 typedef struct pdes_pack_item {  /* one convolution's weights */

@@ -29,6 +29,7 @@ SIGNATURES = {
     'pdes_conv_backward_weight': [_c_p, _c_p, _c_i, _c_p],
     'pdes_conv_backward_data': [_c_p, _c_p, _c_i, _c_p],
     'pdes_backward': [_c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p],
+    'pdes_backward2': [_c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i,
                                   ctypes.c_longlong, _c_p],
     'pdes_conv_wgrad_plan': [_c_p, _c_p, _c_p, _c_p],

@@ -110,13 +110,23 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
 extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream,
                              void* wgrad_stream, const pdes_reduce_item* reduce_items, const int* reduce_index,
                              const pdes_bucket_hook* hook) {
+  return pdes_backward2(ctx, descs, n, stream, wgrad_stream, nullptr, reduce_items, reduce_index, hook);
+}
+
+extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream,
+                              void* wgrad_stream, void* wgrad_stream_b, const pdes_reduce_item* reduce_items,
+                              const int* reduce_index, const pdes_bucket_hook* hook) {
   if (!descs || n <= 0) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipStream_t ws = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : st;
   const bool fork = ws != st;
+  // optional SECOND weight-gradient stream: the weight gradients of successive layers are independent of each other,
+  // odd layers go to it; it is joined into `ws` before a split-K reduce and at the end
+  hipStream_t wsb = (fork && wgrad_stream_b) ? static_cast<hipStream_t>(wgrad_stream_b) : ws;
+  const bool two = wsb != ws;
   // the fork/join events belong to the caller's context (created with it, on its device): one per layer + the join
   const Context* cx = reinterpret_cast<const Context*>(ctx);
-  if (fork && (!cx || (int)cx->events.size() < n + 1)) return PDES_EINVAL;
+  if (fork && (!cx || (int)cx->events.size() < n + 4)) return PDES_EINVAL;
   OptScope scope(ctx);
   const bool have_red = reduce_items && reduce_index;
   auto per_of = [&](int i) { return (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize; };
@@ -133,7 +143,17 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
   size_t nev = 0;
   // layers are released in the order n-1 .. 0, so the enqueued ones always form the suffix [i, n)
   // `signalled`: the fork event already completes with the finalize kernel just launched (its completion signal)
+  bool b_dirty = false;                     // work on the second side stream that `ws` has not waited for yet
+  auto join_b = [&]() -> int {              // ws waits for everything enqueued on wsb so far
+    if (!two || !b_dirty) return PDES_OK;
+    hipEvent_t e = cx->events[nev++];
+    hipError_t he = hipEventRecord(e, wsb);
+    if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
+    b_dirty = false;
+    return he == hipSuccess ? PDES_OK : (int)he;
+  };
   auto release = [&](int i, bool on_main, hipEvent_t signalled) -> int {
+    hipStream_t wsi = (two && (i & 1)) ? wsb : ws;
     if (fork && !on_main) {
       hipEvent_t e = signalled;
       hipError_t he = hipSuccess;
@@ -141,10 +161,11 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
         e = cx->events[nev++];
         he = hipEventRecord(e, st);
       }
-      if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
+      if (he == hipSuccess) he = hipStreamWaitEvent(wsi, e, 0);
       if (he != hipSuccess) return (int)he;
+      if (wsi != ws) b_dirty = true;
     }
-    const int rc = pdes_conv_backward_weight(ctx, &descs[i], 1, on_main ? st : ws);
+    const int rc = pdes_conv_backward_weight(ctx, &descs[i], 1, on_main ? st : wsi);
     if (rc) return rc;
     if (have_red && reduce_index[i] >= 0) per_done += per_of(i);
     // The split-K partials of the last layers (the widest ones: LastTransUp holds ~3/4 of the weights) are reduced
@@ -158,6 +179,8 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
           mx = per_of(k) > mx ? per_of(k) : mx;
         }
       if (first > 0) {
+        const int rcj = join_b();
+        if (rcj) return rcj;
         const int rc2 = pdes_wgrad_reduce_all(reduce_items + first, n_items - first, (int)mx, ws);
         if (rc2) return rc2;
         early_lo = first;
@@ -220,6 +243,8 @@ extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* desc
     }
   }
   if (fork) {
+    const int rcj = join_b();
+    if (rcj) return rcj;
     hipEvent_t e = cx->events[nev++];
     hipError_t he = hipEventRecord(e, ws);
     if (he == hipSuccess) he = hipStreamWaitEvent(st, e, 0);
