@@ -16,6 +16,7 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry 
 int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st);        // nearest-x2 + 3x3, sub-pixel form
 int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st);         // 5x5 with <= 3 output channels
 int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st);             // wide 3x3 layers: bf16 x3 split (conv_mfma_b3.hip)
+int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st);          // nearest-x2 + 3x3, sub-pixel form, bf16 x3 split
 int conv_backward_data_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
@@ -53,7 +54,8 @@ extern "C" int pdes_conv_forward(const pdes_context* ctx, const pdes_conv_desc* 
       if (rc) return rc;
       continue;
     }
-    int rc = force_direct() ? PDES_ENOSUP : conv_forward_up_mfma(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_forward_b3_up(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_fewout(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_b3(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_1x1(descs[i], st);

@@ -40,7 +40,7 @@ class ConvDesc(ctypes.Structure):
         ('g', _P), ('g_ctot', _I), ('g_coff', _I), ('g_fused', _I),
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
         ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
-        ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong),
+        ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong), ('wbu_fwd', _P),
     ]
 
 
@@ -59,6 +59,10 @@ class UpPackItem(ctypes.Structure):
 
 class B3PackItem(ctypes.Structure):
     _fields_ = [('w', _P), ('wb_fwd', _P), ('wb_bwd', _P), ('Cout', _I), ('Cin', _I)]
+
+
+class B3UpPackItem(ctypes.Structure):
+    _fields_ = [('w', _P), ('wbu_fwd', _P), ('Cout', _I), ('Cin', _I)]
 
 
 class ReduceItem(ctypes.Structure):
@@ -353,6 +357,8 @@ class _Engine:
             b3 = net._packed_b3.get(s.conv)
             d.wb_fwd = b3[0].data_ptr() if b3 else None
             d.wb_bwd = b3[1].data_ptr() if b3 else None
+            bu = net._packed_b3u.get(s.conv)
+            d.wbu_fwd = bu.data_ptr() if bu is not None else None
             d.ws, d.ws_bytes, d.ws_defer = net._ws.data_ptr(), net._ws.numel() * 4, 0
             d.nrep, d.rep_stride = self.nrep, self.rep_stride
             if s.bn:
@@ -734,6 +740,24 @@ class _HipNet(nn.Module):
         if bitems:
             arr = (B3PackItem * len(bitems))(*bitems)
             self._bpack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        # split images of the effective sub-pixel weights of the nearest-x2 + 3x3 layers (conv_mfma_b3_up.hip)
+        self._packed_b3u, buitems, bumx = {}, [], 0
+        for s in self._specs:
+            if not (s.up == UP_NEAREST and s.k == 3 and s.stride == 1 and s.norm is not None and s.cin >= 64 and s.cout >= 32):
+                continue
+            nf = ctypes.c_longlong(0)
+            _lib.check(_lib.lib().pdes_b3up_image_elems(s.cout, s.cin, ctypes.byref(nf)), 'pdes_b3up_image_elems')
+            img = torch.zeros(nf.value, device=device, dtype=torch.int16)
+            self._packed_b3u[s.conv] = img
+            it = B3UpPackItem()
+            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.wbu_fwd, it.Cout, it.Cin = img.data_ptr(), s.cout, s.cin
+            buitems.append(it)
+            bumx = max(bumx, nf.value // 24)
+        self._bupack_n, self._bupack_max = len(buitems), bumx
+        if buitems:
+            arr = (B3UpPackItem * len(buitems))(*buitems)
+            self._bupack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._ws = torch.empty(8 << 20, device=device)       # 32 MiB split-K scratch (weight gradients)
         if mitems:
             arr = (MfmaPackItem * len(mitems))(*mitems)
@@ -760,6 +784,9 @@ class _HipNet(nn.Module):
                                       self._bpack_table.data_ptr() if self._bpack_n else None, self._bpack_n,
                                       mx, _lib.stream_ptr())
         _lib.check(rc, 'pdes_pack_all')
+        if self._bupack_n:
+            _lib.check(_lib.lib().pdes_pack_weights_b3up(self._bupack_table.data_ptr(), self._bupack_n, self._bupack_max,
+                                                         _lib.stream_ptr()), 'pdes_pack_weights_b3up')
 
     def _is_flat(self, device):
         if self._flat is None or self._flat.device != device:
