@@ -288,6 +288,10 @@ int pdes_b3up_image_elems(int Cout, int Cin, long long* fwd_elems);
 int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
                   const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
                   int max_elems, void* stream);
+/* The same with a fifth table: the split effective-weight images of the sub-pixel layers (pdes_pack_weights_b3up). */
+int pdes_pack_all2(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
+                   const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
+                   const pdes_b3up_pack_item* buitems, int nbu, int max_elems, void* stream);
 
 typedef struct pdes_bn_item {    /* one BatchNorm layer */
   const double* x_stats;  /* (>=C, 2) batch sums of its input channels */

@@ -229,41 +229,6 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
   }
 }
 
-// split effective-weight image of the forward, rebuilt from the live weights every step:
-//   [(chunk*16 + j)*NT + nt][plane][lane][e] = split_plane( Weff_p[a][b][co = 16 nt + (lane & 15)][ci = 32 chunk + 8 (lane >> 4) + e] )
-// j walks the (tile position, parity) pairs in the order of the kernel's loop; NT = N-tiles rounded up to 4.
-__device__ __forceinline__ void pack_b3up_item(const pdes_b3up_pack_item& it, int bx, int nbx) {
-  const int ntp = (((it.Cout + 15) / 16) + 3) & ~3, nch = (it.Cin + 31) / 32;
-  const int total = nch * 16 * ntp * 64;
-  for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
-    const int l = e & 63, nt = (e >> 6) % ntp, j = ((e >> 6) / ntp) % 16, ch = (e >> 6) / (ntp * 16);
-    int pp = 0, ia = 0, ib = 0, cnt = 0;                       // decode j in the kernel's walking order
-    for (int ty = 0; ty < 3; ++ty)
-      for (int tx = 0; tx < 3; ++tx)
-        for (int ddy = 0; ddy < 2; ++ddy)
-          for (int ddx = 0; ddx < 2; ++ddx) {
-            const int a = ty - ddy, bb = tx - ddx;
-            if (a < 0 || a > 1 || bb < 0 || bb > 1) continue;
-            if (cnt == j) { pp = ddy * 2 + ddx; ia = a; ib = bb; }
-            ++cnt;
-          }
-    const int n = nt * 16 + (l & 15), k0 = ch * 32 + 8 * (l >> 4);
-    u32 hw[4], mw[4], lw[4];
-    float xv[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = k0 + q;
-      xv[q] = (n < it.Cout && k < it.Cin) ? weff(it.w + ((size_t)n * it.Cin + k) * 9, pp >> 1, pp & 1, ia, ib) : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) split3_pair(xv[2 * q], xv[2 * q + 1], hw[q], mw[q], lw[q]);
-    unsigned short* dst = it.wbu_fwd + (((size_t)(ch * 16 + j) * ntp + nt) * 3 * 64 + l) * 8;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-    *reinterpret_cast<uint4*>(dst + 64 * 8) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-    *reinterpret_cast<uint4*>(dst + 2 * 64 * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-  }
-}
-
 __global__ __launch_bounds__(256) void pack_b3up_kernel(const pdes_b3up_pack_item* __restrict__ items) {
   pack_b3up_item(items[blockIdx.y], blockIdx.x, gridDim.x);
 }

@@ -777,16 +777,14 @@ class _HipNet(nn.Module):
     def _pack_weights(self):
         """rebuild every packed weight image from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables)"""
         mx = max(self._pack_max, self._mpack_max if self._mpack_n else 0, self._upack_max if self._upack_n else 0,
-                 self._bpack_max if self._bpack_n else 0)
-        rc = _lib.lib().pdes_pack_all(self._pack_table.data_ptr(), self._pack_n,
-                                      self._mpack_table.data_ptr() if self._mpack_n else None, self._mpack_n,
-                                      self._upack_table.data_ptr() if self._upack_n else None, self._upack_n,
-                                      self._bpack_table.data_ptr() if self._bpack_n else None, self._bpack_n,
-                                      mx, _lib.stream_ptr())
-        _lib.check(rc, 'pdes_pack_all')
-        if self._bupack_n:
-            _lib.check(_lib.lib().pdes_pack_weights_b3up(self._bupack_table.data_ptr(), self._bupack_n, self._bupack_max,
-                                                         _lib.stream_ptr()), 'pdes_pack_weights_b3up')
+                 self._bpack_max if self._bpack_n else 0, self._bupack_max if self._bupack_n else 0)
+        rc = _lib.lib().pdes_pack_all2(self._pack_table.data_ptr(), self._pack_n,
+                                       self._mpack_table.data_ptr() if self._mpack_n else None, self._mpack_n,
+                                       self._upack_table.data_ptr() if self._upack_n else None, self._upack_n,
+                                       self._bpack_table.data_ptr() if self._bpack_n else None, self._bpack_n,
+                                       self._bupack_table.data_ptr() if self._bupack_n else None, self._bupack_n,
+                                       mx, _lib.stream_ptr())
+        _lib.check(rc, 'pdes_pack_all2')
 
     def _is_flat(self, device):
         if self._flat is None or self._flat.device != device:
