@@ -311,7 +311,8 @@ def main():
 
     def batch(i):
         lo = (i * GB + rank * B) % (args.ntrain - B + 1)
-        return data.index_select(0, perm[lo:lo + B])
+        trainer.load_batch(data, perm[lo:lo + B])          # the minibatch gather lands in the trainer's input buffer
+        return None
 
     def sync():
         if world > 1:

@@ -326,6 +326,11 @@ int pdes_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * Returns PDES_EINVAL when a bias correction is not positive (step 0). */
 int pdes_adam_step_host(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                         const float* hyper_host, float grad_scale, int zero_grad, long long n, void* stream);
+/* The same, additionally clearing `nclear` doubles at `clear` (the fp64 statistics arena of the step that just ended:
+ * its last reader, pdes_step_tail, precedes this call in stream order), so the next forward starts without a fill launch. */
+int pdes_adam_step_host2(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                         const float* hyper_host, float grad_scale, int zero_grad, long long n,
+                         double* clear, long long nclear, void* stream);
 
 /* End of a training step in ONE launch: pdes_bn_param_grads, optionally pdes_bn_update_running
  * (update_running != 0; same arithmetic), and -- when `partials` is given -- the reduction of the

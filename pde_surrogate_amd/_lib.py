@@ -47,6 +47,7 @@ SIGNATURES = {
     'pdes_bn_param_grads': [_c_p, _c_i, _c_i, _c_i, ctypes.c_longlong, _c_p],
     'pdes_adam_step': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, ctypes.c_longlong, _c_p],
     'pdes_adam_step_host': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_i, ctypes.c_longlong, _c_p],
+    'pdes_adam_step_host2': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_i, ctypes.c_longlong, _c_p, ctypes.c_longlong, _c_p],
     'pdes_test_metrics': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
     'pdes_mse_partials': [ctypes.c_longlong],
     'pdes_mse_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_p],

@@ -202,8 +202,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_kernel_v(float* __restrict__ p, float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, AdamHyper h,
-                                                     float gscale, long long n) {
+                                                     float gscale, long long n, double* __restrict__ clear, long long nclear) {
   adam_update<ZERO>(p, g, m, v, h, gscale, n);
+  // the fp64 statistics arena of the step that just ended (its last reader, pdes_step_tail, ran before this kernel):
+  // cleared here so that the next forward needs no fill launch of its own
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nclear; i += (long long)gridDim.x * 256) clear[i] = 0.0;
 }
 
 }  // namespace pdes
@@ -304,7 +307,13 @@ extern "C" int pdes_adam_step(float* param, const float* grad, float* exp_avg, f
 
 extern "C" int pdes_adam_step_host(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                                    const float* hyper_host, float grad_scale, int zero_grad, long long n, void* stream) {
-  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper_host || n <= 0) return PDES_EINVAL;
+  return pdes_adam_step_host2(param, grad, exp_avg, exp_avg_sq, hyper_host, grad_scale, zero_grad, n, nullptr, 0, stream);
+}
+
+extern "C" int pdes_adam_step_host2(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                    const float* hyper_host, float grad_scale, int zero_grad, long long n,
+                                    double* clear, long long nclear, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper_host || n <= 0 || nclear < 0 || (nclear && !clear)) return PDES_EINVAL;
   const AdamHyper h = {hyper_host[0], hyper_host[1], hyper_host[2], hyper_host[3], hyper_host[4], hyper_host[5],
                        hyper_host[6]};
   if (!(h.bc1 > 0.f) || !(h.bc2_sqrt > 0.f)) return PDES_EINVAL;
@@ -313,10 +322,10 @@ extern "C" int pdes_adam_step_host(float* param, float* grad, float* exp_avg, fl
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (zero_grad)
     hipLaunchKernelGGL(adam_kernel_v<true>, dim3((unsigned)gx), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, h,
-                       grad_scale, n);
+                       grad_scale, n, clear, nclear);
   else
     hipLaunchKernelGGL(adam_kernel_v<false>, dim3((unsigned)gx), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, h,
-                       grad_scale, n);
+                       grad_scale, n, clear, nclear);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

@@ -278,6 +278,7 @@ class _Engine:
         dev = net._flat.device
         self.dev = dev
         self.ctx = _lib.context(dev)           # options + fork/join events of this device (include/pdes_hip.h)
+        self.arena_clean = False               # True: the statistics arena is already zero (trainer's Adam kernel did it)
         self.busy = False                      # leased to an autograd forward whose backward has not run yet
         self.reserved = False                  # owned by a MixedResidualTrainer: never leased
         specs, bufs = net._specs, net._bufs
@@ -488,7 +489,10 @@ class _Engine:
                 else:
                     self.drop_masks.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
         if training:
-            self.arena.zero_()
+            if self.arena_clean:                       # cleared by the Adam kernel of the previous fused step
+                self.arena_clean = False
+            else:
+                self.arena.zero_()
         net._pack_weights()
         _lib.check(L.pdes_conv_forward(self.ctx, self.descs, len(self.descs), st), 'pdes_conv_forward')
         if training and not defer_running:

@@ -132,6 +132,11 @@ class MixedResidualTrainer:
         else:
             self._hyper_args[:7] = vals          # by value in the kernel arguments: no copy, nothing to race with
 
+    def load_batch(self, data, index):
+        """gather minibatch `data[index]` (device tensors) straight into the static input buffer (one launch instead of
+        index_select + copy); follow with step(None, lr)"""
+        torch.index_select(data, 0, index, out=self.x_static)
+
     def step(self, x=None, lr=None):
         """one training step on minibatch `x` (device tensor (B,C,H,W); None = reuse x_static)."""
         with _lib.device_guard(self.dev):
@@ -165,10 +170,13 @@ class MixedResidualTrainer:
                                         self.flat.numel(), _lib.stream_ptr())
         else:
             # the kernel clears the gradient buffer after reading it: the next step needs no fill launch
-            rc = self._L.pdes_adam_step_host(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
-                                             self.exp_avg_sq.data_ptr(), self._hyper_args, 1.0 / self.world, 1,
-                                             self.flat.numel(), _lib.stream_ptr())
+            # ... and the fp64 statistics arena of this step (read last by the end-of-step launch): no fill launch there either
+            rc = self._L.pdes_adam_step_host2(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), self._hyper_args, 1.0 / self.world, 1,
+                                              self.flat.numel(), self.eng.arena.data_ptr(), self.eng.arena.numel(),
+                                              _lib.stream_ptr())
             self._grad_clean = True
+            self.eng.arena_clean = True
         _lib.check(rc, 'pdes_adam_step')
 
     def _capture(self):
