@@ -165,3 +165,62 @@ def test_solver_script_nonlinear_lbfgs(dev, tmp_path):
     run = [p for p in (tmp_path / 'conv_mixed_residual_nonlinear').iterdir()][0]
     assert (run / 'epoch3.npy').exists() and np.load(run / 'epoch3.npy').shape == (3, 64, 64)
     assert (run / 'model_epoch3.pth').exists() and (run / 'loss.txt').exists()
+
+
+def test_fused_trainer_with_bilinear_upsampling_dropout_and_bottleneck(dev):
+    """the options of the reference's constructors through the FUSED step (not only through autograd): the loss is
+    finite and descends; and the fused step equals the drop-in loop body for upsample='bilinear' (no randomness)"""
+    from pde_surrogate_amd.models import darcy
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    data = torch.from_numpy(grf_kle_fields(64, n_kle=64, cache_dir='/tmp')).to(dev)
+    for kw in (dict(upsample='bilinear'), dict(drop_rate=0.1), dict(bottleneck=True, bn_size=2),
+               dict(upsample='bilinear', drop_rate=0.05, bottleneck=True, bn_size=2)):
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = DenseED(1, 3, 64, [3, 4, 3], growth_rate=16, init_features=48, **kw).to(dev).train()
+        tr = MixedResidualTrainer(net, 16, 64, lr=1e-3, device=dev)
+        losses = []
+        for i in range(10):
+            tr.step(data[(i % 4) * 16:(i % 4 + 1) * 16], 1e-3)
+            losses.append(tr.epoch_means()[0])
+        assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], (kw, losses)
+    # deterministic option: fused step == drop-in loop body
+    x = data[:8]
+    finals = []
+    for fused in (False, True):
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = DenseED(1, 3, 64, [3, 4, 3], upsample='bilinear').to(dev).train()
+        if fused:
+            tr = MixedResidualTrainer(net, 8, 64, lr=1e-3, device=dev)
+            tr.step(x, 1e-3)
+            loss = tr.epoch_means()[0]
+        else:
+            opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+            l = darcy.darcy_mixed_residual_loss(x, net(x), 10.0)[0]
+            l.backward()
+            opt.step()
+            loss = float(l.detach())
+        finals.append((loss, torch.cat([p.detach().reshape(-1) for p in net.parameters()])))
+    assert abs(finals[0][0] - finals[1][0]) <= 1e-5 * finals[0][0]
+    d = (finals[0][1] - finals[1][1]).abs()
+    assert float((d > 1e-6).float().mean()) < 0.02
+
+
+def test_cli_with_reference_options(dev, tmp_path, monkeypatch):
+    """--upsample bilinear --drop-rate 0.1 through the CLI (synthetic inputs), both loop bodies"""
+    import train_codec_mixed_residual as t
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    for mode in ('fused', 'dropin'):
+        argv = ['--exp-dir', str(tmp_path / mode), '--ntrain', '32', '--ntest', '16', '--batch-size', '8', '--test-batch-size', '8',
+                '--epochs', '2', '--ckpt-freq', '2', '--cuda', '0', '--synthetic', '--blocks', '111', '--growth-rate', '8',
+                '--init-features', '16', '--upsample', 'bilinear', '--drop-rate', '0.1', '--mode', mode]
+        with contextlib.redirect_stdout(io.StringIO()):
+            t.main(argv)
+        run = tmp_path / mode / 'codec/mixed_residual/grf_kle512_ntrain32_run1_bs8_lr0.001_epochs2'
+        lt = np.loadtxt(run / 'training/loss_train.txt')
+        assert lt.shape == (2,) and np.isfinite(lt).all() and lt[1] < lt[0]
+        a = json.load(open(run / 'args.txt'))
+        assert a['upsample'] == 'bilinear' and a['drop_rate'] == 0.1
