@@ -384,8 +384,10 @@ __global__ __launch_bounds__(256) void conv_fwd_first7(pdes_conv_desc d) {
 // in registers: per 4 output pixels it reads one float4 of the gradient and the 4*stride + k - 1 input values
 // they touch (aligned float4 LDS reads), i.e. ~5 LDS reads per 28 FMAs for the 7x7 stride-2 first layer.
 // The row groups of one (channel, ky) are adjacent lanes and are combined with two shuffles.
+// part != nullptr: this image's contribution is STORED to part[b][(co, ci, ky, kx)] (every element has exactly one
+// writer) for the fixed-order split-K reduce -- deterministic; nullptr: fp32 atomics straight into dw.
 template <int COT, int K, int S>
-__global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d) {
+__global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
   constexpr int KK = K * K;
   constexpr int RG = 4;                                 // row groups per (channel, ky)
@@ -471,12 +473,27 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d) {
       float v = a[kx];
       v += __shfl_xor(v, 1, 64);
       v += __shfl_xor(v, 2, 64);
-      if (live && grp == 0 && co0 + c < d.Cout) atomicAdd(&d.dw[((size_t)(co0 + c) * d.Cin + ci) * KK + ky * K + kx], v);
+      if (live && grp == 0 && co0 + c < d.Cout) {
+        const size_t idx = ((size_t)(co0 + c) * d.Cin + ci) * KK + ky * K + kx;
+        if (part) part[(size_t)b * d.Cout * d.Cin * KK + idx] = v;
+        else atomicAdd(&d.dw[idx], v);
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------- host dispatch
+// the first convolution's weight gradient through per-image partials + the fixed-order reduce (one split per image)
+bool first_layer_shape(const pdes_conv_desc& d) {
+  if (!(!d.has_bn && !d.upsample && d.Cin <= 4 && d.ksize == 7 && d.stride == 2 && d.Wout % 4 == 0 && d.Hout % 4 == 0 &&
+        d.Win % 4 == 0)) return false;
+  const int LH = d.Hin + 2 * d.pad + 2, LW = ((d.Win + 2 * d.pad + 2 + 4 + 3) / 4) * 4;
+  return ((size_t)d.Cin * LH * LW + (size_t)8 * d.Hout * d.Wout) * sizeof(float) <= 150 * 1024;
+}
+bool first_layer_partials(const pdes_conv_desc& d) {
+  return first_layer_shape(d) && d.ws && d.ws_defer && (long long)d.B * d.Cout * d.Cin * 49 * 4 <= d.ws_bytes;
+}
+
 static int validate(const pdes_conv_desc& d, int mode) {
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
   if (d.B <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return PDES_EINVAL;
@@ -543,7 +560,8 @@ int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st) {
     const int LH = d.Hin + 2 * d.pad + 2, LW = ((d.Win + 2 * d.pad + 2 + 4 + 3) / 4) * 4;
     const size_t lds = ((size_t)d.Cin * LH * LW + (size_t)8 * d.Hout * d.Wout) * sizeof(float);
     if (lds <= 150 * 1024) {
-      hipLaunchKernelGGL((conv_bwd_weight_first<8, 7, 2>), dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d);
+      float* part = first_layer_partials(d) ? d.ws : nullptr;
+      hipLaunchKernelGGL((conv_bwd_weight_first<8, 7, 2>), dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d, part);
       PDES_LAUNCH_CHECK();
       return PDES_OK;
     }

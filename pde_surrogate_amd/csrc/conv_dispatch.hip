@@ -10,6 +10,7 @@ namespace pdes {
 int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st);
+bool first_layer_partials(const pdes_conv_desc& d);     // conv_direct.hip: the 7x7 first layer writes per-image partials
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st);        // PDES_ENOSUP: shape not covered
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);   // dry: capability query only
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
@@ -77,7 +78,7 @@ extern "C" int pdes_conv_backward_weight(const pdes_context* ctx, const pdes_con
     if (rc == PDES_ENOSUP) {
       // the VALU kernel adds straight into dw.  If the caller planned deferred split-K partials for this layer
       // (pdes_conv_wgrad_plan said yes, e.g. before PDES_CONV_IMPL changed), its reduce must then add zeros
-      if (descs[i].ws_defer && descs[i].ws && descs[i].ws_bytes > 0) {
+      if (descs[i].ws_defer && descs[i].ws && descs[i].ws_bytes > 0 && !first_layer_partials(descs[i])) {
         const hipError_t he = hipMemsetAsync(descs[i].ws, 0, (size_t)descs[i].ws_bytes, st);
         if (he != hipSuccess) return (int)he;
       }

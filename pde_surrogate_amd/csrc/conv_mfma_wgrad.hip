@@ -18,6 +18,7 @@
 
 namespace pdes {
 int conv_backward_weight_1x1(const pdes_conv_desc& d, int splits_per_image, hipStream_t st);   // conv_mfma_1x1.hip
+bool first_layer_shape(const pdes_conv_desc& d);                                                 // conv_direct.hip
 bool wgrad_b3_applies(const pdes_conv_desc& d);                                                  // conv_mfma_wgrad_b3.hip
 int wgrad_b3_splits(const pdes_conv_desc& d);
 int conv_backward_weight_b3(const pdes_conv_desc& d, hipStream_t st);
@@ -769,6 +770,11 @@ extern "C" int pdes_conv_wgrad_plan(const pdes_context* ctx, const pdes_conv_des
   if (!d || !nsplit || !floats) return PDES_EINVAL;
   OptScope scope(ctx);
   WgradPlan pl;
+  if (first_layer_shape(*d)) {                 // 7x7 stride-2 first convolution: one partial per image (deterministic)
+    *nsplit = d->B;
+    *floats = (long long)d->B * d->Cout * d->Cin * 49;
+    return (*floats) * 4 <= d->ws_bytes ? PDES_OK : PDES_ENOSUP;
+  }
   if (opt().conv_direct) return PDES_ENOSUP;   // VALU kernels forced: no partials
   if (!wgrad_shape_ok(*d) || !wgrad_plan(*d, &pl)) return PDES_ENOSUP;
   *nsplit = pl.nsplit;

@@ -450,3 +450,26 @@ def test_backward_variants_agree(dev, monkeypatch, option, knob):
     errs = sorted(((rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k) for k in g0), reverse=True)
     print('variant', knob, 'worst gradient tensors:', errs[:3])
     assert errs[0][0] < (1e-5 if knob in ('PDES_WGRAD_STREAM', 'PDES_FORK_SIGNAL') else 1e-3), errs[:8]      # measured: <= 1.7e-4
+
+
+def test_run_to_run_determinism(dev):
+    """the BatchNorm statistics are accumulated with fp64 atomics (order dependent below 1e-16
+    relative).  What that means in practice: the network output, the loss terms and EVERY parameter gradient of the
+    default DenseED are BITWISE identical from run to run (the fp64 sums round to the same fp32 coefficients; all weight
+    gradients, the first layer's included, go through per-split partials and a fixed-order reduce)"""
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    net = _default_net(dev)
+    x = torch.from_numpy(grf_kle_fields(32, n_kle=64, seed=3, cache_dir='/tmp')).to(dev)
+    runs = []
+    for _ in range(4):
+        net.zero_grad()
+        y = net(x)
+        loss = darcy_mixed_residual_loss(x, y, 10.0)[0]
+        loss.backward()
+        runs.append((y.detach().clone(), float(loss.detach()), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    y0, l0, g0 = runs[0]
+    for y, l, g in runs[1:]:
+        assert torch.equal(y, y0) and l == l0
+        differing = [k for k in g0 if not torch.equal(g[k], g0[k])]
+        assert differing == [], differing
