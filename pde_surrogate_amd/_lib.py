@@ -88,6 +88,8 @@ def lib():
 
 # ---- contexts: the library's only state (options + fork/join events), one per device, owned here ------------
 N_EVENTS = 512                      # pdes_backward with a second stream needs n_layers + 1 (default net: 29)
+import threading
+_ctx_lock = threading.Lock()        # autograd's backward thread and the main thread may both ask for a context first
 _contexts = {}                      # device index -> pdes_context*
 _overrides = {}                     # option key -> value, applied to every context (set_option)
 
@@ -108,14 +110,17 @@ def context(device=None):
         idx = torch.cuda.current_device()
     ctx = _contexts.get(idx)
     if ctx is None:
-        L = lib()
-        h = _c_p()
-        with torch.cuda.device(idx):
-            check(L.pdes_context_create(ctypes.byref(h), N_EVENTS), 'pdes_context_create')
-        check(L.pdes_context_load_env(h), 'pdes_context_load_env')
-        for k, v in _overrides.items():
-            check(L.pdes_context_set_option(h, k.encode(), None if v is None else str(v).encode()), f'option {k}')
-        ctx = _contexts[idx] = h
+        with _ctx_lock:
+            ctx = _contexts.get(idx)
+            if ctx is None:
+                L = lib()
+                h = _c_p()
+                with torch.cuda.device(idx):
+                    check(L.pdes_context_create(ctypes.byref(h), N_EVENTS), 'pdes_context_create')
+                check(L.pdes_context_load_env(h), 'pdes_context_load_env')
+                for k, v in _overrides.items():
+                    check(L.pdes_context_set_option(h, k.encode(), None if v is None else str(v).encode()), f'option {k}')
+                ctx = _contexts[idx] = h
     return ctx
 
 
