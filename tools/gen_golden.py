@@ -9,6 +9,7 @@ in the reference's module-creation order (sha256 of the state_dict is stored so 
 whether the local torch reproduces it).
 
     python tools/gen_golden.py            # rewrites tests/golden/*.npz
+    python tools/gen_golden.py glow       # only G18-G20 (conditional Glow)
 """
 import hashlib
 import io
@@ -280,6 +281,154 @@ def gen_bottleneck():
     np.savez_compressed(os.path.join(OUT, 'G17_bottleneck.npz'), **g)
 
 
+def _glow_module():
+    """the reference's models/glow_msc.py, importable under a current PyTorch: GaussianDiag.__init__ (glow_msc.py:435-440)
+    clamps a chunk view in place, which autograd has refused since PyTorch 1.5 ("output of a function that returns
+    multiple views ... modified inplace"); the out-of-place clamp below has the same values and the same gradient.
+    Nothing else of the reference is touched."""
+    import math
+    import models.glow_msc as G
+
+    def _init(self, mean, log_stddev):
+        self.mean = mean
+        self.log_stddev = log_stddev.clamp(min=-10., max=math.log(5.))
+    G.GaussianDiag.__init__ = _init
+    return G
+
+
+def _perturb_glow(net, gen, amp=1.0):
+    """move every parameter off its initial value (the reference initialises the coupling nets' last convolutions, the
+    latent encoders and all ActNorms to the identity map, which would leave most gradients exactly zero)"""
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            r = amp * torch.randn(p.shape, generator=gen)
+            if k.endswith('.scale'):
+                p.add_(0.1 * r)
+            elif 'conv_zero' in k or 'top_latent' in k or 'latent_encoder' in k:
+                p.add_((0.02 if k.endswith('weight') else 0.1) * r)
+            elif k.endswith('.norm.weight'):         # ActNorm: the z -> y path divides by it
+                p.copy_(1 + 0.1 * r)
+            elif 'norm' in k and k.endswith('.weight'):
+                p.copy_(1 + 0.2 * r)
+            elif k.endswith('.bias'):
+                p.add_(0.1 * r)
+            elif k.endswith('.l') or k.endswith('.u'):
+                p.add_(0.05 * r)             # (entries outside the triangular masks never enter the weight)
+            elif k.endswith('.log_s'):
+                p.add_(0.1 * r)
+            elif k.endswith('conv1x1.weight'):
+                p.add_(0.05 * r)
+
+
+def gen_glow():
+    """G18 / G19 / G20: multiscale conditional Glow, the TRAINING path of train_cglow_reverse_kl.py:245-262
+    (generate -> mixed-residual loss + entropy term -> backward), eval-mode generate, and the y -> z direction"""
+    import math
+    G = _glow_module()
+    rng = np.random.default_rng(20190711)
+
+    def run(net, x, eps, imsize, beta, wb, full):
+        sob = SobelFilter(imsize, correct=True)
+        xt = torch.from_numpy(x)
+        el = [torch.from_numpy(e) for e in eps]
+        net.train()
+        net.zero_grad()
+        y, logp = net.generate(xt, eps_list=el)
+        terms = ref_loss(xt, y, sob, wb)
+        neg_entropy = logp.mean() / math.log(2.) / y[0].numel()
+        loss = terms[0] * beta + neg_entropy
+        loss.backward()
+        g = {'x': x, 'beta': np.float64(beta), 'weight_bound': np.float64(wb), 'logp': logp.detach().numpy(),
+             'terms': np.array([float(loss), float(terms[0]), float(neg_entropy)] + [float(t) for t in terms[1:]], np.float64)}
+        for i, e in enumerate(eps):
+            g[f'eps{i}'] = e
+        return g, y.detach()
+
+    # ---- G18: small net, 16x16, every tensor stored
+    torch.manual_seed(7)
+    np.random.seed(7)
+    cfg = dict(imsize=16, enc_blocks=[2, 1, 1], flow_blocks=[2, 2, 1])
+    net = quiet(G.MultiScaleCondGlow, cfg['imsize'], 1, 3, cfg['enc_blocks'], cfg['flow_blocks'], LUdecompose=True,
+                squeeze_factor=2)
+    _perturb_glow(net, torch.Generator().manual_seed(11))
+    sd0 = {k: v.clone().numpy() for k, v in net.state_dict().items()}
+    B = 4
+    x = np.exp(0.5 * rng.standard_normal((B, 1, 16, 16))).astype(np.float32)
+    eps = [rng.standard_normal((B,) + s).astype(np.float32) for s in net._z_shapes()]
+    g, y = run(net, x, eps, 16, 150.0, 50.0, True)
+    g['y'] = y.numpy()
+    g['enc_blocks'], g['flow_blocks'] = np.array(cfg['enc_blocks']), np.array(cfg['flow_blocks'])
+    g['n_params'], g['n_layers'] = np.array(net.model_size[0]), np.array(net.model_size[1])
+    for k, v in sd0.items():
+        g['sd0/' + k] = v
+    for k, p in net.named_parameters():
+        g['grad/' + k] = p.grad.numpy()
+    for k, v in net.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            g['sd1/' + k] = v.numpy()
+    net.eval()
+    with torch.no_grad():
+        ye, lpe = net.generate(torch.from_numpy(x), eps_list=[torch.from_numpy(e) for e in eps])
+        g['y_eval'], g['logp_eval'] = ye.numpy(), lpe.numpy()
+        z, lpf, el = net.forward(ye, torch.from_numpy(x), return_eps=True)
+        g['z_fwd'], g['logp_fwd'] = z.numpy(), lpf.numpy()
+        for i, e in enumerate(el):
+            g[f'eps_fwd{i}'] = e.numpy()
+        samples = net.sample(torch.from_numpy(x[:2]), n_samples=3, eps_list=[torch.from_numpy(
+            np.stack([e[:2]] * 3) * (1 + np.arange(3, dtype=np.float32)).reshape(3, 1, 1, 1, 1)) for e in eps], temperature=0.8)
+        g['samples'] = samples.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G18_cglow_small.npz'), **g)
+
+    # ---- G20: the plain (non-LU) invertible 1x1 convolution, --no-LU-decompose
+    torch.manual_seed(8)
+    np.random.seed(8)
+    net = quiet(G.MultiScaleCondGlow, 16, 1, 3, [1, 1, 1], [2, 1, 1], LUdecompose=False, squeeze_factor=2)
+    _perturb_glow(net, torch.Generator().manual_seed(12))
+    sd0 = {k: v.clone().numpy() for k, v in net.state_dict().items()}
+    eps = [rng.standard_normal((B,) + s).astype(np.float32) for s in net._z_shapes()]
+    g, y = run(net, x, eps, 16, 150.0, 50.0, True)
+    g['y'] = y.numpy()
+    for k, v in sd0.items():
+        g['sd0/' + k] = v
+    g['param_names'] = np.array([k for k, _ in net.named_parameters()])
+    g['grad_norms'] = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    for k, p in net.named_parameters():
+        if 'conv1x1' in k or 'norm.' in k:
+            g['grad/' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G20_cglow_plain1x1.npz'), **g)
+
+    # ---- G19: the default net of train_cglow_reverse_kl.py (enc [3,4,4], flow [6,6,6], 32x32), weights from
+    # torch.manual_seed(1) + np.random.seed(1) in the reference's creation order, then _perturb_glow(seed 13)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = quiet(G.MultiScaleCondGlow, 32, 1, 3, [3, 4, 4], [6, 6, 6], LUdecompose=True, squeeze_factor=2)
+    init_sha = sd_sha({k: v for k, v in net.named_parameters()})
+    init_sha_buffers = sd_sha({k: v for k, v in net.state_dict().items() if 'running' in k})
+    _perturb_glow(net, torch.Generator().manual_seed(13), 0.4)
+    # the reference's constructor pushes one random image through the encoder in train mode (glow_msc.py:713-714:
+    # feature_sizes), which moves the encoder's BatchNorm running statistics; stored so a test can load them
+    B = 8
+    x = np.exp(0.5 * rng.standard_normal((B, 1, 32, 32))).astype(np.float32)
+    eps = [rng.standard_normal((B,) + s).astype(np.float32) for s in net._z_shapes()]
+    names = [k for k, _ in net.named_parameters()]
+    g, y = run(net, x, eps, 32, 150.0, 50.0, False)
+    proj = torch.Generator().manual_seed(14)
+    g.update({'init_sha256': np.array(init_sha), 'init_sha256_running': np.array(init_sha_buffers),
+              'param_sha256': np.array(sd_sha({k: v for k, v in net.named_parameters()})),
+              'y0': y.numpy()[0], 'y_slice': y.numpy()[:, :, ::4, ::4], 'param_names': np.array(names),
+              'grad_norms': np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()]),
+              'grad_proj': np.array([float((p.grad.double() * torch.randn(p.shape, generator=proj).double()).sum())
+                                     for _, p in net.named_parameters()]),
+              'n_params': np.array(net.model_size[0]), 'n_layers': np.array(net.model_size[1]),
+              'n_state': np.array(len(net.state_dict()))})
+    for k in ('encoder.dense_block1.in_conv.weight', 'encoder.top_latent.conv.weight',
+              'flow.revblock1.revlayers.revlayer1.coupling.coupling_nn.reduce.conv_zero.conv.weight',
+              'flow.revblock2.revlayers.revlayer3.conv1x1.l', 'flow.revblock2.revlayers.revlayer3.conv1x1.log_s',
+              'flow.revblock3.revlayers.revlayer6.norm.weight', 'flow.revblock2.split.latent_encoder.conv2d.scale'):
+        g['grad/' + k] = dict(net.named_parameters())[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G19_cglow_default.npz'), **g)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -455,9 +604,14 @@ def main():
     gen_round2()
     gen_dropout()
     gen_bottleneck()
+    gen_glow()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'glow':      # only the conditional-Glow fixtures (G18-G20)
+        torch.set_num_threads(8)
+        gen_glow()
+    else:
+        main()
