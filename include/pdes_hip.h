@@ -131,6 +131,40 @@ int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* im
                                        or 1/(1-p), drawn by the caller), out_stats accumulated here (the convolution before it
                                        passes out_stats = NULL); backward: g[b, g_coff + c] *= w[b * Cout + c] in place, after
                                        the finalize of these channels, which is carried by THIS descriptor's fin_* */
+/* ---- flow ops (models/glow_msc.py of the reference; z -> y direction unless flags & PDES_FLOW_FORWARD).  Descriptors
+ * with ksize = 0 that are not convolutions; they use the fields appended at the end of pdes_conv_desc (x2, t2, p0, p1,
+ * acc, flags).  Buffers without a BatchNorm consumer keep their gradient in the same T tensor (fin_tstats = NULL); a
+ * buffer read BOTH through BatchNorms and directly collects the direct consumers' gradients in a second tensor that
+ * the producer's finalize adds (g_add).  H*W must be a multiple of 4. */
+#define PDES_OP_COPY 4        /* out[:, out_coff + c] = x[:, c], c < Cin = Cout (torch.cat((y1, cond), 1), glow_msc.py:321,339;
+                                 torch.cat((x, out), 1), :43), out_stats accumulated.  Backward: t_in[:, c] (+)= g[:, g_coff + c]
+                                 (after this descriptor's finalize); t_in = NULL: nothing (input data) */
+#define PDES_OP_BIAS_SCALE 5  /* in place: out = (out + p0[c]) * exp(3 p1[c]) on channels [out_coff, out_coff + Cout); p1 = NULL: bias
+                                 only (nn.Conv2d(bias=True), glow_msc.py:34-35; Conv2dZeros, :237-252).  out_stats accumulated when
+                                 given (then this descriptor, not the convolution before it, carries fin_*).  Backward, in place on g:
+                                 g *= exp(3 p1); acc (Cout, 2) += {sum g exp(3 p1), 3 sum g out} = {dbias, dscale} */
+#define PDES_OP_COUPLING 6    /* AffineCouplingLayer.reverse (glow_msc.py:336-345): x (C channels), x2 = the coupling net's output h
+                                 (2 n2 channels, n2 = C / 2, n1 = C - n2): out[:n1] = x[:n1]; s = sigmoid(h[2k+1] + 2);
+                                 out[n1 + k] = x[n1 + k] / s - h[2k]; acc[b] += sum log s.  PDES_FLOW_FORWARD (:317-334):
+                                 out[n1 + k] = (x[n1 + k] + h[2k]) * s.  Backward (z -> y only): t_in = dL/dx (written), t2 = dL/dh,
+                                 p1 = dL/d(logp) per sample (B floats, nullable) */
+#define PDES_OP_MIX 7         /* InvertibleConv1x1[LU].reverse + ActNorm.reverse (glow_msc.py:390-397): out = (W x - p1) / p0 per pixel,
+                                 W = x2 (C, C) row-major, p0 / p1 = ActNorm weight / bias.  PDES_FLOW_FORWARD (:383-388): out = W (p0 x + p1)
+                                 (the caller passes the inverse matrix).  Backward: t_in = W^T (g / p0) (written);
+                                 acc (2 C + C C doubles) += {dL/dp0, dL/dp1, dL/dW} (the log-determinants depend on the parameters
+                                 only: pdes_flow_prepare / pdes_flow_param_grads) */
+#define PDES_OP_UNSQUEEZE 8   /* Squeeze.reverse, factor 2 (glow_msc.py:422-432): out[c][i H + h][j W + w] = x[4 c + 2 i + j][h][w]
+                                 (QUADRANT layout); PDES_FLOW_FORWARD: Squeeze.forward (:410-420), x (Cin, 2H, 2W) -> out (4 Cin, H, W).
+                                 Backward: the inverse permutation of g into t_in (written) */
+#define PDES_OP_GAUSS 9       /* GaussianDiag.sample + log_prob (glow_msc.py:435-458) of a prior x2 = (mean | log-stddev) (2 n channels,
+                                 n = Cout), p0 = eps (B, n, H, W): out = mean + exp(l) eps, l = clamp(log-stddev, -10, log 5);
+                                 acc[b] += sum -0.5 (log 2 pi + 2 l + (out - mean)^2 / exp(2 l)).  PDES_FLOW_FORWARD (Split.forward,
+                                 :561-573): x = the given latent, acc[b] += its log-probability, out (nullable) = (x - mean) / exp(l).
+                                 Backward: t2 = dL/d(prior) (autograd of both uses of the prior; PDES_GAUSS_DETACH_LSD: no gradient to the
+                                 log-stddev, the top latent's `.data`, :524), p1 = dL/d(logp) */
+#define PDES_FLOW_FORWARD 1
+#define PDES_GAUSS_DETACH_LSD 2
+
 typedef struct pdes_conv_desc {
   /* geometry */
   int B, Cin, Cout, Hin, Win, Hout, Wout;
@@ -185,6 +219,16 @@ typedef struct pdes_conv_desc {
   long long rep_stride;
   const unsigned short* wbu_fwd; /* nearest-x2 + 3x3 layers: bf16 hi/mid/lo split image of the effective sub-pixel weights
                                     for the forward (pdes_pack_weights_b3up), or NULL */
+  /* appended in ABI 14 (NULL / 0 for the DenseED chains) */
+  const float* g_add;    /* pdes_backward: the finalize of this descriptor's output channels ADDS g_add (layout of g): the gradient
+                            from consumers that read `out` without a BatchNorm */
+  const float* x2;       /* flow ops: second source (see PDES_OP_*) */
+  int x2_ctot;
+  float* t2;             /* flow ops: gradient of the second source */
+  const float* p0;       /* flow ops: per-channel parameters / noise */
+  const float* p1;
+  double* acc;           /* flow ops: fp64 accumulators (replicated like the statistics: nrep, rep_stride) */
+  int flags;             /* PDES_FLOW_FORWARD, PDES_GAUSS_DETACH_LSD */
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.
@@ -242,6 +286,31 @@ int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* descs, int n, v
 int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
                    void* wgrad_stream_b, const pdes_reduce_item* reduce_items, const int* reduce_index,
                    const pdes_bucket_hook* hook);
+
+/* ---------------------------------------------------------------------------------------------
+ * Parameter side of the flow (models/glow_msc.py): one launch each for ALL invertible 1x1 convolutions + ActNorms.
+ * pdes_flow_prepare: W = P (L * l_mask + I) (U * u_mask + diag(exp(log_s) sign_s)) (InvertibleConv1x1LU.weight, :205-208), or
+ *   W = weight (InvertibleConv1x1, :99-157); optionally W^-1 and log|det W| by fp64 Gauss-Jordan (needed for the plain
+ *   parameterisation and for the y -> z direction); logdet[layer] = HW (sum log|actnorm weight| - log|det W|) (double):
+ *   the layer's contribution to EVERY sample's log p (ActNorm.reverse :90-96, conv1x1.reverse :150-157 / :222-233).
+ * pdes_flow_param_grads: from the accumulators of PDES_OP_MIX's backward (acc: 2 C + C C doubles per layer) and
+ *   cB = sum_b dL/d(logp_b): ActNorm weight / bias gradients (+ cB HW / weight), and dW chained into dl, du, dlog_s
+ *   (- cB HW) or into dweight (- cB HW W^-T); gradients are ACCUMULATED (fp32).  C <= 48 (five-level flows would need 96). */
+typedef struct pdes_flow_item {
+  int C, HW, lu;                       /* lu = 1: l, u, log_s, p, sign_s; 0: weight */
+  const float* l; const float* u; const float* log_s; const float* p; const float* sign_s; const float* weight;
+  const float* an_weight; const float* an_bias;    /* ActNorm (C) */
+  float* W; float* Winv;               /* (C, C) outputs; Winv nullable when lu = 1 */
+  double* logdet;                      /* 1 double, written */
+  const double* acc;                   /* backward accumulators of this layer (replicated) */
+  float* dl; float* du; float* dlog_s; float* dweight; float* dan_weight; float* dan_bias;
+} pdes_flow_item;
+int pdes_flow_prepare(const pdes_flow_item* items, int n, int need_inverse, void* stream);        /* items: DEVICE array */
+int pdes_flow_param_grads(const pdes_flow_item* items, int n, const float* glogp, int B, int nrep, long long rep_stride,
+                          void* stream);
+/* logp[b] = sum of the replicas of acc[b] + sum of logdet[0..n_layers) (fp32 out); what generate() returns as log p(y|x) */
+int pdes_flow_logp(const double* acc, const double* logdet, int n_layers, float* logp, int B, int nrep, long long rep_stride,
+                   void* stream);
 
 /* Table-driven helpers: one launch for the whole network. */
 typedef struct pdes_pack_item {  /* one convolution's weights */

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -52,6 +52,9 @@ SIGNATURES = {
     'pdes_mse_partials': [ctypes.c_longlong],
     'pdes_mse_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_p],
     'pdes_multi_dot': [_c_p, ctypes.c_longlong, _c_i, _c_p, _c_i, ctypes.c_longlong, _c_p, _c_i, _c_p],
+    'pdes_flow_prepare': [_c_p, _c_i, _c_i, _c_p],
+    'pdes_flow_param_grads': [_c_p, _c_i, _c_p, _c_i, _c_i, ctypes.c_longlong, _c_p],
+    'pdes_flow_logp': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_i, ctypes.c_longlong, _c_p],
     'pdes_step_tail': [_c_p, _c_i, _c_i, _c_f, _c_i, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_p, _c_p, _c_i,
                        ctypes.c_longlong, _c_p],
 }
@@ -87,7 +90,7 @@ def lib():
 
 
 # ---- contexts: the library's only state (options + fork/join events), one per device, owned here ------------
-N_EVENTS = 512                      # pdes_backward with a second stream needs n_layers + 1 (default net: 29)
+N_EVENTS = 2048                     # pdes_backward with side streams needs n_descriptors + 4 (DenseED: 28 + 4; default cGlow: ~200)
 import threading
 _ctx_lock = threading.Lock()        # autograd's backward thread and the main thread may both ask for a context first
 _contexts = {}                      # device index -> pdes_context*

@@ -17,7 +17,8 @@ namespace pdes {
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ t, const float* __restrict__ x,
                                                               const double* __restrict__ x_stats,
                                                               const double* __restrict__ t_stats, int B, int ctot,
-                                                              int c0, int HW, float eps, int nrep, long long rs, int early) {
+                                                              int c0, int HW, float eps, int nrep, long long rs, int early,
+                                                              const float* __restrict__ add) {
   const int c = c0 + blockIdx.y, b = blockIdx.z;
   __shared__ float sc[4];
   __shared__ double sums[4];
@@ -64,11 +65,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
       tv.y = invstd * (tv.y - m1 - (xv.y - mean) * invstd * m2);
       tv.z = invstd * (tv.z - m1 - (xv.z - mean) * invstd * m2);
       tv.w = invstd * (tv.w - m1 - (xv.w - mean) * invstd * m2);
+      if (add) {            // gradient from consumers that read the activation without a BatchNorm (pdes_conv_desc.g_add)
+        const float4 a = reinterpret_cast<const float4*>(add + base)[i];
+        tv.x += a.x; tv.y += a.y; tv.z += a.z; tv.w += a.w;
+      }
       t4[i] = tv;
     }
   } else {
     for (int i = i0; i < HW; i += gridDim.x * 256)
-      t[base + i] = invstd * (t[base + i] - m1 - (x[base + i] - mean) * invstd * m2);
+      t[base + i] = invstd * (t[base + i] - m1 - (x[base + i] - mean) * invstd * m2) + (add ? add[base + i] : 0.f);
   }
 }
 
@@ -222,7 +227,7 @@ namespace pdes {
 // stream 3-5 us (27 times per step on the finalize -> data-gradient chain), the completion-signal form costs nothing.
 int bn_backward_finalize_launch(const pdes_context* ctx, float* t, const float* x, const double* x_stats,
                                 const double* t_stats, int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
-                                long long rep_stride, hipStream_t st, hipEvent_t done) {
+                                long long rep_stride, hipStream_t st, hipEvent_t done, const float* add) {
   if (!t || !x || !x_stats || !t_stats || B <= 0 || c1 <= c0 || c0 < 0 || c1 > ctot || HW <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   if (!aligned16(t) || !aligned16(x)) return PDES_EALIGN;
   dim3 grid(cdiv(cdiv(HW, 4), 256), c1 - c0, B), block(256);
@@ -230,10 +235,10 @@ int bn_backward_finalize_launch(const pdes_context* ctx, float* t, const float* 
   const int early = opt().fin_early != 0;
   if (done)
     hipExtLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, st, nullptr, done, 0, t, x, x_stats, t_stats, B, ctot,
-                          c0, HW, eps, nrep, rep_stride, early);
+                          c0, HW, eps, nrep, rep_stride, early, add);
   else
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, block, 0, st, t, x, x_stats, t_stats, B, ctot, c0, HW, eps, nrep,
-                       rep_stride, early);
+                       rep_stride, early, add);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
@@ -243,7 +248,7 @@ extern "C" int pdes_bn_backward_finalize(const pdes_context* ctx, float* t, cons
                                          int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
                                          long long rep_stride, void* stream) {
   return bn_backward_finalize_launch(ctx, t, x, x_stats, t_stats, B, ctot, c0, c1, HW, eps, nrep, rep_stride,
-                                     static_cast<hipStream_t>(stream), nullptr);
+                                     static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 extern "C" int pdes_pack_weights(const pdes_pack_item* items, int n, int max_elems, void* stream) {

@@ -187,17 +187,24 @@ __global__ __launch_bounds__(256) void conv_bwd_data_direct(pdes_conv_desc d) {
     if (ci < d.Cin && active) {
       const float mean = cf[4 * j], invstd = cf[4 * j + 1], gamma = cf[4 * j + 2], beta = cf[4 * j + 3];
       const size_t idx = (size_t)ci * HWi + p;
-      const float x = xb[idx];
-      const float y = (x - mean) * (gamma * invstd) + beta;     // same expression as the forward
-      const float xh = (x - mean) * invstd;
-      const float dyv = (y > 0.f) ? acc[j] : 0.f;
-      db = dyv;
-      dg = dyv * xh;
-      float t = gamma * dyv;
-      if (d.t_accumulate) t += tb[idx];
-      tb[idx] = t;
-      if (ci >= d.final_c0 && ci < d.final_c1) { st = t; sx = t * xh; }
+      if (!d.has_bn) {
+        // a convolution that reads its input as is (glow_msc.py Conv2dZeros on a latent / on the encoder's features):
+        // t_in is the plain gradient of the input, no mask, no BatchNorm sums
+        tb[idx] = d.t_accumulate ? tb[idx] + acc[j] : acc[j];
+      } else {
+        const float x = xb[idx];
+        const float y = (x - mean) * (gamma * invstd) + beta;     // same expression as the forward
+        const float xh = (x - mean) * invstd;
+        const float dyv = (y > 0.f) ? acc[j] : 0.f;
+        db = dyv;
+        dg = dyv * xh;
+        float t = gamma * dyv;
+        if (d.t_accumulate) t += tb[idx];
+        tb[idx] = t;
+        if (ci >= d.final_c0 && ci < d.final_c1) { st = t; sx = t * xh; }
+      }
     }
+    if (!d.has_bn) continue;
     const float r0 = wave_sum(dg), r1 = wave_sum(db), r2 = wave_sum(st), r3 = wave_sum(sx);
     if (lane == 0) {
       double* r = &red[(wave * CIT + j) * 4];
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_direct(pdes_conv_desc d) {
     }
   }
   __syncthreads();
-  if (tid < CIT * 4) {
+  if (d.has_bn && tid < CIT * 4) {
     const int j = tid >> 2, q = tid & 3, ci = ci0 + j;
     if (ci < d.Cin) {
       double t = 0.0;
@@ -506,7 +513,8 @@ static int validate(const pdes_conv_desc& d, int mode) {
   if (d.cout_pad % 16 || d.cin_pad % 16 || d.cout_pad < d.Cout || d.cin_pad < d.Cin) return PDES_EINVAL;
   if (mode == 0 && (!d.out || !d.w_fwd)) return PDES_EINVAL;
   if (mode == 1 && (!d.g || !d.dw)) return PDES_EINVAL;
-  if (mode == 2 && (!d.g || !d.w_bwd || !d.t_in || !d.bn_grad || !d.t_stats || !d.has_bn || d.eval_mode)) return PDES_EINVAL;
+  if (mode == 2 && (!d.g || !d.w_bwd || !d.t_in || d.eval_mode)) return PDES_EINVAL;
+  if (mode == 2 && d.has_bn && (!d.bn_grad || !d.t_stats)) return PDES_EINVAL;
   return PDES_OK;
 }
 

@@ -29,13 +29,44 @@ int channel_mask_backward(const pdes_conv_desc& d, hipStream_t st);
 // descriptors that are not convolutions: no weights, their own forward / backward kernels
 int bn_backward_finalize_launch(const pdes_context* ctx, float* t, const float* x, const double* x_stats,
                                 const double* t_stats, int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
-                                long long rep_stride, hipStream_t st, hipEvent_t done);
-static bool is_resample_op(const pdes_conv_desc& d) { return d.upsample == PDES_UPSAMPLE_BILINEAR_OP || d.upsample == PDES_OP_CHANNEL_MASK; }
+                                long long rep_stride, hipStream_t st, hipEvent_t done, const float* add);
+// flow operators of the conditional Glow (flow_ops.hip)
+int flow_copy_forward(const pdes_conv_desc& d, hipStream_t st);
+int flow_copy_backward(const pdes_conv_desc& d, hipStream_t st);
+int flow_bias_scale_forward(const pdes_conv_desc& d, hipStream_t st);
+int flow_bias_scale_backward(const pdes_conv_desc& d, hipStream_t st);
+int flow_coupling_forward(const pdes_conv_desc& d, hipStream_t st);
+int flow_coupling_backward(const pdes_conv_desc& d, hipStream_t st);
+int flow_mix_forward(const pdes_conv_desc& d, hipStream_t st);
+int flow_mix_backward(const pdes_conv_desc& d, hipStream_t st);
+int flow_unsqueeze_forward(const pdes_conv_desc& d, hipStream_t st);
+int flow_unsqueeze_backward(const pdes_conv_desc& d, hipStream_t st);
+int flow_gauss_forward(const pdes_conv_desc& d, hipStream_t st);
+int flow_gauss_backward(const pdes_conv_desc& d, hipStream_t st);
+static bool is_resample_op(const pdes_conv_desc& d) { return d.upsample >= PDES_UPSAMPLE_BILINEAR_OP && d.upsample <= PDES_OP_GAUSS; }
 static int op_forward(const pdes_conv_desc& d, hipStream_t st) {
-  return d.upsample == PDES_OP_CHANNEL_MASK ? channel_mask_forward(d, st) : upsample_bilinear_forward(d, st);
+  switch (d.upsample) {
+    case PDES_OP_CHANNEL_MASK: return channel_mask_forward(d, st);
+    case PDES_OP_COPY: return flow_copy_forward(d, st);
+    case PDES_OP_BIAS_SCALE: return flow_bias_scale_forward(d, st);
+    case PDES_OP_COUPLING: return flow_coupling_forward(d, st);
+    case PDES_OP_MIX: return flow_mix_forward(d, st);
+    case PDES_OP_UNSQUEEZE: return flow_unsqueeze_forward(d, st);
+    case PDES_OP_GAUSS: return flow_gauss_forward(d, st);
+    default: return upsample_bilinear_forward(d, st);
+  }
 }
 static int op_backward(const pdes_conv_desc& d, hipStream_t st) {
-  return d.upsample == PDES_OP_CHANNEL_MASK ? channel_mask_backward(d, st) : upsample_bilinear_backward(d, st);
+  switch (d.upsample) {
+    case PDES_OP_CHANNEL_MASK: return channel_mask_backward(d, st);
+    case PDES_OP_COPY: return flow_copy_backward(d, st);
+    case PDES_OP_BIAS_SCALE: return flow_bias_scale_backward(d, st);
+    case PDES_OP_COUPLING: return flow_coupling_backward(d, st);
+    case PDES_OP_MIX: return flow_mix_backward(d, st);
+    case PDES_OP_UNSQUEEZE: return flow_unsqueeze_backward(d, st);
+    case PDES_OP_GAUSS: return flow_gauss_backward(d, st);
+    default: return upsample_bilinear_backward(d, st);
+  }
 }
 
 // option PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
@@ -231,7 +262,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       if (fork && use_signal && i != 0 && !is_resample_op(d)) signalled = cx->events[nev++];
       int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
                                            d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
-                                           d.rep_stride, st, signalled);
+                                           d.rep_stride, st, signalled, d.g_add);
       if (rc) return rc;
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
@@ -240,7 +271,8 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       const int rc = release(i, fork && i == 0, signalled);
       if (rc) return rc;
     }
-    if (d.has_bn || is_resample_op(d)) {
+    // (a convolution without a BatchNorm in front has a data gradient only when the caller gave it somewhere to go)
+    if (d.has_bn || is_resample_op(d) || d.t_in) {
       const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
       if (rc) return rc;
     }

@@ -1,0 +1,647 @@
+// Flow operators of the multiscale conditional Glow (reference models/glow_msc.py) as descriptors of the same chain
+// that runs the DenseED convolutions (include/pdes_hip.h: PDES_OP_COPY .. PDES_OP_GAUSS), z -> y direction with its
+// backward pass (the TRAINING path of train_cglow_reverse_kl.py:245-262) and the y -> z direction without one.
+//
+// Every operator is HBM/L2-bandwidth or latency bound (3..48 channels at 32x32 .. 8x8): one thread per pixel (or per
+// float4 of a channel plane), lanes of a wave on consecutive pixels, per-channel / per-sample reductions by wave
+// shuffles -> LDS -> one fp64 atomic per workgroup into a replica of the caller's accumulator arena (like the BatchNorm
+// statistics: order dependence < 1e-16 relative).  The matrix of an invertible 1x1 convolution (C <= 48) sits in LDS.
+#include <math.h>
+#include "pdes_common.h"
+#include "../../include/pdes_hip.h"
+
+namespace pdes {
+
+#define PDES_LOG2PI 1.8378770664093453f
+#define PDES_LSD_MIN (-10.f)
+#define PDES_LSD_MAX 1.6094379124341003f       // log 5
+
+static bool flow_common_ok(const pdes_conv_desc& d) {
+  return d.ksize == 0 && d.B > 0 && d.Cin > 0 && d.Cout > 0 && d.Hin > 0 && d.Win > 0 && d.nrep == PDES_NREP;
+}
+
+// ------------------------------------------------------------------------------------------------ COPY
+// grid (ceil(HW / 1024), C, B), 256 threads x float4
+__global__ __launch_bounds__(256) void flow_copy_kernel(const float* __restrict__ x, int x_ctot, float* __restrict__ out,
+                                                        int out_ctot, int out_coff, int HW, double* __restrict__ stats,
+                                                        int nrep, long long rs) {
+  __shared__ double red[4][2];
+  const int c = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const float4* src = reinterpret_cast<const float4*>(x + ((size_t)b * x_ctot + c) * HW);
+  float4* dst = reinterpret_cast<float4*>(out + ((size_t)b * out_ctot + out_coff + c) * HW);
+  const int i = blockIdx.x * 256 + tid;
+  float s = 0.f, q = 0.f;
+  if (i < HW / 4) {
+    const float4 v = src[i];
+    dst[i] = v;
+    s = (v.x + v.y) + (v.z + v.w);
+    q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (!stats) return;
+  const float ws = wave_sum(s), wq = wave_sum(q);
+  if ((tid & 63) == 0) { red[tid >> 6][0] = ws; red[tid >> 6][1] = wq; }
+  __syncthreads();
+  if (tid < 2) {
+    const double t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    atomicAdd(&stats[(long long)rep_of_block(nrep) * rs + 2 * (out_coff + c) + tid], t);
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_copy_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
+                                                            float* __restrict__ t, int t_ctot, int HW, int accumulate) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float4* src = reinterpret_cast<const float4*>(g + ((size_t)b * g_ctot + g_coff + c) * HW);
+  float4* dst = reinterpret_cast<float4*>(t + ((size_t)b * t_ctot + c) * HW);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW / 4) return;
+  float4 v = src[i];
+  if (accumulate) {
+    const float4 o = dst[i];
+    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+  }
+  dst[i] = v;
+}
+
+static bool copy_ok(const pdes_conv_desc& d) {
+  return flow_common_ok(d) && d.upsample == PDES_OP_COPY && d.Cin == d.Cout && d.Hin == d.Hout && d.Win == d.Wout &&
+         (d.Hin * d.Win) % 4 == 0 && d.x && d.out;
+}
+
+int flow_copy_forward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!copy_ok(d)) return PDES_EINVAL;
+  if (!aligned16(d.x) || !aligned16(d.out)) return PDES_EALIGN;
+  const int HW = d.Hin * d.Win;
+  hipLaunchKernelGGL(flow_copy_kernel, dim3(cdiv(HW / 4, 256), d.Cin, d.B), dim3(256), 0, st, d.x, d.x_ctot, d.out,
+                     d.out_ctot, d.out_coff, HW, d.out_stats, d.nrep, d.rep_stride);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int flow_copy_backward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!copy_ok(d)) return PDES_EINVAL;
+  if (!d.t_in) return PDES_OK;                       // the source is input data
+  if (!d.g || !aligned16(d.g) || !aligned16(d.t_in)) return PDES_EINVAL;
+  const int HW = d.Hin * d.Win;
+  hipLaunchKernelGGL(flow_copy_bwd_kernel, dim3(cdiv(HW / 4, 256), d.Cin, d.B), dim3(256), 0, st, d.g, d.g_ctot, d.g_coff,
+                     d.t_in, d.x_ctot, HW, d.t_accumulate);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+// ------------------------------------------------------------------------------------------ BIAS_SCALE
+// MODE 0: forward, in place on `buf` (+ statistics); MODE 1: backward, in place on `buf` = g, `y` = the forward output
+template <int MODE>
+__global__ __launch_bounds__(256) void flow_bias_scale_kernel(float* __restrict__ buf, int ctot, int coff,
+                                                              const float* __restrict__ y, int y_ctot, int y_coff, int HW,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              double* __restrict__ acc, int nrep, long long rs) {
+  __shared__ double red[4][2];
+  const int c = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const float e = scale ? expf(scale[c] * 3.f) : 1.f;
+  const float bs = bias[c];
+  float4* p = reinterpret_cast<float4*>(buf + ((size_t)b * ctot + coff + c) * HW);
+  const int i = blockIdx.x * 256 + tid;
+  float s = 0.f, q = 0.f;
+  if (i < HW / 4) {
+    float4 v = p[i];
+    if (MODE == 0) {
+      v.x = (v.x + bs) * e; v.y = (v.y + bs) * e; v.z = (v.z + bs) * e; v.w = (v.w + bs) * e;
+      s = (v.x + v.y) + (v.z + v.w);
+      q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    } else {
+      const float4 o = reinterpret_cast<const float4*>(y + ((size_t)b * y_ctot + y_coff + c) * HW)[i];
+      q = 3.f * ((v.x * o.x + v.y * o.y) + (v.z * o.z + v.w * o.w));     // dscale: d/ds (u exp(3 s)) = 3 out
+      v.x *= e; v.y *= e; v.z *= e; v.w *= e;
+      s = (v.x + v.y) + (v.z + v.w);                                     // dbias
+    }
+    p[i] = v;
+  }
+  if (!acc) return;
+  const float ws = wave_sum(s), wq = wave_sum(q);
+  if ((tid & 63) == 0) { red[tid >> 6][0] = ws; red[tid >> 6][1] = wq; }
+  __syncthreads();
+  if (tid < 2) {
+    const double t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const int slot = MODE == 0 ? 2 * (coff + c) + tid : 2 * c + tid;     // statistics of the buffer / {dbias, dscale} of the op
+    atomicAdd(&acc[(long long)rep_of_block(nrep) * rs + slot], t);
+  }
+}
+
+static bool bias_ok(const pdes_conv_desc& d) {
+  return flow_common_ok(d) && d.upsample == PDES_OP_BIAS_SCALE && d.Cin == d.Cout && d.Hin == d.Hout && d.Win == d.Wout &&
+         (d.Hin * d.Win) % 4 == 0 && d.out && d.p0;
+}
+
+int flow_bias_scale_forward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!bias_ok(d)) return PDES_EINVAL;
+  if (!aligned16(d.out)) return PDES_EALIGN;
+  const int HW = d.Hin * d.Win;
+  hipLaunchKernelGGL(flow_bias_scale_kernel<0>, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, d.out, d.out_ctot,
+                     d.out_coff, (const float*)nullptr, 0, 0, HW, d.p0, d.p1, d.out_stats, d.nrep, d.rep_stride);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int flow_bias_scale_backward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!bias_ok(d) || !d.g || !d.acc) return PDES_EINVAL;
+  if (!aligned16(d.g)) return PDES_EALIGN;
+  const int HW = d.Hin * d.Win;
+  hipLaunchKernelGGL(flow_bias_scale_kernel<1>, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st,
+                     const_cast<float*>(d.g), d.g_ctot, d.g_coff, (const float*)d.out, d.out_ctot, d.out_coff, HW, d.p0, d.p1,
+                     d.acc, d.nrep, d.rep_stride);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+// -------------------------------------------------------------------------------------------- COUPLING
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// block-wide sum of `v` (256 threads) added to acc[b] of one replica
+__device__ __forceinline__ void block_add_logp(float v, double* acc, int b, int nrep, long long rs, double* red) {
+  const float ws = wave_sum(v);
+  const int tid = threadIdx.x;
+  if ((tid & 63) == 0) red[tid >> 6] = (double)ws;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&acc[(long long)rep_of_block(nrep) * rs + b], (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// grid (ceil(HW / 256), B)
+__global__ __launch_bounds__(256) void flow_coupling_kernel(pdes_conv_desc d) {
+  __shared__ double red[4];
+  const int HW = d.Hin * d.Win, b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  const int C = d.Cin, n2 = C / 2, n1 = C - n2;
+  const bool act = p < HW;
+  const float* x = d.x + (size_t)b * d.x_ctot * HW + p;
+  const float* h = d.x2 + (size_t)b * d.x2_ctot * HW + p;
+  float* o = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW + p;
+  float ld = 0.f;
+  if (act) {
+    for (int c = 0; c < n1; ++c) o[(size_t)c * HW] = x[(size_t)c * HW];
+    for (int k = 0; k < n2; ++k) {
+      const float shift = h[(size_t)(2 * k) * HW];
+      const float s = sigmoidf_(h[(size_t)(2 * k + 1) * HW] + 2.f);
+      const float v = x[(size_t)(n1 + k) * HW];
+      o[(size_t)(n1 + k) * HW] = (d.flags & PDES_FLOW_FORWARD) ? (v + shift) * s : v / s - shift;
+      ld += logf(s);
+    }
+  }
+  if (d.acc) block_add_logp(ld, d.acc, b, d.nrep, d.rep_stride, red);
+}
+
+__global__ __launch_bounds__(256) void flow_coupling_bwd_kernel(pdes_conv_desc d) {
+  const int HW = d.Hin * d.Win, b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int C = d.Cin, n2 = C / 2, n1 = C - n2;
+  const float cst = d.p1 ? d.p1[b] : 0.f;
+  const float* x = d.x + (size_t)b * d.x_ctot * HW + p;
+  const float* h = d.x2 + (size_t)b * d.x2_ctot * HW + p;
+  const float* g = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HW + p;
+  float* tx = d.t_in + (size_t)b * d.x_ctot * HW + p;
+  float* th = d.t2 + (size_t)b * d.x2_ctot * HW + p;
+  for (int c = 0; c < n1; ++c) {
+    const float v = g[(size_t)c * HW];
+    tx[(size_t)c * HW] = d.t_accumulate ? tx[(size_t)c * HW] + v : v;
+  }
+  for (int k = 0; k < n2; ++k) {
+    const float s = sigmoidf_(h[(size_t)(2 * k + 1) * HW] + 2.f);
+    const float gv = g[(size_t)(n1 + k) * HW], v = x[(size_t)(n1 + k) * HW];
+    const float gx = gv / s;
+    tx[(size_t)(n1 + k) * HW] = d.t_accumulate ? tx[(size_t)(n1 + k) * HW] + gx : gx;
+    th[(size_t)(2 * k) * HW] = -gv;
+    th[(size_t)(2 * k + 1) * HW] = (cst - gx * v) * (1.f - s);     // out = v / s - shift, log s; ds/dh = s (1 - s)
+  }
+}
+
+static bool coupling_ok(const pdes_conv_desc& d) {
+  return flow_common_ok(d) && d.upsample == PDES_OP_COUPLING && d.Cin == d.Cout && d.Cin >= 2 && d.Hin == d.Hout &&
+         d.Win == d.Wout && d.x && d.x2 && d.out && d.x2_ctot >= 2 * (d.Cin / 2);
+}
+
+int flow_coupling_forward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!coupling_ok(d)) return PDES_EINVAL;
+  hipLaunchKernelGGL(flow_coupling_kernel, dim3(cdiv(d.Hin * d.Win, 256), d.B), dim3(256), 0, st, d);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int flow_coupling_backward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!coupling_ok(d) || !d.g || !d.t_in || !d.t2 || (d.flags & PDES_FLOW_FORWARD)) return PDES_EINVAL;
+  hipLaunchKernelGGL(flow_coupling_bwd_kernel, dim3(cdiv(d.Hin * d.Win, 256), d.B), dim3(256), 0, st, d);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- MIX
+// out = (W x - bias) / weight per pixel (z -> y), or out = W (weight x + bias) (y -> z, W = the inverse matrix).
+// grid (ceil(HW / PB), B), PB threads; dynamic LDS: W [C][C] + tile [C][PB + 1]
+template <int PB>
+__global__ __launch_bounds__(PB) void flow_mix_kernel(pdes_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float sm_mix[];
+  const int C = d.Cin, HW = d.Hin * d.Win, b = blockIdx.y, tid = threadIdx.x, p = blockIdx.x * PB + tid;
+  float* Ws = sm_mix;
+  float* xs = sm_mix + C * C;
+  const bool fwd = (d.flags & PDES_FLOW_FORWARD) != 0;
+  for (int i = tid; i < C * C; i += PB) Ws[i] = d.x2[i];
+  const float* x = d.x + (size_t)b * d.x_ctot * HW;
+  if (p < HW)
+    for (int c = 0; c < C; ++c) {
+      float v = x[(size_t)c * HW + p];
+      if (fwd) v = d.p0[c] * v + d.p1[c];
+      xs[c * (PB + 1) + tid] = v;
+    }
+  __syncthreads();
+  if (p >= HW) return;
+  float* o = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW + p;
+  for (int oc = 0; oc < C; ++oc) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += Ws[oc * C + c] * xs[c * (PB + 1) + tid];
+    o[(size_t)oc * HW] = fwd ? a : (a - d.p1[oc]) / d.p0[oc];
+  }
+}
+
+// backward of the z -> y form: gv = g / weight; t_in = W^T gv; acc += {dweight = -sum gv out, dbias = -sum gv, dW = sum gv x^T}
+// dynamic LDS: W [C][C] + xs [C][PB+1] + gs [C][PB+1] + part [2][C][PB/64] floats
+template <int PB>
+__global__ __launch_bounds__(PB) void flow_mix_bwd_kernel(pdes_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float sm_mix[];
+  constexpr int NW = PB / 64;
+  const int C = d.Cin, HW = d.Hin * d.Win, b = blockIdx.y, tid = threadIdx.x, p0 = blockIdx.x * PB;
+  float* Ws = sm_mix;
+  float* xs = Ws + C * C;
+  float* gs = xs + C * (PB + 1);
+  float* part = gs + C * (PB + 1);                       // [2][C][NW]
+  for (int i = tid; i < C * C; i += PB) Ws[i] = d.x2[i];
+  const float* x = d.x + (size_t)b * d.x_ctot * HW;
+  const float* g = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HW;
+  const float* y = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW;
+  const bool act = p0 + tid < HW;
+  for (int c = 0; c < C; ++c) {
+    float xv = 0.f, gv = 0.f, yv = 0.f;
+    if (act) {
+      xv = x[(size_t)c * HW + p0 + tid];
+      gv = g[(size_t)c * HW + p0 + tid] / d.p0[c];
+      yv = y[(size_t)c * HW + p0 + tid];
+    }
+    xs[c * (PB + 1) + tid] = xv;
+    gs[c * (PB + 1) + tid] = gv;
+    const float a = wave_sum(-gv * yv), bsum = wave_sum(-gv);
+    if ((tid & 63) == 0) { part[(0 * C + c) * NW + (tid >> 6)] = a; part[(1 * C + c) * NW + (tid >> 6)] = bsum; }
+  }
+  __syncthreads();
+  if (act) {
+    float* t = d.t_in + (size_t)b * d.x_ctot * HW + p0 + tid;
+    for (int c = 0; c < C; ++c) {
+      float a = 0.f;
+      for (int oc = 0; oc < C; ++oc) a += Ws[oc * C + c] * gs[oc * (PB + 1) + tid];
+      t[(size_t)c * HW] = d.t_accumulate ? t[(size_t)c * HW] + a : a;
+    }
+  }
+  double* acc = d.acc + (long long)rep_of_block(d.nrep) * d.rep_stride;
+  for (int i = tid; i < 2 * C; i += PB) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += part[i * NW + w];
+    atomicAdd(&acc[i], (double)s);
+  }
+  const int np = min(PB, HW - p0);
+  for (int i = tid; i < C * C; i += PB) {
+    const int oc = i / C, c = i % C;
+    float s = 0.f;
+    for (int q = 0; q < np; ++q) s += gs[oc * (PB + 1) + q] * xs[c * (PB + 1) + q];
+    atomicAdd(&acc[2 * C + i], (double)s);
+  }
+}
+
+static bool mix_ok(const pdes_conv_desc& d) {
+  return flow_common_ok(d) && d.upsample == PDES_OP_MIX && d.Cin == d.Cout && d.Cin <= 48 && d.Hin == d.Hout &&
+         d.Win == d.Wout && d.x && d.x2 && d.out && d.p0 && d.p1;
+}
+
+int flow_mix_forward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!mix_ok(d)) return PDES_EINVAL;
+  const int C = d.Cin, HW = d.Hin * d.Win;
+  if (C <= 28) {
+    constexpr int PB = 256;
+    hipLaunchKernelGGL(flow_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), (C * C + C * (PB + 1)) * sizeof(float), st, d);
+  } else {
+    constexpr int PB = 64;
+    hipLaunchKernelGGL(flow_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), (C * C + C * (PB + 1)) * sizeof(float), st, d);
+  }
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int flow_mix_backward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!mix_ok(d) || !d.g || !d.t_in || !d.acc || (d.flags & PDES_FLOW_FORWARD)) return PDES_EINVAL;
+  const int C = d.Cin, HW = d.Hin * d.Win;
+  if (C <= 28) {
+    constexpr int PB = 256;
+    const size_t lds = (C * C + 2 * C * (PB + 1) + 2 * C * (PB / 64)) * sizeof(float);
+    hipLaunchKernelGGL(flow_mix_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+  } else {
+    constexpr int PB = 64;
+    const size_t lds = (C * C + 2 * C * (PB + 1) + 2 * C * (PB / 64)) * sizeof(float);
+    hipLaunchKernelGGL(flow_mix_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+  }
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+// ------------------------------------------------------------------------------------------- UNSQUEEZE
+// big (Cq, 2H, 2W) <-> small (4 Cq, H, W): big[c][i H + h][j W + w] = small[4 c + 2 i + j][h][w].
+// to_big: big <- small (Squeeze.reverse); else small <- big (Squeeze.forward).  grid (ceil(Cq 4 HW / 256), B)
+__global__ __launch_bounds__(256) void flow_requad_kernel(const float* __restrict__ src, int src_ctot, int src_coff,
+                                                          float* __restrict__ dst, int dst_ctot, int dst_coff, int Cq, int H,
+                                                          int W, int to_big, int accumulate) {
+  const int b = blockIdx.y, HW = H * W;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cq * 4 * HW) return;
+  // enumerate in the order of the DESTINATION so that stores are coalesced
+  int c, i, j, h, w;
+  if (to_big) {
+    const int X = idx % (2 * W), Y = (idx / (2 * W)) % (2 * H);
+    c = idx / (4 * HW); i = Y / H; h = Y % H; j = X / W; w = X % W;
+  } else {
+    w = idx % W; h = (idx / W) % H;
+    const int cs = idx / HW;
+    c = cs >> 2; i = (cs >> 1) & 1; j = cs & 1;
+  }
+  const size_t big = ((size_t)c * 2 * H + (i * H + h)) * 2 * W + (j * W + w);
+  const size_t small = ((size_t)(4 * c + 2 * i + j) * H + h) * W + w;
+  if (to_big) {
+    float* q = dst + ((size_t)b * dst_ctot + dst_coff) * 4 * HW + big;
+    const float v = src[((size_t)b * src_ctot + src_coff) * HW + small];
+    *q = accumulate ? *q + v : v;
+  } else {
+    float* q = dst + ((size_t)b * dst_ctot + dst_coff) * HW + small;
+    const float v = src[((size_t)b * src_ctot + src_coff) * 4 * HW + big];
+    *q = accumulate ? *q + v : v;
+  }
+}
+
+static bool unsq_ok(const pdes_conv_desc& d) {
+  if (!flow_common_ok(d) || d.upsample != PDES_OP_UNSQUEEZE || !d.x || !d.out) return false;
+  if (d.flags & PDES_FLOW_FORWARD) return d.Cout == 4 * d.Cin && d.Hin == 2 * d.Hout && d.Win == 2 * d.Wout;
+  return d.Cin == 4 * d.Cout && d.Hout == 2 * d.Hin && d.Wout == 2 * d.Win;
+}
+
+int flow_unsqueeze_forward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!unsq_ok(d)) return PDES_EINVAL;
+  const bool sq = (d.flags & PDES_FLOW_FORWARD) != 0;
+  const int Cq = sq ? d.Cin : d.Cout, H = sq ? d.Hout : d.Hin, W = sq ? d.Wout : d.Win;
+  hipLaunchKernelGGL(flow_requad_kernel, dim3(cdiv(Cq * 4 * H * W, 256), d.B), dim3(256), 0, st, d.x, d.x_ctot, 0, d.out,
+                     d.out_ctot, d.out_coff, Cq, H, W, sq ? 0 : 1, 0);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int flow_unsqueeze_backward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!unsq_ok(d) || !d.g || !d.t_in || (d.flags & PDES_FLOW_FORWARD)) return PDES_EINVAL;
+  hipLaunchKernelGGL(flow_requad_kernel, dim3(cdiv(d.Cout * 4 * d.Hin * d.Win, 256), d.B), dim3(256), 0, st, d.g, d.g_ctot,
+                     d.g_coff, d.t_in, d.x_ctot, 0, d.Cout, d.Hin, d.Win, 0, d.t_accumulate);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- GAUSS
+// grid (ceil(HW / 256), B)
+__global__ __launch_bounds__(256) void flow_gauss_kernel(pdes_conv_desc d) {
+  __shared__ double red[4];
+  const int HW = d.Hout * d.Wout, b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, n = d.Cout;
+  const bool fwd = (d.flags & PDES_FLOW_FORWARD) != 0;
+  float lp = 0.f;
+  if (p < HW) {
+    const float* pr = d.x2 + (size_t)b * d.x2_ctot * HW + p;
+    for (int c = 0; c < n; ++c) {
+      const float m = pr[(size_t)c * HW];
+      const float l = fminf(fmaxf(pr[(size_t)(n + c) * HW], PDES_LSD_MIN), PDES_LSD_MAX);
+      float z;
+      if (fwd) {
+        z = d.x[((size_t)b * d.x_ctot + c) * HW + p];
+        if (d.out) d.out[((size_t)b * d.out_ctot + d.out_coff + c) * HW + p] = (z - m) / expf(l);
+      } else {
+        z = m + expf(l) * d.p0[((size_t)b * n + c) * HW + p];
+        d.out[((size_t)b * d.out_ctot + d.out_coff + c) * HW + p] = z;
+      }
+      const float dd = z - m;
+      lp += -0.5f * (PDES_LOG2PI + l * 2.f + dd * dd / expf(l * 2.f));
+    }
+  }
+  if (d.acc) block_add_logp(lp, d.acc, b, d.nrep, d.rep_stride, red);
+}
+
+__global__ __launch_bounds__(256) void flow_gauss_bwd_kernel(pdes_conv_desc d) {
+  const int HW = d.Hout * d.Wout, b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, n = d.Cout;
+  if (p >= HW) return;
+  const float cst = d.p1 ? d.p1[b] : 0.f;
+  const bool detach = (d.flags & PDES_GAUSS_DETACH_LSD) != 0;
+  const float* pr = d.x2 + (size_t)b * d.x2_ctot * HW + p;
+  float* tp = d.t2 + (size_t)b * d.x2_ctot * HW + p;
+  for (int c = 0; c < n; ++c) {
+    const float m = pr[(size_t)c * HW], raw = pr[(size_t)(n + c) * HW];
+    const float l = fminf(fmaxf(raw, PDES_LSD_MIN), PDES_LSD_MAX);
+    const float sg = expf(l), s2 = expf(l * 2.f);
+    const float eps = d.p0[((size_t)b * n + c) * HW + p];
+    const float z = d.out[((size_t)b * d.out_ctot + d.out_coff + c) * HW + p];
+    const float g = d.g[((size_t)b * d.g_ctot + d.g_coff + c) * HW + p];
+    const float dd = z - m;
+    const float gz = g - cst * dd / s2;               // dL/dz: downstream + the log-probability's own use of z
+    tp[(size_t)c * HW] = gz + cst * dd / s2;          // mean: through z and explicitly (they cancel up to rounding, as in autograd)
+    float gl = 0.f;
+    if (!detach && raw >= PDES_LSD_MIN && raw <= PDES_LSD_MAX) gl = gz * sg * eps + cst * (dd * dd / s2 - 1.f);
+    tp[(size_t)(n + c) * HW] = gl;
+  }
+}
+
+static bool gauss_ok(const pdes_conv_desc& d) {
+  return flow_common_ok(d) && d.upsample == PDES_OP_GAUSS && d.Hin == d.Hout && d.Win == d.Wout && d.x2 &&
+         d.x2_ctot >= 2 * d.Cout && ((d.flags & PDES_FLOW_FORWARD) ? d.x != nullptr : (d.out && d.p0));
+}
+
+int flow_gauss_forward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!gauss_ok(d)) return PDES_EINVAL;
+  hipLaunchKernelGGL(flow_gauss_kernel, dim3(cdiv(d.Hout * d.Wout, 256), d.B), dim3(256), 0, st, d);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int flow_gauss_backward(const pdes_conv_desc& d, hipStream_t st) {
+  if (!gauss_ok(d) || !d.g || !d.t2 || (d.flags & PDES_FLOW_FORWARD)) return PDES_EINVAL;
+  hipLaunchKernelGGL(flow_gauss_bwd_kernel, dim3(cdiv(d.Hout * d.Wout, 256), d.B), dim3(256), 0, st, d);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+// ------------------------------------------------------------------------- parameter side of the flow
+// one workgroup (256 threads) per invertible 1x1 convolution + ActNorm; C <= 48
+__global__ __launch_bounds__(256) void flow_prepare_kernel(const pdes_flow_item* __restrict__ items, int need_inverse) {
+  const pdes_flow_item it = items[blockIdx.x];
+  const int C = it.C, tid = threadIdx.x;
+  __shared__ float A[48 * 48], Bm[48 * 48];
+  __shared__ double aug[48][2 * 48 + 1];       // Gauss-Jordan: [W | I]
+  __shared__ double sh_ld, sh_an;
+  __shared__ int sh_piv;
+  if (it.lu) {
+    // Bm = (l * l_mask + I) (u * u_mask + diag(exp(log_s) sign_s)),  W = p Bm
+    for (int i = tid; i < C * C; i += 256) {
+      const int r = i / C, c = i % C;
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) {
+        const float lv = k < r ? it.l[r * C + k] : (k == r ? 1.f : 0.f);
+        const float uv = k < c ? it.u[k * C + c] : (k == c ? expf(it.log_s[k]) * it.sign_s[k] : 0.f);
+        s += lv * uv;
+      }
+      Bm[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < C * C; i += 256) {
+      const int r = i / C, c = i % C;
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) s += it.p[r * C + k] * Bm[k * C + c];
+      A[i] = s;
+    }
+  } else {
+    for (int i = tid; i < C * C; i += 256) A[i] = it.weight[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < C * C; i += 256) it.W[i] = A[i];
+  double logdet_w = 0.0;
+  const bool inv = need_inverse || !it.lu;
+  if (inv) {
+    for (int i = tid; i < C * 2 * C; i += 256) {
+      const int r = i / (2 * C), c = i % (2 * C);
+      aug[r][c] = c < C ? (double)A[r * C + c] : (c - C == r ? 1.0 : 0.0);
+    }
+    if (tid == 0) sh_ld = 0.0;
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+      if (tid == 0) {                      // partial pivoting
+        int best = k;
+        double mx = fabs(aug[k][k]);
+        for (int r = k + 1; r < C; ++r)
+          if (fabs(aug[r][k]) > mx) { mx = fabs(aug[r][k]); best = r; }
+        sh_piv = best;
+        sh_ld += log(mx);
+      }
+      __syncthreads();
+      const int pv = sh_piv;
+      if (pv != k)
+        for (int c = tid; c < 2 * C; c += 256) { const double t = aug[k][c]; aug[k][c] = aug[pv][c]; aug[pv][c] = t; }
+      __syncthreads();
+      const double piv = aug[k][k];
+      __syncthreads();
+      for (int c = tid; c < 2 * C; c += 256) aug[k][c] /= piv;
+      __syncthreads();
+      for (int i = tid; i < C * 2 * C; i += 256) {
+        const int r = i / (2 * C), c = i % (2 * C);
+        if (r != k && c > k) aug[r][c] -= aug[r][k] * aug[k][c];
+      }
+      __syncthreads();
+      for (int r = tid; r < C; r += 256)
+        if (r != k) aug[r][k] = 0.0;
+      __syncthreads();
+    }
+    if (it.Winv)
+      for (int i = tid; i < C * C; i += 256) it.Winv[i] = (float)aug[i / C][C + i % C];
+    logdet_w = sh_ld;
+  }
+  if (tid == 0) {
+    double an = 0.0, ls = 0.0;
+    for (int c = 0; c < C; ++c) an += (double)logf(fabsf(it.an_weight[c]));
+    if (it.lu) {
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += it.log_s[c];
+      ls = (double)s;
+    } else {
+      ls = (double)(float)logdet_w;
+    }
+    *it.logdet = (double)it.HW * (an - ls);
+  }
+  (void)sh_an;
+}
+
+__global__ __launch_bounds__(256) void flow_param_grads_kernel(const pdes_flow_item* __restrict__ items,
+                                                               const float* __restrict__ glogp, int B, int nrep, long long rs) {
+  const pdes_flow_item it = items[blockIdx.x];
+  const int C = it.C, tid = threadIdx.x;
+  __shared__ float dW[48 * 48], M1[48 * 48], Lf[48 * 48], Uf[48 * 48];
+  __shared__ float red[4];
+  float cb = 0.f;
+  if (glogp)
+    for (int b = tid; b < B; b += 256) cb += glogp[b];
+  cb = wave_sum(cb);
+  if ((tid & 63) == 0) red[tid >> 6] = cb;
+  for (int i = tid; i < C * C; i += 256) dW[i] = (float)rep_sum(it.acc, 2 * C + i, nrep, rs);
+  __syncthreads();
+  const float cB = (red[0] + red[1]) + (red[2] + red[3]);
+  const float hw = (float)it.HW;
+  for (int c = tid; c < C; c += 256) {
+    it.dan_weight[c] += (float)rep_sum(it.acc, c, nrep, rs) + cB * hw / it.an_weight[c];
+    it.dan_bias[c] += (float)rep_sum(it.acc, C + c, nrep, rs);
+  }
+  if (!it.lu) {
+    for (int i = tid; i < C * C; i += 256) it.dweight[i] += dW[i] - cB * hw * it.Winv[(i % C) * C + i / C];
+    return;
+  }
+  for (int i = tid; i < C * C; i += 256) {
+    const int r = i / C, c = i % C;
+    Lf[i] = c < r ? it.l[i] : (c == r ? 1.f : 0.f);
+    Uf[i] = r < c ? it.u[i] : (r == c ? expf(it.log_s[r]) * it.sign_s[r] : 0.f);
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s += it.p[k * C + r] * dW[k * C + c];       // M1 = P^T dW
+    M1[i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < C * C; i += 256) {
+    const int r = i / C, c = i % C;
+    if (c < r) {                              // dl = (M1 Uf^T) * l_mask
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) s += M1[r * C + k] * Uf[c * C + k];
+      it.dl[i] += s;
+    } else {                                  // dUf = Lf^T M1: strictly upper -> du, diagonal -> dlog_s
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) s += Lf[k * C + r] * M1[k * C + c];
+      if (c > r) it.du[i] += s;
+      else it.dlog_s[r] += s * expf(it.log_s[r]) * it.sign_s[r] - cB * hw;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_logp_kernel(const double* __restrict__ acc, const double* __restrict__ logdet,
+                                                        int n_layers, float* __restrict__ logp, int B, int nrep, long long rs) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  double s = rep_sum(acc, b, nrep, rs);
+  // the reference adds each layer's scalar log-determinant to the running fp32 sum; the order of fp32 additions
+  // differs here (fp64 accumulation), within ~1e-7 relative of it
+  for (int k = 0; k < n_layers; ++k) s += logdet[k];
+  logp[b] = (float)s;
+}
+
+}  // namespace pdes
+
+using namespace pdes;
+
+extern "C" int pdes_flow_prepare(const pdes_flow_item* items, int n, int need_inverse, void* stream) {
+  if (!items || n <= 0) return PDES_EINVAL;          // (items live in device memory: C <= 48 is the caller's contract)
+  hipLaunchKernelGGL(flow_prepare_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), items, need_inverse);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_flow_param_grads(const pdes_flow_item* items, int n, const float* glogp, int B, int nrep,
+                                     long long rep_stride, void* stream) {
+  if (!items || n <= 0 || B <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
+  hipLaunchKernelGGL(flow_param_grads_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), items, glogp, B, nrep,
+                     rep_stride);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+extern "C" int pdes_flow_logp(const double* acc, const double* logdet, int n_layers, float* logp, int B, int nrep,
+                              long long rep_stride, void* stream) {
+  if (!acc || !logp || B <= 0 || n_layers < 0 || (n_layers > 0 && !logdet) || nrep != PDES_NREP) return PDES_EINVAL;
+  hipLaunchKernelGGL(flow_logp_kernel, dim3(cdiv(B, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), acc, logdet, n_layers,
+                     logp, B, nrep, rep_stride);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}

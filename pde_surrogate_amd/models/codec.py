@@ -41,6 +41,7 @@ class ConvDesc(ctypes.Structure):
         ('t_in', _P), ('t_accumulate', _I), ('final_c0', _I), ('final_c1', _I),
         ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
         ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong), ('wbu_fwd', _P),
+        ('g_add', _P), ('x2', _P), ('x2_ctot', _I), ('t2', _P), ('p0', _P), ('p1', _P), ('acc', _P), ('flags', _I),
     ]
 
 
@@ -596,7 +597,12 @@ class _NetFn(torch.autograd.Function):
 
 
 class _HipNet(nn.Module):
-    """shared machinery of DenseED and Decoder"""
+    """shared machinery of DenseED and Decoder (and, with the module tree at the top level, MultiScaleCondGlow)"""
+    _prefix = 'features.'          # parameter-name prefix of the modules the specs name
+
+    @property
+    def _root(self):
+        return self.features
 
     def _finish_init(self, specs, bufs, drop_rate, upsample, out_activation):
         if not (0.0 <= float(drop_rate) < 1.0):
@@ -637,7 +643,7 @@ class _HipNet(nn.Module):
         flat = torch.empty(total, device=device, dtype=torch.float32)
         gflat = torch.zeros(total, device=device, dtype=torch.float32)
         self._grad_view = {}
-        conv_names = {'features.' + sp.conv + '.weight' for sp in self._specs if sp.conv is not None}
+        conv_names = {self._prefix + sp.conv + '.weight' for sp in self._specs if sp.conv is not None}
         order = [i for i, (nm, _) in enumerate(named) if nm not in conv_names] + \
                 [i for i, (nm, _) in enumerate(named) if nm in conv_names]
         offsets, off = [0] * len(named), 0
@@ -649,7 +655,7 @@ class _HipNet(nn.Module):
             n = p.numel()
             flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = flat[off:off + n].view(p.shape)
-            key = name[len('features.'):]
+            key = name[len(self._prefix):]
             self._grad_view[key] = gflat[off:off + n].view(p.shape)
             views.append(self._grad_view[key])
         self._offsets = offsets
@@ -660,7 +666,7 @@ class _HipNet(nn.Module):
         for i in range(len(self._specs) - 1, -1, -1):
             sp = self._specs[i]
             if sp.conv is not None:
-                nxt_off = offsets[names.index('features.' + sp.conv + '.weight')]
+                nxt_off = offsets[names.index(self._prefix + sp.conv + '.weight')]
             self._conv_off[i] = nxt_off
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
@@ -680,7 +686,7 @@ class _HipNet(nn.Module):
             wb = torch.zeros(s.cout * kk * _pad16(s.cin), device=device)
             self._packed[s.conv] = (wf, wb)
             it = PackItem()
-            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.w = _get(self._root, s.conv).weight.data_ptr()
             it.w_fwd, it.w_bwd = wf.data_ptr(), wb.data_ptr()
             it.Cout, it.Cin, it.kk, it.cout_pad, it.cin_pad = s.cout, s.cin, kk, _pad16(s.cout), _pad16(s.cin)
             items.append(it)
@@ -701,7 +707,7 @@ class _HipNet(nn.Module):
             wb = torch.zeros(nb, device=device)
             self._packed_mfma[s.conv] = (wf, wb)
             it = MfmaPackItem()
-            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.w = _get(self._root, s.conv).weight.data_ptr()
             it.wm_fwd, it.wm_bwd = wf.data_ptr(), wb.data_ptr()
             it.Cout, it.Cin, it.kk = s.cout, s.cin, kk
             mitems.append(it)
@@ -717,7 +723,7 @@ class _HipNet(nn.Module):
             uf, ub = torch.zeros(nf, device=device), torch.zeros(nb, device=device)
             self._packed_up[s.conv] = (uf, ub)
             it = UpPackItem()
-            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.w = _get(self._root, s.conv).weight.data_ptr()
             it.wu_fwd, it.wu_bwd, it.Cout, it.Cin = uf.data_ptr(), ub.data_ptr(), s.cout, s.cin
             uitems.append(it)
             umx = max(umx, nf, nb)
@@ -736,7 +742,7 @@ class _HipNet(nn.Module):
             bb = torch.zeros(nb.value, device=device, dtype=torch.int16)
             self._packed_b3[s.conv] = (bf, bb)
             it = B3PackItem()
-            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.w = _get(self._root, s.conv).weight.data_ptr()
             it.wb_fwd, it.wb_bwd, it.Cout, it.Cin = bf.data_ptr(), bb.data_ptr(), s.cout, s.cin
             bitems.append(it)
             bmx = max(bmx, nf.value // 24, nb.value // 24)
@@ -754,7 +760,7 @@ class _HipNet(nn.Module):
             img = torch.zeros(nf.value, device=device, dtype=torch.int16)
             self._packed_b3u[s.conv] = img
             it = B3UpPackItem()
-            it.w = _get(self.features, s.conv).weight.data_ptr()
+            it.w = _get(self._root, s.conv).weight.data_ptr()
             it.wbu_fwd, it.Cout, it.Cin = img.data_ptr(), s.cout, s.cin
             buitems.append(it)
             bumx = max(bumx, nf.value // 24)
@@ -808,8 +814,11 @@ class _HipNet(nn.Module):
         pool = self._engines.get(key)
         if pool is None:
             with _lib.device_guard(x.device):
-                pool = self._engines[key] = [_Engine(self, *key)]
+                pool = self._engines[key] = [self._new_engine(key)]
         return key, pool
+
+    def _new_engine(self, key):
+        return _Engine(self, *key)
 
     def _engine(self, x):
         """the primary engine of this (batch, size) -- the one a MixedResidualTrainer drives directly"""
@@ -825,7 +834,7 @@ class _HipNet(nn.Module):
             raise RuntimeError(f'{len(pool)} forward passes of shape {key} are waiting for their backward: call '
                                'backward() (or drop the outputs / use torch.no_grad()) before running more')
         with _lib.device_guard(x.device):
-            eng = _Engine(self, *key)
+            eng = self._new_engine(key)
         pool.append(eng)
         return eng
 

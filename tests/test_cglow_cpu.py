@@ -1,0 +1,78 @@
+"""Host-side checks of the conditional-Glow drop-in that need no GPU: module tree, state_dict keys, parameter counts and
+initial values against what the reference's constructor produced (fixtures from tools/gen_golden.py gen_glow)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pde_surrogate_amd.models.glow_msc import MultiScaleCondGlow, _plan_glow
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _sha(items):
+    h = hashlib.sha256()
+    for k, v in items:
+        h.update(k.encode())
+        h.update(v.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def test_state_dict_keys_and_shapes_match_the_reference_small_net():
+    g = np.load(os.path.join(GOLD, 'G18_cglow_small.npz'))
+    net = MultiScaleCondGlow(16, 1, 3, list(g['enc_blocks']), list(g['flow_blocks']), LUdecompose=True)
+    ref = {k[4:]: g[k].shape for k in g.files if k.startswith('sd0/')}
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert list(mine) == [k[4:] for k in g.files if k.startswith('sd0/')]          # same keys, same order
+    assert mine == ref
+    assert net.model_size == (int(g['n_params']), int(g['n_layers']))
+    assert [tuple(s) for s in net._z_shapes()] == [g['eps0'].shape[1:], g['eps1'].shape[1:]]
+    net.load_state_dict({k: torch.from_numpy(g['sd0/' + k].copy()) for k in mine})
+
+
+def test_plain_1x1_variant_keys():
+    g = np.load(os.path.join(GOLD, 'G20_cglow_plain1x1.npz'))
+    net = MultiScaleCondGlow(16, 1, 3, [1, 1, 1], [2, 1, 1], LUdecompose=False)
+    assert list(net.state_dict()) == [k[4:] for k in g.files if k.startswith('sd0/')]
+
+
+def test_default_net_initial_parameters_reproduce_the_reference_constructor():
+    """torch.manual_seed(1) + np.random.seed(1): the same nn.Conv2d creation order and the same numpy draws for the 1x1
+    rotations give bit-identical initial parameters (sha256 over named_parameters stored by the fixture generator)"""
+    g = np.load(os.path.join(GOLD, 'G19_cglow_default.npz'))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = MultiScaleCondGlow(32, 1, 3, [3, 4, 4], [6, 6, 6], LUdecompose=True)
+    assert net.model_size == (int(g['n_params']), int(g['n_layers'])) and len(net.state_dict()) == int(g['n_state'])
+    assert [k for k, _ in net.named_parameters()] == list(g['param_names'])
+    if _sha(net.named_parameters()) != str(g['init_sha256']):
+        pytest.skip('this torch / numpy / scipy build draws different initial values than the one that made the fixture')
+
+
+def test_constructor_rejects_what_is_not_built():
+    for kw in (dict(flow_coupling='wide'), dict(squeeze_factor=4), dict(train_sampling=False)):
+        with pytest.raises(ValueError):
+            MultiScaleCondGlow(32, 1, 3, [3, 4, 4], [6, 6, 6], **kw)
+    with pytest.raises(ValueError):
+        MultiScaleCondGlow(32, 2, 3, [3, 4, 4], [6, 6, 6])
+    with pytest.raises(ValueError):
+        MultiScaleCondGlow(32, 1, 3, [3, 4], [6, 6, 6])
+
+
+def test_plan_covers_every_parameter_once():
+    net = MultiScaleCondGlow(32, 1, 3, [3, 4, 4], [6, 6, 6], LUdecompose=True)
+    convs = [s.conv + '.weight' for s in net._specs if s.conv is not None]
+    assert len(convs) == len(set(convs))
+    names = {k for k, _ in net.named_parameters()}
+    used = set(convs)
+    for s in net._specs:
+        if s.norm:
+            used |= {s.norm + '.weight', s.norm + '.bias'}
+        for key in ('bias', 'scale_p'):
+            if s.x.get(key):
+                used.add(s.x[key])
+    for c, r, npath, cpath in net._meta['mix']:
+        used |= {npath + '.weight', npath + '.bias', cpath + '.l', cpath + '.u', cpath + '.log_s'}
+    assert used == names
