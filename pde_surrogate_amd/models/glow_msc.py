@@ -126,13 +126,11 @@ class _Spec:
         return self.kind == 'conv'
 
 
-def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features=48):
-    """descriptors of generate(), in execution order, the activation buffers and the tables the engine needs"""
+def _plan_encoder(y_channels, enc_blocks, flow_blocks, growth, init_features, with_grad):
+    """the input encoder and the top latent's prior (glow_msc.py:474-546): shared by both directions of the flow"""
     L = len(flow_blocks)
     specs, bufs = [], {}
     bufs['in'] = [1, (1, 1)]
-    aux, mix, eps = [], [], {}
-    # ---- input encoder (glow_msc.py:474-546)
     conds = []
     c = init_features
     res = (1, 1)
@@ -175,9 +173,36 @@ def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features
     fres = {i: (1, 2 ** (i - 1)) for i in range(1, L + 1)}
     # ---- top latent (glow_msc.py:519-526, :806-811)
     bufs['top'] = [2 * C[L], res]
-    specs.append(_Spec('raw', cur, 'top', c, 2 * C[L], res, conv='encoder.top_latent.conv', k=3, pad=1, grad='D'))
+    specs.append(_Spec('raw', cur, 'top', c, 2 * C[L], res, conv='encoder.top_latent.conv', k=3, pad=1,
+                       grad='D' if with_grad else None))
     specs.append(_Spec(OP_BIAS_SCALE, 'top', 'top', 2 * C[L], 2 * C[L], res, bias='encoder.top_latent.conv.bias',
                        scale_p='encoder.top_latent.scale'))
+    return specs, bufs, conds, C, fres
+
+
+def _coupling_net(specs, bufs, lay, z, nb, hb, n1, n2, cond, cc, r, growth, with_grad):
+    """torch.cat((y1, cond), 1) -> three dense layers -> BatchNorm, ReLU, Conv2dZeros (glow_msc.py:274-293, :321, :339)"""
+    cn = n1 + cc
+    bufs[nb] = [cn + 3 * growth, r]
+    bufs[hb] = [2 * n2, r]
+    specs.append(_Spec(OP_COPY, z, nb, n1, n1, r, grad='T' if with_grad else None))
+    specs.append(_Spec(OP_COPY, cond, nb, cc, cc, r, dst_coff=n1, grad='D' if with_grad else None))
+    cp = lay + '.coupling.coupling_nn'
+    for k in range(1, 4):
+        specs.append(_Spec('conv', nb, nb, cn + (k - 1) * growth, growth, r, dst_coff=cn + (k - 1) * growth,
+                           conv=f'{cp}.denselayer{k}.conv1', norm=f'{cp}.denselayer{k}.norm1', k=3, pad=1))
+    specs.append(_Spec('conv', nb, hb, cn + 3 * growth, 2 * n2, r, conv=cp + '.reduce.conv_zero.conv',
+                       norm=cp + '.reduce.norm1', k=3, pad=1))
+    specs.append(_Spec(OP_BIAS_SCALE, hb, hb, 2 * n2, 2 * n2, r, bias=cp + '.reduce.conv_zero.conv.bias',
+                       scale_p=cp + '.reduce.conv_zero.scale'))
+
+
+def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features=48):
+    """descriptors of generate(), in execution order, the activation buffers and the tables the engine needs"""
+    L = len(flow_blocks)
+    specs, bufs, conds, C, fres = _plan_encoder(y_channels, enc_blocks, flow_blocks, growth, init_features, True)
+    mix, eps = [], {}
+    res = fres[L]
     z = f'z{L}_{flow_blocks[L - 1]}'
     bufs[z] = [C[L], fres[L]]
     eps[L - 2] = f'eps{L - 2}'
@@ -205,19 +230,7 @@ def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features
             first = i == 1 and j == 1
             z = f'z{i}_{j}'
             nb, hb = f'n{i}_{j}', f'h{i}_{j}'
-            cn = n1 + cc
-            bufs[nb] = [cn + 3 * growth, r]
-            bufs[hb] = [2 * n2, r]
-            specs.append(_Spec(OP_COPY, z, nb, n1, n1, r, grad='T'))
-            specs.append(_Spec(OP_COPY, cond, nb, cc, cc, r, dst_coff=n1, grad='D'))
-            cp = lay + '.coupling.coupling_nn'
-            for k in range(1, 4):
-                specs.append(_Spec('conv', nb, nb, cn + (k - 1) * growth, growth, r, dst_coff=cn + (k - 1) * growth,
-                                   conv=f'{cp}.denselayer{k}.conv1', norm=f'{cp}.denselayer{k}.norm1', k=3, pad=1))
-            specs.append(_Spec('conv', nb, hb, cn + 3 * growth, 2 * n2, r, conv=cp + '.reduce.conv_zero.conv',
-                               norm=cp + '.reduce.norm1', k=3, pad=1))
-            specs.append(_Spec(OP_BIAS_SCALE, hb, hb, 2 * n2, 2 * n2, r, bias=cp + '.reduce.conv_zero.conv.bias',
-                               scale_p=cp + '.reduce.conv_zero.scale'))
+            _coupling_net(specs, bufs, lay, z, nb, hb, n1, n2, cond, cc, r, growth, True)
             if first:
                 bufs['out'] = [Ci, r]
                 specs.append(_Spec(OP_COUPLING, z, 'out', Ci, Ci, r, h=hb))
@@ -228,28 +241,76 @@ def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features
                     bufs[zn] = [Ci, r]
                 specs.append(_Spec(OP_COUPLING, z, ub, Ci, Ci, r, h=hb))
                 specs.append(_Spec(OP_MIX, ub, zn, Ci, Ci, r, index=len(mix)))
-                mix.append((Ci, r, lay + '.norm', lay + '.conv1x1'))
+                mix.append((Ci, r, lay + '.norm', lay + '.conv1x1', i, j))
         if i > 1:                                       # Squeeze.reverse (glow_msc.py:629-636, :422-432)
             zt = f'z{i - 1}_{flow_blocks[i - 2]}'
             ct = C[i - 1]
             if zt not in bufs:
                 bufs[zt] = [ct, fres[i - 1]]
             specs.append(_Spec(OP_UNSQUEEZE, f'z{i}_0', zt, Ci, Ci // 4, r))
-    return specs, bufs, dict(C=C, L=L, mix=mix, eps=eps, conds=conds)
+    return specs, bufs, dict(C=C, L=L, mix=mix, eps=eps, conds=conds, inputs=['in'] + list(eps.values()), grad=True)
+
+
+def _plan_glow_forward(y_channels, enc_blocks, flow_blocks, lu, mix_index, growth=16, init_features=48):
+    """descriptors of the y -> z direction (MultiScaleCondGlow.forward, glow_msc.py:746-780), inference only: the same
+    encoder, then per level squeeze, [ActNorm, inverse 1x1,] coupling forward, split with the log-probability of the
+    factored-out half.  mix_index: (level, layer) -> row of the matrix table built for generate()"""
+    L = len(flow_blocks)
+    specs, bufs, conds, C, fres = _plan_encoder(y_channels, enc_blocks, flow_blocks, growth, init_features, False)
+    bufs['yin'] = [C[1], (1, 1)]
+    cur, ccur, eps = 'yin', C[1], {}
+    for i in range(1, L + 1):
+        blk = f'flow.revblock{i}'
+        cond, cc, r = conds[i - 1]
+        Ci, n2 = C[i], C[i] // 2
+        n1 = Ci - n2
+        if i > 1:                                        # Squeeze.forward on the half that continues (glow_msc.py:410-420)
+            nxt = f'f{i}_0'
+            bufs[nxt] = [Ci, r]
+            specs.append(_Spec(OP_UNSQUEEZE, cur, nxt, Ci // 4, Ci, fres[i - 1], flags=FLOW_FORWARD))
+            cur = nxt
+        for j in range(1, flow_blocks[i - 1] + 1):
+            lay = f'{blk}.revlayers.revlayer{j}'
+            if not (i == 1 and j == 1):
+                gb = f'g{i}_{j}'
+                bufs[gb] = [Ci, r]
+                specs.append(_Spec(OP_MIX, cur, gb, Ci, Ci, r, index=mix_index[(i, j)], flags=FLOW_FORWARD))
+                cur = gb
+            nb, hb, fb = f'n{i}_{j}', f'h{i}_{j}', f'f{i}_{j}'
+            _coupling_net(specs, bufs, lay, cur, nb, hb, n1, n2, cond, cc, r, growth, False)
+            bufs[fb] = [Ci, r]
+            specs.append(_Spec(OP_COUPLING, cur, fb, Ci, Ci, r, h=hb, flags=FLOW_FORWARD))
+            cur = fb
+        if 1 < i < L:                                    # Split.forward (glow_msc.py:561-573)
+            p = f'p{i}'
+            bufs[p] = [Ci, r]
+            pc = blk + '.split.latent_encoder.conv2d'
+            specs.append(_Spec('raw', cur, p, Ci // 2, Ci, r, conv=pc + '.conv', k=3, pad=1, grad=None))
+            specs.append(_Spec(OP_BIAS_SCALE, p, p, Ci, Ci, r, bias=pc + '.conv.bias', scale_p=pc + '.scale'))
+            eps[i - 2] = f'eps{i - 2}'
+            bufs[eps[i - 2]] = [Ci // 2, r]
+            specs.append(_Spec(OP_GAUSS, cur, eps[i - 2], Ci // 2, Ci // 2, r, prior=p, src_coff=Ci // 2, flags=FLOW_FORWARD))
+    eps[L - 2] = f'eps{L - 2}'
+    bufs[eps[L - 2]] = [C[L], fres[L]]
+    specs.append(_Spec(OP_GAUSS, cur, eps[L - 2], C[L], C[L], fres[L], prior='top', src_coff=0, flags=FLOW_FORWARD))
+    return specs, bufs, dict(C=C, L=L, mix=None, eps=eps, conds=conds, inputs=['in', 'yin'], grad=False, z=cur)
 
 
 # ------------------------------------------------------------------------------------------------
 class _GlowEngine:
     """activation / gradient buffers, accumulator arena and descriptors of generate() for one (batch, size, device)"""
 
-    def __init__(self, net, B, H, W):
+    def __init__(self, net, B, H, W, plan=None):
         self.net, self.B = net, B
         dev = net._flat.device
         self.dev = dev
         self.ctx = _lib.context(dev)
         self.busy = self.reserved = False
         L = _lib.lib()
-        specs, bufs, meta = net._specs, net._bufs, net._meta
+        specs, bufs, meta = plan if plan is not None else (net._specs, net._bufs, net._meta)
+        self.specs, self.meta = specs, meta
+        self.has_grad = bool(meta['grad'])
+        mixes = net._meta['mix']                      # the matrix table is per reversible layer: shared by both directions
         self.buf_hw = {}
         for k, (c, sc) in bufs.items():
             if H % sc[1] or W % sc[1] or ((H // sc[1]) * (W // sc[1])) % 4:
@@ -257,9 +318,12 @@ class _GlowEngine:
                                  'than 4 pixels there)')
             self.buf_hw[k] = (H // sc[1], W // sc[1])
         f32 = dict(device=dev, dtype=torch.float32)
-        inputs = {'in'} | set(meta['eps'].values())
+        inputs = set(meta['inputs'])
         self.X = {k: torch.empty((B, c) + self.buf_hw[k], **f32) for k, (c, sc) in bufs.items()}
-        self.T = {k: torch.empty((B, c) + self.buf_hw[k], **f32) for k, (c, sc) in bufs.items() if k not in inputs and k != 'out'}
+        self.T = {}
+        if self.has_grad:
+            self.T = {k: torch.empty((B, c) + self.buf_hw[k], **f32) for k, (c, sc) in bufs.items()
+                      if k not in inputs and k != 'out'}
         # gradients of buffers that are read both through BatchNorms and as they are (the encoder's features): one flat
         # allocation, cleared at the start of every backward pass
         direct = [s.src for s in specs if s.x.get('grad') == 'D']
@@ -288,7 +352,7 @@ class _GlowEngine:
                 aux_off[i] = n_aux
                 n_aux += 2 * s.cout
         mix_off, n_mix = [], 0
-        for (c, r, _, _) in meta['mix']:
+        for (c, *_rest) in mixes:
             mix_off.append(n_mix)
             n_mix += 2 * c + c * c
         base_bn, base_aux = 2 * n_stat, 2 * n_stat + n_bn
@@ -303,14 +367,14 @@ class _GlowEngine:
         self.logp = torch.empty(B, **f32)
         self.glogp = torch.zeros(B, **f32)
         # ---- invertible 1x1 convolutions + ActNorms: matrices, log-determinants, the device table of pdes_flow_prepare
-        nm = len(meta['mix'])
-        self.Wtab = torch.zeros(max(sum(c * c for c, _, _, _ in meta['mix']), 1), **f32)
+        nm = len(mixes)
+        self.Wtab = torch.zeros(max(sum(m[0] * m[0] for m in mixes), 1), **f32)
         self.Winv = torch.zeros_like(self.Wtab)
         self.logdet = torch.zeros(max(nm, 1), device=dev, dtype=torch.float64)
         items, woff = [], 0
         self._w_ptr = []
         gv = net._grad_view
-        for m, (c, r, npath, cpath) in enumerate(meta['mix']):
+        for m, (c, r, npath, cpath, _, _) in enumerate(mixes):
             an, cv = _get(net, npath), _get(net, cpath)
             hw = self.buf_hw_of(r, H, W)
             it = FlowItem()
@@ -341,6 +405,9 @@ class _GlowEngine:
             if s.bn:
                 bn_readers.setdefault(s.src, []).append(i)
         consumed = {}
+        # channels of a buffer that some BatchNorm reads: [0, bn_max); what lies above (the last dense layer's output of
+        # the encoder's last block) has direct consumers only -- its gradient is the direct accumulator alone
+        bn_max = {k: max(specs[i].cin for i in v) for k, v in bn_readers.items()}
         pk = net._packed
         self._train_stats = []
         for i, s in enumerate(specs):
@@ -349,7 +416,8 @@ class _GlowEngine:
             ho, wo = self.buf_hw[s.dst]
             d.B, d.Cin, d.Cout, d.Hin, d.Win, d.Hout, d.Wout = B, s.cin, s.cout, hi, wi, ho, wo
             d.ksize, d.stride, d.pad, d.upsample = s.k, s.stride, s.pad, s.up
-            d.x, d.x_ctot = self.X[s.src].data_ptr(), bufs[s.src][0]
+            d.x, d.x_ctot = self.X[s.src].data_ptr() + 4 * s.x.get('src_coff', 0) * hi * wi, bufs[s.src][0]
+            d.flags = s.x.get('flags', 0)
             d.eps, d.nrep, d.rep_stride = 1e-5, self.nrep, self.rep_stride
             d.cout_pad, d.cin_pad = _pad16(s.cout), _pad16(s.cin)
             d.out, d.out_ctot, d.out_coff = self.X[s.dst].data_ptr(), bufs[s.dst][0], s.dst_coff
@@ -357,6 +425,14 @@ class _GlowEngine:
             carried = i + 1 < n and specs[i + 1].kind == OP_BIAS_SCALE and specs[i + 1].dst == s.dst   # ... by the op behind it
             if s.dst in self.T:
                 d.g, d.g_ctot, d.g_coff = self.T[s.dst].data_ptr(), bufs[s.dst][0], s.dst_coff
+            if dst_bn and s.dst_coff >= bn_max[s.dst]:
+                dst_bn = False
+                if self.has_grad:
+                    if s.dst not in self.D:
+                        raise RuntimeError(f'channels [{s.dst_coff}, {s.dst_coff + s.cout}) of {s.dst} have no consumer')
+                    d.g = self.D[s.dst].data_ptr()
+            elif dst_bn and s.dst_coff + s.cout > bn_max[s.dst]:
+                raise RuntimeError(f'{s.dst}: a layer\'s output is only partly read through BatchNorms')
             if dst_bn and not carried and s.kind != OP_COUPLING:
                 d.out_stats = xs(s.dst)
                 d.fin_xstats, d.fin_tstats = xs(s.dst), ts(s.dst)
@@ -379,7 +455,8 @@ class _GlowEngine:
                 d.has_bn = 1
                 d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
                 d.run_mean, d.run_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-                d.x_stats, d.t_in, d.t_stats = xs(s.src), self.T[s.src].data_ptr(), ts(s.src)
+                d.x_stats, d.t_stats = xs(s.src), ts(s.src)
+                d.t_in = self.T[s.src].data_ptr() if self.has_grad else None
                 d.bn_grad = a0 + 8 * (base_bn + bn_off[s.norm])
                 d.t_accumulate = 0 if bn_readers[s.src][-1] == i else 1
                 d.final_c0, d.final_c1 = consumed.get(s.src, 0), s.cin
@@ -400,22 +477,29 @@ class _GlowEngine:
                 d.acc = a0 + 8 * (base_aux + aux_off[i])
             elif s.kind == OP_COUPLING:
                 h = s.x['h']
-                d.x2, d.x2_ctot, d.t2 = self.X[h].data_ptr(), bufs[h][0], self.T[h].data_ptr()
+                d.x2, d.x2_ctot = self.X[h].data_ptr(), bufs[h][0]
                 d.acc, d.p1 = self._logp_acc, self.glogp.data_ptr()
-                d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
+                if self.has_grad:
+                    d.t2 = self.T[h].data_ptr()
+                    d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
             elif s.kind == OP_MIX:
-                w_ptr, _, acc = self._w_ptr[s.x['index']]
-                an = _get(net, meta['mix'][s.x['index']][2])
-                d.x2, d.x2_ctot = w_ptr, s.cin
+                w_ptr, winv_ptr, acc = self._w_ptr[s.x['index']]
+                an = _get(net, mixes[s.x['index']][2])
+                d.x2, d.x2_ctot = (winv_ptr if d.flags & FLOW_FORWARD else w_ptr), s.cin
                 d.p0, d.p1, d.acc = an.weight.data_ptr(), an.bias.data_ptr(), acc
-                d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
+                if self.has_grad:
+                    d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
             elif s.kind == OP_UNSQUEEZE:
-                d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
+                if self.has_grad:
+                    d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
             elif s.kind == OP_GAUSS:
                 pr = s.x['prior']
-                d.x2, d.x2_ctot, d.t2 = self.X[pr].data_ptr(), bufs[pr][0], self.T[pr].data_ptr()
-                d.p0 = self.X[s.x['eps']].data_ptr()
-                d.acc, d.p1, d.flags = self._logp_acc, self.glogp.data_ptr(), s.x['flags']
+                d.x2, d.x2_ctot = self.X[pr].data_ptr(), bufs[pr][0]
+                d.acc, d.p1 = self._logp_acc, self.glogp.data_ptr()
+                if not (d.flags & FLOW_FORWARD):
+                    d.p0 = self.X[s.x['eps']].data_ptr()
+                if self.has_grad:
+                    d.t2 = self.T[pr].data_ptr()
             self._train_stats.append(d.out_stats)
         self._last = n - 1
         # ---- tables of the end-of-step launches: true BatchNorms, and the {dbias, dscale} of the bias/scale ops
@@ -457,7 +541,7 @@ class _GlowEngine:
         L = _lib.lib()
         self._wgrad_ws, items, mx = [], [], 0
         idx = []
-        for i, s in enumerate(self.net._specs):
+        for i, s in enumerate(self.specs):
             d = self.descs[i]
             if s.kind not in ('conv', 'raw'):
                 idx.append(-1)
@@ -496,11 +580,28 @@ class _GlowEngine:
     # -- launches -------------------------------------------------------------------------------
     def forward(self, x, eps_list, training):
         """generate(): -> (y, logp) views of engine buffers (valid until the next forward of this engine)"""
+        feed = {'in': x}
+        for k, name in self.meta['eps'].items():
+            feed[name] = eps_list[k]
+        self.run(feed, training)
+        return self.X['out'], self.logp
+
+    def run(self, feed, training, lo=0, hi=None, first=True, last=True):
+        """execute descriptors [lo, hi) of the chain; `first` / `last`: with the launches that precede / follow the whole
+        chain (a chain is run in pieces only by the data-dependent ActNorm initialisation)"""
         L, st = _lib.lib(), _lib.stream_ptr()
         net = self.net
-        self.X['in'].copy_(x)
-        for k, name in net._meta['eps'].items():
-            self.X[name].copy_(eps_list[k])
+        n = len(self.descs)
+        hi = n if hi is None else hi
+        if not first:
+            if self.n_mix:
+                _lib.check(L.pdes_flow_prepare(self.flow_table.data_ptr(), self.n_mix, 1, st), 'pdes_flow_prepare')
+            self._launch(lo, hi, st)
+            if last:
+                self._finish(training, st)
+            return
+        for name, t in feed.items():
+            self.X[name].copy_(t)
         ev = 0 if training else 1
         for d, os_ in zip(self.descs, self._train_stats):
             d.eval_mode = ev
@@ -508,15 +609,24 @@ class _GlowEngine:
         self.arena.zero_()
         net._pack_weights()
         if self.n_mix:
-            _lib.check(L.pdes_flow_prepare(self.flow_table.data_ptr(), self.n_mix, 0 if net.LUdecompose else 1, st),
-                       'pdes_flow_prepare')
-        _lib.check(L.pdes_conv_forward(self.ctx, self.descs, len(self.descs), st), 'pdes_conv_forward')
+            need_inv = 0 if (net.LUdecompose and self.has_grad) else 1       # the y -> z direction applies the inverse matrices
+            _lib.check(L.pdes_flow_prepare(self.flow_table.data_ptr(), self.n_mix, need_inv, st), 'pdes_flow_prepare')
+        self._launch(lo, hi, st)
+        if last:
+            self._finish(training, st)
+
+    def _launch(self, lo, hi, st):
+        if hi > lo:
+            first = ctypes.byref(self.descs, lo * ctypes.sizeof(ConvDesc))
+            _lib.check(_lib.lib().pdes_conv_forward(self.ctx, first, hi - lo, st), 'pdes_conv_forward')
+
+    def _finish(self, training, st):
+        L = _lib.lib()
         _lib.check(L.pdes_flow_logp(self._logp_acc, self.logdet.data_ptr(), self.n_mix, self.logp.data_ptr(), self.B,
                                     self.nrep, self.rep_stride, st), 'pdes_flow_logp')
         if training:
             _lib.check(L.pdes_bn_update_running(self.bn_table.data_ptr(), self.n_bn, self.max_c, ctypes.c_float(0.1),
                                                 self.nrep, self.rep_stride, st), 'pdes_bn_update_running')
-        return self.X['out'], self.logp
 
     def backward(self, grad_y, grad_logp):
         """parameter gradients are ACCUMULATED into net._gscratch.  grad_y: dL/dy (B, C, H, W) contiguous; grad_logp: dL/dlogp
@@ -813,6 +923,55 @@ class MultiScaleCondGlow(_HipNet):
         raise RuntimeError('MultiScaleCondGlow: construct a new model instead (the initial values depend on the numpy and '
                            'torch seeds at construction, as in the reference)')
 
+    # -- y -> z (inference only) ----------------------------------------------------------------------------------
+    def _forward_engine(self, x):
+        if getattr(self, '_fwd_plan', None) is None:
+            index = {(m[4], m[5]): k for k, m in enumerate(self._meta['mix'])}
+            self._fwd_plan = _plan_glow_forward(self.y_channels, self.enc_blocks, self.flow_blocks, self.LUdecompose, index)
+            self._fwd_engines = {}
+        key = (x.device, x.shape[0], x.shape[2], x.shape[3])
+        eng = self._fwd_engines.get(key)
+        if eng is None:
+            eng = self._fwd_engines[key] = _GlowEngine(self, *key[1:], plan=self._fwd_plan)
+        return eng
+
     def forward(self, y, x, return_eps=False):
-        """y -> z with log p(y|x) (glow_msc.py:746-780), inference only"""
-        raise NotImplementedError('the y -> z direction is being built')
+        """y -> z: (z_top, log p(y|x), [eps per latent] or None) (glow_msc.py:746-780).  Inference only: the outputs
+        carry no autograd graph (the reference trains through this direction only with train_sampling=False).
+        With data_init=True the first call initialises every ActNorm from the statistics of its input (glow_msc.py:70-83),
+        layer by layer."""
+        x = self._check_input(x)
+        _lib.require_cuda(y)
+        if y.dim() != 4 or y.shape[1] != self.y_channels or y.shape[0] != x.shape[0] or y.shape[2:] != x.shape[2:]:
+            raise ValueError(f'expected y of shape ({x.shape[0]}, {self.y_channels}, {x.shape[2]}, {x.shape[3]}); got {tuple(y.shape)}')
+        y = y.to(torch.float32).contiguous()
+        self._engine(x)                                   # parameters flat on this device
+        with torch.no_grad(), _lib.device_guard(x.device):
+            eng = self._forward_engine(x)
+            feed = {'in': x, 'yin': y}
+            if self.data_init and not self.data_initialized:
+                self._data_init(eng, feed)
+            else:
+                eng.run(feed, self.training)
+            z = eng.X[eng.meta['z']].clone()
+            logp = eng.logp.clone()
+            eps = [eng.X[eng.meta['eps'][k]].clone() for k in sorted(eng.meta['eps'])] if return_eps else None
+        return z, logp, eps
+
+    def _data_init(self, eng, feed):
+        """ActNorm._init_parameters (glow_msc.py:70-83) for every ActNorm, in the order the data reaches them: the chain is
+        run up to each invertible layer, whose input then gives bias = -mean / std, weight = 1 / std (std unbiased + 1e-6)"""
+        lo, first = 0, True
+        for i, s in enumerate(eng.specs):
+            if s.kind != OP_MIX:
+                continue
+            eng.run(feed, self.training, lo, i, first=first, last=False)
+            lo, first = i, False
+            act = eng.X[s.src]
+            flat = act.transpose(0, 1).reshape(act.shape[1], -1)
+            mean, std = flat.mean(1), flat.std(1) + 1e-6
+            an = _get(self, self._meta['mix'][s.x['index']][2])
+            an.bias.data.copy_((-(mean / std)).view(-1, 1, 1))
+            an.weight.data.copy_((1. / std).view(-1, 1, 1))
+        eng.run(feed, self.training, lo, None, first=first, last=True)
+        self.init_actnorm()
