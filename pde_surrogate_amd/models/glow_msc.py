@@ -601,7 +601,8 @@ class _GlowEngine:
                 self._finish(training, st)
             return
         for name, t in feed.items():
-            self.X[name].copy_(t)
+            if t is not None and t.data_ptr() != self.X[name].data_ptr():
+                self.X[name].copy_(t)
         ev = 0 if training else 1
         for d, os_ in zip(self.descs, self._train_stats):
             d.eval_mode = ev
@@ -639,7 +640,7 @@ class _GlowEngine:
         self.descs[self._last].g_ctot, self.descs[self._last].g_coff = grad_y.shape[1], 0
         if grad_logp is None:
             self.glogp.zero_()
-        else:
+        elif grad_logp.data_ptr() != self.glogp.data_ptr():
             self.glogp.copy_(grad_logp)
         self.Dflat.zero_()
         side = side_b = None

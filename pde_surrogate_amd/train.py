@@ -234,3 +234,105 @@ class MaxLikelihoodTrainer(MixedResidualTrainer):
         if target is not None:
             self.target_static.copy_(target)
         super().step(x, lr)
+
+
+class ReverseKLTrainer:
+    """The loop body of train_cglow_reverse_kl.py:245-272 as one fused step: draw the latents' noise, generate
+    y ~ p(y|x) with log p(y|x) (the conditional Glow's descriptor chain), loss = beta * loss_pde(y; x) + E[log p] / ln 2 /
+    n_pixels with the fused Sobel + Darcy-residual kernel, backward over the same chain, flat all-reduce (one process per
+    GPU), one-cycle learning rate, flat Adam -- no autograd graph, no per-step host synchronisation.  The loss terms are
+    accumulated on the device and read once per epoch."""
+
+    def __init__(self, model, batch_size, imsize=32, lr=1.5e-3, weight_decay=0.0, weight_bound=50.0, beta=150.0,
+                 betas=(0.9, 0.999), eps=1e-8, device=None, process_group=None):
+        self.model = model
+        self.B, self.n = batch_size, imsize
+        self.dev = torch.device(device if device is not None else 'cuda:0')
+        if self.dev.type != 'cuda':
+            raise RuntimeError('ReverseKLTrainer runs on an MI355X only (no CPU fallback)')
+        self.wb, self.beta = float(weight_bound), float(beta)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.dp = self.world > 1 or process_group is not None
+        model.to(self.dev)
+        probe = torch.zeros((batch_size, 1, imsize, imsize), device=self.dev)
+        with _lib.device_guard(self.dev):
+            self.eng = model._engine(probe)
+        self.eng.reserved = True
+        self.ctx = self.eng.ctx
+        self.x_static = self.eng.X['in']
+        self.x_static.zero_()
+        self.flat, self.gflat = model._flat, model._gscratch
+        if self.dp:
+            parallel.broadcast_parameters(self.flat, process_group)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self._hyper_args = (ctypes.c_float * 8)()
+        self.step_count = 0
+        C = model.y_channels
+        self.grad_y = torch.empty((batch_size, C, imsize, imsize), device=self.dev)
+        self.partials = torch.empty((batch_size, 4), device=self.dev)
+        self.terms = torch.zeros(5, device=self.dev)              # {beta * loss_pde, constitutive, continuity, dirichlet, neumann}
+        self.terms_accum = torch.zeros(6, device=self.dev, dtype=torch.float64)     # ... + sum_b log p(y_b|x_b)
+        self.n_accum = 0
+        self._ne_scale = 1.0 / (batch_size * math.log(2.0) * C * imsize * imsize)
+        self.eng.glogp.fill_(self._ne_scale)                      # d(neg_entropy)/d(logp_b): the same for every sample
+        self._eps_bufs = [self.eng.X[name] for _, name in sorted(model._meta['eps'].items())]
+        self._grad_clean = False
+        self._L = _lib.lib()
+
+    def load_batch(self, data, index):
+        torch.index_select(data, 0, index, out=self.x_static)
+
+    def step(self, x=None, lr=None, eps_list=None):
+        """one step on minibatch `x` (None = reuse the static input buffer); eps_list (tests): the latents' noise"""
+        with _lib.device_guard(self.dev):
+            self._step(x, lr, eps_list)
+
+    def _step(self, x, lr, eps_list):
+        L, st = self._L, _lib.stream_ptr()
+        m, eng = self.model, self.eng
+        assert m._flat is self.flat, 'the model was re-flattened after the trainer was built'
+        if x is not None:
+            self.x_static.copy_(x)
+        for k, buf in enumerate(self._eps_bufs):
+            if eps_list is None:
+                buf.normal_()
+            else:
+                buf.copy_(eps_list[k])
+        eng.run({}, True)
+        y = eng.X['out']
+        b = self.beta
+        rc = L.pdes_darcy_loss(self.ctx, self.x_static.data_ptr(), y.data_ptr(), self.grad_y.data_ptr(),
+                               self.partials.data_ptr(), self.terms.data_ptr(), self.B, self.n, self.n, b, b, b * self.wb,
+                               b * self.wb, 0, 0.0, 0.0, st)
+        _lib.check(rc, 'pdes_darcy_loss')
+        self.terms_accum[:5] += self.terms
+        self.terms_accum[5] += eng.logp.sum()
+        self.n_accum += 1
+        if not self._grad_clean or m._grad_dirty:
+            self.gflat.zero_()
+            m._grad_dirty = False
+        eng.backward(self.grad_y, eng.glogp)
+        if self.dp:
+            torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        self.step_count += 1
+        b1, b2 = self.betas
+        self._hyper_args[:7] = (self.lr if lr is None else lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.step_count,
+                                math.sqrt(1.0 - b2 ** self.step_count))
+        rc = L.pdes_adam_step_host(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
+                                   self.exp_avg_sq.data_ptr(), self._hyper_args, 1.0 / self.world, 1, self.flat.numel(), st)
+        _lib.check(rc, 'pdes_adam_step_host')
+        self._grad_clean = True
+
+    def epoch_means(self):
+        """means since the last call of {loss, residual (constitutive + continuity), boundary (dirichlet + neumann),
+        neg_entropy} (ONE host sync)"""
+        t = (self.terms_accum / max(self.n_accum, 1)).cpu().tolist()
+        self.terms_accum.zero_()
+        self.n_accum = 0
+        neg_entropy = t[5] * self._ne_scale
+        return [t[0] + neg_entropy, t[1] + t[2], t[3] + t[4], neg_entropy]

@@ -135,3 +135,20 @@ def test_solver_flags_match_reference():
         assert getattr(a, k) == v, k
     a.kle = 1024
     assert s.dataset_file(a) == './datasets/64x64/kle1024_lhs1024_test.hdf5'
+
+
+def test_cglow_parser_contract(tmp_path):
+    """train_cglow_reverse_kl.py: the reference's flags and defaults, its run-directory name, the list quirk, rejections"""
+    import train_cglow_reverse_kl as cli
+    a = cli.Parser().parse(['--exp-dir', str(tmp_path)])
+    assert (a.enc_blocks, a.flow_blocks, a.kle, a.imsize, a.beta, a.weight_bound, a.lr, a.batch_size, a.epochs) == \
+        ([3, 4, 4], [6, 6, 6], 100, 32, 150, 50, 1.5e-3, 32, 400)
+    assert a.LU_decompose and not a.data_init
+    assert a.run_dir.endswith('cglow/reverse_kld/kle100_ntrain4096_ENC_blocks[3, 4, 4]_FLOW_blocks[6, 6, 6]_wb50_beta150_'
+                              'batch32_lr0.0015_epochs400')
+    b = cli.Parser().parse(['--exp-dir', str(tmp_path), '--enc-blocks', '211', '--flow-blocks', '221', '--no-LU-decompose'])
+    assert b.enc_blocks == [2, 1, 1] and b.flow_blocks == [2, 2, 1] and not b.LU_decompose
+    for bad in (['--imsize', '48'], ['--enc-blocks', '34'], ['--ntrain', '100'], ['--imsize', '16', '--enc-blocks', '33333',
+                                                                                  '--flow-blocks', '33333']):
+        with pytest.raises(SystemExit):
+            cli.Parser().parse(['--exp-dir', str(tmp_path)] + bad)
