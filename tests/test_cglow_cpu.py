@@ -73,6 +73,6 @@ def test_plan_covers_every_parameter_once():
         for key in ('bias', 'scale_p'):
             if s.x.get(key):
                 used.add(s.x[key])
-    for c, r, npath, cpath in net._meta['mix']:
+    for c, r, npath, cpath, _, _ in net._meta['mix']:
         used |= {npath + '.weight', npath + '.bias', cpath + '.l', cpath + '.u', cpath + '.log_s'}
     assert used == names
