@@ -205,6 +205,62 @@ def config5_timing(dev, n=300):
     return out
 
 
+def cglow_timing(dev, steps=60, warm=15, cpu_steps=3):
+    """one reverse-KL training step of the default multiscale conditional Glow of
+    train_cglow_reverse_kl.py (enc [3, 4, 4], flow [6, 6, 6], 32x32 GRF-KLE100 inputs, bs 32, beta 150, weight_bound 50):
+    noise, generate() chain, fused Darcy loss, backward chain, Adam -- samples/s of the fused trainer, with the CPU
+    restatement (oracle/glow.py, PyTorch-CPU fp32, same math) timed beside it on a bounded sample"""
+    import contextlib
+    import io
+    import numpy as np
+    from pde_surrogate_amd.models.glow_msc import MultiScaleCondGlow
+    from pde_surrogate_amd.train import ReverseKLTrainer
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    B = 32
+    data = torch.from_numpy(grf_kle_fields(4 * B, 32, 100, cache_dir='/tmp')).to(dev)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MultiScaleCondGlow(32, 1, 3, [3, 4, 4], [6, 6, 6], LUdecompose=True).to(dev).train()
+    tr = ReverseKLTrainer(net, B, 32, lr=1.5e-3, weight_bound=50.0, beta=150.0, device=dev)
+    for i in range(warm):
+        tr.step(data[(i % 4) * B:(i % 4 + 1) * B], 1e-3)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(data[(i % 4) * B:(i % 4 + 1) * B], 1e-3)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    means = tr.epoch_means()
+    out = {'workload': 'MultiScaleCondGlow(32, 1, 3, enc [3,4,4], flow [6,6,6], LU) reverse-KL step, bs 32, 32x32, fp32',
+           'n_params': net.model_size[0], 'descriptors_per_generate': len(net._specs),
+           'samples_per_s': round(B / dt, 1), 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
+           'mean_loss_over_the_run': round(means[0], 3), 'finite': bool(np.isfinite(means[0]))}
+    if cpu_steps:
+        from oracle import glow as oglow
+        import math
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        keys = oglow.param_keys(sd)
+        for k in keys:
+            sd[k].requires_grad_(True)
+        opt = torch.optim.Adam([sd[k] for k in keys], lr=1e-3)
+        shapes = oglow.latent_shapes(sd, 3, 32)
+        xc = data[:B].cpu()
+        times = []
+        for i in range(cpu_steps + 1):
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            eps = [torch.randn((B,) + s) for s in shapes]
+            loss = oglow.reverse_kl_loss(sd, xc, eps, 150.0, 50.0, True)[0]
+            loss.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+        cdt = float(np.mean(times[1:]))
+        out['cpu_baseline'] = {'value': round(B / cdt, 2), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                               'sample': f'{cpu_steps} steps after 1 warm-up, bs {B}, oracle/glow.py on PyTorch-CPU fp32'}
+    return out
+
+
 def rendezvous(gpus):
     """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, one process per GPU, backend
     nccl (= RCCL over xGMI) -- gloo only when there is no GPU at all (CPU test of this function).  Returns
@@ -387,6 +443,8 @@ def main():
                                            'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}
         if world == 1 and not args.no_extras:
             out['config5_solver'] = config5_timing(dev)
+        if world == 1 and not args.no_extras:
+            out['cglow_reverse_kl'] = cglow_timing(dev, cpu_steps=0 if args.no_cpu_baseline else 3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(B)
         print(json.dumps(out), flush=True)

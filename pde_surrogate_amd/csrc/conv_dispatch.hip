@@ -20,6 +20,9 @@ int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st);             // wid
 int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st);          // nearest-x2 + 3x3, sub-pixel form, bf16 x3 split
 int conv_backward_data_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
+int conv_forward_small(const pdes_conv_desc& d, hipStream_t st);          // 3x3 on 8x8 maps (conv_small.hip)
+int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
+int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st);
 int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
 int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int upsample_bilinear_forward(const pdes_conv_desc& d, hipStream_t st);   // PDES_UPSAMPLE_BILINEAR_OP descriptors
@@ -86,7 +89,8 @@ extern "C" int pdes_conv_forward(const pdes_context* ctx, const pdes_conv_desc* 
       if (rc) return rc;
       continue;
     }
-    int rc = force_direct() ? PDES_ENOSUP : conv_forward_b3_up(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_forward_small(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_b3_up(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_fewout(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_forward_b3(descs[i], st);
@@ -104,7 +108,8 @@ extern "C" int pdes_conv_backward_weight(const pdes_context* ctx, const pdes_con
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = 0; i < n; ++i) {
     if (is_resample_op(descs[i])) continue;                          // a resampling op has no weights
-    int rc = force_direct() ? PDES_ENOSUP : conv_backward_weight_mfma(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_backward_weight_small(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_weight_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && descs[i].g_fused) return PDES_EINVAL;      // only the matrix-core kernels finalize on load
     if (rc == PDES_ENOSUP) {
       // the VALU kernel adds straight into dw.  If the caller planned deferred split-K partials for this layer
@@ -130,7 +135,8 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
       if (rc) return rc;
       continue;
     }
-    int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_up_mfma(descs[i], st);
+    int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_small(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_b3(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_1x1(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_mfma(descs[i], st);

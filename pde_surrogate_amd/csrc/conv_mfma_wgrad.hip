@@ -584,6 +584,8 @@ __global__ __launch_bounds__(64) void wgrad_reduce_all_kernel(const pdes_reduce_
   }
 }
 
+bool wgrad_small_applies(const pdes_conv_desc& d);     // conv_small.hip
+int wgrad_small_splits(const pdes_conv_desc& d);
 // tile / split plan shared by the launcher and pdes_conv_wgrad_plan
 struct WgradPlan { int twg, tps, tpw, nsplit, ntw, ngroups, gy; long long per; };
 static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
@@ -776,6 +778,11 @@ extern "C" int pdes_conv_wgrad_plan(const pdes_context* ctx, const pdes_conv_des
     return (*floats) * 4 <= d->ws_bytes ? PDES_OK : PDES_ENOSUP;
   }
   if (opt().conv_direct) return PDES_ENOSUP;   // VALU kernels forced: no partials
+  if (wgrad_small_applies(*d)) {               // 3x3 on an 8x8 map (conv_small.hip): one partial per four images
+    *nsplit = wgrad_small_splits(*d);
+    *floats = (long long)(*nsplit) * d->Cout * d->Cin * 9;
+    return (*floats) * 4 <= d->ws_bytes ? PDES_OK : PDES_ENOSUP;
+  }
   if (!wgrad_shape_ok(*d) || !wgrad_plan(*d, &pl)) return PDES_ENOSUP;
   *nsplit = pl.nsplit;
   *floats = (long long)pl.nsplit * pl.per;

@@ -1,0 +1,362 @@
+// 3x3 convolutions on 8x8 feature maps (the coarsest level of the conditional Glow, models/glow_msc.py: 24 coupling-net
+// convolutions + the encoder's last dense block per training step) on v_mfma_f32_16x16x4_f32 -- forward, data gradient
+// and weight gradient.  conv_mfma.hip tiles a map in rows of 16 pixels, so an 8-wide map fell to the VALU kernels
+// (339 / 68 / 70 us per layer at batch 32: 87 % of the conditional Glow's step).  Here a whole 8x8 image is ONE
+// workgroup's tile:
+//   * forward / data gradient: the K-side planes of an image (BatchNorm+ReLU'd input channels, or the raw output
+//     gradient) sit in LDS with a zero halo, [channel][10 x 10] at an ODD channel stride; wave w owns the M-tile of
+//     rows 2w, 2w+1 (16 pixels), the B operand streams from the packed weight image (pack_mfma_item: 4 B per lane
+//     per (k-step, tap, N-tile), coalesced), one MFMA per (k-step of 4 channels, tap, N-tile);
+//     the accumulator of a lane is 4 consecutive pixels of one row and one channel: float4 stores, the statistics
+//     (forward) / ReLU mask, gamma, T, dgamma, dbeta, finished-channel sums (data gradient) are reduced over the
+//     workgroup before one fp64 atomic per channel;
+//   * weight gradient: M = 16 input channels, N = output channels, K = pixels (16 k-steps per image and tap);
+//     a workgroup = (input-channel tile, slice of the batch), each wave one image at a time out of its own LDS
+//     region, the four waves' sums are added in a fixed order and written as one split-K partial (reduced by
+//     pdes_wgrad_reduce_all with every other layer's): deterministic.
+#include "pdes_common.h"
+#include "pdes_options.h"
+#include "../../include/pdes_hip.h"
+
+namespace pdes {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int SM_PITCH = 10;     // 8 columns + halo
+constexpr int SM_CS = 101;       // plane stride: 10 x 10 + 1, odd (channel-major operand reads spread over the banks)
+constexpr int SM_GS = 65;        // stride of a halo-free 64-pixel plane
+
+struct BnS { float mean, invstd, gamma, beta; };
+__device__ __forceinline__ BnS bn_coef_s(const pdes_conv_desc& d, int c) {
+  BnS o;
+  if (d.eval_mode) {
+    o.mean = d.run_mean[c];
+    o.invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
+  } else {
+    const double n = (double)d.B * d.Hin * d.Win;
+    const double m = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
+    double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    o.mean = (float)m;
+    o.invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+  }
+  o.gamma = d.gamma[c];
+  o.beta = d.beta[c];
+  return o;
+}
+
+bool conv_small_applies(const pdes_conv_desc& d) {
+  return opt().mfma_small && !opt().conv_direct && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample && d.has_bn &&
+         d.Hin == 8 && d.Win == 8 && d.Hout == 8 && d.Wout == 8 && d.Cin <= 352 && d.Cout <= 352 && d.nrep == PDES_NREP &&
+         !d.g_fused;
+}
+
+// ------------------------------------------------------------------------------------------------------- forward
+// grid (B, ceil(N-tiles / NT)), 256 threads.  dynamic LDS: coefficients [Cin] float4 + planes [Cin][SM_CS] + red [4][NT][16][2]
+template <int NT>
+__global__ __launch_bounds__(256) void conv_small_fwd_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
+  extern __shared__ __attribute__((aligned(16))) float sm_small[];
+  const int Cin = d.Cin, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  float4* cf = reinterpret_cast<float4*>(sm_small);
+  float* pl = sm_small + 4 * Cin;
+  float* red = pl + Cin * SM_CS;
+  for (int c = tid; c < Cin; c += 256) {
+    const BnS k = bn_coef_s(d, c);
+    cf[c] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
+  }
+  for (int i = tid; i < Cin * SM_CS; i += 256) pl[i] = 0.f;
+  __syncthreads();
+  const float* xb = d.x + (size_t)b * d.x_ctot * 64;
+  for (int e = tid; e < Cin * 64; e += 256) {
+    const int c = e >> 6, p = e & 63;
+    const float4 k = cf[c];
+    pl[c * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = fmaxf(0.f, (xb[e] - k.x) * k.y + k.z);
+  }
+  __syncthreads();
+  const int ntp = (nt_total + 7) & ~7, nt_base = blockIdx.y * NT;
+  const int ksf = ((Cin + 15) >> 4) * 4;
+  const int i = lane & 15, kq = lane >> 4;
+  const int aoff = (2 * wave + (i >> 3) + 1) * SM_PITCH + (i & 7) + 1;
+  v4f acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < ksf; ++ks) {
+    const float* ap = pl + min(4 * ks + kq, Cin - 1) * SM_CS + aoff;      // (channels past Cin meet zero weights)
+    const float* wp = wm + ((size_t)ks * 9 * ntp + nt_base) * 64 + lane;
+    float w[9][NT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w[t][n] = wp[((size_t)t * ntp + n) * 64];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float a = ap[(t / 3 - 1) * SM_PITCH + (t % 3 - 1)];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[t][n], acc[n], 0, 0, 0);
+    }
+  }
+  // lane (n = lane & 15, g = lane >> 4): channel n of each N-tile, pixels 4g .. 4g+3 of the wave's two rows
+  const int g = lane >> 4, n = lane & 15;
+  const int opix = (2 * wave + (g >> 1)) * 8 + 4 * (g & 1);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = (nt_base + t) * 16 + n;
+    float s = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    float q = (acc[t][0] * acc[t][0] + acc[t][1] * acc[t][1]) + (acc[t][2] * acc[t][2] + acc[t][3] * acc[t][3]);
+    if (co < d.Cout)
+      *reinterpret_cast<float4*>(d.out + ((size_t)b * d.out_ctot + d.out_coff + co) * 64 + opix) =
+          make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    if (lane < 16) { red[((wave * NT + t) * 16 + n) * 2] = s; red[((wave * NT + t) * 16 + n) * 2 + 1] = q; }
+  }
+  if (!d.out_stats) return;
+  __syncthreads();
+  if (tid < NT * 32) {
+    const int t = tid >> 5, nn = (tid >> 1) & 15, w = tid & 1;
+    const int co = (nt_base + t) * 16 + nn;
+    if (co < d.Cout) {
+      double v = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) v += (double)red[((wv * NT + t) * 16 + nn) * 2 + w];
+      atomicAdd(&d.out_stats[(long long)rep_of_block(d.nrep) * d.rep_stride + 2 * (d.out_coff + co) + w], v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- data gradient
+// grid (B, ceil(input-channel tiles / NT)).  dynamic LDS: planes of g [Cout][SM_CS] + coefficients [NT * 16] float4 +
+// red [4][NT][16][4]
+template <int NT>
+__global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
+  extern __shared__ __attribute__((aligned(16))) float sm_small[];
+  const int Cout = d.Cout, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int nt_base = blockIdx.y * NT;
+  float* pl = sm_small;
+  float4* cf = reinterpret_cast<float4*>(pl + ((Cout * SM_CS + 3) & ~3));
+  float* red = reinterpret_cast<float*>(cf + NT * 16);
+  for (int c = tid; c < NT * 16; c += 256) {
+    const BnS k = bn_coef_s(d, min(nt_base * 16 + c, d.Cin - 1));
+    cf[c] = make_float4(k.mean, k.invstd, k.gamma, k.beta);
+  }
+  for (int i = tid; i < Cout * SM_CS; i += 256) pl[i] = 0.f;
+  __syncthreads();
+  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff) * 64;
+  for (int e = tid; e < Cout * 64; e += 256) {
+    const int c = e >> 6, p = e & 63;
+    pl[c * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = gb[e];
+  }
+  __syncthreads();
+  const int ntp = (nt_total + 7) & ~7;
+  const int ksb = ((Cout + 15) >> 4) * 4;
+  const int i = lane & 15, kq = lane >> 4;
+  const int aoff = (2 * wave + (i >> 3) + 1) * SM_PITCH + (i & 7) + 1;
+  v4f acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < ksb; ++ks) {
+    const float* ap = pl + min(4 * ks + kq, Cout - 1) * SM_CS + aoff;
+    const float* wp = wm + ((size_t)ks * 9 * ntp + nt_base) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float a = ap[(t / 3 - 1) * SM_PITCH + (t % 3 - 1)];
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wp[((size_t)t * ntp + min(n, ntp - 1 - nt_base)) * 64], acc[n], 0, 0, 0);
+    }
+  }
+  // epilogue: ReLU mask, gamma, T (+)=, dgamma / dbeta, sums of the channels whose T is complete
+  const int g = lane >> 4, n = lane & 15;
+  const int opix = (2 * wave + (g >> 1)) * 8 + 4 * (g & 1);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ci = (nt_base + t) * 16 + n;
+    float dg = 0.f, db = 0.f, st = 0.f, sx = 0.f;
+    if (ci < d.Cin) {
+      const float4 k = cf[t * 16 + n];
+      const size_t idx = ((size_t)b * d.x_ctot + ci) * 64 + opix;
+      const float4 xv = *reinterpret_cast<const float4*>(d.x + idx);
+      float4* tp = reinterpret_cast<float4*>(d.t_in + idx);
+      float4 tv = d.t_accumulate ? *tp : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      float to[4] = {tv.x, tv.y, tv.z, tv.w};
+      const bool fin = ci >= d.final_c0 && ci < d.final_c1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = (xs[r] - k.x) * (k.z * k.y) + k.w;        // the forward's expression
+        const float xh = (xs[r] - k.x) * k.y;
+        const float dyv = y > 0.f ? acc[t][r] : 0.f;
+        db += dyv;
+        dg += dyv * xh;
+        to[r] += k.z * dyv;
+        if (fin) { st += to[r]; sx += to[r] * xh; }
+      }
+      *tp = make_float4(to[0], to[1], to[2], to[3]);
+    }
+    dg += __shfl_xor(dg, 16, 64); dg += __shfl_xor(dg, 32, 64);
+    db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+    st += __shfl_xor(st, 16, 64); st += __shfl_xor(st, 32, 64);
+    sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
+    if (lane < 16) {
+      float* r = red + ((wave * NT + t) * 16 + n) * 4;
+      r[0] = dg; r[1] = db; r[2] = st; r[3] = sx;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NT * 64; e += 256) {
+    const int t = e >> 6, nn = (e >> 2) & 15, q = e & 3;
+    const int ci = (nt_base + t) * 16 + nn;
+    if (ci >= d.Cin) continue;
+    double v = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) v += (double)red[((wv * NT + t) * 16 + nn) * 4 + q];
+    const long long rep = (long long)rep_of_block(d.nrep) * d.rep_stride;
+    if (q < 2) atomicAdd(&d.bn_grad[rep + 2 * ci + q], v);
+    else if (ci >= d.final_c0 && ci < d.final_c1) atomicAdd(&d.t_stats[rep + 2 * ci + (q - 2)], v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- weight gradient
+// grid (ceil(Cin / 16), nsplit), 256 threads.  dynamic LDS: per wave z planes [16][SM_CS] + g planes [NTC * 16][SM_GS];
+// shared: coefficients [16] float4, sums [NTC * 16][16][9]
+template <int NTC>
+__global__ __launch_bounds__(256) void conv_small_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float sm_small[];
+  constexpr int WREG = 16 * SM_CS + NTC * 16 * SM_GS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci0 = blockIdx.x * 16, split = blockIdx.y;
+  const int b0 = (int)(((long long)d.B * split) / nsplit), b1 = (int)(((long long)d.B * (split + 1)) / nsplit);
+  float4* cf = reinterpret_cast<float4*>(sm_small);
+  float* sums = sm_small + 64;                          // [NTC*16 co][16 ci][9]
+  float* zpl = sums + NTC * 16 * 16 * 9 + wave * WREG;
+  float* gpl = zpl + 16 * SM_CS;
+  if (tid < 16) {
+    const BnS k = bn_coef_s(d, min(ci0 + tid, d.Cin - 1));
+    cf[tid] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
+  }
+  for (int e = tid; e < NTC * 16 * 16 * 9; e += 256) sums[e] = 0.f;
+  for (int e = lane; e < 16 * SM_CS; e += 64) zpl[e] = 0.f;
+  __syncthreads();
+  v4f acc[9][NTC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) acc[t][n] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int i = lane & 15, kq = lane >> 4;
+  const int niter = (b1 - b0 + 3) >> 2;
+  for (int it = 0; it < niter; ++it) {
+    const int b = b0 + it * 4 + wave;
+    const bool valid = b < b1;
+    const float* xb = d.x + ((size_t)(valid ? b : b0) * d.x_ctot + ci0) * 64;
+    const float* gb = d.g + ((size_t)(valid ? b : b0) * d.g_ctot + d.g_coff) * 64;
+    for (int e = lane; e < 16 * 64; e += 64) {
+      const int cl = e >> 6, p = e & 63;
+      float z = 0.f;
+      if (valid && ci0 + cl < d.Cin) {
+        const float4 k = cf[cl];
+        z = fmaxf(0.f, (xb[e] - k.x) * k.y + k.z);
+      }
+      zpl[cl * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = z;
+    }
+    for (int e = lane; e < NTC * 16 * 64; e += 64) {
+      const int co = e >> 6, p = e & 63;
+      gpl[co * SM_GS + p] = (valid && co < d.Cout) ? gb[e] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < 16; ++ks) {
+      const int p = 4 * ks + kq;
+      const float* ap = zpl + i * SM_CS + (p >> 3) * SM_PITCH + (p & 7);       // tap (ky, kx) adds ky * pitch + kx
+      float bv[NTC];
+#pragma unroll
+      for (int n = 0; n < NTC; ++n) bv[n] = gpl[(n * 16 + i) * SM_GS + p];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float a = ap[(t / 3) * SM_PITCH + (t % 3)];
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[n], acc[t][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // lane (co = lane & 15, rows ci = 4 (lane >> 4) + r): the four waves add in a fixed order
+  const int g = lane >> 4, n = lane & 15;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sums[((nt * 16 + n) * 16 + 4 * g + r) * 9 + t] += acc[t][nt][r];
+    }
+    __syncthreads();
+  }
+  float* out = part + (size_t)split * d.Cout * d.Cin * 9;
+  for (int e = tid; e < NTC * 16 * 16 * 9; e += 256) {
+    const int t = e % 9, cl = (e / 9) & 15, co = e / 144;
+    if (co < d.Cout && ci0 + cl < d.Cin) out[((size_t)co * d.Cin + ci0 + cl) * 9 + t] = sums[e];
+  }
+}
+
+__global__ __launch_bounds__(64) void small_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int nsplit) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+  dw[i] += s;
+}
+
+int wgrad_small_splits(const pdes_conv_desc& d) { return (d.B + 3) / 4; }       // four images (one per wave) per workgroup
+
+int conv_forward_small(const pdes_conv_desc& d, hipStream_t st) {
+  if (!conv_small_applies(d) || !d.wm_fwd) return PDES_ENOSUP;
+  if (!d.x || !d.out || !d.gamma || !d.beta || (d.eval_mode ? (!d.run_mean || !d.run_var) : !d.x_stats)) return PDES_EINVAL;
+  if (!aligned16(d.x) || !aligned16(d.out)) return PDES_EALIGN;
+  const int nt_total = (d.Cout + 15) / 16;
+  const size_t base = (size_t)(4 * d.Cin + d.Cin * SM_CS) * sizeof(float);
+  if (nt_total == 1) {
+    hipLaunchKernelGGL(conv_small_fwd_kernel<1>, dim3(d.B, 1), dim3(256), base + 4 * 1 * 16 * 2 * sizeof(float), st, d, d.wm_fwd, nt_total);
+  } else {
+    hipLaunchKernelGGL(conv_small_fwd_kernel<2>, dim3(d.B, cdiv(nt_total, 2)), dim3(256), base + 4 * 2 * 16 * 2 * sizeof(float), st, d,
+                       d.wm_fwd, nt_total);
+  }
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry) {
+  if (!conv_small_applies(d) || !d.wm_bwd) return PDES_ENOSUP;
+  if (dry) return PDES_OK;
+  if (!d.g || !d.x || !d.t_in || !d.bn_grad || !d.t_stats || !d.x_stats || d.eval_mode) return PDES_EINVAL;
+  if (!aligned16(d.x) || !aligned16(d.t_in)) return PDES_EALIGN;
+  const int nt_total = (d.Cin + 15) / 16;
+  constexpr int NT = 4;
+  const size_t lds = (size_t)(((d.Cout * SM_CS + 3) & ~3) + NT * 16 * 4 + 4 * NT * 16 * 4) * sizeof(float);
+  hipLaunchKernelGGL(conv_small_bwd_kernel<NT>, dim3(d.B, cdiv(nt_total, NT)), dim3(256), lds, st, d, d.wm_bwd, nt_total);
+  PDES_LAUNCH_CHECK();
+  return PDES_OK;
+}
+
+int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st) {
+  if (!conv_small_applies(d) || d.Cout > 32 || !d.ws) return PDES_ENOSUP;
+  const int nsplit = wgrad_small_splits(d);
+  const long long per = (long long)d.Cout * d.Cin * 9;
+  if (nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
+  if (!d.g || !d.x || !d.dw || !d.x_stats) return PDES_EINVAL;
+  const int ntc = d.Cout > 16 ? 2 : 1;
+  const size_t lds = (size_t)(64 + ntc * 16 * 16 * 9 + 4 * (16 * SM_CS + ntc * 16 * SM_GS)) * sizeof(float);
+  dim3 grid(cdiv(d.Cin, 16), nsplit);
+  if (ntc == 1) hipLaunchKernelGGL(conv_small_wgrad_kernel<1>, grid, dim3(256), lds, st, d, d.ws, nsplit);
+  else hipLaunchKernelGGL(conv_small_wgrad_kernel<2>, grid, dim3(256), lds, st, d, d.ws, nsplit);
+  PDES_LAUNCH_CHECK();
+  if (!d.ws_defer) {
+    hipLaunchKernelGGL(small_reduce_kernel, dim3(cdiv((int)per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)per, nsplit);
+    PDES_LAUNCH_CHECK();
+  }
+  return PDES_OK;
+}
+
+bool wgrad_small_applies(const pdes_conv_desc& d) { return conv_small_applies(d) && d.Cout <= 32; }
+
+}  // namespace pdes

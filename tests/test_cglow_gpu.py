@@ -287,3 +287,30 @@ def test_cli_synthetic_run(dev, tmp_path, mode):
     ck = torch.load(os.path.join(os.path.dirname(run[0]), 'checkpoints', 'model_epoch3.pth'), map_location='cpu', weights_only=False)
     assert set(ck) == {'epoch', 'model_state_dict', 'optimizer_state_dict', 'logger'}
     assert os.path.exists(os.path.join(os.path.dirname(run[0]), 'training', 'loss_train.txt'))
+
+
+def test_small_map_matrix_core_kernels_against_the_generic_ones(dev, option):
+    """conv_small.hip (3x3 on the 8x8 level: forward, data gradient, weight gradient with split-K partials over the
+    batch) against the kernels it replaces (PDES_MFMA_SMALL=0), default net, batch 32"""
+    from pde_surrogate_amd.models.glow_msc import MultiScaleCondGlow
+    torch.manual_seed(5)
+    np.random.seed(5)
+    net = MultiScaleCondGlow(32, 1, 3, [3, 4, 4], [6, 6, 6], LUdecompose=True)
+    perturb_glow(net, torch.Generator().manual_seed(6), 0.4)
+    net = net.to(dev).train()
+    gen = torch.Generator().manual_seed(7)
+    x = torch.exp(0.5 * torch.randn(32, 1, 32, 32, generator=gen)).to(dev)
+    eps = [torch.randn((32,) + s, generator=gen).to(dev) for s in net._z_shapes()]
+    res = {}
+    for small in ('1', '0'):
+        option('PDES_MFMA_SMALL', small)
+        net.zero_grad()
+        loss, _, _, y, logp = reverse_kl(net, x, eps, 150.0, 50.0)
+        loss.backward()
+        res[small] = (y.detach().clone(), logp.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert rel_l2(res['1'][0].cpu().numpy(), res['0'][0].cpu().numpy()) < 1e-5
+    np.testing.assert_allclose(res['1'][1].cpu().numpy(), res['0'][1].cpu().numpy(), rtol=1e-5)
+    dev_rel = sorted(((float((res['1'][2][k] - g0).norm() / g0.norm().clamp_min(1e-20)), k) for k, g0 in res['0'][2].items()
+                      if not k.endswith('in_conv.bias')), reverse=True)
+    assert float(np.median([d for d, _ in dev_rel])) < 2e-5, dev_rel[:5]
+    assert dev_rel[0][0] < 3e-2 and sum(d > 2e-3 for d, _ in dev_rel) <= 16, dev_rel[:10]      # (isolated ReLU flips, see G19)
