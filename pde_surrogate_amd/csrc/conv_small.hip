@@ -45,38 +45,54 @@ __device__ __forceinline__ BnS bn_coef_s(const pdes_conv_desc& d, int c) {
   return o;
 }
 
+// (a convolution without a BatchNorm in front -- Conv2dZeros on the encoder's features, glow_msc.py:519 -- takes the same
+//  kernels: the planes are staged as they are, the data gradient is the plain accumulation)
 bool conv_small_applies(const pdes_conv_desc& d) {
-  return opt().mfma_small && !opt().conv_direct && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample && d.has_bn &&
+  return opt().mfma_small && !opt().conv_direct && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
          d.Hin == 8 && d.Win == 8 && d.Hout == 8 && d.Wout == 8 && d.Cin <= 352 && d.Cout <= 352 && d.nrep == PDES_NREP &&
          !d.g_fused;
+}
+// forward only: also the stride-2 transition onto the 8x8 level (16x16 input planes)
+static bool small_fwd_s2_applies(const pdes_conv_desc& d) {
+  return opt().mfma_small && !opt().conv_direct && d.ksize == 3 && d.stride == 2 && d.pad == 1 && !d.upsample && d.has_bn &&
+         d.Hin == 16 && d.Win == 16 && d.Hout == 8 && d.Wout == 8 && d.Cin <= 112 && d.nrep == PDES_NREP;
 }
 
 // ------------------------------------------------------------------------------------------------------- forward
 // grid (B, ceil(N-tiles / NT)), 256 threads.  dynamic LDS: coefficients [Cin] float4 + planes [Cin][SM_CS] + red [4][NT][16][2]
-template <int NT>
+// S = stride: the input planes are (8 S) x (8 S) with a halo column / row on each side
+template <int NT, int S>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
   extern __shared__ __attribute__((aligned(16))) float sm_small[];
+  constexpr int WI = 8 * S, PITCH = WI + 2, CS = (PITCH * PITCH) | 1, HWI = WI * WI;
   const int Cin = d.Cin, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
   float4* cf = reinterpret_cast<float4*>(sm_small);
   float* pl = sm_small + 4 * Cin;
-  float* red = pl + Cin * SM_CS;
-  for (int c = tid; c < Cin; c += 256) {
-    const BnS k = bn_coef_s(d, c);
-    cf[c] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
-  }
-  for (int i = tid; i < Cin * SM_CS; i += 256) pl[i] = 0.f;
+  float* red = pl + Cin * CS;
+  if (d.has_bn)
+    for (int c = tid; c < Cin; c += 256) {
+      const BnS k = bn_coef_s(d, c);
+      cf[c] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
+    }
+  for (int i = tid; i < Cin * CS; i += 256) pl[i] = 0.f;
   __syncthreads();
-  const float* xb = d.x + (size_t)b * d.x_ctot * 64;
-  for (int e = tid; e < Cin * 64; e += 256) {
-    const int c = e >> 6, p = e & 63;
-    const float4 k = cf[c];
-    pl[c * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = fmaxf(0.f, (xb[e] - k.x) * k.y + k.z);
+  const float* xb = d.x + (size_t)b * d.x_ctot * HWI;
+  for (int e = tid; e < Cin * HWI; e += 256) {
+    const int c = e / HWI, p = e % HWI;
+    float z = xb[e];
+    if (d.has_bn) {
+      const float4 k = cf[c];
+      z = fmaxf(0.f, (z - k.x) * k.y + k.z);
+    }
+    pl[c * CS + (p / WI + 1) * PITCH + (p % WI) + 1] = z;
   }
   __syncthreads();
   const int ntp = (nt_total + 7) & ~7, nt_base = blockIdx.y * NT;
   const int ksf = ((Cin + 15) >> 4) * 4;
   const int i = lane & 15, kq = lane >> 4;
-  const int aoff = (2 * wave + (i >> 3) + 1) * SM_PITCH + (i & 7) + 1;
+  // output pixel (oy, ox) reads input (S oy + ky - 1, S ox + kx - 1): with the halo, plane[(S oy + ky) PITCH + S ox + kx]
+  const int aoff = (S * (2 * wave + (i >> 3)) + 1) * PITCH + S * (i & 7) + 1;
+  constexpr int SM_PITCH = PITCH, SM_CS = CS;                    // (shadow the 8x8 constants below)
   v4f acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -135,10 +151,11 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
   float* pl = sm_small;
   float4* cf = reinterpret_cast<float4*>(pl + ((Cout * SM_CS + 3) & ~3));
   float* red = reinterpret_cast<float*>(cf + NT * 16);
-  for (int c = tid; c < NT * 16; c += 256) {
-    const BnS k = bn_coef_s(d, min(nt_base * 16 + c, d.Cin - 1));
-    cf[c] = make_float4(k.mean, k.invstd, k.gamma, k.beta);
-  }
+  if (d.has_bn)
+    for (int c = tid; c < NT * 16; c += 256) {
+      const BnS k = bn_coef_s(d, min(nt_base * 16 + c, d.Cin - 1));
+      cf[c] = make_float4(k.mean, k.invstd, k.gamma, k.beta);
+    }
   for (int i = tid; i < Cout * SM_CS; i += 256) pl[i] = 0.f;
   __syncthreads();
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff) * 64;
@@ -151,33 +168,52 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
   const int ksb = ((Cout + 15) >> 4) * 4;
   const int i = lane & 15, kq = lane >> 4;
   const int aoff = (2 * wave + (i >> 3) + 1) * SM_PITCH + (i & 7) + 1;
+  // the epilogue's operands (raw activation, accumulator T) do not depend on the matrix loop: fetch them first
+  const int opix = (2 * wave + (lane >> 5)) * 8 + 4 * ((lane >> 4) & 1);
+  float4 xpre[NT], tpre[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ci = min((nt_base + t) * 16 + (lane & 15), d.Cin - 1);
+    const size_t idx = ((size_t)b * d.x_ctot + ci) * 64 + opix;
+    xpre[t] = *reinterpret_cast<const float4*>(d.x + idx);
+    tpre[t] = d.t_accumulate ? *reinterpret_cast<const float4*>(d.t_in + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   v4f acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = (v4f){0.f, 0.f, 0.f, 0.f};
   for (int ks = 0; ks < ksb; ++ks) {
     const float* ap = pl + min(4 * ks + kq, Cout - 1) * SM_CS + aoff;
     const float* wp = wm + ((size_t)ks * 9 * ntp + nt_base) * 64 + lane;
+    // all 9 x NT weight fragments of the k-step first (independent loads in flight together), then the MFMAs: with the
+    // load inside the MFMA loop every MFMA waited for its own round trip (54 us per layer instead of ~15)
+    float w[9][NT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w[t][n] = wp[((size_t)t * ntp + n) * 64];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float a = ap[(t / 3 - 1) * SM_PITCH + (t % 3 - 1)];
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wp[((size_t)t * ntp + min(n, ntp - 1 - nt_base)) * 64], acc[n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[t][n], acc[n], 0, 0, 0);
     }
   }
   // epilogue: ReLU mask, gamma, T (+)=, dgamma / dbeta, sums of the channels whose T is complete
-  const int g = lane >> 4, n = lane & 15;
-  const int opix = (2 * wave + (g >> 1)) * 8 + 4 * (g & 1);
+  const int n = lane & 15;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int ci = (nt_base + t) * 16 + n;
     float dg = 0.f, db = 0.f, st = 0.f, sx = 0.f;
-    if (ci < d.Cin) {
+    if (ci < d.Cin && !d.has_bn) {             // plain gradient of an input that is read as it is
+      const size_t idx = ((size_t)b * d.x_ctot + ci) * 64 + opix;
+      *reinterpret_cast<float4*>(d.t_in + idx) = make_float4(tpre[t].x + acc[t][0], tpre[t].y + acc[t][1],
+                                                             tpre[t].z + acc[t][2], tpre[t].w + acc[t][3]);
+    } else if (ci < d.Cin) {
       const float4 k = cf[t * 16 + n];
       const size_t idx = ((size_t)b * d.x_ctot + ci) * 64 + opix;
-      const float4 xv = *reinterpret_cast<const float4*>(d.x + idx);
+      const float4 xv = xpre[t];
       float4* tp = reinterpret_cast<float4*>(d.t_in + idx);
-      float4 tv = d.t_accumulate ? *tp : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 tv = tpre[t];
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
       float to[4] = {tv.x, tv.y, tv.z, tv.w};
       const bool fin = ci >= d.final_c0 && ci < d.final_c1;
@@ -202,6 +238,7 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
       r[0] = dg; r[1] = db; r[2] = st; r[3] = sx;
     }
   }
+  if (!d.has_bn) return;
   __syncthreads();
   for (int e = tid; e < NT * 64; e += 256) {
     const int t = e >> 6, nn = (e >> 2) & 15, q = e & 3;
@@ -230,7 +267,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(pdes_conv_desc d,
   float* sums = sm_small + 64;                          // [NTC*16 co][16 ci][9]
   float* zpl = sums + NTC * 16 * 16 * 9 + wave * WREG;
   float* gpl = zpl + 16 * SM_CS;
-  if (tid < 16) {
+  if (tid < 16 && d.has_bn) {
     const BnS k = bn_coef_s(d, min(ci0 + tid, d.Cin - 1));
     cf[tid] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
   }
@@ -253,8 +290,11 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(pdes_conv_desc d,
       const int cl = e >> 6, p = e & 63;
       float z = 0.f;
       if (valid && ci0 + cl < d.Cin) {
-        const float4 k = cf[cl];
-        z = fmaxf(0.f, (xb[e] - k.x) * k.y + k.z);
+        z = xb[e];
+        if (d.has_bn) {
+          const float4 k = cf[cl];
+          z = fmaxf(0.f, (z - k.x) * k.y + k.z);
+        }
       }
       zpl[cl * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = z;
     }
@@ -310,17 +350,17 @@ __global__ __launch_bounds__(64) void small_reduce_kernel(const float* __restric
 int wgrad_small_splits(const pdes_conv_desc& d) { return (d.B + 3) / 4; }       // four images (one per wave) per workgroup
 
 int conv_forward_small(const pdes_conv_desc& d, hipStream_t st) {
-  if (!conv_small_applies(d) || !d.wm_fwd) return PDES_ENOSUP;
-  if (!d.x || !d.out || !d.gamma || !d.beta || (d.eval_mode ? (!d.run_mean || !d.run_var) : !d.x_stats)) return PDES_EINVAL;
+  const bool s2 = small_fwd_s2_applies(d);
+  if ((!conv_small_applies(d) && !s2) || !d.wm_fwd) return PDES_ENOSUP;
+  if (!d.x || !d.out) return PDES_EINVAL;
+  if (d.has_bn && (!d.gamma || !d.beta || (d.eval_mode ? (!d.run_mean || !d.run_var) : !d.x_stats))) return PDES_EINVAL;
   if (!aligned16(d.x) || !aligned16(d.out)) return PDES_EALIGN;
   const int nt_total = (d.Cout + 15) / 16;
-  const size_t base = (size_t)(4 * d.Cin + d.Cin * SM_CS) * sizeof(float);
-  if (nt_total == 1) {
-    hipLaunchKernelGGL(conv_small_fwd_kernel<1>, dim3(d.B, 1), dim3(256), base + 4 * 1 * 16 * 2 * sizeof(float), st, d, d.wm_fwd, nt_total);
-  } else {
-    hipLaunchKernelGGL(conv_small_fwd_kernel<2>, dim3(d.B, cdiv(nt_total, 2)), dim3(256), base + 4 * 2 * 16 * 2 * sizeof(float), st, d,
-                       d.wm_fwd, nt_total);
-  }
+  const int cs = s2 ? ((18 * 18) | 1) : SM_CS;
+  // one N-tile per workgroup: the staging of a tile is duplicated, but twice the CUs work on the layer
+  const size_t lds = (size_t)(4 * d.Cin + d.Cin * cs + 4 * 16 * 2) * sizeof(float);
+  if (s2) hipLaunchKernelGGL((conv_small_fwd_kernel<1, 2>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
+  else hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
@@ -328,7 +368,8 @@ int conv_forward_small(const pdes_conv_desc& d, hipStream_t st) {
 int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   if (!conv_small_applies(d) || !d.wm_bwd) return PDES_ENOSUP;
   if (dry) return PDES_OK;
-  if (!d.g || !d.x || !d.t_in || !d.bn_grad || !d.t_stats || !d.x_stats || d.eval_mode) return PDES_EINVAL;
+  if (!d.g || !d.x || !d.t_in || d.eval_mode) return PDES_EINVAL;
+  if (d.has_bn && (!d.bn_grad || !d.t_stats || !d.x_stats)) return PDES_EINVAL;
   if (!aligned16(d.x) || !aligned16(d.t_in)) return PDES_EALIGN;
   const int nt_total = (d.Cin + 15) / 16;
   constexpr int NT = 4;
@@ -339,16 +380,17 @@ int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry) 
 }
 
 int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st) {
-  if (!conv_small_applies(d) || d.Cout > 32 || !d.ws) return PDES_ENOSUP;
+  if (!conv_small_applies(d) || d.Cout > 48 || !d.ws) return PDES_ENOSUP;
   const int nsplit = wgrad_small_splits(d);
   const long long per = (long long)d.Cout * d.Cin * 9;
   if (nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
-  if (!d.g || !d.x || !d.dw || !d.x_stats) return PDES_EINVAL;
-  const int ntc = d.Cout > 16 ? 2 : 1;
+  if (!d.g || !d.x || !d.dw || (d.has_bn && !d.x_stats)) return PDES_EINVAL;
+  const int ntc = (d.Cout + 15) / 16;
   const size_t lds = (size_t)(64 + ntc * 16 * 16 * 9 + 4 * (16 * SM_CS + ntc * 16 * SM_GS)) * sizeof(float);
   dim3 grid(cdiv(d.Cin, 16), nsplit);
   if (ntc == 1) hipLaunchKernelGGL(conv_small_wgrad_kernel<1>, grid, dim3(256), lds, st, d, d.ws, nsplit);
-  else hipLaunchKernelGGL(conv_small_wgrad_kernel<2>, grid, dim3(256), lds, st, d, d.ws, nsplit);
+  else if (ntc == 2) hipLaunchKernelGGL(conv_small_wgrad_kernel<2>, grid, dim3(256), lds, st, d, d.ws, nsplit);
+  else hipLaunchKernelGGL(conv_small_wgrad_kernel<3>, grid, dim3(256), lds, st, d, d.ws, nsplit);
   PDES_LAUNCH_CHECK();
   if (!d.ws_defer) {
     hipLaunchKernelGGL(small_reduce_kernel, dim3(cdiv((int)per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)per, nsplit);
@@ -357,6 +399,6 @@ int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st) {
   return PDES_OK;
 }
 
-bool wgrad_small_applies(const pdes_conv_desc& d) { return conv_small_applies(d) && d.Cout <= 32; }
+bool wgrad_small_applies(const pdes_conv_desc& d) { return conv_small_applies(d) && d.Cout <= 48; }
 
 }  // namespace pdes

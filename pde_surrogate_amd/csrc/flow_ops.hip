@@ -275,17 +275,27 @@ __global__ __launch_bounds__(PB) void flow_mix_bwd_kernel(pdes_conv_desc d) {
   const float* g = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HW;
   const float* y = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW;
   const bool act = p0 + tid < HW;
-  for (int c = 0; c < C; ++c) {
-    float xv = 0.f, gv = 0.f, yv = 0.f;
-    if (act) {
-      xv = x[(size_t)c * HW + p0 + tid];
-      gv = g[(size_t)c * HW + p0 + tid] / d.p0[c];
-      yv = y[(size_t)c * HW + p0 + tid];
+  // eight channels' loads in flight together (one channel at a time, the wave reductions in between serialised the
+  // round trips: 30 us per layer on the 16x16 / 8x8 levels)
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    float xv[8], gv[8], yv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = min(c0 + j, C - 1);
+      xv[j] = act ? x[(size_t)c * HW + p0 + tid] : 0.f;
+      gv[j] = act ? g[(size_t)c * HW + p0 + tid] : 0.f;
+      yv[j] = act ? y[(size_t)c * HW + p0 + tid] : 0.f;
     }
-    xs[c * (PB + 1) + tid] = xv;
-    gs[c * (PB + 1) + tid] = gv;
-    const float a = wave_sum(-gv * yv), bsum = wave_sum(-gv);
-    if ((tid & 63) == 0) { part[(0 * C + c) * NW + (tid >> 6)] = a; part[(1 * C + c) * NW + (tid >> 6)] = bsum; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      if (c >= C) break;
+      const float gq = gv[j] / d.p0[c];
+      xs[c * (PB + 1) + tid] = xv[j];
+      gs[c * (PB + 1) + tid] = gq;
+      const float a = wave_sum(-gq * yv[j]), bsum = wave_sum(-gq);
+      if ((tid & 63) == 0) { part[(0 * C + c) * NW + (tid >> 6)] = a; part[(1 * C + c) * NW + (tid >> 6)] = bsum; }
+    }
   }
   __syncthreads();
   if (act) {

@@ -697,7 +697,8 @@ class _HipNet(nn.Module):
         # matrix-core weight images for the 1x1 / 3x3 stride-1 convolutions with >= 16 input channels
         self._packed_mfma, mitems, mmx = {}, [], 0
         for s in self._specs:
-            if s.conv is None or s.k not in (1, 3, 5) or not s.bn or (s.stride != 1 and not (s.stride == 2 and s.k == 3)):
+            raw3 = getattr(s, 'kind', None) == 'raw' and s.k == 3 and s.stride == 1      # conditional Glow: Conv2dZeros on raw features
+            if s.conv is None or s.k not in (1, 3, 5) or not (s.bn or raw3) or (s.stride != 1 and not (s.stride == 2 and s.k == 3)):
                 continue
             kk = s.k * s.k
             pad128 = lambda n: (n + 127) // 128 * 128            # N-tiles are padded to a multiple of 8
