@@ -136,9 +136,10 @@ int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* im
  * acc, flags).  Buffers without a BatchNorm consumer keep their gradient in the same T tensor (fin_tstats = NULL); a
  * buffer read BOTH through BatchNorms and directly collects the direct consumers' gradients in a second tensor that
  * the producer's finalize adds (g_add).  H*W must be a multiple of 4. */
-#define PDES_OP_COPY 4        /* out[:, out_coff + c] = x[:, c], c < Cin = Cout (torch.cat((y1, cond), 1), glow_msc.py:321,339;
-                                 torch.cat((x, out), 1), :43), out_stats accumulated.  Backward: t_in[:, c] (+)= g[:, g_coff + c]
-                                 (after this descriptor's finalize); t_in = NULL: nothing (input data) */
+#define PDES_OP_COPY 4        /* out[:, out_coff + c] = x[:, c], c < Cin, and (Cout > Cin) out[:, out_coff + Cin + c] = x2[:, c],
+                                 c < Cout - Cin: torch.cat((y1, cond), 1) of glow_msc.py:321,339 in one launch (torch.cat((x, out), 1),
+                                 :43, with Cout = Cin); out_stats accumulated.  Backward (after this descriptor's finalize):
+                                 t_in[:, c] (+)= g[:, g_coff + c], t2[:, c] += g[:, g_coff + Cin + c]; NULL targets: input data */
 #define PDES_OP_BIAS_SCALE 5  /* in place: out = (out + p0[c]) * exp(3 p1[c]) on channels [out_coff, out_coff + Cout); p1 = NULL: bias
                                  only (nn.Conv2d(bias=True), glow_msc.py:34-35; Conv2dZeros, :237-252).  out_stats accumulated when
                                  given (then this descriptor, not the convolution before it, carries fin_*).  Backward, in place on g:

@@ -61,23 +61,25 @@ static bool small_fwd_s2_applies(const pdes_conv_desc& d) {
 // ------------------------------------------------------------------------------------------------------- forward
 // grid (B, ceil(N-tiles / NT)), 256 threads.  dynamic LDS: coefficients [Cin] float4 + planes [Cin][SM_CS] + red [4][NT][16][2]
 // S = stride: the input planes are (8 S) x (8 S) with a halo column / row on each side
-template <int NT, int S>
-__global__ __launch_bounds__(256) void conv_small_fwd_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
+// KG = K-split wave groups: group g (waves 4g .. 4g+3) multiplies every KG-th k-step; the groups' sums meet in LDS
+// (one workgroup per image is all the parallelism an 8x8 map offers: the serial chain of a wave is what a layer costs)
+template <int NT, int S, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_small_fwd_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
   extern __shared__ __attribute__((aligned(16))) float sm_small[];
-  constexpr int WI = 8 * S, PITCH = WI + 2, CS = (PITCH * PITCH) | 1, HWI = WI * WI;
-  const int Cin = d.Cin, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  constexpr int WI = 8 * S, PITCH = WI + 2, CS = (PITCH * PITCH) | 1, HWI = WI * WI, NTH = 256 * KG;
+  const int Cin = d.Cin, tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kgrp = tid >> 8, b = blockIdx.x;
   float4* cf = reinterpret_cast<float4*>(sm_small);
   float* pl = sm_small + 4 * Cin;
   float* red = pl + Cin * CS;
   if (d.has_bn)
-    for (int c = tid; c < Cin; c += 256) {
+    for (int c = tid; c < Cin; c += NTH) {
       const BnS k = bn_coef_s(d, c);
       cf[c] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
     }
-  for (int i = tid; i < Cin * CS; i += 256) pl[i] = 0.f;
+  for (int i = tid; i < Cin * CS; i += NTH) pl[i] = 0.f;
   __syncthreads();
   const float* xb = d.x + (size_t)b * d.x_ctot * HWI;
-  for (int e = tid; e < Cin * HWI; e += 256) {
+  for (int e = tid; e < Cin * HWI; e += NTH) {
     const int c = e / HWI, p = e % HWI;
     float z = xb[e];
     if (d.has_bn) {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(pdes_conv_desc d, c
   v4f acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = (v4f){0.f, 0.f, 0.f, 0.f};
-  for (int ks = 0; ks < ksf; ++ks) {
+  for (int ks = kgrp; ks < ksf; ks += KG) {
     const float* ap = pl + min(4 * ks + kq, Cin - 1) * SM_CS + aoff;      // (channels past Cin meet zero weights)
     const float* wp = wm + ((size_t)ks * 9 * ntp + nt_base) * 64 + lane;
     float w[9][NT];
@@ -110,6 +112,21 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(pdes_conv_desc d, c
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[t][n], acc[n], 0, 0, 0);
     }
+  }
+  if (KG > 1) {                      // the other groups' partial sums: through LDS (the planes are no longer needed)
+    __syncthreads();
+    v4f* xch = reinterpret_cast<v4f*>(pl);
+    if (kgrp > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) xch[((kgrp - 1) * NT + t) * 256 + (tid & 255)] = acc[t];
+    }
+    __syncthreads();
+    if (kgrp > 0) return;
+#pragma unroll
+    for (int q = 0; q < KG - 1; ++q)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] += xch[(q * NT + t) * 256 + tid];
+    __syncthreads();
   }
   // lane (n = lane & 15, g = lane >> 4): channel n of each N-tile, pixels 4g .. 4g+3 of the wave's two rows
   const int g = lane >> 4, n = lane & 15;
@@ -359,8 +376,10 @@ int conv_forward_small(const pdes_conv_desc& d, hipStream_t st) {
   const int cs = s2 ? ((18 * 18) | 1) : SM_CS;
   // one N-tile per workgroup: the staging of a tile is duplicated, but twice the CUs work on the layer
   const size_t lds = (size_t)(4 * d.Cin + d.Cin * cs + 4 * 16 * 2) * sizeof(float);
-  if (s2) hipLaunchKernelGGL((conv_small_fwd_kernel<1, 2>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
-  else hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
+  if (s2) hipLaunchKernelGGL((conv_small_fwd_kernel<1, 2, 1>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
+  else if (d.Cin >= 64 && opt().mfma_small != 2)
+    hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1, 2>), dim3(d.B, nt_total), dim3(512), lds, st, d, d.wm_fwd, nt_total);
+  else hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1, 1>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

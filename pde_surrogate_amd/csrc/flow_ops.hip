@@ -22,12 +22,15 @@ static bool flow_common_ok(const pdes_conv_desc& d) {
 
 // ------------------------------------------------------------------------------------------------ COPY
 // grid (ceil(HW / 1024), C, B), 256 threads x float4
-__global__ __launch_bounds__(256) void flow_copy_kernel(const float* __restrict__ x, int x_ctot, float* __restrict__ out,
+// channels [0, c1) come from x, the rest from x2 (torch.cat((y1, cond), 1) in one launch)
+__global__ __launch_bounds__(256) void flow_copy_kernel(const float* __restrict__ x, int x_ctot, int c1,
+                                                        const float* __restrict__ x2, int x2_ctot, float* __restrict__ out,
                                                         int out_ctot, int out_coff, int HW, double* __restrict__ stats,
                                                         int nrep, long long rs) {
   __shared__ double red[4][2];
   const int c = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-  const float4* src = reinterpret_cast<const float4*>(x + ((size_t)b * x_ctot + c) * HW);
+  const float4* src = reinterpret_cast<const float4*>(c < c1 ? x + ((size_t)b * x_ctot + c) * HW
+                                                             : x2 + ((size_t)b * x2_ctot + (c - c1)) * HW);
   float4* dst = reinterpret_cast<float4*>(out + ((size_t)b * out_ctot + out_coff + c) * HW);
   const int i = blockIdx.x * 256 + tid;
   float s = 0.f, q = 0.f;
@@ -48,10 +51,19 @@ __global__ __launch_bounds__(256) void flow_copy_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void flow_copy_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
-                                                            float* __restrict__ t, int t_ctot, int HW, int accumulate) {
+                                                            float* __restrict__ t, int t_ctot, int c1, float* __restrict__ t2,
+                                                            int t2_ctot, int HW, int accumulate) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float4* src = reinterpret_cast<const float4*>(g + ((size_t)b * g_ctot + g_coff + c) * HW);
-  float4* dst = reinterpret_cast<float4*>(t + ((size_t)b * t_ctot + c) * HW);
+  float4* dst;
+  if (c < c1) {
+    if (!t) return;
+    dst = reinterpret_cast<float4*>(t + ((size_t)b * t_ctot + c) * HW);
+  } else {
+    if (!t2) return;
+    dst = reinterpret_cast<float4*>(t2 + ((size_t)b * t2_ctot + (c - c1)) * HW);
+    accumulate = 1;                       // the second source's gradient always collects several consumers
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= HW / 4) return;
   float4 v = src[i];
@@ -63,27 +75,30 @@ __global__ __launch_bounds__(256) void flow_copy_bwd_kernel(const float* __restr
 }
 
 static bool copy_ok(const pdes_conv_desc& d) {
-  return flow_common_ok(d) && d.upsample == PDES_OP_COPY && d.Cin == d.Cout && d.Hin == d.Hout && d.Win == d.Wout &&
-         (d.Hin * d.Win) % 4 == 0 && d.x && d.out;
+  if (!(flow_common_ok(d) && d.upsample == PDES_OP_COPY && d.Hin == d.Hout && d.Win == d.Wout && (d.Hin * d.Win) % 4 == 0 &&
+        d.x && d.out))
+    return false;
+  if (d.Cout == d.Cin) return true;
+  return d.Cout > d.Cin && d.x2 && d.Cout - d.Cin <= d.x2_ctot && aligned16(d.x2);
 }
 
 int flow_copy_forward(const pdes_conv_desc& d, hipStream_t st) {
   if (!copy_ok(d)) return PDES_EINVAL;
   if (!aligned16(d.x) || !aligned16(d.out)) return PDES_EALIGN;
   const int HW = d.Hin * d.Win;
-  hipLaunchKernelGGL(flow_copy_kernel, dim3(cdiv(HW / 4, 256), d.Cin, d.B), dim3(256), 0, st, d.x, d.x_ctot, d.out,
-                     d.out_ctot, d.out_coff, HW, d.out_stats, d.nrep, d.rep_stride);
+  hipLaunchKernelGGL(flow_copy_kernel, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, d.x, d.x_ctot, d.Cin, d.x2,
+                     d.x2_ctot, d.out, d.out_ctot, d.out_coff, HW, d.out_stats, d.nrep, d.rep_stride);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
 
 int flow_copy_backward(const pdes_conv_desc& d, hipStream_t st) {
   if (!copy_ok(d)) return PDES_EINVAL;
-  if (!d.t_in) return PDES_OK;                       // the source is input data
-  if (!d.g || !aligned16(d.g) || !aligned16(d.t_in)) return PDES_EINVAL;
+  if (!d.t_in && !d.t2) return PDES_OK;              // the sources are input data
+  if (!d.g || !aligned16(d.g) || (d.t_in && !aligned16(d.t_in)) || (d.t2 && !aligned16(d.t2))) return PDES_EINVAL;
   const int HW = d.Hin * d.Win;
-  hipLaunchKernelGGL(flow_copy_bwd_kernel, dim3(cdiv(HW / 4, 256), d.Cin, d.B), dim3(256), 0, st, d.g, d.g_ctot, d.g_coff,
-                     d.t_in, d.x_ctot, HW, d.t_accumulate);
+  hipLaunchKernelGGL(flow_copy_bwd_kernel, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, d.g, d.g_ctot, d.g_coff,
+                     d.t_in, d.x_ctot, d.Cin, d.t2, d.x2_ctot, HW, d.t_accumulate);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

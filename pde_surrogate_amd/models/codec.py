@@ -271,7 +271,63 @@ def _get(root, path):
 
 
 # ------------------------------------------------------------------------------------------------
-class _Engine:
+class _EngineBase:
+    """what every descriptor-chain engine shares: the split-K scratch plan of its weight gradients and the side streams"""
+
+    def _chain_specs(self):
+        return self.net._specs
+
+    def _plan_wgrad_scratch(self):
+        """per-layer split-K scratch so that ONE reduce launch finishes every weight gradient"""
+        L = _lib.lib()
+        self._wgrad_ws, items, mx = [], [], 0
+        for i, s in enumerate(self._chain_specs()):
+            d = self.descs[i]
+            if s.conv is None:                         # an operator descriptor: no weights
+                continue
+            d.ws_bytes = 1 << 40                       # plan without a scratch limit
+            ns, fl = _I(0), ctypes.c_longlong(0)
+            rc = L.pdes_conv_wgrad_plan(self.ctx, ctypes.byref(d), ctypes.byref(ns), ctypes.byref(fl))
+            if rc != 0:                                # generic kernel: atomics into dw, shared scratch unused
+                d.ws, d.ws_bytes, d.ws_defer = self.net._ws.data_ptr(), self.net._ws.numel() * 4, 0
+                continue
+            buf = torch.empty(fl.value, device=self.dev, dtype=torch.float32)
+            self._wgrad_ws.append(buf)
+            d.ws, d.ws_bytes, d.ws_defer = buf.data_ptr(), fl.value * 4, 1
+            it = ReduceItem()
+            it.part, it.dw, it.n, it.nsplit = buf.data_ptr(), d.dw, s.cout * s.cin * s.k * s.k, ns.value
+            items.append(it)
+            mx = max(mx, it.n)
+        self._reduce_n, self._reduce_max = len(items), mx
+        # host map descriptor -> row of the reduce table (-1: no deferred scratch), for pdes_backward
+        idx, k = [], 0
+        for d in self.descs:
+            if d.ws_defer:
+                idx.append(k); k += 1
+            else:
+                idx.append(-1)
+        self._reduce_index = (_I * len(idx))(*idx)
+        if items:
+            arr = (ReduceItem * len(items))(*items)
+            self._reduce_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+
+    def _side_stream(self, which='a'):
+        """second HIP stream for the weight gradients (one per network and device), at the LOWEST queue priority: free
+        workgroup slots go to the finalize -> data-gradient chain on the main stream first, the weight gradients fill
+        what is left"""
+        key = self.dev if which == 'a' else (self.dev, which)
+        side = self.net._side_streams.get(key)
+        if side is None:
+            try:
+                least = torch.cuda.Stream.priority_range()[0]
+            except Exception:
+                least = 0
+            side = self.net._side_streams[key] = torch.cuda.Stream(self.dev, priority=least)
+        return side
+
+
+
+class _Engine(_EngineBase):
     """Activation/accumulator buffers + kernel descriptors for one (batch, size, device)."""
 
     def __init__(self, net, B, hin, win):
@@ -417,52 +473,6 @@ class _Engine:
         self.max_c = max(it.C for it in items)
         arr = (BnItem * len(items))(*items)
         self.bn_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-
-    def _plan_wgrad_scratch(self):
-        """per-layer split-K scratch so that ONE reduce launch finishes every weight gradient"""
-        L = _lib.lib()
-        self._wgrad_ws, items, mx = [], [], 0
-        for i, s in enumerate(self.net._specs):
-            d = self.descs[i]
-            d.ws_bytes = 1 << 40                       # plan without a scratch limit
-            ns, fl = _I(0), ctypes.c_longlong(0)
-            rc = L.pdes_conv_wgrad_plan(self.ctx, ctypes.byref(d), ctypes.byref(ns), ctypes.byref(fl))
-            if rc != 0:                                # generic kernel: atomics into dw, shared scratch unused
-                d.ws, d.ws_bytes, d.ws_defer = self.net._ws.data_ptr(), self.net._ws.numel() * 4, 0
-                continue
-            buf = torch.empty(fl.value, device=self.dev, dtype=torch.float32)
-            self._wgrad_ws.append(buf)
-            d.ws, d.ws_bytes, d.ws_defer = buf.data_ptr(), fl.value * 4, 1
-            it = ReduceItem()
-            it.part, it.dw, it.n, it.nsplit = buf.data_ptr(), d.dw, s.cout * s.cin * s.k * s.k, ns.value
-            items.append(it)
-            mx = max(mx, it.n)
-        self._reduce_n, self._reduce_max = len(items), mx
-        # host map descriptor -> row of the reduce table (-1: no deferred scratch), for pdes_backward
-        idx, k = [], 0
-        for d in self.descs:
-            if d.ws_defer:
-                idx.append(k); k += 1
-            else:
-                idx.append(-1)
-        self._reduce_index = (_I * len(idx))(*idx)
-        if items:
-            arr = (ReduceItem * len(items))(*items)
-            self._reduce_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
-
-    def _side_stream(self, which='a'):
-        """second HIP stream for the weight gradients (one per network and device), at the LOWEST queue priority: free
-        workgroup slots go to the finalize -> data-gradient chain on the main stream first, the weight gradients fill
-        what is left"""
-        key = self.dev if which == 'a' else (self.dev, which)
-        side = self.net._side_streams.get(key)
-        if side is None:
-            try:
-                least = torch.cuda.Stream.priority_range()[0]
-            except Exception:
-                least = 0
-            side = self.net._side_streams[key] = torch.cuda.Stream(self.dev, priority=least)
-        return side
 
     # -- launches -------------------------------------------------------------------------------
     def forward(self, x, training, defer_running=False):

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from .codec import BnItem, ConvDesc, ReduceItem, _HipNet, _Lease, _get, _pad16
+from .codec import BnItem, ConvDesc, _EngineBase, _HipNet, _Lease, _get, _pad16
 
 _I = ctypes.c_int
 _P = ctypes.c_void_p
@@ -32,6 +32,7 @@ _P = ctypes.c_void_p
 OP_COPY, OP_BIAS_SCALE, OP_COUPLING, OP_MIX, OP_UNSQUEEZE, OP_GAUSS = 4, 5, 6, 7, 8, 9       # include/pdes_hip.h
 FLOW_FORWARD, GAUSS_DETACH_LSD = 1, 2
 MAX_MIX_CHANNELS = 48
+_MERGE_COPY = True        # torch.cat((y1, cond), 1) as ONE two-source copy descriptor (False: one per source; A/B only)
 
 
 class FlowItem(ctypes.Structure):
@@ -185,8 +186,12 @@ def _coupling_net(specs, bufs, lay, z, nb, hb, n1, n2, cond, cc, r, growth, with
     cn = n1 + cc
     bufs[nb] = [cn + 3 * growth, r]
     bufs[hb] = [2 * n2, r]
-    specs.append(_Spec(OP_COPY, z, nb, n1, n1, r, grad='T' if with_grad else None))
-    specs.append(_Spec(OP_COPY, cond, nb, cc, cc, r, dst_coff=n1, grad='D' if with_grad else None))
+    if _MERGE_COPY:
+        specs.append(_Spec(OP_COPY, z, nb, n1, n1 + cc, r, grad='T' if with_grad else None, src2=cond,
+                           grad2='D' if with_grad else None))
+    else:
+        specs.append(_Spec(OP_COPY, z, nb, n1, n1, r, grad='T' if with_grad else None))
+        specs.append(_Spec(OP_COPY, cond, nb, cc, cc, r, dst_coff=n1, grad='D' if with_grad else None))
     cp = lay + '.coupling.coupling_nn'
     for k in range(1, 4):
         specs.append(_Spec('conv', nb, nb, cn + (k - 1) * growth, growth, r, dst_coff=cn + (k - 1) * growth,
@@ -297,7 +302,7 @@ def _plan_glow_forward(y_channels, enc_blocks, flow_blocks, lu, mix_index, growt
 
 
 # ------------------------------------------------------------------------------------------------
-class _GlowEngine:
+class _GlowEngine(_EngineBase):
     """activation / gradient buffers, accumulator arena and descriptors of generate() for one (batch, size, device)"""
 
     def __init__(self, net, B, H, W, plan=None):
@@ -326,7 +331,7 @@ class _GlowEngine:
                       if k not in inputs and k != 'out'}
         # gradients of buffers that are read both through BatchNorms and as they are (the encoder's features): one flat
         # allocation, cleared at the start of every backward pass
-        direct = [s.src for s in specs if s.x.get('grad') == 'D']
+        direct = [s.src for s in specs if s.x.get('grad') == 'D'] + [s.x['src2'] for s in specs if s.x.get('grad2') == 'D']
         self.direct = sorted(set(direct))
         n_d = sum(bufs[k][0] * self.buf_hw[k][0] * self.buf_hw[k][1] * B for k in self.direct)
         self.Dflat = torch.zeros(max(n_d, 1), **f32)
@@ -471,6 +476,10 @@ class _GlowEngine:
                 if tgt is not None:
                     d.t_in = (self.D if tgt == 'D' else self.T)[s.src].data_ptr()
                     d.t_accumulate = 1
+                if s.x.get('src2'):
+                    d.x2, d.x2_ctot = self.X[s.x['src2']].data_ptr(), bufs[s.x['src2']][0]
+                    if s.x.get('grad2') == 'D':
+                        d.t2 = self.D[s.x['src2']].data_ptr()
             elif s.kind == OP_BIAS_SCALE:
                 d.p0 = _get_param(net, s.x['bias']).data_ptr()
                 d.p1 = _get_param(net, s.x['scale_p']).data_ptr() if s.x['scale_p'] else None
@@ -536,46 +545,8 @@ class _GlowEngine:
     def buf_hw_of(res, H, W):
         return H // res[1], W // res[1]
 
-    def _plan_wgrad_scratch(self):
-        """per-layer split-K scratch so that ONE reduce launch finishes every weight gradient (as codec._Engine)"""
-        L = _lib.lib()
-        self._wgrad_ws, items, mx = [], [], 0
-        idx = []
-        for i, s in enumerate(self.specs):
-            d = self.descs[i]
-            if s.kind not in ('conv', 'raw'):
-                idx.append(-1)
-                continue
-            d.ws_bytes = 1 << 40
-            ns, fl = _I(0), ctypes.c_longlong(0)
-            rc = L.pdes_conv_wgrad_plan(self.ctx, ctypes.byref(d), ctypes.byref(ns), ctypes.byref(fl))
-            if rc != 0:
-                d.ws, d.ws_bytes, d.ws_defer = self.net._ws.data_ptr(), self.net._ws.numel() * 4, 0
-                idx.append(-1)
-                continue
-            buf = torch.empty(fl.value, device=self.dev, dtype=torch.float32)
-            self._wgrad_ws.append(buf)
-            d.ws, d.ws_bytes, d.ws_defer = buf.data_ptr(), fl.value * 4, 1
-            it = ReduceItem()
-            it.part, it.dw, it.n, it.nsplit = buf.data_ptr(), d.dw, s.cout * s.cin * s.k * s.k, ns.value
-            idx.append(len(items))
-            items.append(it)
-            mx = max(mx, it.n)
-        self._reduce_n, self._reduce_max = len(items), mx
-        self._reduce_index = (_I * len(idx))(*idx)
-        if items:
-            self._reduce_table = torch.frombuffer(bytearray(bytes((ReduceItem * len(items))(*items))), dtype=torch.uint8).to(self.dev)
-
-    def _side_stream(self, which='a'):
-        key = self.dev if which == 'a' else (self.dev, which)
-        side = self.net._side_streams.get(key)
-        if side is None:
-            try:
-                least = torch.cuda.Stream.priority_range()[0]
-            except Exception:
-                least = 0
-            side = self.net._side_streams[key] = torch.cuda.Stream(self.dev, priority=least)
-        return side
+    def _chain_specs(self):
+        return self.specs
 
     # -- launches -------------------------------------------------------------------------------
     def forward(self, x, eps_list, training):

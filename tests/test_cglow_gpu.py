@@ -314,3 +314,37 @@ def test_small_map_matrix_core_kernels_against_the_generic_ones(dev, option):
                       if not k.endswith('in_conv.bias')), reverse=True)
     assert float(np.median([d for d, _ in dev_rel])) < 2e-5, dev_rel[:5]
     assert dev_rel[0][0] < 3e-2 and sum(d > 2e-3 for d, _ in dev_rel) <= 16, dev_rel[:10]      # (isolated ReLU flips, see G19)
+
+
+def test_reverse_kl_trainer_data_parallel_path_one_rank(dev):
+    """the trainer's data-parallel branch (parameter broadcast, flat all-reduce over RCCL, grad_scale = 1 / world) with a
+    process group of ONE rank must reproduce the single-process step"""
+    import os
+    import torch.distributed as dist
+    from pde_surrogate_amd.train import ReverseKLTrainer
+    g = golden('G18_cglow_small.npz')
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29741')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        pg = dist.new_group([0])
+        x = torch.from_numpy(g['x']).to(dev)
+        gen = torch.Generator().manual_seed(9)
+        noise = [[torch.randn(e.shape, generator=gen).to(dev) for e in _eps(g, dev)] for _ in range(3)]
+        finals = []
+        for group in (None, pg):
+            net = _small(g, dev).train()
+            tr = ReverseKLTrainer(net, 4, 16, lr=1e-3, device=dev, process_group=group)
+            assert tr.dp == (group is not None)
+            for eps in noise:
+                tr.step(x, 1e-3, eps_list=eps)
+            torch.cuda.synchronize()
+            finals.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), tr.epoch_means()))
+        np.testing.assert_allclose(finals[1][1], finals[0][1], rtol=1e-5)
+        assert rel_l2(finals[1][0].cpu().numpy(), finals[0][0].cpu().numpy()) < 1e-4
+    finally:
+        if created:
+            dist.destroy_process_group()

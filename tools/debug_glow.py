@@ -57,7 +57,7 @@ def main():
                 if nx.x['scale_p']:
                     exp = exp * torch.exp(G._get_param(net, nx.x['scale_p']).view(1, -1, 1, 1) * 3)
         elif s.kind == G.OP_COPY:
-            exp = src[:, :s.cin]
+            exp = src[:, :s.cin] if not s.x.get('src2') else torch.cat([src[:, :s.cin], X[s.x['src2']]], 1)
         elif s.kind == G.OP_COUPLING:
             h = X[s.x['h']]
             n2 = s.cin // 2
