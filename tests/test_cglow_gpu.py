@@ -350,3 +350,42 @@ def test_reverse_kl_trainer_data_parallel_path_one_rank(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_four_levels_odd_batch_against_the_cpu_oracle(dev):
+    """a four-level flow (48-channel invertible convolution at the top: the 64-pixel-block variant of the mix kernels; a
+    4x4 coarsest level on the generic convolution kernels) at batch 6 (weight-gradient splits of unequal size) against
+    oracle/glow.py on the CPU -- there is no reference fixture for this configuration, the oracle is pinned by G18-G20"""
+    from oracle import glow as oglow
+    from pde_surrogate_amd.models.glow_msc import MultiScaleCondGlow
+    torch.manual_seed(21)
+    np.random.seed(21)
+    net = MultiScaleCondGlow(32, 1, 3, [2, 2, 2, 2], [2, 2, 2, 2], LUdecompose=True)
+    perturb_glow(net, torch.Generator().manual_seed(22), 0.7)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(23)
+    x = torch.exp(0.5 * torch.randn(6, 1, 32, 32, generator=gen))
+    eps = [torch.randn((6,) + s, generator=gen) for s in net._z_shapes()]
+    assert [tuple(e.shape[1:]) for e in eps] == oglow.latent_shapes(sd, 3, 32) == [(6, 16, 16), (12, 8, 8), (48, 4, 4)]
+    keys = oglow.param_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    loss_o, _, _, y_o = oglow.reverse_kl_loss(sd, x, eps, 150.0, 50.0, True)
+    loss_o.backward()
+    net = net.to(dev).train()
+    loss, _, _, y, logp = reverse_kl(net, x.to(dev), [e.to(dev) for e in eps], 150.0, 50.0)
+    loss.backward()
+    assert rel_l2(y.detach().cpu().numpy(), y_o.detach().numpy()) < 2e-5
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 5e-5 * abs(float(loss_o.detach()))
+    gmax = max(float(sd[k].grad.norm()) for k in keys)
+    dev_rel = sorted(((float((p.grad.cpu() - sd[k].grad).norm()) / (float(sd[k].grad.norm()) + 1e-6 * gmax), k)
+                      for k, p in net.named_parameters() if not k.endswith('in_conv.bias')), reverse=True)   # (rounding noise)
+    assert float(np.median([d for d, _ in dev_rel])) < 1e-4, dev_rel[:5]
+    assert dev_rel[0][0] < 3e-2 and sum(d > 2e-3 for d, _ in dev_rel) <= 8, dev_rel[:10]
+    # the y -> z direction recovers the noise at every level
+    net.eval()
+    with torch.no_grad():
+        ye, _ = net.generate(x.to(dev), [e.to(dev) for e in eps])
+        _, _, rec = net(ye, x.to(dev), return_eps=True)
+    for r, e in zip(rec, eps):
+        assert rel_l2(r.cpu().numpy(), e.numpy()) < 2e-3
