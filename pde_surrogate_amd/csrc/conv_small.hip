@@ -377,7 +377,11 @@ int conv_forward_small(const pdes_conv_desc& d, hipStream_t st) {
   // one N-tile per workgroup: the staging of a tile is duplicated, but twice the CUs work on the layer
   const size_t lds = (size_t)(4 * d.Cin + d.Cin * cs + 4 * 16 * 2) * sizeof(float);
   if (s2) hipLaunchKernelGGL((conv_small_fwd_kernel<1, 2, 1>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
-  else if (d.Cin >= 64 && opt().mfma_small != 2)
+  // K-split wave groups (PDES_MFMA_SMALL=2: none, =3: at most two): stand-alone 40.8 -> 23.0 us (two groups) for the
+  // 176 -> 24 layer, 24.0 -> 14.6 us for 84 -> 16
+  else if (d.Cin >= (opt().mfma_small == 4 ? 128 : 96) && opt().mfma_small != 2 && opt().mfma_small != 3)
+    hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1, 4>), dim3(d.B, nt_total), dim3(1024), lds, st, d, d.wm_fwd, nt_total);
+  else if (d.Cin >= (opt().mfma_small == 4 ? 64 : 32) && opt().mfma_small != 2)
     hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1, 2>), dim3(d.B, nt_total), dim3(512), lds, st, d, d.wm_fwd, nt_total);
   else hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1, 1>), dim3(d.B, nt_total), dim3(256), lds, st, d, d.wm_fwd, nt_total);
   PDES_LAUNCH_CHECK();
