@@ -139,7 +139,9 @@ int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* im
 #define PDES_OP_COPY 4        /* out[:, out_coff + c] = x[:, c], c < Cin, and (Cout > Cin) out[:, out_coff + Cin + c] = x2[:, c],
                                  c < Cout - Cin: torch.cat((y1, cond), 1) of glow_msc.py:321,339 in one launch (torch.cat((x, out), 1),
                                  :43, with Cout = Cin); out_stats accumulated.  Backward (after this descriptor's finalize):
-                                 t_in[:, c] (+)= g[:, g_coff + c], t2[:, c] += g[:, g_coff + Cin + c]; NULL targets: input data */
+                                 t_in[:, c] (+)= g[:, g_coff + c], t2[:, c] += g[:, g_coff + Cin + c]; NULL targets: input data.
+                                 With g_fused = 1 (set by the CALLER for this operator) pdes_backward skips the finalize launch and the
+                                 backward kernel applies it while reading g = T */
 #define PDES_OP_BIAS_SCALE 5  /* in place: out = (out + p0[c]) * exp(3 p1[c]) on channels [out_coff, out_coff + Cout); p1 = NULL: bias
                                  only (nn.Conv2d(bias=True), glow_msc.py:34-35; Conv2dZeros, :237-252).  out_stats accumulated when
                                  given (then this descriptor, not the convolution before it, carries fin_*).  Backward, in place on g:

@@ -50,10 +50,39 @@ __global__ __launch_bounds__(256) void flow_copy_kernel(const float* __restrict_
   }
 }
 
+// FUSED (pdes_conv_desc.g_fused): `g` still holds the accumulator T of the copied channels; the BatchNorm-backward
+// finalize  dL/dx = invstd (T - mean(T) - xhat mean(T xhat))  is applied here, on the way to the sources' gradients
+// (`act` = the copied activation, the statistics as in bn_bwd_finalize_kernel), instead of a separate pass over T
+template <bool FUSED>
 __global__ __launch_bounds__(256) void flow_copy_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
                                                             float* __restrict__ t, int t_ctot, int c1, float* __restrict__ t2,
-                                                            int t2_ctot, int HW, int accumulate) {
+                                                            int t2_ctot, int HW, int accumulate, const float* __restrict__ act,
+                                                            const double* __restrict__ x_stats, const double* __restrict__ t_stats,
+                                                            int B, float eps, long long rs) {
   const int c = blockIdx.y, b = blockIdx.z;
+  __shared__ float sc[4];
+  __shared__ double sums[4];
+  if (FUSED) {
+    if (threadIdx.x < 64) {          // 4 quantities x PDES_NREP(=16) replicas: one load per lane, 16-lane shuffle reduction
+      const int q = threadIdx.x >> 4, r = threadIdx.x & 15;
+      double v = (q < 2 ? x_stats : t_stats)[(long long)r * rs + 2 * (g_coff + c) + (q & 1)];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+      if (r == 0) sums[q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double inv_n = 1.0 / ((double)B * HW);
+      const double m = sums[0] * inv_n;
+      double var = sums[1] * inv_n - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      sc[0] = (float)m;
+      sc[1] = (float)(1.0 / sqrt(var + (double)eps));
+      sc[2] = (float)(sums[2] * inv_n);
+      sc[3] = (float)(sums[3] * inv_n);
+    }
+    __syncthreads();
+  }
   const float4* src = reinterpret_cast<const float4*>(g + ((size_t)b * g_ctot + g_coff + c) * HW);
   float4* dst;
   if (c < c1) {
@@ -67,6 +96,14 @@ __global__ __launch_bounds__(256) void flow_copy_bwd_kernel(const float* __restr
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= HW / 4) return;
   float4 v = src[i];
+  if (FUSED) {
+    const float4 xv = reinterpret_cast<const float4*>(act + ((size_t)b * g_ctot + g_coff + c) * HW)[i];
+    const float mean = sc[0], invstd = sc[1], m1 = sc[2], m2 = sc[3];
+    v.x = invstd * (v.x - m1 - (xv.x - mean) * invstd * m2);
+    v.y = invstd * (v.y - m1 - (xv.y - mean) * invstd * m2);
+    v.z = invstd * (v.z - m1 - (xv.z - mean) * invstd * m2);
+    v.w = invstd * (v.w - m1 - (xv.w - mean) * invstd * m2);
+  }
   if (accumulate) {
     const float4 o = dst[i];
     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -97,8 +134,16 @@ int flow_copy_backward(const pdes_conv_desc& d, hipStream_t st) {
   if (!d.t_in && !d.t2) return PDES_OK;              // the sources are input data
   if (!d.g || !aligned16(d.g) || (d.t_in && !aligned16(d.t_in)) || (d.t2 && !aligned16(d.t2))) return PDES_EINVAL;
   const int HW = d.Hin * d.Win;
-  hipLaunchKernelGGL(flow_copy_bwd_kernel, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, d.g, d.g_ctot, d.g_coff,
-                     d.t_in, d.x_ctot, d.Cin, d.t2, d.x2_ctot, HW, d.t_accumulate);
+  if (d.g_fused) {
+    if (!d.fin_xstats || !d.fin_tstats || d.g_ctot != d.out_ctot || d.g_coff != d.out_coff || d.g_add) return PDES_EINVAL;
+    hipLaunchKernelGGL(flow_copy_bwd_kernel<true>, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, d.g, d.g_ctot,
+                       d.g_coff, d.t_in, d.x_ctot, d.Cin, d.t2, d.x2_ctot, HW, d.t_accumulate, (const float*)d.out, d.fin_xstats,
+                       d.fin_tstats, d.B, d.eps, d.rep_stride);
+  } else {
+    hipLaunchKernelGGL(flow_copy_bwd_kernel<false>, dim3(cdiv(HW / 4, 256), d.Cout, d.B), dim3(256), 0, st, d.g, d.g_ctot,
+                       d.g_coff, d.t_in, d.x_ctot, d.Cin, d.t2, d.x2_ctot, HW, d.t_accumulate, (const float*)nullptr,
+                       (const double*)nullptr, (const double*)nullptr, d.B, d.eps, d.rep_stride);
+  }
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

@@ -32,6 +32,7 @@ _P = ctypes.c_void_p
 OP_COPY, OP_BIAS_SCALE, OP_COUPLING, OP_MIX, OP_UNSQUEEZE, OP_GAUSS = 4, 5, 6, 7, 8, 9       # include/pdes_hip.h
 FLOW_FORWARD, GAUSS_DETACH_LSD = 1, 2
 MAX_MIX_CHANNELS = 48
+_FUSE_COPY_FINALIZE = True   # PDES_OP_COPY backward applies its channels' finalize on load (False: separate launch; A/B only)
 _MERGE_COPY = True        # torch.cat((y1, cond), 1) as ONE two-source copy descriptor (False: one per source; A/B only)
 
 
@@ -476,6 +477,8 @@ class _GlowEngine(_EngineBase):
                 if tgt is not None:
                     d.t_in = (self.D if tgt == 'D' else self.T)[s.src].data_ptr()
                     d.t_accumulate = 1
+                if d.fin_tstats and not d.g_add and _FUSE_COPY_FINALIZE:
+                    d.g_fused = 1                     # the copy's backward applies the BatchNorm-backward finalize itself
                 if s.x.get('src2'):
                     d.x2, d.x2_ctot = self.X[s.x['src2']].data_ptr(), bufs[s.x['src2']][0]
                     if s.x.get('grad2') == 'D':
