@@ -192,8 +192,10 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     b_dirty = false;
     return he == hipSuccess ? PDES_OK : (int)he;
   };
+  const int dbg = opt().debug_chain;
   auto release = [&](int i, bool on_main, hipEvent_t signalled) -> int {
     hipStream_t wsi = (two && (i & 1)) ? wsb : ws;
+    if (dbg == 2) return PDES_OK;
     if (fork && !on_main) {
       hipEvent_t e = signalled;
       hipError_t he = hipSuccess;
@@ -205,6 +207,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       if (he != hipSuccess) return (int)he;
       if (wsi != ws) b_dirty = true;
     }
+    if (dbg == 1) return PDES_OK;
     const int rc = pdes_conv_backward_weight(ctx, &descs[i], 1, on_main ? st : wsi);
     if (rc) return rc;
     if (have_red && reduce_index[i] >= 0) per_done += per_of(i);
@@ -265,7 +268,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     if (d.fin_tstats && !d.g_fused) {
       // this layer's weight gradient is released by the completion of ITS finalize kernel: the fork event rides on
       // that kernel's completion signal, no barrier packet sits between the finalize and the data gradient
-      if (fork && use_signal && i != 0 && !is_resample_op(d)) signalled = cx->events[nev++];
+      if (fork && use_signal && i != 0 && !is_resample_op(d) && dbg != 2) signalled = cx->events[nev++];
       int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
                                            d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
                                            d.rep_stride, st, signalled, d.g_add);
