@@ -882,6 +882,26 @@ class MultiScaleCondGlow(_HipNet):
         pred = self.sample(x_test, n_samples, temperature=temperature)
         return pred.mean(0), pred.var(0)
 
+    def propagate(self, mc_loader, n_samples=20, temperature=1.0, var_samples=10):
+        """uncertainty propagation over a loader of inputs (glow_msc.py:934-968): E[Y] = E_X E[Y|X],
+        Var[Y] = E_X Var(Y|X) + Var_X E[Y|X], each estimated `var_samples` times -> (mean and variance of the estimate of
+        E[Y], mean and variance of the estimate of Var[Y]), every one (C, H, W)"""
+        ey = eyy = None
+        for i in range(var_samples):
+            print(f'propagating for the {i}-th time...')
+            for batch in mc_loader:
+                x_mc = batch[0].to(self.device)
+                y = self.sample(x_mc, n_samples=n_samples, temperature=temperature)
+                if ey is None:
+                    ey = torch.zeros((var_samples,) + tuple(y.shape[2:]), device=self.device)
+                    eyy = torch.zeros_like(ey)
+                ey[i] += y.mean(0).mean(0)
+                eyy[i] += y.pow(2).mean(0).mean(0)
+        ey /= len(mc_loader)
+        eyy /= len(mc_loader)
+        vy = eyy - ey ** 2
+        return ey.mean(0), ey.var(0), vy.mean(0), vy.var(0)
+
     def create_fixed_noise(self, n_samples, batch_size=1):
         return [torch.randn(n_samples, batch_size, *s, device=self.device) for s in self._z_shapes()]
 

@@ -389,3 +389,16 @@ def test_four_levels_odd_batch_against_the_cpu_oracle(dev):
         _, _, rec = net(ye, x.to(dev), return_eps=True)
     for r, e in zip(rec, eps):
         assert rel_l2(r.cpu().numpy(), e.numpy()) < 2e-3
+
+
+def test_propagate_statistics(dev):
+    """MultiScaleCondGlow.propagate (glow_msc.py:934-968): shapes and the identities its four outputs satisfy"""
+    g = golden('G18_cglow_small.npz')
+    net = _small(g, dev).eval()
+    x = torch.from_numpy(g['x']).to(dev)
+    loader = [(x[:2],), (x[2:],)]
+    torch.manual_seed(0)
+    m_mean, m_var, v_mean, v_var = net.propagate(loader, n_samples=3, temperature=1.0, var_samples=2)
+    for t in (m_mean, m_var, v_mean, v_var):
+        assert t.shape == (3, 16, 16) and bool(torch.isfinite(t).all())
+    assert bool((m_var >= 0).all()) and bool((v_var >= 0).all())
