@@ -181,6 +181,8 @@ def main(argv=None):
         logger = checkpoint['logger']
         say(f'Loaded checkpoint at epoch {args.ckpt_epoch}')
     model = model.to(device)
+    if world > 1:
+        torch.manual_seed(args.seed + 1000 * rank)      # the latents' noise differs between the ranks (the parameters do not)
     scheduler = OneCycleScheduler(lr_max=args.lr, div_factor=args.lr_div, pct_start=args.lr_pct)
     sobel_filter = SobelFilter(args.imsize, correct=True, device=device)
     if args.mode == 'fused':
