@@ -62,7 +62,7 @@ __device__ __forceinline__ BnB bn_coef_b3(const pdes_conv_desc& d, int c) {
 }
 
 // grid: (tiles of the map, B, ceil(N-tiles / 8)); dynamic LDS: [kpad32] float4 coefficients (forward) + 2 buffers
-template <int TWG, int MTP, int MODE>
+template <int TWG, int MTP, int MODE, bool APIPE = false>
 __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pdes_conv_desc d, const unsigned short* __restrict__ wb,
                                                           int nt_total) {
   using G = B3Geo<TWG, MTP>;
@@ -205,15 +205,56 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
 
   // one chunk: 9 taps, the weights of the next tap stream into the other register set while this tap multiplies.
   // 9 is odd, so the roles of the two sets swap from chunk to chunk (b0 = set holding tap 0 of this chunk).
+  // A-operand pipeline (PDES_B3_APIPE): the three fragments of the NEXT (tap, M-tile) are read from LDS before the twelve
+  // MFMAs of the current one are issued (a scheduling barrier pins the order), so their ~100-cycle latency hides behind
+  // 192 cycles of matrix work instead of stalling every few instructions (the compiler otherwise reads just in time)
+  auto lda = [&](const unsigned short* tb, int t, int mt, v8bf (&a)[3]) __attribute__((always_inline)) {
+    const unsigned short* ap = tb + (((mt / TWG) + t / 3) * G::PW + (mt % TWG) * 16 + t % 3) * G::KC + a_lane;
+    a[0] = *reinterpret_cast<const v8bf*>(ap);
+    a[1] = *reinterpret_cast<const v8bf*>(ap + G::PLANE);
+    a[2] = *reinterpret_cast<const v8bf*>(ap + 2 * G::PLANE);
+  };
+  auto mfma12 = [&](int mt, const v8bf (&a)[3], const v8bf (&bw)[3][NT_W]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bw[1][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bw[0][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bw[2][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bw[0][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bw[1][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bw[0][nt], acc[mt][nt], 0, 0, 0);
+  };
+  const bool apipe = APIPE;
   auto step = [&](int chunk, Stage& sfree, const Stage& snext, v8bf (&b0)[3][NT_W], v8bf (&b1)[3][NT_W])
       __attribute__((always_inline)) {
     const int buf = chunk & 1;
     const unsigned short* tb = tile + buf * G::BUF;
     issue(min(chunk + 2, nchunk - 1), sfree);
+    if (apipe) {
+      v8bf a0[3], a1[3];
+      lda(tb, 0, 0, a0);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      load_b(chunk * 9 + t + 1, (t & 1) ? b0 : b1);
-      mfma_tap(tb, t / 3, t % 3, (t & 1) ? b1 : b0);
+      for (int t = 0; t < 9; ++t) {
+        load_b(chunk * 9 + t + 1, (t & 1) ? b0 : b1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int k = t * MT + mt;                       // flat index of this (tap, M-tile); the next one is k + 1
+          if (k + 1 < 9 * MT) lda(tb, (k + 1) / MT, (k + 1) % MT, (k & 1) ? a0 : a1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma12(mt, (k & 1) ? a1 : a0, (t & 1) ? b1 : b0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        load_b(chunk * 9 + t + 1, (t & 1) ? b0 : b1);
+        mfma_tap(tb, t / 3, t % 3, (t & 1) ? b1 : b0);
+      }
     }
     if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, snext);
     __syncthreads();
@@ -349,7 +390,10 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
   do {                                                                                                        \
     using GL = B3Geo<TWG_, MT_>;                                                                              \
     const size_t lds = cf + 2 * (size_t)GL::BUF * 2;                                                          \
-    hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE>), grid, block, lds, st, d, wb, nt_total);        \
+    if (opt().b3_apipe && MT_ == 4)                                                                           \
+      hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, true>), grid, block, lds, st, d, wb, nt_total);  \
+    else                                                                                                      \
+      hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, false>), grid, block, lds, st, d, wb, nt_total); \
   } while (0)
   if (twg == 2) { if (mt == 8) PDES_B3_LAUNCH(2, 8); else PDES_B3_LAUNCH(2, 4); }
   else { if (mt == 8) PDES_B3_LAUNCH(1, 8); else PDES_B3_LAUNCH(1, 4); }
