@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void flow_prepare_kernel(const pdes_flow_item*
   const int C = it.C, tid = threadIdx.x;
   __shared__ float A[48 * 48], Bm[48 * 48];
   __shared__ double aug[48][2 * 48 + 1];       // Gauss-Jordan: [W | I]
-  __shared__ double sh_ld, sh_an;
+  __shared__ double sh_ld;
   __shared__ int sh_piv;
   if (it.lu) {
     // Bm = (l * l_mask + I) (u * u_mask + diag(exp(log_s) sign_s)),  W = p Bm
@@ -626,7 +626,6 @@ __global__ __launch_bounds__(256) void flow_prepare_kernel(const pdes_flow_item*
     }
     *it.logdet = (double)it.HW * (an - ls);
   }
-  (void)sh_an;
 }
 
 __global__ __launch_bounds__(256) void flow_param_grads_kernel(const pdes_flow_item* __restrict__ items,

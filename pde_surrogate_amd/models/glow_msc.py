@@ -15,7 +15,6 @@ training through the y -> z direction: that direction is inference-only here), s
 ``x_channels != 1`` (the reference's own encoder only works for 1: glow_msc.py:34-36 vs :495).
 """
 import ctypes
-import math
 import os
 
 import numpy as np

@@ -1,6 +1,6 @@
 """same-process A/B of a plan flag of pde_surrogate_amd.models.glow_msc (two models, alternating):
     python tools/ab_cglow_copy.py [_MERGE_COPY | _FUSE_COPY_FINALIZE]"""
-import contextlib, io, os, sys, time
+import contextlib, io, sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from pde_surrogate_amd.models import glow_msc
