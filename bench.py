@@ -238,7 +238,6 @@ def cglow_timing(dev, steps=60, warm=15, cpu_steps=3):
            'mean_loss_over_the_run': round(means[0], 3), 'finite': bool(np.isfinite(means[0]))}
     if cpu_steps:
         from oracle import glow as oglow
-        import math
         sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
         keys = oglow.param_keys(sd)
         for k in keys:
