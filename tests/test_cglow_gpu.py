@@ -402,3 +402,46 @@ def test_propagate_statistics(dev):
     for t in (m_mean, m_var, v_mean, v_var):
         assert t.shape == (3, 16, 16) and bool(torch.isfinite(t).all())
     assert bool((m_var >= 0).all()) and bool((v_var >= 0).all())
+
+
+def test_clamped_log_stddev_values_and_gradients(dev):
+    """GaussianDiag clamps the log-stddev to [-10, log 5] (glow_msc.py:438): push the split prior's and the top latent's
+    log-stddev channels out of range on both sides through their biases and compare y, log p and every gradient with the
+    CPU oracle (the clamp passes no gradient where it is active; the top latent's log-stddev is detached anyway)"""
+    from oracle import glow as oglow
+    g = golden('G18_cglow_small.npz')
+    net = _small(g, dev).train()
+    with torch.no_grad():
+        b = net.flow.revblock2.split.latent_encoder.conv2d.conv.bias          # 12 = 6 means | 6 log-stddevs
+        b[6:9] += 40.0                                                          # far above log 5 (even after exp(3 scale))
+        b[9:12] -= 200.0                                                        # far below -10
+        t = net.encoder.top_latent.conv.bias                                    # 48 = 24 | 24
+        t[24:30] += 40.0
+        t[30:36] -= 200.0
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.from_numpy(g['x'])
+    eps = [torch.from_numpy(g[f'eps{i}']) for i in range(2)]
+    keys = oglow.param_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    loss_o, _, _, y_o = oglow.reverse_kl_loss(sd, x, eps, 150.0, 50.0, True)
+    loss_o.backward()
+    loss, _, _, y, logp = reverse_kl(net, x.to(dev), [e.to(dev) for e in eps], 150.0, 50.0)
+    loss.backward()
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(logp).all())
+    assert rel_l2(y.detach().cpu().numpy(), y_o.detach().numpy()) < 2e-5
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 5e-5 * abs(float(loss_o.detach()))
+    gmax = max(float(sd[k].grad.norm()) for k in keys)
+    params = dict(net.named_parameters())
+    bad = []
+    for k in keys:
+        if k.endswith('in_conv.bias'):
+            continue
+        ref = sd[k].grad
+        err = float((params[k].grad.cpu() - ref).norm())
+        if not err < 1e-3 * float(ref.norm()) + 1e-6 * gmax:
+            bad.append((k, err, float(ref.norm())))
+    assert len(bad) <= 3, bad[:6]
+    # the clamped channels of the split prior's bias receive exactly no gradient
+    gb = params['flow.revblock2.split.latent_encoder.conv2d.conv.bias'].grad
+    assert float(gb[6:12].abs().max()) == 0.0 and float(sd['flow.revblock2.split.latent_encoder.conv2d.conv.bias'].grad[6:12].abs().max()) == 0.0
