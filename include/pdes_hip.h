@@ -42,7 +42,7 @@ extern "C" {
  *   pdes_context_set_option  key = one of "PDES_CONV_IMPL" ("direct" | "auto"), "PDES_FUSE_FINALIZE",
  *                         "PDES_FUSE_MAXC", "PDES_FUSE_MAXHW", "PDES_FIN_EARLY", "PDES_MFMA_NTW", "PDES_MFMA_MT",
  *                         "PDES_MFMA_NG", "PDES_MFMA_1X1", "PDES_1X1_KSPLIT", "PDES_MFMA_1X1W", "PDES_1X1W_SPI",
- *                         "PDES_MFMA_B3", "PDES_MFMA_B3W", "PDES_MFMA_B3U", "PDES_MFMA_SMALL", "PDES_B3_APIPE", "PDES_B3_MT", "PDES_FEW_R", "PDES_WGRAD_WGS", "PDES_LOSS_NT",
+ *                         "PDES_MFMA_B3", "PDES_MFMA_B3W", "PDES_MFMA_B3U", "PDES_MFMA_SMALL", "PDES_MFMA_B3UB", "PDES_B3_APIPE", "PDES_B3_MT", "PDES_FEW_R", "PDES_WGRAD_WGS", "PDES_LOSS_NT",
  *                         "PDES_LOSS_DMA", "PDES_DEBUG_CHAIN" (timing experiments only, gradients are WRONG: 1 = pdes_backward skips the
  *                         weight-gradient kernels, 2 = and the fork events), "PDES_FORK_SIGNAL" (1: pdes_backward's fork events ride on the finalize
  *                         kernel's completion signal, 0: hipEventRecord); value = decimal string (NULL = default).
@@ -233,6 +233,9 @@ typedef struct pdes_conv_desc {
   const float* p1;
   double* acc;           /* flow ops: fp64 accumulators (replicated like the statistics: nrep, rep_stride) */
   int flags;             /* PDES_FLOW_FORWARD, PDES_GAUSS_DETACH_LSD */
+  /* appended in ABI 15 */
+  const unsigned short* wbu_bwd; /* nearest-x2 + 3x3 layers: split image of the effective sub-pixel weights for the DATA gradient
+                                    (pdes_pack_weights_b3up), or NULL */
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.
@@ -349,11 +352,12 @@ typedef struct pdes_b3_pack_item { /* one wide 3x3 convolution: three-way bf16 s
  * pdes_b3_image_elems (bf16 elements; buffers 16-byte aligned).  total = max elements / 24 over the items. */
 int pdes_pack_weights_b3(const pdes_b3_pack_item* items, int n, int max_elems, void* stream);
 int pdes_b3_image_elems(int Cout, int Cin, long long* fwd_elems, long long* bwd_elems);
-typedef struct pdes_b3up_pack_item { /* one nearest-x2 + 3x3 convolution: split image of its effective 2x2 weights (conv_mfma_b3_up.hip) */
-  const float* w; unsigned short* wbu_fwd; int Cout, Cin;
+typedef struct pdes_b3up_pack_item { /* one nearest-x2 + 3x3 convolution: split images of its effective 2x2 weights (conv_mfma_b3_up.hip,
+                                        and conv_mfma_b3.hip's sub-pixel data gradient); either image may be NULL */
+  const float* w; unsigned short* wbu_fwd; unsigned short* wbu_bwd; int Cout, Cin;
 } pdes_b3up_pack_item;
 int pdes_pack_weights_b3up(const pdes_b3up_pack_item* items, int n, int max_elems, void* stream);   /* max_elems = elements / 24 */
-int pdes_b3up_image_elems(int Cout, int Cin, long long* fwd_elems);
+int pdes_b3up_image_elems(int Cout, int Cin, long long* fwd_elems, long long* bwd_elems);
 /* The four tables above in ONE launch (any of them may be empty: n = 0); max_elems = the largest packed image
  * (work items: elements, or elements / 24 for the bf16 split images).
  * No reference counterpart: the packed images replace the (Cout,Cin,k,k) weight reads of nn.Conv2d

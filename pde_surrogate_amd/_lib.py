@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -42,7 +42,7 @@ SIGNATURES = {
     'pdes_pack_weights_b3': [_c_p, _c_i, _c_i, _c_p],
     'pdes_b3_image_elems': [_c_i, _c_i, _c_p, _c_p],
     'pdes_pack_weights_b3up': [_c_p, _c_i, _c_i, _c_p],
-    'pdes_b3up_image_elems': [_c_i, _c_i, _c_p],
+    'pdes_b3up_image_elems': [_c_i, _c_i, _c_p, _c_p],
     'pdes_bn_update_running': [_c_p, _c_i, _c_i, _c_f, _c_i, ctypes.c_longlong, _c_p],
     'pdes_bn_param_grads': [_c_p, _c_i, _c_i, _c_i, ctypes.c_longlong, _c_p],
     'pdes_adam_step': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, ctypes.c_longlong, _c_p],

@@ -19,6 +19,7 @@ int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st);         // 5x5
 int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st);             // wide 3x3 layers: bf16 x3 split (conv_mfma_b3.hip)
 int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st);          // nearest-x2 + 3x3, sub-pixel form, bf16 x3 split
 int conv_backward_data_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
+int conv_backward_data_b3_up(const pdes_conv_desc& d, hipStream_t st, bool dry = false);     // sub-pixel data gradient, bf16 x3 split
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_forward_small(const pdes_conv_desc& d, hipStream_t st);          // 3x3 on 8x8 maps (conv_small.hip)
 int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
@@ -136,6 +137,7 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
       continue;
     }
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_data_small(descs[i], st);
+    if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_b3_up(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_up_mfma(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_b3(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_data_1x1(descs[i], st);

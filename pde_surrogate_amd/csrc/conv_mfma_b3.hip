@@ -28,7 +28,12 @@ namespace pdes {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
-enum { B3_FWD = 0, B3_BWD = 1 };
+enum { B3_FWD = 0, B3_BWD = 1, B3_UPBWD = 2 };
+// B3_UPBWD: data gradient of nearest-x2 upsampling + 3x3 (sub-pixel form, conv_mfma_up.hip): the K operand is the four
+// parity sub-images G_p[Y][X] = g[2Y + dy][2X + dx] of the output gradient (each a low-resolution map, gathered with
+// stride 2 on the way into LDS), a virtual chunk = (parity, 32 output channels), and each chunk uses the 4 taps of its
+// parity's effective 2x2 kernel at tile offsets (2 - a - dy, 2 - b - dx) instead of 9:
+//     dz[y][x] = sum_p sum_{a,b} Weff_p[a][b] . G_p[y - a - dy + 1][x - b - dx + 1]
 
 template <int TWG, int MT_>
 struct B3Geo {
@@ -74,17 +79,23 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   const int ntp = (nt_total + 7) & ~7;
   const int nt_base = (blockIdx.z * 4 + wave) * NT_W;
 
+  constexpr bool UPB = MODE == B3_UPBWD;
+  constexpr int NTAP = UPB ? 4 : 9;
   const float* kbase;
   int kC, H, W;
   if (MODE == B3_FWD) {
     kC = d.Cin; H = d.Hin; W = d.Win;
     kbase = d.x + (size_t)b * d.x_ctot * H * W;
-  } else {
+  } else if (MODE == B3_BWD) {
     kC = d.Cout; H = d.Hout; W = d.Wout;
     kbase = d.g + ((size_t)b * d.g_ctot + d.g_coff) * H * W;
+  } else {                                    // the tiles are those of the LOW-resolution map
+    kC = d.Cout; H = d.Hin; W = d.Win;
+    kbase = d.g + ((size_t)b * d.g_ctot + d.g_coff) * 4 * H * W;
   }
-  const int HW = H * W;
-  const int nchunk = (kC + G::KC - 1) / G::KC, kpad = nchunk * G::KC;
+  const int HW = UPB ? 4 * H * W : H * W;     // plane stride of the K operand
+  const int nch1 = (kC + G::KC - 1) / G::KC, kpad = nch1 * G::KC;
+  const int nchunk = UPB ? 4 * nch1 : nch1;   // virtual chunks: (parity, 32 channels)
   float4* cf4 = reinterpret_cast<float4*>(smem_b3);                                   // forward only
   unsigned short* tile = reinterpret_cast<unsigned short*>(smem_b3 + (MODE == B3_FWD ? 16 * kpad : 0));
   const int tiles_x = W / G::TW;
@@ -106,23 +117,29 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   const int gy = oy0 - 1 + it_r, gx = ox0 - 1 + it_c;
   const bool row_ok = gy >= 0 && gy < H;
   const bool px_ok = row_ok && (interior || (halo && gx >= 0 && gx < W));
-  const int goff = min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+  const int goff = UPB ? 4 * W * min(max(gy, 0), H - 1) + 2 * min(max(gx, 0), W - 1)       // + dy * 2W + dx per parity
+                       : min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
   const int lds_off = (it_r * G::PW + it_c) * G::KC + 8 * it_o;       // bf16 elements, plane 0
 
   struct Stage { float4 v[8]; };
   Stage sA, sB;
   auto issue = [&](int chunk, Stage& st) __attribute__((always_inline)) {
-    const int c0 = chunk * G::KC + 8 * it_o;
+    const int cq = UPB ? chunk % nch1 : chunk, par = UPB ? chunk / nch1 : 0;
+    const int c0 = cq * G::KC + 8 * it_o;
+    const int poff = UPB ? (par >> 1) * 2 * W + (par & 1) : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float* p = kbase + (size_t)min(c0 + j, kC - 1) * HW + goff;
-      if (interior) st.v[j] = *reinterpret_cast<const float4*>(p);
+      const float* p = kbase + (size_t)min(c0 + j, kC - 1) * HW + goff + poff;
+      if (UPB) {                                                     // every other pixel of the high-resolution row
+        st.v[j].x = p[0];
+        if (interior) { st.v[j].y = p[2]; st.v[j].z = p[4]; st.v[j].w = p[6]; }
+      } else if (interior) st.v[j] = *reinterpret_cast<const float4*>(p);
       else st.v[j].x = *p;                                           // halo (and idle threads: a valid dummy load)
     }
   };
   auto commit = [&](int chunk, int buf, const Stage& st) __attribute__((always_inline)) {
     if (!(interior || halo)) return;
-    const int c0 = chunk * G::KC + 8 * it_o;
+    const int c0 = (UPB ? chunk % nch1 : chunk) * G::KC + 8 * it_o;
     unsigned short* t = tile + buf * G::BUF + lds_off;
     const int npx = interior ? 4 : 1;
 #pragma unroll
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   // B operand: image [(chunk*9 + tap)*ntp + nt][plane][64 lanes][8 bf16]; one 16-byte load per (N-tile, plane)
   v8bf bA[3][NT_W], bB[3][NT_W];
   auto load_b = [&](int ct, v8bf (&dst)[3][NT_W]) __attribute__((always_inline)) {     // ct = chunk * 9 + tap (clamped)
-    const int cc = min(ct, nchunk * 9 - 1);
+    const int cc = min(ct, nchunk * NTAP - 1);
     const unsigned short* p = wb + (((size_t)cc * ntp + nt_base) * 3 * 64 + lane) * 8;
 #pragma unroll
     for (int nt = 0; nt < NT_W; ++nt)
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
 
   // data gradient: the BatchNorm coefficients of the epilogue are fetched before the matrix loop
   BnB kepi[NT_W];
-  if (MODE == B3_BWD) {
+  if (MODE != B3_FWD) {
 #pragma unroll
     for (int nt = 0; nt < NT_W; ++nt) kepi[nt] = bn_coef_b3(d, min((nt_base + nt) * 16 + (lane & 15), d.Cin - 1));
   }
@@ -208,8 +225,12 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   // A-operand pipeline (PDES_B3_APIPE): the three fragments of the NEXT (tap, M-tile) are read from LDS before the twelve
   // MFMAs of the current one are issued (a scheduling barrier pins the order), so their ~100-cycle latency hides behind
   // 192 cycles of matrix work instead of stalling every few instructions (the compiler otherwise reads just in time)
-  auto lda = [&](const unsigned short* tb, int t, int mt, v8bf (&a)[3]) __attribute__((always_inline)) {
-    const unsigned short* ap = tb + (((mt / TWG) + t / 3) * G::PW + (mt % TWG) * 16 + t % 3) * G::KC + a_lane;
+  // tile offset (rows, columns) of tap t: the 3x3 position, or (sub-pixel data gradient) position (2 - a - dy, 2 - b - dx)
+  // of tap (a, b) = (t >> 1, t & 1) of parity `par`
+  auto tap_ky = [&](int t, int par) __attribute__((always_inline)) { return UPB ? 2 - (t >> 1) - (par >> 1) : t / 3; };
+  auto tap_kx = [&](int t, int par) __attribute__((always_inline)) { return UPB ? 2 - (t & 1) - (par & 1) : t % 3; };
+  auto lda = [&](const unsigned short* tb, int t, int mt, int par, v8bf (&a)[3]) __attribute__((always_inline)) {
+    const unsigned short* ap = tb + (((mt / TWG) + tap_ky(t, par)) * G::PW + (mt % TWG) * 16 + tap_kx(t, par)) * G::KC + a_lane;
     a[0] = *reinterpret_cast<const v8bf*>(ap);
     a[1] = *reinterpret_cast<const v8bf*>(ap + G::PLANE);
     a[2] = *reinterpret_cast<const v8bf*>(ap + 2 * G::PLANE);
@@ -233,17 +254,18 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
       __attribute__((always_inline)) {
     const int buf = chunk & 1;
     const unsigned short* tb = tile + buf * G::BUF;
+    const int par = UPB ? chunk / nch1 : 0;
     issue(min(chunk + 2, nchunk - 1), sfree);
     if (apipe) {
       v8bf a0[3], a1[3];
-      lda(tb, 0, 0, a0);
+      lda(tb, 0, 0, par, a0);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        load_b(chunk * 9 + t + 1, (t & 1) ? b0 : b1);
+      for (int t = 0; t < NTAP; ++t) {
+        load_b(chunk * NTAP + t + 1, (t & 1) ? b0 : b1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int k = t * MT + mt;                       // flat index of this (tap, M-tile); the next one is k + 1
-          if (k + 1 < 9 * MT) lda(tb, (k + 1) / MT, (k + 1) % MT, (k & 1) ? a0 : a1);
+          if (k + 1 < NTAP * MT) lda(tb, (k + 1) / MT, (k + 1) % MT, par, (k & 1) ? a0 : a1);
           __builtin_amdgcn_sched_barrier(0);
           mfma12(mt, (k & 1) ? a1 : a0, (t & 1) ? b1 : b0);
           __builtin_amdgcn_sched_barrier(0);
@@ -251,9 +273,9 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        load_b(chunk * 9 + t + 1, (t & 1) ? b0 : b1);
-        mfma_tap(tb, t / 3, t % 3, (t & 1) ? b1 : b0);
+      for (int t = 0; t < NTAP; ++t) {
+        load_b(chunk * NTAP + t + 1, (t & 1) ? b0 : b1);
+        mfma_tap(tb, tap_ky(t, par), tap_kx(t, par), (t & 1) ? b1 : b0);
       }
     }
     if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, snext);
@@ -261,7 +283,11 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   };
   {
     int chunk = 0;
-    for (; chunk + 1 < nchunk; chunk += 2) { step(chunk, sA, sB, bA, bB); step(chunk + 1, sB, sA, bB, bA); }
+    for (; chunk + 1 < nchunk; chunk += 2) {
+      step(chunk, sA, sB, bA, bB);
+      if constexpr (NTAP & 1) step(chunk + 1, sB, sA, bB, bA);       // an odd tap count swaps the roles of the weight sets
+      else step(chunk + 1, sB, sA, bA, bB);
+    }
     if (chunk < nchunk) step(chunk, sA, sB, bA, bB);
   }
 
@@ -375,7 +401,7 @@ static bool b3_shape_ok(const pdes_conv_desc& d, bool bwd) {
 
 template <int MODE>
 static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStream_t st) {
-  const bool bwd = MODE == B3_BWD;
+  const bool bwd = MODE != B3_FWD;
   const int kC = bwd ? d.Cout : d.Cin, nC = bwd ? d.Cin : d.Cout;
   const int nchunk = (kC + 31) / 32, kpad = nchunk * 32, nt_total = (nC + 15) / 16;
   const int W = d.Win, H = d.Hin, twg = W >= 32 ? 2 : 1;
@@ -405,6 +431,18 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
 int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st) {
   if (!b3_enabled() || !d.wb_fwd || !b3_shape_ok(d, false)) return PDES_ENOSUP;
   return launch_b3<B3_FWD>(d, d.wb_fwd, st);
+}
+
+// data gradient of nearest-x2 + 3x3 in the sub-pixel form (B3_UPBWD)
+int conv_backward_data_b3_up(const pdes_conv_desc& d, hipStream_t st, bool dry) {
+  if (!opt().mfma_b3ub || !d.wbu_bwd || d.eval_mode || d.g_fused) return PDES_ENOSUP;
+  if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.upsample != PDES_UPSAMPLE_NEAREST || !d.has_bn || d.nrep != PDES_NREP)
+    return PDES_ENOSUP;
+  if (d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win || d.Cout < 32 || d.Cin < 64) return PDES_ENOSUP;
+  const int W = d.Win, H = d.Hin;
+  if (W % 16 || (W >= 32 && W % 32) || H % (W >= 32 ? 4 : 8)) return PDES_ENOSUP;
+  if (dry) return PDES_OK;
+  return launch_b3<B3_UPBWD>(d, d.wbu_bwd, st);
 }
 
 // dry = true: only report whether this implementation would take the descriptor

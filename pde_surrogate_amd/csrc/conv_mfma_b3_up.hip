@@ -274,9 +274,11 @@ extern "C" int pdes_pack_weights_b3up(const pdes_b3up_pack_item* items, int n, i
   return PDES_OK;
 }
 
-extern "C" int pdes_b3up_image_elems(int Cout, int Cin, long long* fwd_elems) {
-  if (Cout <= 0 || Cin <= 0 || !fwd_elems) return PDES_EINVAL;
+extern "C" int pdes_b3up_image_elems(int Cout, int Cin, long long* fwd_elems, long long* bwd_elems) {
+  if (Cout <= 0 || Cin <= 0 || !fwd_elems || !bwd_elems) return PDES_EINVAL;
   const long long ntf = (((Cout + 15) / 16) + 3) & ~3;
   *fwd_elems = (long long)((Cin + 31) / 32) * 16 * ntf * 3 * 64 * 8;
+  const long long ntb = (((Cin + 15) / 16) + 7) & ~7;
+  *bwd_elems = (long long)4 * ((Cout + 31) / 32) * 4 * ntb * 3 * 64 * 8;      // (parity, 32-channel chunk) x 4 taps
   return PDES_OK;
 }

@@ -118,7 +118,35 @@ __device__ __forceinline__ void pack_b3_item(const pdes_b3_pack_item& it, int bx
 // split effective-weight image of the forward, rebuilt from the live weights every step:
 //   [(chunk*16 + j)*NT + nt][plane][lane][e] = split_plane( Weff_p[a][b][co = 16 nt + (lane & 15)][ci = 32 chunk + 8 (lane >> 4) + e] )
 // j walks the (tile position, parity) pairs in the order of the kernel's loop; NT = N-tiles rounded up to 4.
+// ... and of the data gradient (conv_mfma_b3.hip, B3_UPBWD): K = (parity, output channel), N = input channels,
+//   [((p * NCH + chunk) * 4 + a * 2 + b) * NT + nt][plane][lane][e] =
+//       split_plane( Weff_p[a][b][co = 32 chunk + 8 (lane >> 4) + e][ci = 16 nt + (lane & 15)] ),   NT rounded up to 8
+__device__ __forceinline__ void pack_b3up_bwd(const pdes_b3up_pack_item& it, int bx, int nbx) {
+  const int ntp = (((it.Cin + 15) / 16) + 7) & ~7, nch = (it.Cout + 31) / 32;
+  const int total = 4 * nch * 4 * ntp * 64;
+  for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+    const int l = e & 63, nt = (e >> 6) % ntp, t = ((e >> 6) / ntp) & 3, vc = (e >> 6) / (ntp * 4);
+    const int pp = vc / nch, ch = vc % nch;
+    const int n = nt * 16 + (l & 15), k0 = ch * 32 + 8 * (l >> 4);
+    u32 hw[4], mw[4], lw[4];
+    float xv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + q;
+      xv[q] = (n < it.Cin && k < it.Cout) ? weff(it.w + ((size_t)k * it.Cin + n) * 9, pp >> 1, pp & 1, t >> 1, t & 1) : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split3_pair(xv[2 * q], xv[2 * q + 1], hw[q], mw[q], lw[q]);
+    unsigned short* dst = it.wbu_bwd + (((size_t)(vc * 4 + t) * ntp + nt) * 3 * 64 + l) * 8;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    *reinterpret_cast<uint4*>(dst + 64 * 8) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+    *reinterpret_cast<uint4*>(dst + 2 * 64 * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+  }
+}
+
 __device__ __forceinline__ void pack_b3up_item(const pdes_b3up_pack_item& it, int bx, int nbx) {
+  if (it.wbu_bwd) pack_b3up_bwd(it, bx, nbx);
+  if (!it.wbu_fwd) return;
   const int ntp = (((it.Cout + 15) / 16) + 3) & ~3, nch = (it.Cin + 31) / 32;
   const int total = nch * 16 * ntp * 64;
   for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {

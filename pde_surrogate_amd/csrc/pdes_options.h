@@ -25,6 +25,7 @@ struct Options {
   int mfma_b3w = 1;             // PDES_MFMA_B3W         : bf16 x3 split kernel for the weight gradient of the wide 3x3 layers
   int mfma_b3u = 1;             // PDES_MFMA_B3U         : bf16 x3 split kernel for the forward of the nearest-x2 + 3x3 layers
   int mfma_small = 1;           // PDES_MFMA_SMALL       : matrix-core kernels for 3x3 convolutions on 8x8 maps (conv_small.hip)
+  int mfma_b3ub = 1;            // PDES_MFMA_B3UB        : bf16 x3 split kernel for the data gradient of the nearest-x2 + 3x3 layers
   int b3_mt = 4;                // PDES_B3_MT
   int b3_apipe = 1;             // PDES_B3_APIPE         : A-operand fragments of the next (tap, M-tile) read before this one's MFMAs
   int few_r = 2;                // PDES_FEW_R

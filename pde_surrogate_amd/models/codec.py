@@ -42,6 +42,7 @@ class ConvDesc(ctypes.Structure):
         ('t_stats', _P), ('bn_grad', _P), ('dw', _P), ('ws', _P), ('ws_bytes', ctypes.c_longlong),
         ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong), ('wbu_fwd', _P),
         ('g_add', _P), ('x2', _P), ('x2_ctot', _I), ('t2', _P), ('p0', _P), ('p1', _P), ('acc', _P), ('flags', _I),
+        ('wbu_bwd', _P),
     ]
 
 
@@ -63,7 +64,7 @@ class B3PackItem(ctypes.Structure):
 
 
 class B3UpPackItem(ctypes.Structure):
-    _fields_ = [('w', _P), ('wbu_fwd', _P), ('Cout', _I), ('Cin', _I)]
+    _fields_ = [('w', _P), ('wbu_fwd', _P), ('wbu_bwd', _P), ('Cout', _I), ('Cin', _I)]
 
 
 class ReduceItem(ctypes.Structure):
@@ -416,7 +417,8 @@ class _Engine(_EngineBase):
             d.wb_fwd = b3[0].data_ptr() if b3 else None
             d.wb_bwd = b3[1].data_ptr() if b3 else None
             bu = net._packed_b3u.get(s.conv)
-            d.wbu_fwd = bu.data_ptr() if bu is not None else None
+            d.wbu_fwd = bu[0].data_ptr() if bu is not None else None
+            d.wbu_bwd = bu[1].data_ptr() if bu is not None else None
             d.ws, d.ws_bytes, d.ws_defer = net._ws.data_ptr(), net._ws.numel() * 4, 0
             d.nrep, d.rep_stride = self.nrep, self.rep_stride
             if s.bn:
@@ -766,15 +768,16 @@ class _HipNet(nn.Module):
         for s in self._specs:
             if not (s.up == UP_NEAREST and s.k == 3 and s.stride == 1 and s.norm is not None and s.cin >= 64 and s.cout >= 32):
                 continue
-            nf = ctypes.c_longlong(0)
-            _lib.check(_lib.lib().pdes_b3up_image_elems(s.cout, s.cin, ctypes.byref(nf)), 'pdes_b3up_image_elems')
+            nf, nb = ctypes.c_longlong(0), ctypes.c_longlong(0)
+            _lib.check(_lib.lib().pdes_b3up_image_elems(s.cout, s.cin, ctypes.byref(nf), ctypes.byref(nb)), 'pdes_b3up_image_elems')
             img = torch.zeros(nf.value, device=device, dtype=torch.int16)
-            self._packed_b3u[s.conv] = img
+            imgb = torch.zeros(nb.value, device=device, dtype=torch.int16)
+            self._packed_b3u[s.conv] = (img, imgb)
             it = B3UpPackItem()
             it.w = _get(self._root, s.conv).weight.data_ptr()
-            it.wbu_fwd, it.Cout, it.Cin = img.data_ptr(), s.cout, s.cin
+            it.wbu_fwd, it.wbu_bwd, it.Cout, it.Cin = img.data_ptr(), imgb.data_ptr(), s.cout, s.cin
             buitems.append(it)
-            bumx = max(bumx, nf.value // 24)
+            bumx = max(bumx, nf.value // 24, nb.value // 24)
         self._bupack_n, self._bupack_max = len(buitems), bumx
         if buitems:
             arr = (B3UpPackItem * len(buitems))(*buitems)
