@@ -20,31 +20,42 @@ __device__ __forceinline__ void pack_direct_item(const pdes_pack_item& it, int b
   }
 }
 
+// (the zero tiles that pad N to a multiple of 8 are written once, at allocation: only the real tiles are rebuilt)
 __device__ __forceinline__ void pack_mfma_item(const pdes_mfma_pack_item& it, int bx, int nbx) {
-  const int ntf = (((it.Cout + 15) / 16) + 7) & ~7, ksf = ((it.Cin + 15) / 16) * 4;
-  const int totf = ksf * it.kk * ntf * 64;
+  const int ntrf = (it.Cout + 15) / 16, ntf = (ntrf + 7) & ~7, ksf = ((it.Cin + 15) / 16) * 4;
+  const int totf = ksf * it.kk * ntrf * 64;
   for (int i = bx * 256 + threadIdx.x; i < totf; i += nbx * 256) {
-    const int l = i & 63, nt = (i >> 6) % ntf, t = ((i >> 6) / ntf) % it.kk, ks = (i >> 6) / (ntf * it.kk);
+    const int l = i & 63, nt = (i >> 6) % ntrf, t = ((i >> 6) / ntrf) % it.kk, ks = (i >> 6) / (ntrf * it.kk);
     const int co = nt * 16 + (l & 15), ci = 4 * ks + (l >> 4);
-    it.wm_fwd[i] = (co < it.Cout && ci < it.Cin) ? it.w[((size_t)co * it.Cin + ci) * it.kk + t] : 0.f;
+    it.wm_fwd[((size_t)(ks * it.kk + t) * ntf + nt) * 64 + l] =
+        (co < it.Cout && ci < it.Cin) ? it.w[((size_t)co * it.Cin + ci) * it.kk + t] : 0.f;
   }
   if (!it.wm_bwd) return;
-  const int ntb = (((it.Cin + 15) / 16) + 7) & ~7, ksb = ((it.Cout + 15) / 16) * 4;
-  const int totb = ksb * it.kk * ntb * 64;
+  const int ntrb = (it.Cin + 15) / 16, ntb = (ntrb + 7) & ~7, ksb = ((it.Cout + 15) / 16) * 4;
+  const int totb = ksb * it.kk * ntrb * 64;
   for (int i = bx * 256 + threadIdx.x; i < totb; i += nbx * 256) {
-    const int l = i & 63, nt = (i >> 6) % ntb, t = ((i >> 6) / ntb) % it.kk, ks = (i >> 6) / (ntb * it.kk);
+    const int l = i & 63, nt = (i >> 6) % ntrb, t = ((i >> 6) / ntrb) % it.kk, ks = (i >> 6) / (ntrb * it.kk);
     const int ci = nt * 16 + (l & 15), co = 4 * ks + (l >> 4);
-    it.wm_bwd[i] = (co < it.Cout && ci < it.Cin) ? it.w[((size_t)co * it.Cin + ci) * it.kk + (it.kk - 1 - t)] : 0.f;
+    it.wm_bwd[((size_t)(ks * it.kk + t) * ntb + nt) * 64 + l] =
+        (co < it.Cout && ci < it.Cin) ? it.w[((size_t)co * it.Cin + ci) * it.kk + (it.kk - 1 - t)] : 0.f;
   }
 }
 
-// R(d, i): the 3x3 taps that land on position i of the 2x2 kernel of parity d
+// R(d, i): the 3x3 taps that land on position i of the 2x2 kernel of parity d.  Rows (and, likewise, columns): parity 0:
+// position 0 <- {0}, 1 <- {1, 2}; parity 1: position 0 <- {0, 1}, 1 <- {2}.  Branch free: the nine loads are
+// unconditional and independent (with data-dependent loop bounds every tap was a serial round trip to L2, and the
+// packing launch -- on the serial chain at the start of every step -- spent 12 us in these images).
+__device__ __forceinline__ int weff_mask(int d, int i) { return d == 0 ? (i == 0 ? 1 : 6) : (i == 0 ? 3 : 4); }
 __device__ __forceinline__ float weff(const float* w9, int dy, int dx, int a, int b) {
-  const int y0 = dy == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), y1 = dy == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
-  const int x0 = dx == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), x1 = dx == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+  const int rm = weff_mask(dy, a), cm = weff_mask(dx, b);
+  float v[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) v[t] = w9[t];
   float s = 0.f;
-  for (int ky = y0; ky <= y1; ++ky)
-    for (int kx = x0; kx <= x1; ++kx) s += w9[ky * 3 + kx];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) s += ((rm >> ky) & (cm >> kx) & 1) ? v[ky * 3 + kx] : 0.f;
   return s;
 }
 
@@ -55,7 +66,8 @@ __device__ __forceinline__ void pack_up_item(const pdes_up_pack_item& it, int bx
     const int l = i & 63, nt = (i >> 6) % ntf, q = ((i >> 6) / ntf) % 16, ks = (i >> 6) / (ntf * 16);
     const int co = nt * 16 + (l & 15), ci = 4 * ks + (l >> 4);
     const int p = q >> 2, a = (q >> 1) & 1, b = q & 1;
-    it.wu_fwd[i] = (co < it.Cout && ci < it.Cin) ? weff(it.w + ((size_t)co * it.Cin + ci) * 9, p >> 1, p & 1, a, b) : 0.f;
+    const float v = weff(it.w + ((size_t)min(co, it.Cout - 1) * it.Cin + min(ci, it.Cin - 1)) * 9, p >> 1, p & 1, a, b);
+    it.wu_fwd[i] = (co < it.Cout && ci < it.Cin) ? v : 0.f;       // clamped address + select: no branch around the loads
   }
   const int ntb = (((it.Cin + 15) / 16) + 7) & ~7, ksb = ((it.Cout + 15) / 16) * 4;
   const int totb = ksb * 16 * ntb * 64;
@@ -63,7 +75,8 @@ __device__ __forceinline__ void pack_up_item(const pdes_up_pack_item& it, int bx
     const int l = i & 63, nt = (i >> 6) % ntb, q = ((i >> 6) / ntb) % 16, ks = (i >> 6) / (ntb * 16);
     const int ci = nt * 16 + (l & 15), co = 4 * ks + (l >> 4);
     const int p = q >> 2, a = (q >> 1) & 1, b = q & 1;
-    it.wu_bwd[i] = (co < it.Cout && ci < it.Cin) ? weff(it.w + ((size_t)co * it.Cin + ci) * 9, p >> 1, p & 1, a, b) : 0.f;
+    const float v = weff(it.w + ((size_t)min(co, it.Cout - 1) * it.Cin + min(ci, it.Cin - 1)) * 9, p >> 1, p & 1, a, b);
+    it.wu_bwd[i] = (co < it.Cout && ci < it.Cin) ? v : 0.f;
   }
 }
 
@@ -100,10 +113,9 @@ __device__ __forceinline__ void pack_b3_item(const pdes_b3_pack_item& it, int bx
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = k0 + j;
-        float x = 0.f;
-        if (n < nC && k < kC)
-          x = dir == 0 ? it.w[((size_t)n * it.Cin + k) * 9 + t] : it.w[((size_t)k * it.Cin + n) * 9 + (8 - t)];
-        xv[j] = x;
+        const int nc = min(n, nC - 1), kc = min(k, kC - 1);   // clamped address + select: eight independent loads
+        const float x = dir == 0 ? it.w[((size_t)nc * it.Cin + kc) * 9 + t] : it.w[((size_t)kc * it.Cin + nc) * 9 + (8 - t)];
+        xv[j] = (n < nC && k < kC) ? x : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) split3_pair(xv[2 * j], xv[2 * j + 1], hw[j], mw[j], lw[j]);
@@ -133,7 +145,8 @@ __device__ __forceinline__ void pack_b3up_bwd(const pdes_b3up_pack_item& it, int
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = k0 + q;
-      xv[q] = (n < it.Cin && k < it.Cout) ? weff(it.w + ((size_t)k * it.Cin + n) * 9, pp >> 1, pp & 1, t >> 1, t & 1) : 0.f;
+      const float v = weff(it.w + ((size_t)min(k, it.Cout - 1) * it.Cin + min(n, it.Cin - 1)) * 9, pp >> 1, pp & 1, t >> 1, t & 1);
+      xv[q] = (n < it.Cin && k < it.Cout) ? v : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) split3_pair(xv[2 * q], xv[2 * q + 1], hw[q], mw[q], lw[q]);
@@ -167,7 +180,8 @@ __device__ __forceinline__ void pack_b3up_item(const pdes_b3up_pack_item& it, in
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = k0 + q;
-      xv[q] = (n < it.Cout && k < it.Cin) ? weff(it.w + ((size_t)n * it.Cin + k) * 9, pp >> 1, pp & 1, ia, ib) : 0.f;
+      const float v = weff(it.w + ((size_t)min(n, it.Cout - 1) * it.Cin + min(k, it.Cin - 1)) * 9, pp >> 1, pp & 1, ia, ib);
+      xv[q] = (n < it.Cout && k < it.Cin) ? v : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) split3_pair(xv[2 * q], xv[2 * q + 1], hw[q], mw[q], lw[q]);
