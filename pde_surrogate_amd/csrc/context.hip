@@ -30,7 +30,7 @@ static const Knob kKnobs[] = {
     {"PDES_LOSS_DMA", &Options::loss_dma},           {"PDES_FORK_SIGNAL", &Options::fork_signal},     {"PDES_DEBUG_CHAIN", &Options::debug_chain},     {"PDES_MFMA_B3W", &Options::mfma_b3w},
     {"PDES_MFMA_B3U", &Options::mfma_b3u},
     {"PDES_MFMA_SMALL", &Options::mfma_small},       {"PDES_B3_APIPE", &Options::b3_apipe},
-    {"PDES_MFMA_B3UB", &Options::mfma_b3ub},
+    {"PDES_MFMA_B3UB", &Options::mfma_b3ub},         {"PDES_MFMA_B3WU", &Options::mfma_b3wu},
 };
 
 static int set_knob(Options& o, const char* key, const char* value) {

@@ -217,10 +217,221 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_kernel(pdes_conv_desc d,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same kernel for nearest-x2 + 3x3 (reference models/codec.py:130-150, :172-176 LastTransUp.conv2: 98 -> 49 at
+// 32 x 32 -> 64 x 64) in SUB-PIXEL form (the arithmetic of conv_mfma_wgrad_up_kernel, conv_mfma_wgrad.hip):
+//     dWeff[p][a][b][co][ci] = sum_{b, y, x} G_p[co][y][x] * z[ci][y + a + py - 1][x + b + px - 1],   G_p[y][x] = g[2y + py][2x + px]
+//     dW[ky][kx] = sum_{py, px} dWeff[(py, px)][a(ky, py)][b(kx, px)]
+// 16 (parity, a, b) products on the LOW-res pixels instead of 9 taps on four times as many (4/9 of the flops), at the
+// bf16 rate.  K = 32 low-res pixels = one row of z; the z ring and its three column-shifted copies are unchanged (row
+// shift a + py - 1, column shift b + px - 1, both in {-1, 0, +1}); the two hi-res rows 2y, 2y + 1 of g are de-interleaved
+// into the four parity rows on the way into LDS (a thread owns 8 hi-res columns of one row = 4 pixels of two parities).
+// One N-tile per wave (Cout <= 64): 16 accumulators, 96 MFMAs per wave and row.  LDS: Z 27 KB + G [4][3][nco][32] 48 KB,
+// G single-buffered (both barriers of a row lie between its write and the next one): two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc d, float* __restrict__ part, int rows) {
+  using namespace wb3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_wb3[];
+  unsigned short* Z = reinterpret_cast<unsigned short*>(smem_wb3);            // [kx][plane][slot][16][32]
+  unsigned short* G = Z + ZSIZE;                                              // [parity][plane][nco][32]
+  __shared__ float cf[16][3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = d.Hin, HW = H * W, WH = 2 * W, HWh = 4 * HW;                  // low-res rows / map, hi-res width / map
+  const int ntiles = (d.Cout + 15) >> 4, nco = ntiles * 16;
+  const int hs_n = H / rows;
+  const int b = blockIdx.x / hs_n, y0 = (blockIdx.x % hs_n) * rows;
+  const int ci0 = blockIdx.y * 16;
+  const long long per = (long long)d.Cout * d.Cin * 9;
+
+  if (tid < 16) {                         // BatchNorm coefficients of this workgroup's 16 input channels
+    const int c = ci0 + tid;
+    float m = 0.f, s = 0.f, bt = 0.f;
+    if (c < d.Cin) {
+      double mean, invstd;
+      if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
+      else {
+        const double n = (double)d.B * HW;
+        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
+        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        invstd = 1.0 / sqrt(var + (double)d.eps);
+      }
+      m = (float)mean; s = d.gamma[c] * (float)invstd; bt = d.beta[c];
+    }
+    cf[tid][0] = m; cf[tid][1] = s; cf[tid][2] = bt;
+  }
+
+  const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HW;
+  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HWh;
+  const int crem = d.Cin - ci0;
+  // staging roles: threads 0..127 own one float4 of the z row; everyone owns up to four items of the g rows, an item =
+  // (channel e >> 4, row parity (e >> 3) & 1, hi-res columns 8 (e & 7) ..)
+  const bool zt = tid < 128;
+  const int zc = (tid >> 3) & 15, zj = tid & 7;
+  const int ng = nco * 16;
+  struct Stage { float4 z; float4 g[4][2]; };
+  Stage s;
+  auto issue = [&](int y, Stage& st) __attribute__((always_inline)) {
+    const int zr = min(max(y + 1, 0), H - 1), gr = min(max(y, 0), H - 1);
+    st.z = *reinterpret_cast<const float4*>(xb + (size_t)min(zc, crem - 1) * HW + zr * W + 4 * zj);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = min(tid + 256 * i, ng - 1);
+      const int co = min(e >> 4, d.Cout - 1);
+      const float* src = gb + (size_t)co * HWh + (2 * gr + ((e >> 3) & 1)) * WH + 8 * (e & 7);
+      st.g[i][0] = *reinterpret_cast<const float4*>(src);
+      st.g[i][1] = *reinterpret_cast<const float4*>(src + 4);
+    }
+  };
+  auto commit = [&](int y, const Stage& st, bool with_g) __attribute__((always_inline)) {
+    if (zt) {                              // z row y + 1 -> ring slot, three column-shifted copies
+      const int row = y + 1;
+      const bool ok = row >= 0 && row < H && zc < crem;
+      const float mean = cf[zc][0], sc = cf[zc][1], bt = cf[zc][2];
+      float v[4] = {st.z.x, st.z.y, st.z.z, st.z.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = ok ? fmaxf(0.f, (v[i] - mean) * sc + bt) : 0.f;
+      u32 w0[3], w1[3];
+      split3_pair(v[0], v[1], w0[0], w0[1], w0[2]);
+      split3_pair(v[2], v[3], w1[0], w1[1], w1[2]);
+      const int slot = (row + 3) % 3;
+      unsigned short* zp = Z + slot * ZROW + zc * W + 8 * swz(zc, zj >> 1) + 4 * (zj & 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        u32 prev1 = __shfl_up(w1[p], 1, 64), next0 = __shfl_down(w0[p], 1, 64);
+        if (zj == 0) prev1 = 0u;
+        if (zj == 7) next0 = 0u;
+        const u32 mid = (w0[p] >> 16) | (w1[p] << 16);
+        unsigned short* q = zp + p * ZPLANE;
+        *reinterpret_cast<uint2*>(q) = make_uint2((prev1 >> 16) | (w0[p] << 16), mid);              // kx = 0: z[x - 1]
+        *reinterpret_cast<uint2*>(q + ZCOPY) = make_uint2(w0[p], w1[p]);                             // kx = 1: z[x]
+        *reinterpret_cast<uint2*>(q + 2 * ZCOPY) = make_uint2(mid, (w1[p] >> 16) | (next0 << 16));  // kx = 2: z[x + 1]
+      }
+    }
+    if (!with_g) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      if (e < ng) {
+        const int co = e >> 4, py = (e >> 3) & 1, jj = e & 7;
+        const bool ok = co < d.Cout;
+        const float4 a = st.g[i][0], c = st.g[i][1];
+        unsigned short* q = G + (size_t)(py * 2) * 3 * nco * W + co * W + 8 * swz(co & 15, jj >> 1) + 4 * (jj & 1);
+        u32 h0[3], h1[3];
+        split3_pair(ok ? a.x : 0.f, ok ? a.z : 0.f, h0[0], h0[1], h0[2]);      // px = 0: hi-res columns 0, 2 | 4, 6
+        split3_pair(ok ? c.x : 0.f, ok ? c.z : 0.f, h1[0], h1[1], h1[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(q + p * nco * W) = make_uint2(h0[p], h1[p]);
+        split3_pair(ok ? a.y : 0.f, ok ? a.w : 0.f, h0[0], h0[1], h0[2]);      // px = 1: hi-res columns 1, 3 | 5, 7
+        split3_pair(ok ? c.y : 0.f, ok ? c.w : 0.f, h1[0], h1[1], h1[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(q + (3 + p) * nco * W) = make_uint2(h0[p], h1[p]);
+      }
+    }
+  };
+
+  v4f acc[16];                              // [(py, px)][a][b]
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();                          // coefficients visible
+  issue(y0 - 2, s); commit(y0 - 2, s, false);      // z row y0 - 1
+  issue(y0 - 1, s); commit(y0 - 1, s, false);      // z row y0
+  issue(y0, s);
+  const int frag = (lane & 15) * W + 8 * swz(lane & 15, lane >> 4);
+  const int tile = min(wave, ntiles - 1);
+  const int ylast = y0 + rows - 1;
+  for (int y = y0; y <= ylast; ++y) {
+    __syncthreads();                        // the fragment reads of row y - 1 are done
+    commit(y, s, true);                     // z row y + 1, the four parity rows of g rows 2y, 2y + 1
+    __syncthreads();
+    issue(min(y + 1, ylast), s);            // in flight during the matrix work below
+    __builtin_amdgcn_sched_barrier(0);
+    v8bf bh[4], bm[4], bl[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const unsigned short* q = G + (size_t)pp * 3 * nco * W + tile * 16 * W + frag;
+      bh[pp] = *reinterpret_cast<const v8bf*>(q);
+      bm[pp] = *reinterpret_cast<const v8bf*>(q + nco * W);
+      bl[pp] = *reinterpret_cast<const v8bf*>(q + 2 * nco * W);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {        // row shift ky - 1 of z
+      const int slot = (y + ky + 2) % 3;
+      v8bf ah[3], am[3], al[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const unsigned short* zp = Z + kx * ZCOPY + slot * ZROW + frag;
+        ah[kx] = *reinterpret_cast<const v8bf*>(zp);
+        am[kx] = *reinterpret_cast<const v8bf*>(zp + ZPLANE);
+        al[kx] = *reinterpret_cast<const v8bf*>(zp + 2 * ZPLANE);
+      }
+      // (py, a) with a + py == ky, (px, b) with b + px == kx: 4 / 8 / 4 products for ky = 0 / 1 / 2, all on distinct
+      // accumulators inside one cross term
+#define PDES_WB3U_TERM(A_, B_)                                                                                   \
+      _Pragma("unroll") for (int py = 0; py < 2; ++py) {                                                         \
+        const int ia = ky - py;                                                                                  \
+        if (ia < 0 || ia > 1) continue;                                                                          \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                         \
+          _Pragma("unroll") for (int px = 0; px < 2; ++px) {                                                     \
+            const int ib = kx - px;                                                                              \
+            if (ib < 0 || ib > 1) continue;                                                                      \
+            const int q = (py * 2 + px) * 4 + ia * 2 + ib;                                                       \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[kx], B_[py * 2 + px], acc[q], 0, 0, 0);          \
+          }                                                                                                      \
+      }
+      PDES_WB3U_TERM(am, bm);               // six cross terms, smallest first
+      PDES_WB3U_TERM(al, bh);
+      PDES_WB3U_TERM(ah, bl);
+      PDES_WB3U_TERM(am, bh);
+      PDES_WB3U_TERM(ah, bm);
+      PDES_WB3U_TERM(ah, bh);
+#undef PDES_WB3U_TERM
+    }
+  }
+
+  // ---- epilogue: the 16 effective-kernel gradients fold into the 9 taps; accumulator tile = D[ci = (lane >> 4) * 4 + r]
+  // [co = lane & 15]; through LDS as [co][ci][tap]
+  __syncthreads();
+  float* outl = reinterpret_cast<float*>(smem_wb3);
+  if (wave < ntiles) {
+    const int co = wave * 16 + (lane & 15);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        v4f sum = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int ia = py == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+            const int ib = px == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+            sum += acc[(py * 2 + px) * 4 + ia * 2 + ib];
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outl[(co * 16 + (lane >> 4) * 4 + r) * 9 + ky * 3 + kx] = sum[r];
+      }
+  }
+  __syncthreads();
+  float* pb = part + (size_t)blockIdx.x * per;
+  const int run = min(16, crem) * 9;                       // contiguous floats per output channel
+  for (int e = tid; e < d.Cout * run; e += 256) {
+    const int co = e / run, k = e - co * run;
+    pb[((size_t)co * d.Cin + ci0) * 9 + k] = outl[co * 144 + k];
+  }
+}
+
 // ------------------------------------------------------------------------------- host side
+static bool wgrad_b3_up_shape(const pdes_conv_desc& d) {      // nearest-x2 + 3x3 from a 32-wide map, at most four N-tiles
+  return opt().mfma_b3wu && d.upsample == PDES_UPSAMPLE_NEAREST && d.Win == wb3::W && d.Wout == 2 * wb3::W &&
+         d.Hout == 2 * d.Hin && d.Cin >= 64 && d.Cout >= 32 && d.Cout <= 64;
+}
+
 bool wgrad_b3_applies(const pdes_conv_desc& d) {
-  if (!opt().mfma_b3w || d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.upsample || !d.has_bn || d.g_fused) return false;
-  if (d.Win != wb3::W || d.Wout != wb3::W || d.Hin != d.Hout || d.nrep != PDES_NREP) return false;
+  if (!opt().mfma_b3w || d.ksize != 3 || d.stride != 1 || d.pad != 1 || !d.has_bn || d.g_fused || d.nrep != PDES_NREP) return false;
+  if (d.upsample) return wgrad_b3_up_shape(d);
+  if (d.Win != wb3::W || d.Wout != wb3::W || d.Hin != d.Hout) return false;
   return d.Cin >= 64 && d.Cout >= 32 && d.Cout <= 128;
 }
 
@@ -228,21 +439,27 @@ bool wgrad_b3_applies(const pdes_conv_desc& d) {
 int wgrad_b3_splits(const pdes_conv_desc& d) {
   const int mtiles = (d.Cin + 15) / 16;
   int hs = 1;
-  while (d.B * hs * mtiles < 384 && hs * 2 <= d.Hout / 8 && d.Hout % (hs * 2) == 0) hs *= 2;
+  while (d.B * hs * mtiles < 384 && hs * 2 <= d.Hin / 8 && d.Hin % (hs * 2) == 0) hs *= 2;
   return d.B * hs;
 }
 
 int conv_backward_weight_b3(const pdes_conv_desc& d, hipStream_t st) {
   if (!wgrad_b3_applies(d) || !d.ws) return PDES_ENOSUP;
-  const int nsplit = wgrad_b3_splits(d), rows = d.Hout / (nsplit / d.B);
+  const int nsplit = wgrad_b3_splits(d), rows = d.Hin / (nsplit / d.B);
   const long long per = (long long)d.Cout * d.Cin * 9;
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
   const int ntiles = (d.Cout + 15) / 16, nco = ntiles * 16;
-  size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)2 * 3 * nco * wb3::W * 2;
   const size_t epi = (size_t)nco * 144 * sizeof(float);
-  if (epi > lds) lds = epi;
   dim3 grid(nsplit, (d.Cin + 15) / 16), block(256);
-  hipLaunchKernelGGL(conv_wgrad_b3_kernel, grid, block, lds, st, d, d.ws, rows);
+  if (d.upsample) {
+    size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)4 * 3 * nco * wb3::W * 2;
+    if (epi > lds) lds = epi;
+    hipLaunchKernelGGL(conv_wgrad_b3_up_kernel, grid, block, lds, st, d, d.ws, rows);
+  } else {
+    size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)2 * 3 * nco * wb3::W * 2;
+    if (epi > lds) lds = epi;
+    hipLaunchKernelGGL(conv_wgrad_b3_kernel, grid, block, lds, st, d, d.ws, rows);
+  }
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

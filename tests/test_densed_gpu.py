@@ -428,7 +428,7 @@ def test_mfma_kernels_match_direct_kernels(dev, option, cfg):
 
 
 @pytest.mark.parametrize('knob', ['PDES_FUSE_FINALIZE', 'PDES_WGRAD_STREAM', 'PDES_MFMA_B3', 'PDES_MFMA_B3W', 'PDES_MFMA_B3U', 'PDES_MFMA_1X1',
-                                  'PDES_MFMA_1X1W', 'PDES_FORK_SIGNAL', 'PDES_MFMA_B3UB', 'PDES_B3_APIPE'])
+                                  'PDES_MFMA_1X1W', 'PDES_FORK_SIGNAL', 'PDES_MFMA_B3UB', 'PDES_B3_APIPE', 'PDES_MFMA_B3WU'])
 def test_backward_variants_agree(dev, monkeypatch, option, knob):
     """finalize fused into the operand load vs the in-place kernel; weight gradients on a second stream vs one
     stream; the 196->98 layer on the bf16 pipe (three-way split, fp32-accurate) vs the f32 pipe; the 1x1 layers
@@ -436,14 +436,15 @@ def test_backward_variants_agree(dev, monkeypatch, option, knob):
     generic ones: same outputs and gradients (fp64 atomics of the statistics are order dependent in the last bits only; two different fp32
     summation orders can flip an individual ReLU mask, hence 1e-3 and not 1e-6 on the parameter gradients); the sub-pixel
     layers' data gradient on the bf16 pipe (PDES_MFMA_B3UB) vs the f32 pipe; the explicit A-operand prefetch of the bf16
-    kernels (PDES_B3_APIPE: same instruction sequence per accumulator, bitwise identical results)"""
+    kernels (PDES_B3_APIPE: same instruction sequence per accumulator, bitwise identical results); the 98->49 sub-pixel
+    layer's weight gradient on the bf16 pipe (PDES_MFMA_B3WU) vs the f32 pipe"""
     # PDES_WGRAD_STREAM is read by the model at construction; the others are options of the library's context
     setk = (lambda v: monkeypatch.setenv(knob, v)) if knob == 'PDES_WGRAD_STREAM' else (lambda v: option(knob, v))
     setk('0')
     y0, l0, g0 = _run_default(dev, B=32)
     setk('1')
     y1, l1, g1 = _run_default(dev, B=32)
-    if knob == 'PDES_MFMA_B3W':       # the split-K plan of the weight gradients depends on the option: fresh engines only
+    if knob in ('PDES_MFMA_B3W', 'PDES_MFMA_B3WU'):       # the split-K plan of the weight gradients depends on the option: fresh engines only
         import gc
         gc.collect()
     ytol = 2e-6 if knob in ('PDES_MFMA_B3', 'PDES_MFMA_B3U', 'PDES_MFMA_1X1') else 1e-6
