@@ -226,8 +226,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_kernel(pdes_conv_desc d,
 // bf16 rate.  K = 32 low-res pixels = one row of z; the z ring and its three column-shifted copies are unchanged (row
 // shift a + py - 1, column shift b + px - 1, both in {-1, 0, +1}); the two hi-res rows 2y, 2y + 1 of g are de-interleaved
 // into the four parity rows on the way into LDS (a thread owns 8 hi-res columns of one row = 4 pixels of two parities).
-// One N-tile per wave (Cout <= 64): 16 accumulators, 96 MFMAs per wave and row.  LDS: Z 27 KB + G [4][3][nco][32] 48 KB,
-// G single-buffered (both barriers of a row lie between its write and the next one): two workgroups per CU.
+// One N-tile per wave (64 output channels per workgroup, the rest over gridDim.z): 16 accumulators, 96 MFMAs per wave and
+// row.  LDS: Z 27 KB + G [4][3][64][32] 48 KB, G single-buffered (both barriers of a row lie between its write and the
+// next one): two workgroups per CU.
+// WL = 16 (TransUp1.conv2: 100 -> 100 at 16 x 16 -> 32 x 32): a k-row is a PAIR of map rows (32 contiguous pixels); the
+// column-shifted copies are zero padded at both 16-pixel boundaries, and a row shift moves a lane's 8-pixel group by two
+// groups -- into the neighbouring k-row's ring slot for half of the lanes (still one aligned 16-byte read).
+template <int WL>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc d, float* __restrict__ part, int rows) {
   using namespace wb3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_wb3[];
@@ -236,8 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
   __shared__ float cf[16][3];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = d.Hin, HW = H * W, WH = 2 * W, HWh = 4 * HW;                  // low-res rows / map, hi-res width / map
-  const int ntiles = (d.Cout + 15) >> 4, nco = ntiles * 16;
+  const int H = d.Hin * WL / W, HW = H * W, WH = 2 * WL, HWh = 4 * HW;         // k-rows (32 low-res pixels each), hi-res width / map
+  const int co0 = blockIdx.z * 64, corem = d.Cout - co0;                      // this workgroup's output channels
+  const int ntiles = min((corem + 15) >> 4, 4), nco = ntiles * 16;
   const int hs_n = H / rows;
   const int b = blockIdx.x / hs_n, y0 = (blockIdx.x % hs_n) * rows;
   const int ci0 = blockIdx.y * 16;
@@ -262,10 +268,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
   }
 
   const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HW;
-  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HWh;
+  const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWh;
   const int crem = d.Cin - ci0;
   // staging roles: threads 0..127 own one float4 of the z row; everyone owns up to four items of the g rows, an item =
-  // (channel e >> 4, row parity (e >> 3) & 1, hi-res columns 8 (e & 7) ..)
+  // (channel e >> 4, row parity (e >> 3) & 1, low-res pixels 4 (e & 7) .. of the k-row = 8 hi-res columns of one hi-res row)
   const bool zt = tid < 128;
   const int zc = (tid >> 3) & 15, zj = tid & 7;
   const int ng = nco * 16;
@@ -277,8 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = min(tid + 256 * i, ng - 1);
-      const int co = min(e >> 4, d.Cout - 1);
-      const float* src = gb + (size_t)co * HWh + (2 * gr + ((e >> 3) & 1)) * WH + 8 * (e & 7);
+      const int co = min(e >> 4, corem - 1), py = (e >> 3) & 1, jj = e & 7;          // jj: the item's 4 low-res pixels 4 jj ..
+      const float* src = WL == 32 ? gb + (size_t)co * HWh + (2 * gr + py) * WH + 8 * jj
+                                  : gb + (size_t)co * HWh + (4 * gr + 2 * (jj >> 2) + py) * WH + 8 * (jj & 3);
       st.g[i][0] = *reinterpret_cast<const float4*>(src);
       st.g[i][1] = *reinterpret_cast<const float4*>(src + 4);
     }
@@ -299,8 +306,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         u32 prev1 = __shfl_up(w1[p], 1, 64), next0 = __shfl_down(w0[p], 1, 64);
-        if (zj == 0) prev1 = 0u;
-        if (zj == 7) next0 = 0u;
+        constexpr int ZM = WL / 4 - 1;     // float4 per map row - 1: zero padding left / right of every map row
+        if ((zj & ZM) == 0) prev1 = 0u;
+        if ((zj & ZM) == ZM) next0 = 0u;
         const u32 mid = (w0[p] >> 16) | (w1[p] << 16);
         unsigned short* q = zp + p * ZPLANE;
         *reinterpret_cast<uint2*>(q) = make_uint2((prev1 >> 16) | (w0[p] << 16), mid);              // kx = 0: z[x - 1]
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
       const int e = tid + 256 * i;
       if (e < ng) {
         const int co = e >> 4, py = (e >> 3) & 1, jj = e & 7;
-        const bool ok = co < d.Cout;
+        const bool ok = co < corem;
         const float4 a = st.g[i][0], c = st.g[i][1];
         unsigned short* q = G + (size_t)(py * 2) * 3 * nco * W + co * W + 8 * swz(co & 15, jj >> 1) + 4 * (jj & 1);
         u32 h0[3], h1[3];
@@ -339,11 +347,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
   issue(y0 - 1, s); commit(y0 - 1, s, false);      // z row y0
   issue(y0, s);
   const int frag = (lane & 15) * W + 8 * swz(lane & 15, lane >> 4);
+  // WL = 16: the A fragment of row shift ky - 1 is the lane's group moved by 2 (ky - 1) groups: afrag[ky] inside a slot,
+  // adk[ky] = k-row offset of that slot (-1, 0, +1)
+  int afrag[3], adk[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int g2 = (lane >> 4) + (WL == 16 ? 2 * (ky - 1) : 0);
+    adk[ky] = WL == 16 ? (g2 < 0 ? -1 : (g2 > 3 ? 1 : 0)) : ky - 1;
+    afrag[ky] = (lane & 15) * W + 8 * swz(lane & 15, g2 & 3);
+  }
   const int tile = min(wave, ntiles - 1);
   const int ylast = y0 + rows - 1;
   for (int y = y0; y <= ylast; ++y) {
     __syncthreads();                        // the fragment reads of row y - 1 are done
-    commit(y, s, true);                     // z row y + 1, the four parity rows of g rows 2y, 2y + 1
+    commit(y, s, true);                     // z row y + 1, the four parity rows of the hi-res rows under k-row y
     __syncthreads();
     issue(min(y + 1, ylast), s);            // in flight during the matrix work below
     __builtin_amdgcn_sched_barrier(0);
@@ -357,11 +374,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
     }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {        // row shift ky - 1 of z
-      const int slot = (y + ky + 2) % 3;
+      const int slot = (y + adk[ky] + 3) % 3;       // (lane dependent for WL = 16)
       v8bf ah[3], am[3], al[3];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const unsigned short* zp = Z + kx * ZCOPY + slot * ZROW + frag;
+        const unsigned short* zp = Z + kx * ZCOPY + slot * ZROW + afrag[ky];
         ah[kx] = *reinterpret_cast<const v8bf*>(zp);
         am[kx] = *reinterpret_cast<const v8bf*>(zp + ZPLANE);
         al[kx] = *reinterpret_cast<const v8bf*>(zp + 2 * ZPLANE);
@@ -416,16 +433,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
   __syncthreads();
   float* pb = part + (size_t)blockIdx.x * per;
   const int run = min(16, crem) * 9;                       // contiguous floats per output channel
-  for (int e = tid; e < d.Cout * run; e += 256) {
+  for (int e = tid; e < min(corem, 64) * run; e += 256) {
     const int co = e / run, k = e - co * run;
-    pb[((size_t)co * d.Cin + ci0) * 9 + k] = outl[co * 144 + k];
+    pb[((size_t)(co0 + co) * d.Cin + ci0) * 9 + k] = outl[co * 144 + k];
   }
 }
 
 // ------------------------------------------------------------------------------- host side
-static bool wgrad_b3_up_shape(const pdes_conv_desc& d) {      // nearest-x2 + 3x3 from a 32-wide map, at most four N-tiles
-  return opt().mfma_b3wu && d.upsample == PDES_UPSAMPLE_NEAREST && d.Win == wb3::W && d.Wout == 2 * wb3::W &&
-         d.Hout == 2 * d.Hin && d.Cin >= 64 && d.Cout >= 32 && d.Cout <= 64;
+static bool wgrad_b3_up_shape(const pdes_conv_desc& d) {      // nearest-x2 + 3x3 from a 32- or 16-wide map
+  if (!opt().mfma_b3wu || d.upsample != PDES_UPSAMPLE_NEAREST || d.Wout != 2 * d.Win || d.Hout != 2 * d.Hin) return false;
+  if (!(d.Win == 32 || (d.Win == 16 && d.Hin % 2 == 0))) return false;
+  return d.Cin >= 64 && d.Cout >= 32 && d.Cout <= 128;
 }
 
 bool wgrad_b3_applies(const pdes_conv_desc& d) {
@@ -437,24 +455,26 @@ bool wgrad_b3_applies(const pdes_conv_desc& d) {
 
 // rows per workgroup: the whole image (one split per sample) unless that leaves most of the chip idle
 int wgrad_b3_splits(const pdes_conv_desc& d) {
-  const int mtiles = (d.Cin + 15) / 16;
+  const int mtiles = (d.Cin + 15) / 16 * (d.upsample ? (d.Cout + 63) / 64 : 1);
+  const int H = d.Hin * d.Win / wb3::W;                   // k-rows of 32 pixels
   int hs = 1;
-  while (d.B * hs * mtiles < 384 && hs * 2 <= d.Hin / 8 && d.Hin % (hs * 2) == 0) hs *= 2;
+  while (d.B * hs * mtiles < 384 && hs * 2 <= H / 8 && H % (hs * 2) == 0) hs *= 2;
   return d.B * hs;
 }
 
 int conv_backward_weight_b3(const pdes_conv_desc& d, hipStream_t st) {
   if (!wgrad_b3_applies(d) || !d.ws) return PDES_ENOSUP;
-  const int nsplit = wgrad_b3_splits(d), rows = d.Hin / (nsplit / d.B);
+  const int nsplit = wgrad_b3_splits(d), rows = d.Hin * d.Win / wb3::W / (nsplit / d.B);
   const long long per = (long long)d.Cout * d.Cin * 9;
   if ((long long)nsplit * per * 4 > d.ws_bytes) return PDES_ENOSUP;
   const int ntiles = (d.Cout + 15) / 16, nco = ntiles * 16;
   const size_t epi = (size_t)nco * 144 * sizeof(float);
   dim3 grid(nsplit, (d.Cin + 15) / 16), block(256);
   if (d.upsample) {
-    size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)4 * 3 * nco * wb3::W * 2;
-    if (epi > lds) lds = epi;
-    hipLaunchKernelGGL(conv_wgrad_b3_up_kernel, grid, block, lds, st, d, d.ws, rows);
+    const size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)4 * 3 * 64 * wb3::W * 2;      // (>= the 64 x 144 floats of the epilogue)
+    grid.z = (d.Cout + 63) / 64;
+    if (d.Win == 32) hipLaunchKernelGGL(conv_wgrad_b3_up_kernel<32>, grid, block, lds, st, d, d.ws, rows);
+    else hipLaunchKernelGGL(conv_wgrad_b3_up_kernel<16>, grid, block, lds, st, d, d.ws, rows);
   } else {
     size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)2 * 3 * nco * wb3::W * 2;
     if (epi > lds) lds = epi;
