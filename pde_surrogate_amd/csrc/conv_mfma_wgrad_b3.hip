@@ -41,6 +41,8 @@ __device__ __forceinline__ int swz(int row, int kg) { return kg ^ ((0x6C >> (2 *
 }  // namespace wb3
 
 // grid: (B * H / rows, M-tiles); dynamic LDS: Z + G[2][3][nco][32] (bf16), reused for the [nco][16][9] fp32 epilogue
+// PF: rows of lead of the operand loads (1 or 2 register stages)
+template <int PF>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_kernel(pdes_conv_desc d, float* __restrict__ part, int rows) {
   using namespace wb3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_wb3[];
@@ -147,16 +149,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_kernel(pdes_conv_desc d,
   __syncthreads();                          // coefficients visible
   issue(y0 - 2, s); commit(y0 - 2, s);      // z row y0 - 1
   issue(y0 - 1, s); commit(y0 - 1, s);      // z row y0
-  issue(y0, s);
   const int frag = (lane & 15) * W + 8 * swz(lane & 15, lane >> 4);     // a lane's 8 pixels inside a [16][32] tile
   const int ylast = y0 + rows - 1;
-  for (int y = y0; y <= ylast; ++y) {
-    __syncthreads();                        // the fragment reads of row y - 1 are done: its oldest slot may be overwritten
-    commit(y, s);                           // z row y + 1, g row y
-    __syncthreads();
-    issue(min(y + 1, ylast), s);            // in flight during the matrix work below
-    __builtin_amdgcn_sched_barrier(0);      // (without it the scheduler sinks these loads to their use at the top of
-                                            //  the next iteration and every row pays the full memory latency)
+  // the matrix work of row y: 108 MFMAs per wave
+  auto mma = [&](int y) __attribute__((always_inline)) {
     const unsigned short* gbuf = G + (y & 1) * 3 * nco * W;
     v8bf bh[2], bm[2], bl[2];
 #pragma unroll
@@ -191,6 +187,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_kernel(pdes_conv_desc d,
       PDES_WB3_TERM(ah, bm);
       PDES_WB3_TERM(ah, bh);
 #undef PDES_WB3_TERM
+    }
+  };
+  // one row: commit its operands (loaded PF rows ago), start the loads of row y + PF into the freed registers, matrix
+  // work.  Two rows of lead instead of one: 119 -> 117 us (the kernel is not latency bound: see DESIGN.md, matrix and
+  // vector instructions of one SIMD do not overlap, and this kernel issues about as many cycles of each).
+  auto row = [&](int y, Stage& st) __attribute__((always_inline)) {
+    __syncthreads();                        // the fragment reads of row y - 1 are done: its oldest slot may be overwritten
+    commit(y, st);                          // z row y + 1, g row y
+    __syncthreads();
+    issue(min(y + PF, ylast), st);          // in flight during the matrix work of PF rows
+    __builtin_amdgcn_sched_barrier(0);      // (without it the scheduler sinks these loads to their use and every row
+                                            //  pays the full memory latency)
+    mma(y);
+  };
+  if constexpr (PF == 1) {
+    issue(y0, s);
+    for (int y = y0; y <= ylast; ++y) row(y, s);
+  } else {
+    Stage s2;
+    issue(y0, s);
+    issue(min(y0 + 1, ylast), s2);
+    for (int y = y0; y <= ylast; y += 2) {
+      row(y, s);
+      if (y + 1 <= ylast) row(y + 1, s2);
     }
   }
 
@@ -478,7 +498,8 @@ int conv_backward_weight_b3(const pdes_conv_desc& d, hipStream_t st) {
   } else {
     size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)2 * 3 * nco * wb3::W * 2;
     if (epi > lds) lds = epi;
-    hipLaunchKernelGGL(conv_wgrad_b3_kernel, grid, block, lds, st, d, d.ws, rows);
+    if (opt().b3w_pf == 1) hipLaunchKernelGGL(conv_wgrad_b3_kernel<1>, grid, block, lds, st, d, d.ws, rows);
+    else hipLaunchKernelGGL(conv_wgrad_b3_kernel<2>, grid, block, lds, st, d, d.ws, rows);
   }
   PDES_LAUNCH_CHECK();
   return PDES_OK;

@@ -24,6 +24,7 @@ struct Options {
   int mfma_b3 = 1;              // PDES_MFMA_B3          : bf16 x3 split kernel for the wide 3x3 layer
   int mfma_b3w = 1;             // PDES_MFMA_B3W         : bf16 x3 split kernel for the weight gradient of the wide 3x3 layers
   int mfma_b3wu = 1;            // PDES_MFMA_B3WU        : ... and of the nearest-x2 + 3x3 layer with a 32-wide input (sub-pixel form)
+  int b3w_pf = 2;               // PDES_B3W_PF           : rows of lead of the operand loads of the bf16 x3 weight-gradient kernel (1 or 2)
   int mfma_b3u = 1;             // PDES_MFMA_B3U         : bf16 x3 split kernel for the forward of the nearest-x2 + 3x3 layers
   int mfma_small = 1;           // PDES_MFMA_SMALL       : matrix-core kernels for 3x3 convolutions on 8x8 maps (conv_small.hip)
   int mfma_b3ub = 1;            // PDES_MFMA_B3UB        : bf16 x3 split kernel for the data gradient of the nearest-x2 + 3x3 layers
