@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
   const bool row_ok = gy >= 0 && gy < H;
   const bool px_ok = row_ok && (interior || (halo && gx >= 0 && gx < W));
   const int goff = min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
-  const int lds_off = (it_r * G::PW + it_c) * G::KC + 8 * it_o;
+  const int lds_off = (it_r * G::PW + it_c) * G::KC;
+  // LDS swizzle of conv_mfma_b3.hip (octet bit 1 ^= bit 2 of the pixel's tile column: conflict-free fragment reads)
+  auto swz_oct = [](int col, int oct) __attribute__((always_inline)) { return oct ^ (((col >> 2) & 1) << 1); };
 
   struct Stage { float4 v[8]; };
   Stage sA;                           // ONE register stage: the next chunk's loads have a whole matrix phase to land
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) split3_pair(xv[2 * j], xv[2 * j + 1], hw[j], mw[j], lw[j]);
-      unsigned short* q = t + p * G::KC;
+      unsigned short* q = t + p * G::KC + 8 * swz_oct(it_c + p, it_o);
       *reinterpret_cast<uint4*>(q) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
       *reinterpret_cast<uint4*>(q + G::PLANE) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
       *reinterpret_cast<uint4*>(q + 2 * G::PLANE) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
@@ -142,7 +144,9 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const v8bf*>(p + (size_t)pl * 64 * 8);
   };
-  const int a_lane = (lane & 15) * G::KC + 8 * (lane >> 4);
+  int a_lane_k[3];                   // per tap column tx: the lane's pixel is tile column tx + (lane & 15) (+ 16 per M-tile)
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) a_lane_k[tx] = (lane & 15) * G::KC + 8 * swz_oct(tx + (lane & 15), lane >> 4);
 
   load_b(0, bS[0]);
   issue(0, sA);
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
         v8bf ah[MT], am[MT], al[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const unsigned short* ap = tb + (((mt / TWG) + ty) * G::PW + (mt % TWG) * 16 + tx) * G::KC + a_lane;
+          const unsigned short* ap = tb + (((mt / TWG) + ty) * G::PW + (mt % TWG) * 16 + tx) * G::KC + a_lane_k[tx];
           ah[mt] = *reinterpret_cast<const v8bf*>(ap);
           am[mt] = *reinterpret_cast<const v8bf*>(ap + G::PLANE);
           al[mt] = *reinterpret_cast<const v8bf*>(ap + 2 * G::PLANE);
