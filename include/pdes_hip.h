@@ -42,7 +42,7 @@ extern "C" {
  *   pdes_context_set_option  key = one of "PDES_CONV_IMPL" ("direct" | "auto"), "PDES_FUSE_FINALIZE",
  *                         "PDES_FUSE_MAXC", "PDES_FUSE_MAXHW", "PDES_FIN_EARLY", "PDES_MFMA_NTW", "PDES_MFMA_MT",
  *                         "PDES_MFMA_NG", "PDES_MFMA_1X1", "PDES_1X1_KSPLIT", "PDES_MFMA_1X1W", "PDES_1X1W_SPI",
- *                         "PDES_MFMA_B3", "PDES_MFMA_B3W", "PDES_MFMA_B3U", "PDES_MFMA_SMALL", "PDES_MFMA_B3UB", "PDES_MFMA_B3WU", "PDES_B3W_PF", "PDES_B3_APIPE", "PDES_B3_MT", "PDES_FEW_R", "PDES_WGRAD_WGS", "PDES_LOSS_NT",
+ *                         "PDES_MFMA_B3", "PDES_MFMA_B3W", "PDES_MFMA_B3U", "PDES_MFMA_SMALL", "PDES_MFMA_B3UB", "PDES_MFMA_B3WU", "PDES_B3W_PF", "PDES_B3_TAIL", "PDES_B3_APIPE", "PDES_B3_MT", "PDES_FEW_R", "PDES_WGRAD_WGS", "PDES_LOSS_NT",
  *                         "PDES_LOSS_DMA", "PDES_DEBUG_CHAIN" (timing experiments only, gradients are WRONG: 1 = pdes_backward skips the
  *                         weight-gradient kernels, 2 = and the fork events), "PDES_FORK_SIGNAL" (1: pdes_backward's fork events ride on the finalize
  *                         kernel's completion signal, 0: hipEventRecord); value = decimal string (NULL = default).

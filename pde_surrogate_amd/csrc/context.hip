@@ -31,7 +31,7 @@ static const Knob kKnobs[] = {
     {"PDES_MFMA_B3U", &Options::mfma_b3u},
     {"PDES_MFMA_SMALL", &Options::mfma_small},       {"PDES_B3_APIPE", &Options::b3_apipe},
     {"PDES_MFMA_B3UB", &Options::mfma_b3ub},         {"PDES_MFMA_B3WU", &Options::mfma_b3wu},
-    {"PDES_B3W_PF", &Options::b3w_pf},
+    {"PDES_B3W_PF", &Options::b3w_pf},               {"PDES_B3_TAIL", &Options::b3_tail},
 };
 
 static int set_knob(Options& o, const char* key, const char* value) {

@@ -45,6 +45,8 @@ struct B3Geo {
   static constexpr int NI = ROWS * QX * 4;                     // interior work items (row, quad, channel octet)
   static constexpr int NHI = ROWS * 2 * 4;                     // halo work items (row, side, channel octet)
   static_assert(NI + NHI <= 256, "one work item per thread");
+  // K tail on the f32 pipe: [4 channels][ROWS][FPW] floats behind the two bf16 buffers
+  static constexpr int FPW = PW + 2, FCS = ROWS * FPW;
 };
 
 struct BnB { float mean, invstd, gamma, beta; };
@@ -69,7 +71,7 @@ __device__ __forceinline__ BnB bn_coef_b3(const pdes_conv_desc& d, int c) {
 // grid: (tiles of the map, B, ceil(N-tiles / 8)); dynamic LDS: [kpad32] float4 coefficients (forward) + 2 buffers
 template <int TWG, int MTP, int MODE, bool APIPE = false>
 __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pdes_conv_desc d, const unsigned short* __restrict__ wb,
-                                                          int nt_total) {
+                                                          int nt_total, int tail_on) {
   using G = B3Geo<TWG, MTP>;
   constexpr int MT = G::MT, NT_W = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b3[];
@@ -96,8 +98,18 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   const int HW = UPB ? 4 * H * W : H * W;     // plane stride of the K operand
   const int nch1 = (kC + G::KC - 1) / G::KC, kpad = nch1 * G::KC;
   const int nchunk = UPB ? 4 * nch1 : nch1;   // virtual chunks: (parity, 32 channels)
+  // K tail.  196 = 6 x 32 + 4 input channels (forward) and 98 = 3 x 32 + 2 gradient channels (data gradient): the last
+  // 32-channel chunk would spend 9 taps x 6 MFMAs on 4 resp. 2 real channels (1/7 resp. 1/4 of the kernel's matrix cycles).
+  // Up to four tail channels go through ONE v_mfma_f32_16x16x4_f32 per (tap, M-tile, N-tile) instead -- exact fp32, a
+  // third of the cycles, no split -- from a small fp32 tile, the weights read straight from the (Cout, Cin, 3, 3) tensor.
+  const int rtail = kC - G::KC * (nch1 - 1);
+  const bool tail = !UPB && tail_on && nch1 >= 2 && rtail <= 4;
+  const int nb = tail ? nchunk - 1 : nchunk;  // chunks on the bf16 pipe
   float4* cf4 = reinterpret_cast<float4*>(smem_b3);                                   // forward only
   unsigned short* tile = reinterpret_cast<unsigned short*>(smem_b3 + (MODE == B3_FWD ? 16 * kpad : 0));
+  float* ftile = reinterpret_cast<float*>(tile + 2 * G::BUF);
+  if (tail)
+    for (int i = tid; i < 4 * G::FCS; i += 256) ftile[i] = 0.f;      // channels >= rtail stay zero (their weights are zero, 0 * NaN is not)
   const int tiles_x = W / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
 
@@ -170,6 +182,28 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
       *reinterpret_cast<uint4*>(q) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
       *reinterpret_cast<uint4*>(q + G::PLANE) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
       *reinterpret_cast<uint4*>(q + 2 * G::PLANE) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+  };
+  auto commit_tail = [&](const Stage& st) __attribute__((always_inline)) {       // the tail chunk's <= 4 channels as fp32
+    if (!(interior || halo) || it_o != 0) return;
+    const int c0 = (nch1 - 1) * G::KC;
+    float* t = ftile + it_r * G::FPW + it_c;
+    const int npx = interior ? 4 : 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < rtail) {
+        float xv[4] = {st.v[j].x, st.v[j].y, st.v[j].z, st.v[j].w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (p >= npx) break;
+          float x = xv[p];
+          if (MODE == B3_FWD) {
+            const float4 k = cf4[c0 + j];
+            x = fmaxf(0.f, (x - k.x) * k.y + k.z);
+          }
+          t[j * G::FCS + p] = px_ok ? x : 0.f;
+        }
+      }
     }
   };
 
@@ -261,6 +295,34 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
 #pragma unroll
     for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bw[0][nt], acc[mt][nt], 0, 0, 0);
   };
+  // tail: B operand of v_mfma_f32_16x16x4_f32 = W[k = tail channel lane >> 4][n = lane & 15] of tap t, from the weight tensor
+  float bft[9][NT_W];
+  auto load_tail_b = [&]() __attribute__((always_inline)) {
+    const int ch = lane >> 4, kc = kC - rtail + min(ch, rtail - 1);
+#pragma unroll
+    for (int nt = 0; nt < NT_W; ++nt) {
+      const int n = (nt_base + nt) * 16 + (lane & 15);
+      const int nC = MODE == B3_FWD ? d.Cout : d.Cin, nc = min(n, nC - 1);
+      const bool ok = ch < rtail && n < nC;
+      const float* wp = MODE == B3_FWD ? d.w + ((size_t)nc * d.Cin + kc) * 9 : d.w + ((size_t)kc * d.Cin + nc) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float v = wp[MODE == B3_FWD ? t : 8 - t];
+        bft[t][nt] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto tail_mma = [&]() __attribute__((always_inline)) {
+    const float* fa = ftile + (lane >> 4) * G::FCS + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float a = fa[((mt / TWG) + t / 3) * G::FPW + (mt % TWG) * 16 + t % 3];
+#pragma unroll
+        for (int nt = 0; nt < NT_W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bft[t][nt], acc[mt][nt], 0, 0, 0);
+      }
+  };
   const bool apipe = APIPE;
   auto step = [&](int chunk, Stage& sfree, const Stage& snext, v8bf (&b0)[3][NT_W], v8bf (&b1)[3][NT_W])
       __attribute__((always_inline)) {
@@ -268,6 +330,7 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
     const unsigned short* tb = tile + buf * G::BUF;
     const int par = UPB ? chunk / nch1 : 0;
     issue(min(chunk + 2, nchunk - 1), sfree);
+    if (!UPB && tail && chunk + 1 == nb) load_tail_b();      // in flight during the last bf16 chunk
     if (apipe) {
       v8bf a0[3], a1[3];
       lda(tb, 0, 0, par, a0);
@@ -290,17 +353,19 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
         mfma_tap(tb, tap_ky(t, par), tap_kx(t, par), (t & 1) ? b1 : b0);
       }
     }
-    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, snext);
+    if (chunk + 1 < nb) commit(chunk + 1, buf ^ 1, snext);
+    else if (!UPB && tail) commit_tail(snext);               // (chunk + 1 == nb: the tail chunk's loads are in `snext`)
     __syncthreads();
   };
   {
     int chunk = 0;
-    for (; chunk + 1 < nchunk; chunk += 2) {
+    for (; chunk + 1 < nb; chunk += 2) {
       step(chunk, sA, sB, bA, bB);
       if constexpr (NTAP & 1) step(chunk + 1, sB, sA, bB, bA);       // an odd tap count swaps the roles of the weight sets
       else step(chunk + 1, sB, sA, bA, bB);
     }
-    if (chunk < nchunk) step(chunk, sA, sB, bA, bB);
+    if (chunk < nb) step(chunk, sA, sB, bA, bB);
+    if (!UPB && tail) tail_mma();
   }
 
   // ---- epilogues (accumulator layout = v_mfma_f32_16x16x4_f32's: col = lane & 15, rows (lane >> 4) * 4 + r)
@@ -427,11 +492,12 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
 #define PDES_B3_LAUNCH(TWG_, MT_)                                                                             \
   do {                                                                                                        \
     using GL = B3Geo<TWG_, MT_>;                                                                              \
-    const size_t lds = cf + 2 * (size_t)GL::BUF * 2;                                                          \
+    const size_t lds = cf + 2 * (size_t)GL::BUF * 2 + 4 * (size_t)GL::FCS * sizeof(float);                    \
+    const int tail_on = (opt().b3_tail && d.w) ? 1 : 0;                                                       \
     if (opt().b3_apipe && MT_ == 4)                                                                           \
-      hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, true>), grid, block, lds, st, d, wb, nt_total);  \
+      hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, true>), grid, block, lds, st, d, wb, nt_total, tail_on);  \
     else                                                                                                      \
-      hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, false>), grid, block, lds, st, d, wb, nt_total); \
+      hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, false>), grid, block, lds, st, d, wb, nt_total, tail_on); \
   } while (0)
   if (twg == 2) { if (mt == 8) PDES_B3_LAUNCH(2, 8); else PDES_B3_LAUNCH(2, 4); }
   else { if (mt == 8) PDES_B3_LAUNCH(1, 8); else PDES_B3_LAUNCH(1, 4); }

@@ -30,6 +30,7 @@ struct Options {
   int mfma_b3ub = 1;            // PDES_MFMA_B3UB        : bf16 x3 split kernel for the data gradient of the nearest-x2 + 3x3 layers
   int b3_mt = 4;                // PDES_B3_MT
   int b3_apipe = 1;             // PDES_B3_APIPE         : A-operand fragments of the next (tap, M-tile) read before this one's MFMAs
+  int b3_tail = 1;              // PDES_B3_TAIL          : <= 4 channels of the last 32-channel chunk on the f32 pipe (one MFMA per tap instead of six)
   int few_r = 2;                // PDES_FEW_R
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS        : workgroup target of the split-K weight-gradient plan
   int loss_nt = -1;             // PDES_LOSS_NT          : -1 = by working-set size
