@@ -30,6 +30,7 @@ struct B3UGeo {
   static constexpr int NI = ROWS * QX * 4;                     // interior work items (row, quad, channel octet)
   static constexpr int NHI = ROWS * 2 * 4;                     // halo work items (row, side, channel octet)
   static_assert(NI + NHI <= 256, "one work item per thread");
+  static constexpr int FPW = PW + 2, FCS = ROWS * FPW;         // K tail on the f32 pipe: [4 channels][ROWS][FPW] floats
 };
 
 struct BnBU { float mean, invstd, gamma, beta; };
@@ -54,7 +55,7 @@ __device__ __forceinline__ BnBU bn_coef_b3u(const pdes_conv_desc& d, int c) {
 // grid: (tiles of the LOW-res map, B, ceil(N-tiles / 4)); dynamic LDS: [kpad32] float4 coefficients + 2 buffers
 template <int TWG>
 __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d, const unsigned short* __restrict__ wb,
-                                                                int nt_total) {
+                                                                int nt_total, int tail_on) {
   using G = B3UGeo<TWG>;
   constexpr int MT = G::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b3u[];
@@ -69,6 +70,14 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
   const int nchunk = (kC + G::KC - 1) / G::KC, kpad = nchunk * G::KC;
   float4* cf4 = reinterpret_cast<float4*>(smem_b3u);
   unsigned short* tile = reinterpret_cast<unsigned short*>(smem_b3u + 16 * kpad);
+  // K tail (98 = 3 x 32 + 2 input channels): the <= 4 channels of the last chunk on v_mfma_f32_16x16x4_f32, one per
+  // (position, parity) pair instead of six bf16 ones (conv_mfma_b3.hip); the effective weights are summed in registers
+  const int rtail = kC - G::KC * (nchunk - 1);
+  const bool tail = tail_on && nchunk >= 2 && rtail <= 4;
+  const int nb = tail ? nchunk - 1 : nchunk;
+  float* ftile = reinterpret_cast<float*>(tile + 2 * G::BUF);
+  if (tail)
+    for (int i = tid; i < 4 * G::FCS; i += 256) ftile[i] = 0.f;
   const int tiles_x = W / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
 
@@ -128,6 +137,24 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
       *reinterpret_cast<uint4*>(q + 2 * G::PLANE) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
   };
+  auto commit_tail = [&](const Stage& st) __attribute__((always_inline)) {
+    if (!(interior || halo) || it_o != 0) return;
+    const int c0 = (nchunk - 1) * G::KC;
+    float* t = ftile + it_r * G::FPW + it_c;
+    const int npx = interior ? 4 : 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < rtail) {
+        const float4 k = cf4[c0 + j];
+        float xv[4] = {st.v[j].x, st.v[j].y, st.v[j].z, st.v[j].w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (p >= npx) break;
+          t[j * G::FCS + p] = px_ok ? fmaxf(0.f, (xv[p] - k.x) * k.y + k.z) : 0.f;
+        }
+      }
+    }
+  };
 
   v4f acc[MT][4];
 #pragma unroll
@@ -148,6 +175,50 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
 #pragma unroll
   for (int tx = 0; tx < 3; ++tx) a_lane_k[tx] = (lane & 15) * G::KC + 8 * swz_oct(tx + (lane & 15), lane >> 4);
 
+  // tail: B operand of the f32 MFMA = Weff_p[a][b][co = lane & 15][tail channel lane >> 4], from the 9 taps of the tensor
+  float wf[4][4];                    // [parity][a * 2 + b]
+  auto load_tail_b = [&]() __attribute__((always_inline)) {
+    const int ch = lane >> 4, n = nt_w * 16 + (lane & 15);
+    const bool ok = ch < rtail && n < d.Cout;
+    const float* wp = d.w + ((size_t)min(n, d.Cout - 1) * d.Cin + (kC - rtail + min(ch, rtail - 1))) * 9;
+    float w9[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { const float v = wp[t]; w9[t] = ok ? v : 0.f; }
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) {
+        const int rm = weff_mask(pp >> 1, ab >> 1), cm = weff_mask(pp & 1, ab & 1);
+        float sum = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            if ((rm >> ky) & (cm >> kx) & 1) sum += w9[ky * 3 + kx];
+        wf[pp][ab] = sum;
+      }
+  };
+  auto tail_mma = [&]() __attribute__((always_inline)) {
+    const float* fa = ftile + (lane >> 4) * G::FCS + (lane & 15);
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = fa[((mt / TWG) + ty) * G::FPW + (mt % TWG) * 16 + tx];
+#pragma unroll
+          for (int ddy = 0; ddy < 2; ++ddy)
+#pragma unroll
+            for (int ddx = 0; ddx < 2; ++ddx) {
+              const int ia = ty - ddy, ib = tx - ddx;
+              if (ia < 0 || ia > 1 || ib < 0 || ib > 1) continue;
+              const int pp = ddy * 2 + ddx;
+              acc[mt][pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wf[pp][ia * 2 + ib], acc[mt][pp], 0, 0, 0);
+            }
+        }
+  };
+
   load_b(0, bS[0]);
   issue(0, sA);
   __syncthreads();                   // coefficients visible
@@ -158,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
     const int buf = chunk & 1;
     const unsigned short* tb = tile + buf * G::BUF;
     issue(min(chunk + 1, nchunk - 1), sA);
+    if (tail && chunk + 1 == nb) load_tail_b();            // in flight during the last bf16 chunk
     __builtin_amdgcn_sched_barrier(0);
     int j = 0;                         // compile-time after unrolling: index of the (position, parity) pair
 #pragma unroll
@@ -197,10 +269,12 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
             ++j;
           }
       }
-    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, sA);
+    if (chunk + 1 < nb) commit(chunk + 1, buf ^ 1, sA);
+    else if (tail) commit_tail(sA);
     __syncthreads();
   };
-  for (int chunk = 0; chunk < nchunk; ++chunk) step(chunk);
+  for (int chunk = 0; chunk < nb; ++chunk) step(chunk);
+  if (tail) tail_mma();
 
   // ---- epilogue: accumulator = D[pixel (lane >> 4) * 4 + r][channel lane & 15] per parity
   const int px = (lane >> 4) * 4;
@@ -253,13 +327,14 @@ int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st) {
   if (!opt().mfma_b3u || !d.wbu_fwd || !b3up_shape_ok(d)) return PDES_ENOSUP;
   const int nchunk = (d.Cin + 31) / 32, kpad = nchunk * 32, nt_total = (d.Cout + 15) / 16;
   const int twg = d.Win >= 32 ? 2 : 1;
+  const int tail_on = (opt().b3_tail && d.w) ? 1 : 0;
   dim3 grid((d.Win / (16 * twg)) * (d.Hin / (4 / twg)), d.B, (nt_total + 3) / 4), block(256);
   if (twg == 2) {
-    const size_t lds = 16 * (size_t)kpad + 2 * (size_t)B3UGeo<2>::BUF * 2;
-    hipLaunchKernelGGL((conv_b3_up_fwd_kernel<2>), grid, block, lds, st, d, d.wbu_fwd, nt_total);
+    const size_t lds = 16 * (size_t)kpad + 2 * (size_t)B3UGeo<2>::BUF * 2 + 4 * (size_t)B3UGeo<2>::FCS * sizeof(float);
+    hipLaunchKernelGGL((conv_b3_up_fwd_kernel<2>), grid, block, lds, st, d, d.wbu_fwd, nt_total, tail_on);
   } else {
-    const size_t lds = 16 * (size_t)kpad + 2 * (size_t)B3UGeo<1>::BUF * 2;
-    hipLaunchKernelGGL((conv_b3_up_fwd_kernel<1>), grid, block, lds, st, d, d.wbu_fwd, nt_total);
+    const size_t lds = 16 * (size_t)kpad + 2 * (size_t)B3UGeo<1>::BUF * 2 + 4 * (size_t)B3UGeo<1>::FCS * sizeof(float);
+    hipLaunchKernelGGL((conv_b3_up_fwd_kernel<1>), grid, block, lds, st, d, d.wbu_fwd, nt_total, tail_on);
   }
   PDES_LAUNCH_CHECK();
   return PDES_OK;
