@@ -418,10 +418,13 @@ def main():
                            'note': 'bucket A (conv weights of the last layers, ~3/4 of the bytes) is all-reduced from the '
                                    'weight-gradient stream inside pdes_backward; allreduce_us_standalone is the exchange '
                                    'timed alone after the run (what the step would pay without the overlap)'},
-                       'arithmetic': 'fp32 end to end; convolutions on v_mfma_f32_16x16x4_f32, except the 196->98 3x3 layer '
-                                     '(forward + data gradient): both operands split into three bf16 terms, six cross '
-                                     'products accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (24-bit significand '
-                                     'coverage, error vs fp64 equal to the f32 pipe; PDES_MFMA_B3=0 disables)'},
+                       'arithmetic': 'fp32 end to end; convolutions on v_mfma_f32_16x16x4_f32, except the three wide 3x3 '
+                                     'layers (196->98: forward, data and weight gradient; the nearest-x2 layers 98->49 and '
+                                     '100->100: sub-pixel forward (98->49), data and weight gradients): both operands split '
+                                     'into three bf16 terms, six cross products accumulated in fp32 on '
+                                     'v_mfma_f32_16x16x32_bf16 (24-bit significand coverage, error vs fp64 equal to the f32 '
+                                     'pipe: layer-level adversarial test; PDES_MFMA_B3 / _B3W / _B3U / _B3UB / _B3WU = 0 '
+                                     'put them back on the f32 pipe)'},
             'loss_mean_over_run': round(means[0], 4),
             'roofline': {'bound': 'hbm', 'kernel': 'darcy_loss_kernel<64,bwd> (fused Sobel+Darcy residual+boundary, fwd+bwd)',
                          'achieved': round(gbL, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
