@@ -78,31 +78,38 @@ int pdes_stat_replicas(void);
  *           (the reference's loss is w = (1, 1, weight_bound, weight_bound))
  *   flags & PDES_LOSS_NONLINEAR: sigma + beta1*sqrt(K)*sigma^2 + beta2*K*sigma^3 constitutive law.
  *   flags & PDES_LOSS_NO_TB: conv_continuity_constraint(use_tb=False), models/darcy.py:224 -- rows 0 and H-1 are left
- *           out of the continuity residual (mean over (H-2) W pixels); linear law only (PDES_ENOSUP with NONLINEAR).
- *   H == W in {16, 32, 64}.
+ *           out of the continuity residual (mean over (H-2) W pixels).
+ *   flags & PDES_LOSS_UNCORRECTED: the gradients of SobelFilter(correct=False) (utils/image_gradient.py:72-75, :89-92:
+ *           no boundary `modifier`).
+ *   Any square field, H == W >= 2 (SobelFilter(imsize) holds one imsize x imsize modifier for both axes; the
+ *   reference's docstrings use 65 x 65, models/darcy.py:165-167).  H in {16, 32, 64} with correct=True runs the
+ *   specialised one-image-per-workgroup kernel (16-byte aligned K / y / grad_y required); every other size or flag
+ *   combination the tiled kernel of csrc/darcy_loss_generic.hip (same results, same (B, 4) partials, scalar accesses).
  */
 #define PDES_LOSS_NONLINEAR 1
 #define PDES_LOSS_NO_TB 2
+#define PDES_LOSS_UNCORRECTED 4
 int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
                     int B, int H, int W, float w_const, float w_cont, float w_dir, float w_neu,
                     int flags, float beta1, float beta2, void* stream);
 
-/* Stand-alone Sobel gradients of `nimg` single-channel images (either output may be NULL).
+/* Stand-alone Sobel gradients of `nimg` single-channel images (either output may be NULL); correct = the
+ * SobelFilter's flag.  Any square H == W >= 2.
  * Replaces utils/image_gradient.py:50-75 (grad_h) and :77-92 (grad_v), filter_size=3. */
 int pdes_sobel_grad(const float* img, float* gh, float* gv, int nimg, int H, int W, int correct,
                     void* stream);
 
-/* img_bar = grad_h^T(gh_bar) + grad_v^T(gv_bar) (either input may be NULL); correct=True only.
+/* img_bar = grad_h^T(gh_bar) + grad_v^T(gv_bar) (either input may be NULL) for the same `correct`.
  * This is what autograd computes for the reference's pad/conv2d/matmul chain. */
 int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg, int H,
-                            int W, void* stream);
+                            int W, int correct, void* stream);
 
 /* The same two calls for filter_size = 5 (utils/image_gradient.py:35-41 kernel, :65-67 / :82-84 selection): replicate
- * pad 2, 5x5 cross-correlation, the same boundary `modifier`.  Square images, 4 <= H <= 64.  No reference caller
+ * pad 2, 5x5 cross-correlation, the same boundary `modifier`.  Any square H == W >= 2.  No reference caller
  * passes filter_size = 5; provided for completeness of SobelFilter's signature. */
 int pdes_sobel5_grad(const float* img, float* gh, float* gv, int nimg, int H, int W, int correct, void* stream);
 int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg, int H, int W,
-                             void* stream);
+                             int correct, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DenseED / Decoder building blocks (models/codec.py).  One descriptor per convolution; the

@@ -99,10 +99,11 @@ def sobel_grad_v5(img, correct=True):
     return _sobel5(img, _SOBEL5.T, img.shape[-2], correct, 'v')
 
 
-def constitutive(K, y, beta1=0.0, beta2=0.0, nonlinear=False):
-    """mean[(sigma1 + K du/dx [+nl])^2 + (sigma2 + K du/dy [+nl])^2]; darcy.py:162-176 / :179-191."""
+def constitutive(K, y, beta1=0.0, beta2=0.0, nonlinear=False, correct=True):
+    """mean[(sigma1 + K du/dx [+nl])^2 + (sigma2 + K du/dy [+nl])^2]; darcy.py:162-176 / :179-191.
+    `correct` is the SobelFilter's flag (image_gradient.py:26, :72-75, :89-92)."""
     u, s1, s2 = y[:, 0:1], y[:, 1:2], y[:, 2:3]
-    gh, gv = sobel_grad_h(u), sobel_grad_v(u)
+    gh, gv = sobel_grad_h(u, correct), sobel_grad_v(u, correct)
     if nonlinear:
         sq = torch.sqrt(K)
         r1 = s1 + beta1 * sq * s1 ** 2 + beta2 * K * s1 ** 3 + K * gh
@@ -113,9 +114,9 @@ def constitutive(K, y, beta1=0.0, beta2=0.0, nonlinear=False):
     return (r1 ** 2 + r2 ** 2).mean()
 
 
-def continuity(y, use_tb=True):
+def continuity(y, use_tb=True, correct=True):
     """mean[(d sigma1/dx + d sigma2/dy)^2]; darcy.py:210-224."""
-    c = sobel_grad_h(y[:, 1:2]) + sobel_grad_v(y[:, 2:3])
+    c = sobel_grad_h(y[:, 1:2], correct) + sobel_grad_v(y[:, 2:3], correct)
     if use_tb:
         return (c ** 2).mean()
     return (c ** 2)[:, :, 1:-1, :].mean()
@@ -130,19 +131,19 @@ def boundary(y):
     return dirichlet, neumann
 
 
-def mixed_residual_loss(K, y, weight_bound=10.0, beta1=0.0, beta2=0.0, nonlinear=False):
+def mixed_residual_loss(K, y, weight_bound=10.0, beta1=0.0, beta2=0.0, nonlinear=False, correct=True, use_tb=True):
     """train_codec_mixed_residual.py:228-232. Returns (loss, l_const, l_cont, l_dir, l_neu)."""
-    lc = constitutive(K, y, beta1, beta2, nonlinear)
-    lt = continuity(y)
+    lc = constitutive(K, y, beta1, beta2, nonlinear, correct)
+    lt = continuity(y, use_tb, correct)
     ld, ln = boundary(y)
     return lc + lt + (ld + ln) * weight_bound, lc, lt, ld, ln
 
 
 def loss_and_grad_autograd(K, y, weight_bound=10.0, beta1=0.0, beta2=0.0, nonlinear=False,
-                           weights=None):
+                           weights=None, correct=True, use_tb=True):
     """dL/dy by autograd. `weights`=(w_const,w_cont,w_dir,w_neu) overrides the default (1,1,wb,wb)."""
     y = y.detach().clone().requires_grad_(True)
-    loss, lc, lt, ld, ln = mixed_residual_loss(K, y, weight_bound, beta1, beta2, nonlinear)
+    loss, lc, lt, ld, ln = mixed_residual_loss(K, y, weight_bound, beta1, beta2, nonlinear, correct, use_tb)
     if weights is not None:
         loss = weights[0] * lc + weights[1] * lt + weights[2] * ld + weights[3] * ln
     (g,) = torch.autograd.grad(loss, y)

@@ -27,7 +27,7 @@ static const Knob kKnobs[] = {
     {"PDES_1X1W_SPI", &Options::w1x1_spi},           {"PDES_MFMA_B3", &Options::mfma_b3},
     {"PDES_B3_MT", &Options::b3_mt},                 {"PDES_FEW_R", &Options::few_r},
     {"PDES_WGRAD_WGS", &Options::wgrad_wgs},         {"PDES_LOSS_NT", &Options::loss_nt},
-    {"PDES_LOSS_DMA", &Options::loss_dma},           {"PDES_FORK_SIGNAL", &Options::fork_signal},     {"PDES_DEBUG_CHAIN", &Options::debug_chain},     {"PDES_MFMA_B3W", &Options::mfma_b3w},
+    {"PDES_FORK_SIGNAL", &Options::fork_signal},     {"PDES_DEBUG_CHAIN", &Options::debug_chain},     {"PDES_MFMA_B3W", &Options::mfma_b3w},
     {"PDES_MFMA_B3U", &Options::mfma_b3u},
     {"PDES_MFMA_SMALL", &Options::mfma_small},       {"PDES_B3_APIPE", &Options::b3_apipe},
     {"PDES_MFMA_B3UB", &Options::mfma_b3ub},         {"PDES_MFMA_B3WU", &Options::mfma_b3wu},

@@ -27,18 +27,17 @@
 #include <stdlib.h>
 #include "pdes_common.h"
 #include "pdes_options.h"
+#include "darcy_generic.h"      // LossParams; the any-size kernels live in darcy_loss_generic.hip
 #include "../../include/pdes_hip.h"
 
 namespace pdes {
 
-struct LossParams {
-  float a_const;   // w_const * 2 / (B n n)
-  float a_cont;    // w_cont  * 2 / (B n n)
-  float b_dir;     // w_dir   * 2 / (B n)
-  float b_neu;     // w_neu   * 2 / (2 B n)
-  float beta1, beta2;
-  int nt;          // 1: streaming (non-temporal) global loads / stores
-};
+// darcy_loss_generic.hip: any square n >= 2, SobelFilter(correct=False), filter_size = 5
+int launch_loss_generic(const float* K, const float* y, float* gy, float* partials, int B, int n, LossParams p,
+                        int flags, hipStream_t st);
+int launch_sobel_generic(const float* img, float* gh, float* gv, int nimg, int n, int correct, int five, hipStream_t st);
+int launch_sobel_adjoint_generic(const float* ghb, const float* gvb, float* out, int nimg, int n, int correct, int five,
+                                 hipStream_t st);
 
 struct F4 {
   float v[4];
@@ -333,154 +332,6 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS)
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Large batches (n = 64, forward + backward): persistent workgroups with asynchronous global -> LDS
-// copies (global_load_lds_dwordx4, no staging registers).  One 1024-thread workgroup per CU walks
-// images b, b + gridDim.x, ...; while image i is being processed out of one 64 KiB LDS buffer
-// (K, u, sigma1, sigma2), the four planes of image i+1 stream into the other, so every CU always has
-// a full image of reads (plus the previous image's 48 KiB of writes) in flight instead of
-// alternating load and compute phases.  The copies retire in order on the wave's VM counter:
-// younger than image i's four copies are at most the 3 gradient stores of image i-1 and the 4 copies
-// of image i+1, hence the counted vmcnt waits below.  Barriers are raw s_barrier + lgkmcnt(0): a
-// __syncthreads() fence would drain vmcnt and with it the prefetch.
-__device__ __forceinline__ void glds16(const float4* g, float4* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <bool NONLIN>
-__global__ __launch_bounds__(1024) void darcy_loss_dma_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
-                                                             float* __restrict__ gyp, float* __restrict__ partials,
-                                                             LossParams p, int B) {
-  constexpr int N = 64, SPR = 16, NSTRIP = 1024, NW = 16;
-  // TWO separate LDS objects: the compiler orders LDS accesses against in-flight LDS-DMA by alias analysis, and
-  // only distinct objects let it see that the copy into one buffer does not touch the other (with a single
-  // array it drains vmcnt(0) -- the whole prefetch -- before the first ds_write of every image)
-  __shared__ __attribute__((aligned(16))) float4 bufA[4 * NSTRIP];
-  __shared__ __attribute__((aligned(16))) float4 bufB[4 * NSTRIP];
-  __shared__ float red[NW * 4];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float fn = (float)N;
-  auto dma = [&](int b, float4* bufp) __attribute__((always_inline)) {
-    const float4* K4 = reinterpret_cast<const float4*>(Kp + (size_t)b * N * N);
-    const float4* y4 = reinterpret_cast<const float4*>(yp + (size_t)b * 3 * N * N);
-    float4* dst = bufp + wave * 64;                               // wave-uniform base; lane l lands at dst[l]
-    glds16(K4 + tid, dst);
-    glds16(y4 + tid, dst + NSTRIP);
-    glds16(y4 + NSTRIP + tid, dst + 2 * NSTRIP);
-    glds16(y4 + 2 * NSTRIP + tid, dst + 3 * NSTRIP);
-  };
-  int b = blockIdx.x;
-  if (b >= B) return;
-  const int s = tid, r = s / SPR, cs = s % SPR;
-  const bool first = cs == 0, last = cs == SPR - 1;
-  const RowGeom g = row_geom<N>(r, true);
-  const bool tb = (r == 0) || (r == N - 1);
-  dma(b, bufA);
-  // one image out of `pl`, the next one streaming into `nx`
-  auto process = [&](int b, int it, float4* pl, float4* nx) __attribute__((always_inline)) {
-    const bool more = b + (int)gridDim.x < B;
-    if (more) dma(b + gridDim.x, nx);
-    if (more) { if (it == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
-    else { if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-    lds_barrier();                       // every wave's copies of image b have landed
-    float4* lds = pl + NSTRIP;           // planes u, sigma1, sigma2 (same indexing as darcy_loss_kernel)
-
-    float sum_const = 0.f, sum_cont = 0.f, sum_dir = 0.f, sum_neu = 0.f;
-    F4 R1, R2, P1, P2, CC;
-    float dub;
-    {
-      const F4 kk(pl[s]);
-      const F4 u_own(lds[s]), s1_own(lds[NSTRIP + s]), s2_own(lds[2 * NSTRIP + s]);
-      const F4 u_up(lds[g.up * SPR + cs]), u_dn(lds[g.dn * SPR + cs]), u_far(lds[g.farF * SPR + cs]);
-      const F4 a_up(lds[NSTRIP + g.up * SPR + cs]), a_dn(lds[NSTRIP + g.dn * SPR + cs]);
-      const F4 b_up(lds[2 * NSTRIP + g.up * SPR + cs]), b_dn(lds[2 * NSTRIP + g.dn * SPR + cs]),
-          b_far(lds[2 * NSTRIP + g.farF * SPR + cs]);
-      const F4 ghu = hdiff(vsmooth3(u_up, u_own, u_dn), first, last, true, fn);
-      const F4 gvu = hsmooth(comb4(g.f_own, u_own, g.f_up, u_up, g.f_dn, u_dn, g.f_far, u_far), first, last, fn);
-      const F4 gh1 = hdiff(vsmooth3(a_up, s1_own, a_dn), first, last, true, fn);
-      const F4 gv2 = hsmooth(comb4(g.f_own, s2_own, g.f_up, b_up, g.f_dn, b_dn, g.f_far, b_far), first, last, fn);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float K = kk.v[i];
-        float r1 = s1_own.v[i] + K * ghu.v[i];
-        float r2 = s2_own.v[i] + K * gvu.v[i];
-        float q1 = 1.f, q2 = 1.f;
-        if (NONLIN) {
-          const float sq = sqrtf(K), x1 = s1_own.v[i], x2 = s2_own.v[i];
-          r1 += p.beta1 * sq * x1 * x1 + p.beta2 * K * x1 * x1 * x1;
-          r2 += p.beta1 * sq * x2 * x2 + p.beta2 * K * x2 * x2 * x2;
-          q1 += 2.f * p.beta1 * sq * x1 + 3.f * p.beta2 * K * x1 * x1;
-          q2 += 2.f * p.beta1 * sq * x2 + 3.f * p.beta2 * K * x2 * x2;
-        }
-        const float c = gh1.v[i] + gv2.v[i];
-        sum_const += r1 * r1 + r2 * r2;
-        sum_cont += c * c;
-        if (tb) sum_neu += s2_own.v[i] * s2_own.v[i];
-        R1.v[i] = p.a_const * r1 * q1;
-        R2.v[i] = p.a_const * r2 * q2 + (tb ? p.b_neu * s2_own.v[i] : 0.f);
-        P1.v[i] = p.a_const * K * r1;
-        P2.v[i] = p.a_const * K * r2;
-        CC.v[i] = p.a_cont * c;
-      }
-      float db = 0.f;
-      if (first) { const float e = u_own.v[0] - 1.f; sum_dir += e * e; db = p.b_dir * e; }
-      if (last) { const float e = u_own.v[3]; sum_dir += e * e; db = p.b_dir * e; }
-      dub = db;
-    }
-    {
-      const float t0 = wave_sum(sum_const), t1 = wave_sum(sum_cont), t2 = wave_sum(sum_dir), t3 = wave_sum(sum_neu);
-      if ((tid & 63) == 0) { red[wave * 4 + 0] = t0; red[wave * 4 + 1] = t1; red[wave * 4 + 2] = t2; red[wave * 4 + 3] = t3; }
-    }
-    lds_barrier();                       // also: every read of the input planes is done
-    if (tid < 4) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) t += red[w * 4 + tid];
-      partials[(size_t)b * 4 + tid] = t;
-    }
-    lds[s] = P1.f4();
-    lds[NSTRIP + s] = P2.f4();
-    lds[2 * NSTRIP + s] = CC.f4();
-    lds_barrier();
-    {
-      const F4 p1_own(lds[s]), p2_own(lds[NSTRIP + s]), c_own(lds[2 * NSTRIP + s]);
-      const F4 p1_up(lds[g.up * SPR + cs]), p1_dn(lds[g.dn * SPR + cs]);
-      const F4 p2_up(lds[NSTRIP + g.up * SPR + cs]), p2_dn(lds[NSTRIP + g.dn * SPR + cs]),
-          p2_far(lds[NSTRIP + g.farA * SPR + cs]);
-      const F4 c_up(lds[2 * NSTRIP + g.up * SPR + cs]), c_dn(lds[2 * NSTRIP + g.dn * SPR + cs]),
-          c_far(lds[2 * NSTRIP + g.farA * SPR + cs]);
-      const F4 ghT_c = hdiff_adj(vsmooth3(c_up, c_own, c_dn), first, last, fn);
-      const F4 gvT_c = hsmooth(comb4(g.a_own, c_own, g.a_up, c_up, g.a_dn, c_dn, g.a_far, c_far), first, last, fn);
-      const F4 ghT_p1 = hdiff_adj(vsmooth3(p1_up, p1_own, p1_dn), first, last, fn);
-      const F4 gvT_p2 = hsmooth(comb4(g.a_own, p2_own, g.a_up, p2_up, g.a_dn, p2_dn, g.a_far, p2_far), first, last, fn);
-      F4 du, d1, d2;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        du.v[i] = ghT_p1.v[i] + gvT_p2.v[i];
-        d1.v[i] = R1.v[i] + ghT_c.v[i];
-        d2.v[i] = R2.v[i] + gvT_c.v[i];
-      }
-      if (first) du.v[0] += dub;
-      if (last) du.v[3] += dub;
-      float4* g4 = reinterpret_cast<float4*>(gyp + (size_t)b * 3 * N * N);
-      nt_store4(g4 + s, du.f4());
-      nt_store4(g4 + NSTRIP + s, d1.f4());
-      nt_store4(g4 + 2 * NSTRIP + s, d2.f4());
-    }
-    lds_barrier();                       // the next iteration's copies overwrite this buffer
-  };
-  for (int it = 0; b < B; it += 2) {
-    process(b, it, bufA, bufB);
-    b += gridDim.x;
-    if (b >= B) break;
-    process(b, it + 1, bufB, bufA);
-    b += gridDim.x;
-  }
-}
-
 // The adjoint of hsmooth is hsmooth (S is symmetric) and the adjoint of vsmooth3 is vsmooth3,
 // so the backward above reuses them; only the difference operators have distinct adjoints.
 
@@ -586,108 +437,6 @@ __global__ __launch_bounds__(Geo<N>::NT) void sobel_adjoint_kernel(const float* 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// filter_size = 5 (image_gradient.py:35-41, :65-67, :82-84): replicate pad 2, the 5x5 kernel below (NOT separable),
-// x image size, and the same 3-point boundary `modifier`.  No reference caller selects it; one thread per pixel,
-// plane in LDS, any square n <= 64.
-__constant__ float kSobel5[5][5] = {{-5.f / 240, -4.f / 240, 0.f, 4.f / 240, 5.f / 240},
-                                    {-8.f / 240, -10.f / 240, 0.f, 10.f / 240, 8.f / 240},
-                                    {-10.f / 240, -20.f / 240, 0.f, 20.f / 240, 10.f / 240},
-                                    {-8.f / 240, -10.f / 240, 0.f, 10.f / 240, 8.f / 240},
-                                    {-5.f / 240, -4.f / 240, 0.f, 4.f / 240, 5.f / 240}};   // d/dx; transposed = d/dy
-
-__device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
-
-// raw (uncorrected) 5x5 response at (r, c) of the plane in LDS; horiz: d/dx, else d/dy
-__device__ __forceinline__ float sobel5_raw(const float* pl, int n, int r, int c, bool horiz) {
-  float a = 0.f;
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const float w = horiz ? kSobel5[i][j] : kSobel5[j][i];
-      a += w * pl[clampi(r + i - 2, n) * n + clampi(c + j - 2, n)];
-    }
-  return a * (float)n;
-}
-
-__global__ __launch_bounds__(256) void sobel5_grad_kernel(const float* __restrict__ img, float* __restrict__ gh,
-                                                          float* __restrict__ gv, int n, int correct) {
-  extern __shared__ float pl[];
-  const float* src = img + (size_t)blockIdx.x * n * n;
-  for (int i = threadIdx.x; i < n * n; i += 256) pl[i] = src[i];
-  __syncthreads();
-  for (int p = threadIdx.x; p < n * n; p += 256) {
-    const int r = p / n, c = p % n;
-    if (gh) {
-      float g = sobel5_raw(pl, n, r, c, true);
-      if (correct && c == 0) g = 4.f * g - sobel5_raw(pl, n, r, 1, true);              // grad @ modifier, column 0
-      if (correct && c == n - 1) g = 4.f * g - sobel5_raw(pl, n, r, n - 2, true);
-      gh[(size_t)blockIdx.x * n * n + p] = g;
-    }
-    if (gv) {
-      float g = sobel5_raw(pl, n, r, c, false);
-      if (correct && r == 0) g = 4.f * g - sobel5_raw(pl, n, 1, c, false);              // modifier^T @ grad, row 0
-      if (correct && r == n - 1) g = 4.f * g - sobel5_raw(pl, n, n - 2, c, false);
-      gv[(size_t)blockIdx.x * n * n + p] = g;
-    }
-  }
-}
-
-// adjoint: img_bar = grad_h^T(gh_bar) + grad_v^T(gv_bar), correct = True.  First the adjoint of the modifier
-// (column / row 0 and n-1 couple to their neighbour), then a gather over every (output pixel, tap) whose clamped
-// source is this pixel.
-__global__ __launch_bounds__(256) void sobel5_adjoint_kernel(const float* __restrict__ ghb, const float* __restrict__ gvb,
-                                                             float* __restrict__ out, int n) {
-  extern __shared__ float sm[];
-  float* a = sm;              // modifier-adjoint of gh_bar
-  float* b = sm + n * n;      // modifier-adjoint of gv_bar
-  const size_t base = (size_t)blockIdx.x * n * n;
-  for (int p = threadIdx.x; p < n * n; p += 256) {
-    const int r = p / n, c = p % n;
-    float va = 0.f, vb = 0.f;
-    if (ghb) {
-      va = ghb[base + p];
-      if (c == 0) va *= 4.f;
-      if (c == n - 1) va *= 4.f;
-      if (c == 1) va -= ghb[base + r * n];
-      if (c == n - 2) va -= ghb[base + r * n + n - 1];
-    }
-    if (gvb) {
-      vb = gvb[base + p];
-      if (r == 0) vb *= 4.f;
-      if (r == n - 1) vb *= 4.f;
-      if (r == 1) vb -= gvb[base + c];
-      if (r == n - 2) vb -= gvb[base + (size_t)(n - 1) * n + c];
-    }
-    a[p] = va; b[p] = vb;
-  }
-  __syncthreads();
-  for (int p = threadIdx.x; p < n * n; p += 256) {
-    const int r = p / n, c = p % n;
-    float acc = 0.f;
-    // output rows orow and taps i with clamp(orow + i - 2) == r
-    for (int i = 0; i < 5; ++i) {
-      int olo = r - (i - 2), ohi = olo;                       // interior: exactly one output row per tap
-      if (r == 0) { olo = 0; ohi = -(i - 2); }                // orow + i - 2 <= 0
-      if (r == n - 1) { olo = n - 1 - (i - 2); ohi = n - 1; } // orow + i - 2 >= n - 1
-      if (olo < 0) olo = 0;
-      if (ohi > n - 1) ohi = n - 1;
-      for (int orow = olo; orow <= ohi; ++orow)
-        for (int j = 0; j < 5; ++j) {
-          int clo = c - (j - 2), chi = clo;
-          if (c == 0) { clo = 0; chi = -(j - 2); }
-          if (c == n - 1) { clo = n - 1 - (j - 2); chi = n - 1; }
-          if (clo < 0) clo = 0;
-          if (chi > n - 1) chi = n - 1;
-          for (int ocol = clo; ocol <= chi; ++ocol)
-            acc += kSobel5[i][j] * a[orow * n + ocol] + kSobel5[j][i] * b[orow * n + ocol];
-        }
-    }
-    out[base + p] = acc * (float)n;
-  }
-}
-
 template <int N>
 static int launch_loss(const float* K, const float* y, float* gy, float* partials, int B, LossParams p,
                        int nonlinear, int no_tb, hipStream_t st) {
@@ -711,15 +460,19 @@ static int launch_loss(const float* K, const float* y, float* gy, float* partial
 
 using namespace pdes;
 
+static bool fast_size(int H) { return H == 16 || H == 32 || H == 64; }
+
 extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
                                float* loss_out, int B, int H, int W, float w_const, float w_cont,
                                float w_dir, float w_neu, int flags, float beta1, float beta2,
                                void* stream) {
   if (!K || !y || !partials || B <= 0) return PDES_EINVAL;
   const int nonlinear = flags & PDES_LOSS_NONLINEAR, no_tb = (flags & PDES_LOSS_NO_TB) ? 1 : 0;
-  if (nonlinear && no_tb) return PDES_ENOSUP;
-  if (H != W || !(H == 16 || H == 32 || H == 64)) return PDES_ENOSUP;
-  if (!aligned16(K) || !aligned16(y) || !aligned16(partials) || (grad_y && !aligned16(grad_y))) return PDES_EALIGN;
+  if (H != W || H < 2) return PDES_ENOSUP;       // SobelFilter has ONE imsize x imsize modifier: square fields (image_gradient.py:43-46)
+  // the specialised kernel: 16 / 32 / 64, correct=True, not (nonlinear and no top/bottom rows); everything else: generic
+  const bool fast = fast_size(H) && !(flags & PDES_LOSS_UNCORRECTED) && !(nonlinear && no_tb);
+  if (!aligned16(partials)) return PDES_EALIGN;
+  if (fast && (!aligned16(K) || !aligned16(y) || (grad_y && !aligned16(grad_y)))) return PDES_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double ntot = (double)B * H * W;
   LossParams p;
@@ -734,20 +487,10 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
   // batch sizes y was just produced and grad_y is consumed next, so those stay cacheable
   OptScope scope(ctx);
   p.nt = opt().loss_nt >= 0 ? opt().loss_nt : ((long long)B * H * W * 28 > (200ll << 20));
-  // PDES_LOSS_DMA=1: persistent workgroups + asynchronous global->LDS copies (n = 64, with gradients).  Off by
-  // default: measured 5.0-5.1 TB/s at B = 16384 against 5.1-5.6 TB/s for the register-staged kernel on the same
-  // box (it is steadier, and faster at B = 2048: 4.7-4.9 vs 4.0-4.9 TB/s) -- with 16 waves per CU the stencil
-  // arithmetic and LDS traffic of one image take about as long as its HBM traffic.
-  { const bool dma = opt().loss_dma != 0;
-    if (dma && H == 64 && grad_y && !no_tb) {
-      const int nwg = B < 256 ? B : 256;
-      const size_t lds = 0;      // static LDS: two 64 KiB image buffers
-      if (nonlinear) hipLaunchKernelGGL(darcy_loss_dma_kernel<true>, dim3(nwg), dim3(1024), lds, st, K, y, grad_y, partials, p, B);
-      else hipLaunchKernelGGL(darcy_loss_dma_kernel<false>, dim3(nwg), dim3(1024), lds, st, K, y, grad_y, partials, p, B);
-      H = 0;    // launched
-    }
+  if (!fast) {
+    const int rc = launch_loss_generic(K, y, grad_y, partials, B, H, p, flags, st);
+    if (rc) return rc;
   }
-  if (H == 0) { H = 64; }
   else if (H == 64) launch_loss<64>(K, y, grad_y, partials, B, p, nonlinear, no_tb, st);
   else if (H == 32) launch_loss<32>(K, y, grad_y, partials, B, p, nonlinear, no_tb, st);
   else launch_loss<16>(K, y, grad_y, partials, B, p, nonlinear, no_tb, st);
@@ -763,9 +506,15 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
 extern "C" int pdes_sobel_grad(const float* img, float* gh, float* gv, int nimg, int H, int W,
                                int correct, void* stream) {
   if (!img || (!gh && !gv) || nimg <= 0) return PDES_EINVAL;
-  if (H != W || !(H == 16 || H == 32 || H == 64)) return PDES_ENOSUP;
-  if (!aligned16(img) || (gh && !aligned16(gh)) || (gv && !aligned16(gv))) return PDES_EALIGN;
+  if (H != W || H < 2) return PDES_ENOSUP;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!fast_size(H)) {
+    const int rc = launch_sobel_generic(img, gh, gv, nimg, H, correct, 0, st);
+    if (rc) return rc;
+    PDES_LAUNCH_CHECK();
+    return PDES_OK;
+  }
+  if (!aligned16(img) || (gh && !aligned16(gh)) || (gv && !aligned16(gv))) return PDES_EALIGN;
   if (H == 64) hipLaunchKernelGGL(sobel_grad_kernel<64>, dim3(nimg), dim3(Geo<64>::NT), 0, st, img, gh, gv, correct);
   else if (H == 32) hipLaunchKernelGGL(sobel_grad_kernel<32>, dim3(nimg), dim3(Geo<32>::NT), 0, st, img, gh, gv, correct);
   else hipLaunchKernelGGL(sobel_grad_kernel<16>, dim3(nimg), dim3(Geo<16>::NT), 0, st, img, gh, gv, correct);
@@ -774,11 +523,17 @@ extern "C" int pdes_sobel_grad(const float* img, float* gh, float* gv, int nimg,
 }
 
 extern "C" int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg,
-                                       int H, int W, void* stream) {
+                                       int H, int W, int correct, void* stream) {
   if ((!gh_bar && !gv_bar) || !img_bar || nimg <= 0) return PDES_EINVAL;
-  if (H != W || !(H == 16 || H == 32 || H == 64)) return PDES_ENOSUP;
-  if ((gh_bar && !aligned16(gh_bar)) || (gv_bar && !aligned16(gv_bar)) || !aligned16(img_bar)) return PDES_EALIGN;
+  if (H != W || H < 2) return PDES_ENOSUP;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!fast_size(H) || !correct) {
+    const int rc = launch_sobel_adjoint_generic(gh_bar, gv_bar, img_bar, nimg, H, correct, 0, st);
+    if (rc) return rc;
+    PDES_LAUNCH_CHECK();
+    return PDES_OK;
+  }
+  if ((gh_bar && !aligned16(gh_bar)) || (gv_bar && !aligned16(gv_bar)) || !aligned16(img_bar)) return PDES_EALIGN;
   if (H == 64) hipLaunchKernelGGL(sobel_adjoint_kernel<64>, dim3(nimg), dim3(Geo<64>::NT), 0, st, gh_bar, gv_bar, img_bar);
   else if (H == 32) hipLaunchKernelGGL(sobel_adjoint_kernel<32>, dim3(nimg), dim3(Geo<32>::NT), 0, st, gh_bar, gv_bar, img_bar);
   else hipLaunchKernelGGL(sobel_adjoint_kernel<16>, dim3(nimg), dim3(Geo<16>::NT), 0, st, gh_bar, gv_bar, img_bar);
@@ -789,21 +544,21 @@ extern "C" int pdes_sobel_grad_adjoint(const float* gh_bar, const float* gv_bar,
 extern "C" int pdes_sobel5_grad(const float* img, float* gh, float* gv, int nimg, int H, int W, int correct,
                                 void* stream) {
   if (!img || (!gh && !gv) || nimg <= 0) return PDES_EINVAL;
-  if (H != W || H < 4 || H > 64) return PDES_ENOSUP;
-  hipLaunchKernelGGL(sobel5_grad_kernel, dim3(nimg), dim3(256), (size_t)H * W * 4, static_cast<hipStream_t>(stream), img,
-                     gh, gv, H, correct);
+  if (H != W || H < 2) return PDES_ENOSUP;
+  const int rc = launch_sobel_generic(img, gh, gv, nimg, H, correct, 1, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
 
 extern "C" int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* img_bar, int nimg, int H,
-                                        int W, void* stream) {
+                                        int W, int correct, void* stream) {
   if ((!gh_bar && !gv_bar) || !img_bar || nimg <= 0) return PDES_EINVAL;
-  if (H != W || H < 4 || H > 64) return PDES_ENOSUP;
-  hipLaunchKernelGGL(sobel5_adjoint_kernel, dim3(nimg), dim3(256), (size_t)2 * H * W * 4,
-                     static_cast<hipStream_t>(stream), gh_bar, gv_bar, img_bar, H);
+  if (H != W || H < 2) return PDES_ENOSUP;
+  const int rc = launch_sobel_adjoint_generic(gh_bar, gv_bar, img_bar, nimg, H, correct, 1, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
 
-extern "C" int pdes_abi_version(void) { return 15; }
+extern "C" int pdes_abi_version(void) { return 16; }

@@ -34,7 +34,6 @@ struct Options {
   int few_r = 2;                // PDES_FEW_R
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS        : workgroup target of the split-K weight-gradient plan
   int loss_nt = -1;             // PDES_LOSS_NT          : -1 = by working-set size
-  int loss_dma = 0;             // PDES_LOSS_DMA
   int debug_chain = 0;          // PDES_DEBUG_CHAIN      : TIMING EXPERIMENTS ONLY (wrong gradients): 1 = pdes_backward skips the
                                 //                         weight-gradient kernels but keeps the fork events, 2 = skips both
   int fork_signal = 1;          // PDES_FORK_SIGNAL      : fork events ride on the finalize kernel's completion signal (0: hipEventRecord)

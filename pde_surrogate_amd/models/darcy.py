@@ -32,19 +32,19 @@ def _check_fields(input, output):
 
 
 def _check_sobel(sobel_filter, H):
+    """-> the filter's `correct` flag (image_gradient.py:26); the kernels apply its stencils themselves"""
     if sobel_filter is None:
-        return
-    if not getattr(sobel_filter, 'correct', True):
-        raise NotImplementedError('fused Darcy loss implements SobelFilter(correct=True) only '
-                                  '(every reference caller constructs it that way)')
+        return True
     n = getattr(sobel_filter, 'imsize', H)
     if n != H:
         raise ValueError(f'sobel_filter was built for imsize {n}, fields are {H}')
+    return bool(getattr(sobel_filter, 'correct', True))
 
 
-def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta2=0.0, use_tb=True):
+def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta2=0.0, use_tb=True, correct=True):
     """Raw launch: returns (terms[5] = {total, const, cont, dir, neu} device tensor, grad_y or None).
-    use_tb=False: the continuity term leaves out rows 0 and H-1 (darcy.py:224; linear law only)."""
+    use_tb=False: the continuity term leaves out rows 0 and H-1 (darcy.py:224); correct=False: the gradients of
+    SobelFilter(correct=False) (image_gradient.py:72-75).  Any square field size."""
     B, H, W = _check_fields(K, y)
     if K is None:
         K = torch.zeros((B, 1, H, W), device=y.device, dtype=torch.float32)
@@ -57,7 +57,8 @@ def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta
     with _lib.device_guard(y.device):
         rc = _lib.lib().pdes_darcy_loss(_lib.context(y.device), _lib.ptr(K), _lib.ptr(y), _lib.ptr(grad),
                                         _lib.ptr(partials), _lib.ptr(terms), B, H, W, w[0], w[1], w[2], w[3],
-                                        (1 if nonlinear else 0) | (0 if use_tb else 2), float(beta1), float(beta2),
+                                        (1 if nonlinear else 0) | (0 if use_tb else 2) | (0 if correct else 4),
+                                        float(beta1), float(beta2),
                                         _lib.stream_ptr(y.device))
     _lib.check(rc, 'pdes_darcy_loss')
     return terms, grad
@@ -67,10 +68,10 @@ class _MixedResidual(torch.autograd.Function):
     """loss and dL/dy in one launch; backward is a scale by the upstream scalar."""
 
     @staticmethod
-    def forward(ctx, K, y, weight_bound, nonlinear, beta1, beta2):
+    def forward(ctx, K, y, weight_bound, nonlinear, beta1, beta2, correct=True):
         need = y.requires_grad
         terms, grad = darcy_loss_launch(K, y, (1.0, 1.0, weight_bound, weight_bound), need,
-                                        nonlinear, beta1, beta2)
+                                        nonlinear, beta1, beta2, True, correct)
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(terms)
         return terms[0].clone(), terms
@@ -78,16 +79,16 @@ class _MixedResidual(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_terms):
         (grad,) = ctx.saved_tensors
-        return None, grad * g_loss, None, None, None, None
+        return None, grad * g_loss, None, None, None, None, None
 
 
-def darcy_mixed_residual_loss(input, output, weight_bound=10.0, nonlinear=False, beta1=0.0, beta2=0.0):
-    """Fused loss of train_codec_mixed_residual.py:228-232.
+def darcy_mixed_residual_loss(input, output, weight_bound=10.0, nonlinear=False, beta1=0.0, beta2=0.0, correct=True):
+    """Fused loss of train_codec_mixed_residual.py:228-232 (`correct`: the SobelFilter's flag, :155 passes True).
 
     Returns (loss, loss_pde, loss_dirichlet, loss_neumann): `loss` is differentiable wrt `output`,
     the other three are detached 0-dim tensors for logging."""
     loss, terms = _MixedResidual.apply(input, output, float(weight_bound), bool(nonlinear),
-                                       float(beta1), float(beta2))
+                                       float(beta1), float(beta2), bool(correct))
     return loss, terms[1] + terms[2], terms[3], terms[4]
 
 
@@ -96,10 +97,10 @@ class _Terms(torch.autograd.Function):
     weights are the upstream gradients (exactly autograd's linear combination)."""
 
     @staticmethod
-    def forward(ctx, K, y, nonlinear, beta1, beta2, use_tb=True):
-        terms, _ = darcy_loss_launch(K, y, (1.0, 1.0, 1.0, 1.0), False, nonlinear, beta1, beta2, use_tb)
+    def forward(ctx, K, y, nonlinear, beta1, beta2, use_tb=True, correct=True):
+        terms, _ = darcy_loss_launch(K, y, (1.0, 1.0, 1.0, 1.0), False, nonlinear, beta1, beta2, use_tb, correct)
         ctx.save_for_backward(K, y)
-        ctx.cfg = (nonlinear, beta1, beta2, use_tb)
+        ctx.cfg = (nonlinear, beta1, beta2, use_tb, correct)
         return terms[1:5].clone()
 
     @staticmethod
@@ -107,25 +108,25 @@ class _Terms(torch.autograd.Function):
         K, y = ctx.saved_tensors
         w = g.detach().float().cpu().tolist()
         _, grad = darcy_loss_launch(K, y, w, True, *ctx.cfg)
-        return None, grad, None, None, None, None
+        return None, grad, None, None, None, None, None
 
 
 def conv_constitutive_constraint(input, output, sobel_filter):
     """sigma = -K grad(u): mean[(sigma1 + K u_x)^2 + (sigma2 + K u_y)^2]   (darcy.py:162-176)"""
-    _check_sobel(sobel_filter, output.shape[-1])
-    return _Terms.apply(input, output, False, 0.0, 0.0)[0]
+    correct = _check_sobel(sobel_filter, output.shape[-1])
+    return _Terms.apply(input, output, False, 0.0, 0.0, True, correct)[0]
 
 
 def conv_constitutive_constraint_nonlinear(input, output, sobel_filter, beta1, beta2):
     """-K grad(u) = sigma + beta1 sqrt(K) sigma^2 + beta2 K sigma^3          (darcy.py:179-191)"""
-    _check_sobel(sobel_filter, output.shape[-1])
-    return _Terms.apply(input, output, True, float(beta1), float(beta2))[0]
+    correct = _check_sobel(sobel_filter, output.shape[-1])
+    return _Terms.apply(input, output, True, float(beta1), float(beta2), True, correct)[0]
 
 
 def conv_continuity_constraint(output, sobel_filter, use_tb=True):
     """div(sigma) = 0: mean[(d sigma1/dx + d sigma2/dy)^2]                    (darcy.py:210-224)"""
-    _check_sobel(sobel_filter, output.shape[-1])
-    return _Terms.apply(None, output, False, 0.0, 0.0, bool(use_tb))[1]
+    correct = _check_sobel(sobel_filter, output.shape[-1])
+    return _Terms.apply(None, output, False, 0.0, 0.0, bool(use_tb), correct)[1]
 
 
 def conv_boundary_condition(output):

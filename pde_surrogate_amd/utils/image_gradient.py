@@ -1,8 +1,8 @@
 """SobelFilter on MI355X -- drop-in for the reference's utils/image_gradient.py:24-92.
 
-grad_h / grad_v are HIP kernels (csrc/darcy_loss.hip: `pdes_sobel_grad`, and
-`pdes_sobel_grad_adjoint` for autograd, `pdes_sobel5_*` for filter_size=5) instead of pad + conv2d + matmul;
-correct=False is forward-only.
+grad_h / grad_v are HIP kernels (`pdes_sobel_grad`, and `pdes_sobel_grad_adjoint` for autograd, `pdes_sobel5_*` for
+filter_size=5) instead of pad + conv2d + matmul, for any square imsize >= 2 and both values of `correct`
+(csrc/darcy_loss.hip: 16 / 32 / 64 specialisations; csrc/darcy_loss_generic.hip: everything else).
 """
 import numpy as np
 import torch
@@ -36,15 +36,13 @@ class _Grad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if not ctx.correct:
-            raise NotImplementedError('backward of SobelFilter(correct=False) is not implemented')
         g = g.contiguous()
         B, _, H, W = g.shape
         out = torch.empty_like(g)
         a, b = (g, None) if ctx.horizontal else (None, g)
         fn = _lib.lib().pdes_sobel_grad_adjoint if ctx.filter_size == 3 else _lib.lib().pdes_sobel5_grad_adjoint
         with _lib.device_guard(g.device):
-            rc = fn(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), B, H, W, _lib.stream_ptr(g.device))
+            rc = fn(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), B, H, W, 1 if ctx.correct else 0, _lib.stream_ptr(g.device))
         _lib.check(rc, 'pdes_sobel_grad_adjoint')
         return out, None, None, None
 

@@ -43,12 +43,17 @@ def test_parser_flags_defaults_and_run_dir(tmp_path, capsys):
 
 
 def test_parser_rejects_what_the_hip_path_cannot_run_before_creating_directories(tmp_path):
-    """--imsize 65 used to fail with PDES_ENOSUP after the run directory existed; the global batch must
-    divide the dataset under torchrun; only rank 0 writes"""
+    """--imsize: any size DenseED maps back onto itself (multiples of 4 for the default blocks; 65 -> a 64 x 64 output,
+    which the reference's loss cannot multiply with the 65 x 65 input either) -- the loss kernels take any square
+    size; the global batch must divide the dataset under torchrun; only rank 0 writes"""
     import train_codec_mixed_residual as t
     with pytest.raises(SystemExit, match='imsize'):
         t.Parser().parse(['--exp-dir', str(tmp_path / 'a'), '--imsize', '65'])
     assert not (tmp_path / 'a').exists()
+    for n in (48, 96, 128):
+        assert t.Parser().parse(['--exp-dir', str(tmp_path / 'ok'), '--imsize', str(n)]).imsize == n
+    with pytest.raises(SystemExit, match='imsize'):          # [3, 4, 3, 4, 3]: two encoding stages -> multiples of 8
+        t.Parser().parse(['--exp-dir', str(tmp_path / 'a'), '--imsize', '20', '--blocks', '34343'])
     with pytest.raises(SystemExit, match='global batch'):
         t.Parser().parse(['--exp-dir', str(tmp_path / 'b'), '--ntrain', '4096', '--batch-size', '32'], rank=0, world=3)
     assert not (tmp_path / 'b').exists()
@@ -148,7 +153,7 @@ def test_cglow_parser_contract(tmp_path):
                               'batch32_lr0.0015_epochs400')
     b = cli.Parser().parse(['--exp-dir', str(tmp_path), '--enc-blocks', '211', '--flow-blocks', '221', '--no-LU-decompose'])
     assert b.enc_blocks == [2, 1, 1] and b.flow_blocks == [2, 2, 1] and not b.LU_decompose
-    for bad in (['--imsize', '48'], ['--enc-blocks', '34'], ['--ntrain', '100'], ['--imsize', '16', '--enc-blocks', '33333',
+    for bad in (['--imsize', '50'], ['--enc-blocks', '34'], ['--ntrain', '100'], ['--imsize', '16', '--enc-blocks', '33333',
                                                                                   '--flow-blocks', '33333']):
         with pytest.raises(SystemExit):
             cli.Parser().parse(['--exp-dir', str(tmp_path)] + bad)

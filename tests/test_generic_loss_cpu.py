@@ -1,0 +1,196 @@
+"""CPU: the arithmetic and tile geometry of the any-size Sobel / Darcy-loss kernels (csrc/darcy_generic.h, shared by
+csrc/darcy_loss_generic.hip) compiled as plain C++ (tests/emu/darcy_generic_emu.cpp) against the oracle -- every halo
+case (tiles of 1..n rows / columns, first / last two rows and columns, n = 2 .. 130), correct=True/False, use_tb,
+the nonlinear law, the 5x5 filter.  fp32 emulation vs fp64 oracle: the tolerances of the GPU tests apply."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import darcy as od
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F, I, P, LL = ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
+BUDGET = 32768          # floats of LDS the kernel has (GEN_LDSF)
+
+
+@pytest.fixture(scope='module')
+def emu(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp('emu') / 'libdarcy_emu.so')
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off',
+                           os.path.join(ROOT, 'tests', 'emu', 'darcy_generic_emu.cpp'), '-o', so])
+    L = ctypes.CDLL(so)
+    L.emu_darcy_loss.argtypes = [P, P, P, P, I, I, F, F, F, F, F, F, I, I, I, LL]
+    L.emu_sobel.argtypes = [P, P, P, I, I, I, I]
+    L.emu_sobel_adjoint.argtypes = [P, P, P, I, I, I, I]
+    L.emu_choose_tile.argtypes = [I, LL, P, P]
+    L.emu_tile_floats.argtypes = [I, I, I]
+    L.emu_tile_floats.restype = LL
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(P)
+
+
+def _loss(emu, K, y, weights, flags=0, b1=0.0, b2=0.0, tr=0, tc=0, grad=True):
+    B, _, n, _ = y.shape
+    ncont = B * (n - 2) * n if flags & 2 else B * n * n
+    gy = np.full_like(y, np.nan) if grad else None
+    part = np.zeros((B, 4), np.float32)
+    nt = emu.emu_darcy_loss(_p(K), _p(y), _p(gy), _p(part), B, n, 2.0 * weights[0] / (B * n * n), 2.0 * weights[1] / ncont,
+                            2.0 * weights[2] / (B * n), 2.0 * weights[3] / (2 * B * n), b1, b2, flags, tr, tc, BUDGET)
+    assert nt > 0
+    s = part.astype(np.float64).sum(0)
+    terms = np.array([s[0] / (B * n * n), s[1] / ncont, s[2] / (B * n), s[3] / (2 * B * n)])
+    return terms, gy, nt
+
+
+def _fields(B, n, seed):
+    rng = np.random.default_rng(seed)
+    K = np.exp(0.5 * rng.standard_normal((B, 1, n, n))).astype(np.float32)
+    y = rng.standard_normal((B, 3, n, n)).astype(np.float32)
+    return K, y
+
+
+def _oracle(K, y, weights, flags=0, b1=0.0, b2=0.0):
+    terms, g = od.loss_and_grad_autograd(torch.from_numpy(K).double(), torch.from_numpy(y).double(), 10.0, b1, b2,
+                                         bool(flags & 1), weights=weights, correct=not (flags & 4), use_tb=not (flags & 2))
+    return np.array([float(t) for t in terms[1:]]), g.numpy()
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 7, 12, 20, 33, 48, 60])
+@pytest.mark.parametrize('flags', [0, 4])
+def test_loss_whole_image_tiles(emu, n, flags):
+    K, y = _fields(2, n, 100 + n)
+    w = (1.0, 1.0, 10.0, 10.0)
+    terms, gy, nt = _loss(emu, K, y, w, flags, tr=n, tc=n)
+    ref_t, ref_g = _oracle(K, y, w, flags)
+    np.testing.assert_allclose(terms, ref_t, rtol=1e-5)
+    assert rel_l2(gy, ref_g) < 1e-5
+    assert nt == 1
+
+
+@pytest.mark.parametrize('n,tr,tc', [(5, 1, 1), (7, 2, 3), (9, 1, 9), (9, 9, 1), (16, 3, 5), (21, 4, 21), (33, 7, 6),
+                                     (40, 13, 40), (65, 33, 65), (65, 16, 20)])
+@pytest.mark.parametrize('flags', [0, 4, 2, 1])
+def test_loss_tiled_equals_oracle(emu, n, tr, tc, flags):
+    """forced small tiles: every combination of halo clipping at the image edges and tile seams"""
+    K, y = _fields(2, n, 7 * n + tr)
+    w = (0.7, 1.3, 9.0, 11.0)
+    terms, gy, nt = _loss(emu, K, y, w, flags, 0.1, 0.2, tr, tc)
+    ref_t, ref_g = _oracle(K, y, w, flags, 0.1, 0.2)
+    np.testing.assert_allclose(terms, ref_t, rtol=1e-5)
+    assert rel_l2(gy, ref_g) < 1e-5
+    assert nt == -(-n // tr) * -(-n // tc)
+
+
+@pytest.mark.parametrize('n', [64, 65, 96, 128, 130, 300])
+def test_loss_kernel_tile_choice(emu, n):
+    """the tile the kernel picks for its 128 KiB of LDS fits, covers the image, and gives the oracle's loss"""
+    tr, tc = I(0), I(0)
+    assert emu.emu_choose_tile(n, BUDGET, ctypes.byref(tr), ctypes.byref(tc)) == 1
+    assert emu.emu_tile_floats(tr.value, tc.value, n) <= BUDGET
+    assert 1 <= tr.value <= n and 1 <= tc.value <= n
+    if n > 130:
+        return                                    # geometry only (the fp64 oracle at 300 x 300 is slow)
+    K, y = _fields(1, n, n)
+    w = (1.0, 1.0, 10.0, 10.0)
+    terms, gy, nt = _loss(emu, K, y, w)
+    ref_t, ref_g = _oracle(K, y, w)
+    np.testing.assert_allclose(terms, ref_t, rtol=1e-5)
+    assert rel_l2(gy, ref_g) < 1e-5
+    assert nt == -(-n // tr.value) * -(-n // tc.value)
+
+
+def test_forward_only_leaves_no_gradient(emu):
+    K, y = _fields(1, 20, 5)
+    t0, _, _ = _loss(emu, K, y, (1, 1, 10, 10), grad=False, tr=6, tc=20)
+    t1, _, _ = _loss(emu, K, y, (1, 1, 10, 10), grad=True, tr=6, tc=20)
+    np.testing.assert_array_equal(t0, t1)
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 6, 17, 65])
+@pytest.mark.parametrize('correct', [1, 0])
+@pytest.mark.parametrize('five', [0, 1])
+def test_sobel_and_adjoint(emu, n, correct, five):
+    rng = np.random.default_rng(n + 10 * correct + 100 * five)
+    img = (rng.standard_normal((3, 1, n, n)) * 2 + 0.5).astype(np.float32)
+    gh, gv = np.empty_like(img), np.empty_like(img)
+    emu.emu_sobel(_p(img), _p(gh), _p(gv), 3, n, correct, five)
+    fh, fv = (od.sobel_grad_h5, od.sobel_grad_v5) if five else (od.sobel_grad_h, od.sobel_grad_v)
+    t = torch.from_numpy(img).double().requires_grad_(True)
+    rh, rv = fh(t, bool(correct)), fv(t, bool(correct))
+    np.testing.assert_allclose(gh, rh.detach().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(gv, rv.detach().numpy(), rtol=1e-5, atol=1e-4)
+    wh = rng.standard_normal(img.shape).astype(np.float32)
+    wv = rng.standard_normal(img.shape).astype(np.float32)
+    ((rh * torch.from_numpy(wh).double()).sum() + (rv * torch.from_numpy(wv).double()).sum()).backward()
+    out = np.empty_like(img)
+    emu.emu_sobel_adjoint(_p(wh), _p(wv), _p(out), 3, n, correct, five)
+    assert rel_l2(out, t.grad.numpy()) < 1e-5
+    # one-sided calls (grad_h alone / grad_v alone)
+    emu.emu_sobel_adjoint(_p(wh), None, _p(out), 3, n, correct, five)
+    t2 = torch.from_numpy(img).double().requires_grad_(True)
+    (fh(t2, bool(correct)) * torch.from_numpy(wh).double()).sum().backward()
+    assert rel_l2(out, t2.grad.numpy()) < 1e-5
+
+
+# ---- against the REAL reference (tests/golden/G21_any_size.npz, tools/gen_golden.py round3) --------------------------
+@pytest.mark.parametrize('n', [20, 48, 65, 128])
+@pytest.mark.parametrize('correct', [True, False])
+def test_g21_reference_fields_and_loss(emu, n, correct):
+    from conftest import golden
+    g = golden('G21_any_size.npz')
+    sfx = '' if correct else '_nocorrect'
+    if f'terms{n}{sfx}' not in g:
+        pytest.skip('not recorded')
+    K, y, img = g[f'K{n}'], g[f'y{n}'], g[f'img{n}']
+    B = K.shape[0]
+    # oracle (fp64) and emulation (fp32 kernel arithmetic) against the reference's fp32 outputs
+    t = torch.from_numpy(img).double()
+    np.testing.assert_allclose(od.sobel_grad_h(t, correct).numpy(), g[f'gh{n}{sfx}'], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(od.sobel_grad_v(t, correct).numpy(), g[f'gv{n}{sfx}'], rtol=1e-5, atol=1e-4)
+    gh, gv = np.empty_like(img), np.empty_like(img)
+    emu.emu_sobel(_p(img), _p(gh), _p(gv), B, n, int(correct), 0)
+    np.testing.assert_allclose(gh, g[f'gh{n}{sfx}'], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(gv, g[f'gv{n}{sfx}'], rtol=1e-5, atol=1e-4)
+    flags = 0 if correct else 4
+    w = (1.0, 1.0, 10.0, 10.0)
+    ref = g[f'terms{n}{sfx}']
+    ot, og = _oracle(K, y, w, flags)
+    np.testing.assert_allclose(ot, ref[1:], rtol=1e-5)
+    assert rel_l2(og, g[f'grad{n}{sfx}']) < 1e-5
+    terms, gy, _ = _loss(emu, K, y, w, flags)
+    np.testing.assert_allclose(terms, ref[1:], rtol=1e-5)
+    np.testing.assert_allclose(terms[0] + terms[1] + 10.0 * (terms[2] + terms[3]), ref[0], rtol=1e-5)
+    assert rel_l2(gy, g[f'grad{n}{sfx}']) < 1e-5
+
+
+def test_g21_reference_variants_at_65(emu):
+    from conftest import golden
+    g = golden('G21_any_size.npz')
+    K, y, img = g['K65'], g['y65'], g['img65']
+    w = (1.0, 1.0, 10.0, 10.0)
+    terms, gy, _ = _loss(emu, K, y, w, 1, 0.1, 0.1)                # nonlinear law
+    np.testing.assert_allclose(terms, g['terms65_nl'][1:], rtol=1e-5)
+    assert rel_l2(gy, g['grad65_nl']) < 1e-5
+    terms, gy, _ = _loss(emu, K, y, (0.0, 1.0, 0.0, 0.0), 2)       # use_tb=False, continuity term alone
+    np.testing.assert_allclose(terms[1], float(g['cont65_no_tb']), rtol=1e-5)
+    assert rel_l2(gy, g['grad65_no_tb']) < 1e-5
+    ot, og = _oracle(K, y, (0.0, 1.0, 0.0, 0.0), 2)
+    np.testing.assert_allclose(ot[1], float(g['cont65_no_tb']), rtol=1e-5)
+    wh, wv = g['wh65'], g['wv65']
+    for correct in (1, 0):
+        sfx = '' if correct else '_nocorrect'
+        gh, gv, out = np.empty_like(img), np.empty_like(img), np.empty_like(img)
+        emu.emu_sobel(_p(img), _p(gh), _p(gv), 2, 65, correct, 1)
+        np.testing.assert_allclose(gh, g['gh65_f5' + sfx], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(gv, g['gv65_f5' + sfx], rtol=1e-5, atol=1e-4)
+        for five in (0, 1):
+            emu.emu_sobel_adjoint(_p(wh), _p(wv), _p(out), 2, 65, correct, five)
+            assert rel_l2(out, g[f'adj65_f{3 + 2 * five}{sfx}']) < 1e-5

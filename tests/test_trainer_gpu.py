@@ -224,3 +224,63 @@ def test_cli_with_reference_options(dev, tmp_path, monkeypatch):
         assert lt.shape == (2,) and np.isfinite(lt).all() and lt[1] < lt[0]
         a = json.load(open(run / 'args.txt'))
         assert a['upsample'] == 'bilinear' and a['drop_rate'] == 0.1
+
+
+@pytest.mark.parametrize('imsize', [48, 128])
+def test_other_field_sizes_end_to_end(dev, tmp_path, monkeypatch, imsize):
+    """--imsize other than 16 / 32 / 64: DenseED + the any-size loss kernel against the CPU oracle
+    (output, loss, a gradient), the fused step against the reference loop body on the drop-in modules, and the CLI"""
+    from oracle import codec as oc, darcy as od
+    from pde_surrogate_amd.models import darcy
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    blocks = [1, 1, 1]
+
+    def net():
+        torch.manual_seed(3)
+        with contextlib.redirect_stdout(io.StringIO()):
+            return DenseED(1, 3, imsize, blocks, growth_rate=8, init_features=16)
+    m = net()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(imsize)
+    x = torch.from_numpy(np.exp(0.5 * rng.standard_normal((4, 1, imsize, imsize))).astype(np.float32))
+    m = m.to(dev).train()
+    xd = x.to(dev)
+    y = m(xd)
+    assert tuple(y.shape) == (4, 3, imsize, imsize)
+    sob = SobelFilter(imsize, device=dev)
+    lp = darcy.conv_constitutive_constraint(xd, y, sob) + darcy.conv_continuity_constraint(y, sob)
+    ld, ln = darcy.conv_boundary_condition(y)
+    loss = lp + (ld + ln) * 10.0
+    loss.backward()
+    for k in oc.param_keys(sd):
+        sd[k].requires_grad_(True)
+    yo = oc.densed_forward(sd, x, blocks, imsize, True)
+    lo = od.mixed_residual_loss(x, yo, 10.0)[0]
+    lo.backward()
+    assert rel_l2(y.detach().cpu().numpy(), yo.detach().numpy()) < 1e-5
+    assert abs(float(loss) - float(lo)) < 1e-5 * abs(float(lo))
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), sd[k].grad.numpy()) < 1e-3, k
+    # fused step == the loop body above followed by Adam
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt.step()
+    m2 = net().to(dev).train()
+    tr = MixedResidualTrainer(m2, 4, imsize, lr=1e-3, weight_bound=10.0, device=dev)
+    tr.step(xd, 1e-3)
+    assert abs(tr.epoch_means()[0] - float(loss)) < 1e-5 * float(loss)
+    a = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    b = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
+    assert float(((a - b).abs() > 1e-6).float().mean()) < 0.02
+    if imsize == 48:
+        import train_codec_mixed_residual as t
+        monkeypatch.setenv('WORLD_SIZE', '1')
+        argv = ['--exp-dir', str(tmp_path), '--ntrain', '16', '--ntest', '8', '--batch-size', '8', '--test-batch-size', '8',
+                '--epochs', '2', '--cuda', '0', '--synthetic', '--imsize', '48', '--blocks', '111', '--growth-rate', '8',
+                '--init-features', '16']
+        with contextlib.redirect_stdout(io.StringIO()):
+            t.main(argv)
+        run = tmp_path / 'codec/mixed_residual/grf_kle512_ntrain16_run1_bs8_lr0.001_epochs2'
+        lt = np.loadtxt(run / 'training/loss_train.txt')
+        assert lt.shape == (2,) and np.isfinite(lt).all() and lt[1] < lt[0]

@@ -10,6 +10,7 @@ whether the local torch reproduces it).
 
     python tools/gen_golden.py            # rewrites tests/golden/*.npz
     python tools/gen_golden.py glow       # only G18-G20 (conditional Glow)
+    python tools/gen_golden.py round3     # only G21 (any field size; correct=False through the loss functions)
 """
 import hashlib
 import io
@@ -194,6 +195,61 @@ def gen_round2():
                         losses=np.array(losses), lrs=np.array(lrs), grad_norms_step1=gn1, grad_In_conv_step1=g_in,
                         grad_last_conv3_step1=g_last, mse_eval=np.array(mse_eval), nrmse_eval=rel, r2_eval=r2,
                         y_variation=yvar, y_eval=o.numpy())
+
+
+def gen_round3():
+    """G21: field sizes other than 16 / 32 / 64 and SobelFilter(correct=False) THROUGH the loss functions -- the reference
+    takes any square imsize (image_gradient.py:26-47; its docstrings use 65 x 65, darcy.py:165-167) and hands the
+    filter's `correct` flag to every gradient (image_gradient.py:72-75, :89-92).  Sobel fields, the four loss terms and
+    dL/dy (autograd of the reference) at n = 20, 48, 65, 128; use_tb=False, the nonlinear law and the 5x5 filter with
+    its autograd adjoint at n = 65."""
+    rng = np.random.default_rng(20190621)
+    out = {}
+    for n, B in ((20, 2), (48, 2), (65, 2), (128, 1)):
+        K = np.exp(0.5 * rng.standard_normal((B, 1, n, n))).astype(np.float32)
+        y = rng.standard_normal((B, 3, n, n)).astype(np.float32)
+        img = (rng.standard_normal((B, 1, n, n)) * 2 + 0.5).astype(np.float32)
+        out[f'K{n}'], out[f'y{n}'], out[f'img{n}'] = K, y, img
+        for correct in (True, False):
+            if n == 128 and not correct:
+                continue
+            sfx = '' if correct else '_nocorrect'
+            sob = SobelFilter(n, correct=correct)
+            it = torch.from_numpy(img)
+            out[f'gh{n}{sfx}'] = sob.grad_h(it).numpy()
+            out[f'gv{n}{sfx}'] = sob.grad_v(it).numpy()
+            yt = torch.from_numpy(y).requires_grad_(True)
+            terms = ref_loss(torch.from_numpy(K), yt, sob, 10.0)
+            terms[0].backward()
+            out[f'terms{n}{sfx}'] = np.array([float(t) for t in terms], np.float64)
+            out[f'grad{n}{sfx}'] = yt.grad.numpy()
+    n = 65
+    K, y, img = (torch.from_numpy(out[f'{k}{n}']) for k in ('K', 'y', 'img'))
+    sob = SobelFilter(n, correct=True)
+    yt = y.clone().requires_grad_(True)
+    terms = ref_loss(K, yt, sob, 10.0, True, 0.1, 0.1)
+    terms[0].backward()
+    out['terms65_nl'] = np.array([float(t) for t in terms], np.float64)
+    out['grad65_nl'] = yt.grad.numpy()
+    yt = y.clone().requires_grad_(True)
+    lt = rdarcy.conv_continuity_constraint(yt, sob, use_tb=False)
+    lt.backward()
+    out['cont65_no_tb'] = np.array(float(lt))
+    out['grad65_no_tb'] = yt.grad.numpy()
+    wh = rng.standard_normal(img.shape).astype(np.float32)
+    wv = rng.standard_normal(img.shape).astype(np.float32)
+    out['wh65'], out['wv65'] = wh, wv
+    for correct in (True, False):
+        sfx = '' if correct else '_nocorrect'
+        s5 = SobelFilter(n, correct=correct)
+        for fs in (3, 5):
+            it = img.clone().requires_grad_(True)
+            gh, gv = s5.grad_h(it, filter_size=fs), s5.grad_v(it, filter_size=fs)
+            ((gh * torch.from_numpy(wh)).sum() + (gv * torch.from_numpy(wv)).sum()).backward()
+            if fs == 5:
+                out[f'gh65_f5{sfx}'], out[f'gv65_f5{sfx}'] = gh.detach().numpy(), gv.detach().numpy()
+            out[f'adj65_f{fs}{sfx}'] = it.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G21_any_size.npz'), **out)
 
 
 def gen_dropout():
@@ -605,6 +661,7 @@ def main():
     gen_dropout()
     gen_bottleneck()
     gen_glow()
+    gen_round3()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
@@ -613,5 +670,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'glow':      # only the conditional-Glow fixtures (G18-G20)
         torch.set_num_threads(8)
         gen_glow()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round3':  # only G21 (any field size, correct=False through the loss)
+        torch.set_num_threads(8)
+        gen_round3()
     else:
         main()

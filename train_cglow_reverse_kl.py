@@ -66,8 +66,6 @@ def validate_args(args, world):
     levels = len(args.flow_blocks)
     if len(args.enc_blocks) != levels:
         raise SystemExit('--enc-blocks and --flow-blocks must have the same length')
-    if args.imsize not in (16, 32, 64):
-        raise SystemExit(f'--imsize {args.imsize}: the HIP Sobel / Darcy-residual kernels support 16, 32 and 64')
     if args.imsize % (1 << (levels - 1)) or args.imsize >> (levels - 1) < 2:
         raise SystemExit(f'--imsize {args.imsize} cannot be squeezed {levels - 1} times')
     if args.x_channels != 1 or args.y_channels != 3:

@@ -61,15 +61,18 @@ _REFERENCE_FLAGS = [
 ]
 
 
-SUPPORTED_IMSIZES = (16, 32, 64)       # the fused Sobel + residual kernels (csrc/darcy_loss.hip) are built for these
-
-
 def validate_args(args, world):
-    """reject what the HIP path cannot run BEFORE any directory is created (clear message instead of a late
-    PDES_ENOSUP): image sizes of the loss kernels, divisibility of the dataset by the GLOBAL batch"""
-    if args.imsize not in SUPPORTED_IMSIZES:
-        raise SystemExit(f'--imsize {args.imsize}: the HIP Sobel/Darcy-residual kernels support square fields of '
-                         f'{SUPPORTED_IMSIZES} pixels (the reference default is 64)')
+    """reject what cannot run BEFORE any directory is created: field sizes the network does not map back onto
+    themselves, divisibility of the dataset by the GLOBAL batch.  The Sobel / Darcy-residual kernels take any square
+    size (16 / 32 / 64: specialised kernels, everything else: csrc/darcy_loss_generic.hip); what restricts --imsize is
+    DenseED itself, in the reference too: one stride-2 convolution per encoding stage (codec.py:242, :113-118) and one
+    x2 upsampling per decoding stage give an output of the input's size -- which the loss needs (darcy.py:172-176
+    multiplies input and output fields) -- only when imsize is a multiple of 2^(1 + encoding blocks)."""
+    down = 2 ** (1 + len(args.blocks) // 2)
+    if args.imsize < down or args.imsize % down:
+        raise SystemExit(f'--imsize {args.imsize}: DenseED with blocks {args.blocks} halves the field {len(args.blocks) // 2 + 1} '
+                         f'times and doubles it back; the output matches the {args.imsize} x {args.imsize} input only for '
+                         f'multiples of {down}')
     if not (0.0 <= args.drop_rate < 1.0):
         raise SystemExit(f'--drop-rate {args.drop_rate} must be in [0, 1)')
     gb = args.batch_size * world
