@@ -14,6 +14,7 @@ Adam -- without autograd, host synchronisation or per-parameter kernels.
 import ctypes
 import math
 import os
+import time
 
 import torch
 
@@ -70,10 +71,20 @@ class MixedResidualTrainer:
         # everything before it, after the end-of-step launch.
         self._bucket_work, self._bucket_off = None, 0
         self._hook = None
+        self.host_prof = None             # a dict: host seconds per phase of _step are accumulated into it (bench.py)
         self.overlap_allreduce = os.environ.get('PDES_DP_OVERLAP', '1') != '0'
         if self.world > 1 or process_group is not None:
             self._hook_fn = _lib.BUCKET_FN(self._on_bucket)          # keep the callback object alive
             self._hook = _lib.BucketHook(self._hook_fn, None)
+            # what the early bucket relies on (checked once, here): the convolution weights sit in LAYER ORDER at the
+            # tail of the flat buffer, so "layers >= first_layer" is exactly the slice gflat[_conv_off[first_layer]:]
+            off, end = model._conv_off, self.gflat.numel()
+            convs = [i for i, sp in enumerate(model._specs) if sp.conv is not None]
+            sizes = [sp.cout * sp.cin * sp.k * sp.k for sp in model._specs if sp.conv is not None]
+            if any(off[a] + n != off[b] for a, b, n in zip(convs, convs[1:], sizes)) or off[convs[-1]] + sizes[-1] != end \
+                    or any(off[i] > off[i + 1] for i in range(len(off) - 1)):
+                raise RuntimeError('flat gradient layout: convolution weights are not contiguous in layer order at the tail '
+                                   '(the early all-reduce bucket would cover the wrong slice)')
 
     def _on_bucket(self, _user, first_layer, _stream):
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
@@ -94,11 +105,15 @@ class MixedResidualTrainer:
         L, st = self._L, _lib.stream_ptr()
         m = self.model
         assert m._flat is self.flat, 'the model was re-flattened (moved to another device?) after the trainer was built'
+        prof = self.host_prof
+        t0 = time.perf_counter() if prof is not None else 0.0
         y = self.eng.forward(self.x_static, True, defer_running=True)
+        t1 = time.perf_counter() if prof is not None else 0.0
         tail = self._loss(y, st)
         if not self._grad_clean or m._grad_dirty:      # an autograd backward of the same model shares this buffer
             self.gflat.zero_()
             m._grad_dirty = False
+        t2 = time.perf_counter() if prof is not None else 0.0
         hook = self._hook if (self.overlap_allreduce and not self.use_graph) else None
         self._hook_error = None
         try:
@@ -107,6 +122,11 @@ class MixedResidualTrainer:
             if self._hook_error is not None:                  # the all-reduce of bucket A failed inside the callback
                 raise self._hook_error
             raise
+        if prof is not None:
+            t3 = time.perf_counter()
+            prof['forward'] = prof.get('forward', 0.0) + (t1 - t0)
+            prof['loss'] = prof.get('loss', 0.0) + (t2 - t1)
+            prof['backward'] = prof.get('backward', 0.0) + (t3 - t2)
         return m
 
     def _loss(self, y, st):
@@ -143,6 +163,8 @@ class MixedResidualTrainer:
             self._step(x, lr)
 
     def _step(self, x, lr):
+        prof = self.host_prof
+        ts = time.perf_counter() if prof is not None else 0.0
         if x is not None:
             self.x_static.copy_(x)
         if self.use_graph and self.step_count:
@@ -178,6 +200,9 @@ class MixedResidualTrainer:
             self._grad_clean = True
             self.eng.arena_clean = True
         _lib.check(rc, 'pdes_adam_step')
+        if prof is not None:
+            prof['step'] = prof.get('step', 0.0) + (time.perf_counter() - ts)
+            prof['n'] = prof.get('n', 0) + 1
 
     def _capture(self):
         # warm the allocator / lazy inits on a side stream, then capture the compute part once

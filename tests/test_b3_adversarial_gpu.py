@@ -1,8 +1,9 @@
-"""Layer-level adversarial test of the bf16 x3 split kernel (csrc/conv_mfma_b3.hip: the 196 -> 98 3x3 layer on
-v_mfma_f32_16x16x32_bf16, both operands split into hi/mid/lo bf16 terms, six of the nine cross products kept) against
-an fp64 convolution -- VERDICT r1 weak #4.  The claim under test: the kernel is fp32-EQUIVALENT, i.e. its error against
-fp64 is of the size of the exact-f32 pipe's (v_mfma_f32_16x16x4_f32, option PDES_MFMA_B3=0) on the same data, also
-where the dropped cross terms could matter:
+"""Layer-level adversarial test of EVERY kernel of the bf16 x3 family (csrc/conv_mfma_b3.hip, conv_mfma_b3_up.hip,
+conv_mfma_wgrad_b3.hip: the wide 3x3 layers on v_mfma_f32_16x16x32_bf16, both operands split into hi/mid/lo bf16 terms,
+six of the nine cross products kept; forward, data gradient and weight gradient, plain and sub-pixel forms, with and
+without the f32 K-tail path) against fp64 convolutions -- VERDICT r1 weak #4, r2 weak #2.  The claim under test: each
+kernel is fp32-EQUIVALENT, i.e. its error against fp64 is of the size of the exact-f32 pipe's
+(v_mfma_f32_16x16x4_f32, the kernel's option = 0) on the same data, also where the dropped cross terms could matter:
   * wide dynamic range across the 196 * 9 = 1764-long contraction (1e-6 .. 1e3 in the activations, 1e-2 .. 1e2 in
     the weights),
   * post-ReLU sparsity (90 % exact zeros),
@@ -23,32 +24,23 @@ pytestmark = pytest.mark.gpu
 U = 2.0 ** -24
 
 
-@pytest.fixture(scope='module')
-def rig():
-    """the default DenseED's engine at B = 2 and the descriptor of its bf16-split layer, with an identity BatchNorm in
-    front (gamma 1, beta 0, statistics {0, n (1 - eps)}), so that the kernel's operand is exactly the buffer content"""
-    from pde_surrogate_amd.models.codec import DenseED
-    dev = torch.device('cuda:0')
-    torch.manual_seed(1)
-    with contextlib.redirect_stdout(io.StringIO()):
-        net = DenseED(1, 3, 64, [6, 8, 6]).to(dev).train()
-    x = torch.exp(0.5 * torch.randn(2, 1, 64, 64, device=dev))
-    with torch.no_grad():
-        net(x)
-    eng = net._engine(x)
-    i = [k for k, s in enumerate(net._specs) if s.conv == 'LastTransUp.conv1'][0]
-    s, d = net._specs[i], eng.descs[i]
-    assert (s.cin, s.cout, s.k) == (196, 98, 3) and d.wb_fwd and d.wb_bwd          # the bf16-split layer
-    one, zero, _ = net._identity_bn(dev, s.cin)
-    d.gamma, d.beta = one.data_ptr(), zero.data_ptr()
-    n = 2 * 32 * 32
-    eng.arena.zero_()
-    off = eng.stat_off[s.src]
-    stats = torch.zeros(2 * s.cin, dtype=torch.float64, device=dev)
-    stats[1::2] = n * (1.0 - 1e-5)
-    eng.arena[off:off + 2 * s.cin] = stats
-    d.out_stats = None
-    return dict(net=net, eng=eng, i=i, s=s, d=d, dev=dev, conv=net.features.LastTransUp.conv1)
+LAYERS = {           # name -> (convolution, Cin, Cout, input map size, nearest-x2 in front of the 3x3)
+    'wide': ('LastTransUp.conv1', 196, 98, 32, False),
+    'up32': ('LastTransUp.conv2', 98, 49, 32, True),
+    'up16': ('TransUp1.conv2', 100, 100, 16, True),
+}
+# every kernel of the bf16 x3 family: (layer, pass, the option that moves it to the exact-f32 pipe)
+KERNELS = {
+    'conv_mfma_b3_kernel<FWD> 196->98': ('wide', 'fwd', 'PDES_MFMA_B3'),
+    'conv_mfma_b3_kernel<BWD> 196->98': ('wide', 'dgrad', 'PDES_MFMA_B3'),
+    'conv_wgrad_b3_kernel 196->98': ('wide', 'wgrad', 'PDES_MFMA_B3W'),
+    'conv_b3_up_fwd_kernel 98->49': ('up32', 'fwd', 'PDES_MFMA_B3U'),
+    'conv_mfma_b3_kernel<UPBWD> 98->49': ('up32', 'dgrad', 'PDES_MFMA_B3UB'),
+    'conv_mfma_b3_kernel<UPBWD> 100->100': ('up16', 'dgrad', 'PDES_MFMA_B3UB'),
+    'conv_wgrad_b3_up_kernel<32> 98->49': ('up32', 'wgrad', 'PDES_MFMA_B3WU'),
+    'conv_wgrad_b3_up_kernel<16> 100->100': ('up16', 'wgrad', 'PDES_MFMA_B3WU'),
+}
+B = 2
 
 
 def _inputs(kind, rng, shape_x, shape_w):
@@ -79,42 +71,116 @@ def _errors(got, ref, scale):
     return float(np.linalg.norm(e) / np.linalg.norm(ref)), float(np.max(np.abs(e) / scale) / U)
 
 
-@pytest.mark.parametrize('kind', ['wide', 'sparse', 'boundary', 'cancel'])
-def test_bf16x3_forward_and_data_gradient_are_fp32_equivalent(rig, option, kind):
-    from pde_surrogate_amd import _lib
+def _rig(layer):
+    """a fresh default DenseED engine at B = 2 (the split-K plan of a weight gradient depends on the options in force
+    when it is made) and the descriptor of `layer`, with an identity BatchNorm in front (gamma 1, beta 0, statistics
+    {0, n (1 - eps)}), so that the kernels' operand is exactly the buffer content"""
+    from pde_surrogate_amd.models.codec import DenseED
+    dev = torch.device('cuda:0')
+    conv_name, cin, cout, hw, up = LAYERS[layer]
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DenseED(1, 3, 64, [6, 8, 6]).to(dev).train()
+    x = torch.exp(0.5 * torch.randn(B, 1, 64, 64, device=dev))
+    with torch.no_grad():
+        net(x)
+    eng = net._engine(x)
+    eng._plan_wgrad_scratch()
+    i = [k for k, s in enumerate(net._specs) if s.conv == conv_name][0]
+    s, d = net._specs[i], eng.descs[i]
+    assert (s.cin, s.cout, s.k, bool(s.up)) == (cin, cout, 3, up) and eng.buf_hw[s.src] == (hw, hw)
+    one, zero, _ = net._identity_bn(dev, s.cin)
+    d.gamma, d.beta = one.data_ptr(), zero.data_ptr()
+    eng.arena.zero_()
+    off = eng.stat_off[s.src]
+    stats = torch.zeros(2 * s.cin, dtype=torch.float64, device=dev)
+    stats[1::2] = B * hw * hw * (1.0 - 1e-5)
+    eng.arena[off:off + 2 * s.cin] = stats
+    d.out_stats = None
+    conv = net.features
+    for part in conv_name.split('.'):
+        conv = conv._modules[part]
+    return dict(net=net, eng=eng, i=i, s=s, d=d, dev=dev, conv=conv, up=up, hw=hw)
+
+
+def _reference(x, w, g, up):
+    """fp64 forward, data gradient and weight gradient of [nearest x2 +] 3x3 convolution, and the sums of absolute
+    products |w| * |x| each result is a rounding of (the componentwise error scale)"""
     import torch.nn.functional as F
-    eng, s, d, dev, conv = rig['eng'], rig['s'], rig['d'], rig['dev'], rig['conv']
+
+    def run(xa, wa, ga):
+        xa = xa.clone().requires_grad_(True)
+        wa = wa.clone().requires_grad_(True)
+        z = F.interpolate(xa, scale_factor=2, mode='nearest') if up else xa
+        out = F.conv2d(z, wa, padding=1)
+        gx, gw = torch.autograd.grad(out, (xa, wa), ga)
+        return out.detach().numpy(), gx.numpy(), gw.numpy()
+    xd, wd, gd = (torch.from_numpy(a).double() for a in (x, w, g))
+    ref = run(xd, wd, gd)
+    scale = run(xd.abs(), wd.abs(), gd.abs())
+    return ref, tuple(a + 1e-300 for a in scale)
+
+
+def _run_kernel(rig, what, x, w, g):
+    from pde_surrogate_amd import _lib
+    eng, s, d, conv, net = rig['eng'], rig['s'], rig['d'], rig['conv'], rig['net']
     L, st = _lib.lib(), _lib.stream_ptr()
-    rng = np.random.default_rng({'wide': 1, 'sparse': 2, 'boundary': 3, 'cancel': 4}[kind])
-    x, w = _inputs(kind, rng, (2, 196, 32, 32), (98, 196, 3, 3))
     with torch.no_grad():
         conv.weight.copy_(torch.from_numpy(w))
-    eng.X[s.src].copy_(torch.from_numpy(x))
-    xd, wd = torch.from_numpy(x).double(), torch.from_numpy(w).double()
-    ref = F.conv2d(xd, wd, padding=1).numpy()
-    scale = F.conv2d(xd.abs(), wd.abs(), padding=1).numpy() + 1e-300
-    # data gradient: T_in = conv^T(g) (identity BatchNorm, operand > 0 -> mask 1; zeros of `sparse` mask their own T)
-    g = (rng.standard_normal((2, 98, 32, 32)) * np.exp(rng.uniform(-3, 3, (2, 98, 32, 32)))).astype(np.float32)
-    gd = torch.from_numpy(g).double()
-    ref_t = F.conv_transpose2d(gd, wd, padding=1).numpy()
-    scale_t = F.conv_transpose2d(gd.abs(), wd.abs(), padding=1).numpy() + 1e-300
-    mask = (x > 0)
-    res = {}
-    for tag, b3 in (('b3', '1'), ('f32', '0')):
-        option('PDES_MFMA_B3', b3)
-        rig['net']._pack_weights()
-        _lib.check(L.pdes_conv_forward(eng.ctx, ctypes.byref(d), 1, st), 'forward')
-        out = eng.X[s.dst][:, s.dst_coff:s.dst_coff + 98].cpu().numpy()
-        eng.T[s.dst][:, s.dst_coff:s.dst_coff + 98].copy_(torch.from_numpy(g))
-        saved = (d.fin_tstats, d.t_accumulate)
+    eng.X[s.src][:, :s.cin].copy_(torch.from_numpy(x))
+    net._pack_weights()
+    ref = ctypes.byref(d)
+    if what == 'fwd':
+        _lib.check(L.pdes_conv_forward(eng.ctx, ref, 1, st), 'forward')
+        return eng.X[s.dst][:, s.dst_coff:s.dst_coff + s.cout].cpu().numpy()
+    eng.T[s.dst][:, s.dst_coff:s.dst_coff + s.cout].copy_(torch.from_numpy(g))
+    if what == 'dgrad':
+        saved = d.t_accumulate
         d.t_accumulate = 0
-        _lib.check(L.pdes_conv_backward_data(eng.ctx, ctypes.byref(d), 1, st), 'backward_data')
-        d.t_accumulate = saved[1]
-        t = eng.T[s.src][:, :196].cpu().numpy()
-        res[tag] = (_errors(out, ref, scale), _errors(t * mask, ref_t * mask, scale_t))
-    (f_b3, t_b3), (f_32, t_32) = res['b3'], res['f32']
-    print(f'{kind:9s} forward rel-L2 b3 {f_b3[0]:.2e} f32 {f_32[0]:.2e} | max scaled err (ulp of sum|w||x|) b3 {f_b3[1]:.2f} '
-          f'f32 {f_32[1]:.2f} || dgrad rel-L2 b3 {t_b3[0]:.2e} f32 {t_32[0]:.2e} | b3 {t_b3[1]:.2f} f32 {t_32[1]:.2f}')
-    for (b3e, f32e) in ((f_b3, f_32), (t_b3, t_32)):
-        assert b3e[0] <= 2.0 * f32e[0] + 1e-7                # normwise: within 2x of the exact-f32 pipe
-        assert b3e[1] <= max(2.0 * f32e[1], 4.0)             # componentwise: a few fp32 rounding units of sum |w||x|
+        _lib.check(L.pdes_conv_backward_data(eng.ctx, ref, 1, st), 'backward_data')
+        d.t_accumulate = saved
+        return eng.T[s.src][:, :s.cin].cpu().numpy()
+    gw = net._grad_view[s.conv + '.weight']
+    gw.zero_()
+    _lib.check(L.pdes_conv_backward_weight(eng.ctx, ref, 1, st), 'backward_weight')
+    row = eng._reduce_index[rig['i']]
+    assert row >= 0 and d.ws_defer                      # split-K partials, reduced in a fixed order
+    _lib.check(L.pdes_wgrad_reduce_all(eng._reduce_table.data_ptr() + 24 * row, 1, s.cout * s.cin * 9, st), 'reduce')
+    return gw.cpu().numpy().copy()
+
+
+@pytest.mark.parametrize('kind', ['wide', 'sparse', 'boundary', 'cancel'])
+@pytest.mark.parametrize('kernel', list(KERNELS))
+@pytest.mark.parametrize('tail', ['1', '0'])
+def test_bf16x3_kernels_are_fp32_equivalent(option, kernel, kind, tail):
+    """all six kernels of the bf16 x3 family (eight layer / pass combinations) x four adversarial input families x the
+    f32 K-tail path on and off: error against fp64 within 2x of the exact-f32 pipe's on the same data, and at most 4
+    fp32 rounding units of sum |w| |x| componentwise"""
+    layer, what, knob = KERNELS[kernel]
+    if tail == '0' and (what == 'wgrad' or layer == 'up16'):
+        pytest.skip('no K tail in this kernel (the weight gradients contract over pixels; 100 = 3 x 32 + 4 goes through '
+                    'PDES_B3_TAIL only in the forward / data-gradient kernels of the 98- and 196-channel layers)')
+    conv_name, cin, cout, hw, up = LAYERS[layer]
+    ho = 2 * hw if up else hw
+    rng = np.random.default_rng({'wide': 1, 'sparse': 2, 'boundary': 3, 'cancel': 4}[kind] + 10 * list(KERNELS).index(kernel))
+    x, w = _inputs(kind, rng, (B, cin, hw, hw), (cout, cin, 3, 3))
+    g = (rng.standard_normal((B, cout, ho, ho)) * np.exp(rng.uniform(-3, 3, (B, cout, ho, ho)))).astype(np.float32)
+    refs, scales = _reference(x, w, g, up)
+    k = {'fwd': 0, 'dgrad': 1, 'wgrad': 2}[what]
+    # data gradient: T_in = mask * conv^T(g) under the identity BatchNorm (operand > 0 -> mask 1; the exact zeros of
+    # `sparse` mask their own T)
+    mask = (x > 0) if what == 'dgrad' else 1.0
+    res, raw = {}, {}
+    option('PDES_B3_TAIL', tail)
+    for tag, v in (('b3', '1'), ('f32', '0')):
+        option(knob, v)
+        rig = _rig(layer)
+        raw[tag] = _run_kernel(rig, what, x, w, g)
+        res[tag] = _errors(raw[tag] * mask, refs[k] * mask, scales[k])
+        del rig
+    (b3, f32) = res['b3'], res['f32']
+    print(f'{kernel:40s} {kind:9s} tail {tail}: rel-L2 b3 {b3[0]:.2e} f32 {f32[0]:.2e} | max err in ulp of sum|w||x| '
+          f'b3 {b3[1]:.2f} f32 {f32[1]:.2f}')
+    assert not np.array_equal(raw['b3'], raw['f32']), 'the option did not change the kernel: is the bf16 path taken?'
+    assert b3[0] <= 2.0 * f32[0] + 1e-7                # normwise: within 2x of the exact-f32 pipe
+    assert b3[1] <= max(2.0 * f32[1], 4.0)             # componentwise: a few fp32 rounding units of sum |w||x|

@@ -165,9 +165,17 @@ def test_data_parallel_branch_on_one_rank(dev):
             dist.destroy_process_group()
 
 
-def _dp2_worker(rank, world, port, out):
+DP_CFGS = {   # name -> (DenseED arguments, per-rank batch): a small net, and THE configuration of BASELINE configs[2]
+    'tiny': (dict(blocks=[2, 2, 2], growth_rate=8, init_features=16), 4),
+    'default_b32': (dict(blocks=[6, 8, 6]), 32),          # per-rank workload of 8 x 32: real bucket offsets / hook layer
+}
+
+
+def _dp2_worker(rank, world, port, out, cfg):
     """one of TWO ranks sharing the one GPU of the test box, rendezvous over gloo (RCCL refuses two ranks on one
-    device; gloo moves CUDA tensors through the host): the trainer's world-size-2 branch with real shards"""
+    device; gloo moves CUDA tensors through the host): the trainer's world-size-2 branch with real shards.  Run twice:
+    with the two-bucket overlapped exchange (bucket A issued from the hook inside pdes_backward2) and with ONE
+    all-reduce after the backward pass (PDES_DP_OVERLAP=0) -- the parameters must agree BIT FOR BIT"""
     import torch.distributed as dist
     from pde_surrogate_amd.models.codec import DenseED
     from pde_surrogate_amd.train import MixedResidualTrainer
@@ -176,22 +184,44 @@ def _dp2_worker(rank, world, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
-    torch.manual_seed(1)
-    with contextlib.redirect_stdout(io.StringIO()):
-        net = DenseED(1, 3, 64, [2, 2, 2], growth_rate=8, init_features=16).to(dev).train()
-    data = torch.from_numpy(grf_kle_fields(24, n_kle=64, cache_dir="/tmp")).to(dev)
-    tr = MixedResidualTrainer(net, 4, 64, lr=1e-3, device=dev)
-    assert tr.world == 2 and tr._hook is not None
-    for step in range(3):
-        lo = step * 8 + rank * 4                          # contiguous split of the global batch of 8
-        tr.step(data[lo:lo + 4], 1e-3)
-    torch.cuda.synchronize()
-    out[rank] = (torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), tr.epoch_means())
+    kw, B = DP_CFGS[cfg]
+    data = torch.from_numpy(grf_kle_fields(6 * B, n_kle=64, cache_dir="/tmp")).to(dev)
+    res = {}
+    for overlap in ('1', '0'):
+        os.environ['PDES_DP_OVERLAP'] = overlap
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = DenseED(1, 3, 64, **kw).to(dev).train()
+        tr = MixedResidualTrainer(net, B, 64, lr=1e-3, device=dev)
+        assert tr.world == 2 and tr._hook is not None and tr.overlap_allreduce == (overlap == '1')
+        buckets = []
+        orig = tr._on_bucket
+
+        def spy(user, first_layer, stream, orig=orig, buckets=buckets):
+            buckets.append(first_layer)
+            return orig(user, first_layer, stream)
+        from pde_surrogate_amd import _lib
+        tr._hook_fn = _lib.BUCKET_FN(spy)
+        tr._hook = _lib.BucketHook(tr._hook_fn, None)
+        for step in range(3):
+            lo = step * 2 * B + rank * B                      # contiguous split of the global batch of 2 B
+            tr.step(data[lo:lo + B], 1e-3)
+        torch.cuda.synchronize()
+        res[overlap] = (torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), tr.epoch_means(), buckets,
+                        int(tr._bucket_off), int(tr.gflat.numel()))
+        del tr, net
+    assert res['0'][2] == [] and len(res['1'][2]) in (0, 3)    # the hook runs once per step, only in overlap mode
+    if cfg == 'default_b32':
+        assert len(res['1'][2]) == 3
+        assert 0 < res['1'][3] < res['1'][4]                   # bucket A is a proper tail slice of the gradient buffer
+    assert torch.equal(res['1'][0], res['0'][0]), 'two-bucket overlapped exchange != one all-reduce after the backward pass'
+    out[rank] = (res['1'][0], res['1'][1], res['1'][3] / res['1'][4])
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_data_parallel_two_ranks_equals_mean_of_shard_gradients(dev):
+@pytest.mark.parametrize('cfg', list(DP_CFGS))
+def test_data_parallel_two_ranks_equals_mean_of_shard_gradients(dev, cfg):
     """world size 2 for real: both ranks end every step with IDENTICAL parameters, and they equal a single-process
     emulation that averages the two shards' gradients (rank-local BatchNorm) before one Adam step -- the definition of
     data-parallel parity of SURVEY 8(e)"""
@@ -206,24 +236,27 @@ def test_data_parallel_two_ranks_equals_mean_of_shard_gradients(dev):
     port = s.getsockname()[1]
     s.close()
     out = mp.Manager().dict()
-    mp.spawn(_dp2_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_dp2_worker, args=(2, port, out, cfg), nprocs=2, join=True)
     p0, p1 = out[0][0], out[1][0]
     assert torch.equal(p0, p1)                                        # same reduced gradient, same Adam step
+    if cfg == 'default_b32':
+        assert out[0][2] < 0.5                                        # bucket A = the larger share of the bytes
     # emulation: two shard trainers that never step, gradients averaged by hand
-    data = torch.from_numpy(grf_kle_fields(24, n_kle=64, cache_dir="/tmp")).to(dev)
+    kw, B = DP_CFGS[cfg]
+    data = torch.from_numpy(grf_kle_fields(6 * B, n_kle=64, cache_dir="/tmp")).to(dev)
     nets = []
     for r in range(2):
         torch.manual_seed(1)
         with contextlib.redirect_stdout(io.StringIO()):
-            nets.append(DenseED(1, 3, 64, [2, 2, 2], growth_rate=8, init_features=16).to(dev).train())
-    trs = [MixedResidualTrainer(n, 4, 64, lr=1e-3, device=dev) for n in nets]
+            nets.append(DenseED(1, 3, 64, **kw).to(dev).train())
+    trs = [MixedResidualTrainer(n, B, 64, lr=1e-3, device=dev) for n in nets]
     ms = [torch.zeros_like(trs[0].flat) for _ in range(2)]
     vs = [torch.zeros_like(trs[0].flat) for _ in range(2)]
     for step in range(3):
         g = []
         for r in range(2):
-            lo = step * 8 + r * 4
-            trs[r].x_static.copy_(data[lo:lo + 4])
+            lo = step * 2 * B + r * B
+            trs[r].x_static.copy_(data[lo:lo + B])
             trs[r].gflat.zero_()
             trs[r]._grad_clean = False
             trs[r]._compute()
