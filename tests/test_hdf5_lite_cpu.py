@@ -73,3 +73,46 @@ def test_rejects_what_it_does_not_implement(tmp_path):
         hdf5_lite.File(str(p))
     with pytest.raises(ValueError):
         hdf5_lite.File(str(p), 'w')
+
+
+# ---- files written by the HDF5 library itself (h5py 3.3 / libhdf5 1.10.6; tools/gen_hdf5_fixtures.py) ------------------
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'hdf5')
+FOREIGN = ['default_contiguous.hdf5', 'chunked_gzip_shuffle.hdf5', 'btree_depth2.hdf5', 'latest_fixed_array.hdf5',
+           'latest_fixed_array_paged.hdf5', 'bigendian_userblock.hdf5', 'resizable_earliest.hdf5', 'resizable_latest.hdf5']
+REFUSED = {('resizable_latest.hdf5', 'input'): 'extensible array'}
+
+
+@pytest.mark.parametrize('name', FOREIGN)
+def test_reads_library_written_layouts(name):
+    """every layout h5py emits for `create_dataset(name, data=..., [chunks, compression, shuffle, fletcher32])` with the
+    default and with libver='latest' (the reader is checked against bytes it did not write);
+    what it does not implement it must refuse BY NAME"""
+    import hashlib
+    import json
+    path = os.path.join(FIX, name)
+    manifest = json.load(open(os.path.join(FIX, 'MANIFEST.json')))
+    assert hashlib.sha256(open(path, 'rb').read()).hexdigest() == manifest[name]['sha256']     # the library's bytes, untouched
+    exp = np.load(path + '.expected.npz')
+    with hdf5_lite.File(path) as f:
+        for key in exp.files:
+            why = REFUSED.get((name, key))
+            if why:
+                with pytest.raises(NotImplementedError, match=why):
+                    f[key][...]
+                continue
+            d = f[key]
+            assert d.shape == exp[key].shape and d.dtype.itemsize == exp[key].dtype.itemsize
+            np.testing.assert_array_equal(np.asarray(d[...], exp[key].dtype), exp[key])
+            np.testing.assert_array_equal(np.asarray(d[:3], exp[key].dtype), exp[key][:3])
+
+
+def test_loader_contract_on_a_library_written_file():
+    """utils/load.py:18-37 of the reference (`f['input'][:ndata]`, fp32 tensors, y_variation) through a file h5py wrote"""
+    path = os.path.join(FIX, 'chunked_gzip_shuffle.hdf5')
+    exp = np.load(path + '.expected.npz')
+    x, y = read_arrays(path, 10, only_input=False)
+    np.testing.assert_array_equal(x, exp['input'][:10])
+    np.testing.assert_array_equal(y, exp['output'][:10])
+    loader, stats = load_data(path, 8, 4, only_input=False, return_stats=True)
+    np.testing.assert_allclose(stats['y_variation'], y_variation(exp['output'][:8]), rtol=1e-6)
+    assert len(loader) == 2 and next(iter(loader))[0].dtype == torch.float32
