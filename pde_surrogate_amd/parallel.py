@@ -7,13 +7,69 @@ The reference has no distributed code at all; data parallelism is what this buil
   * gradients are ONE flat fp32 buffer -> one all-reduce(SUM) per step over RCCL/xGMI (2.96 MB for the
     default net: latency-bound), then Adam with grad_scale = 1/world_size on every rank;
   * parameters start identical (same seed, checked/enforced by `broadcast_parameters`).
-These helpers are pure torch (`torch.distributed` with the `nccl` backend = RCCL on ROCm; the CPU
-tests run them over `gloo` with world_size 2).
+Rendezvous, broadcasts and the once-per-epoch scalar means go through `torch.distributed` (backend `nccl` = RCCL on
+ROCm; the CPU tests run them over `gloo` with world_size 2).  The PER-STEP gradient exchange does not: `DirectRccl`
+holds its own RCCL communicator and enqueues `ncclAllReduce` on a HIP stream by pointer (ctypes into the librccl.so
+torch ships) -- a `torch.distributed.all_reduce` costs the host ~0.3 ms per call (Work objects, stream guards, event
+bookkeeping: 1.63 vs 0.97 ms of host time per step measured with two buckets on one rank), the direct call a few
+microseconds, and the step of an 8-rank job must not become host-bound.
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
+
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [('internal', ctypes.c_char * 128)]
+
+
+class DirectRccl:
+    """one RCCL communicator over the ranks of a torch process group (backend nccl), driven through ctypes.
+    `all_reduce_sum_(ptr, count, stream)` enqueues an in-place fp32 SUM all-reduce on the given hipStream_t."""
+    NCCL_FLOAT32, NCCL_SUM = 7, 0
+
+    def __init__(self, group=None, device=None):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != 'nccl':
+            raise RuntimeError('DirectRccl needs an initialised torch.distributed process group with backend nccl (RCCL)')
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        L = ctypes.CDLL(path)                                # the library torch itself loaded: the same RCCL, the same HIP runtime
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p]
+        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        L.ncclGetErrorString.argtypes = [ctypes.c_int]
+        L.ncclGetErrorString.restype = ctypes.c_char_p
+        self._L = L
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            self._check(L.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        payload = [bytes(bytearray(uid)) if self.rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(payload, src=src, group=group, device=self.device)      # 128 bytes, once
+        ctypes.memmove(ctypes.byref(uid), payload[0], 128)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(L.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        self._comm = comm
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f'{what} failed: {self._L.ncclGetErrorString(rc).decode()} ({rc})')
+
+    def all_reduce_sum_(self, ptr, count, stream_ptr):
+        rc = self._L.ncclAllReduce(ptr, ptr, count, self.NCCL_FLOAT32, self.NCCL_SUM, self._comm, stream_ptr)
+        if rc != 0:
+            self._check(rc, 'ncclAllReduce')
+
+    def close(self):
+        if getattr(self, '_comm', None):
+            self._L.ncclCommDestroy(self._comm)
+            self._comm = None
 
 
 def init_from_env(backend=None):

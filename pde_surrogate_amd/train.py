@@ -22,6 +22,70 @@ from . import _lib, parallel
 from .models.darcy import darcy_loss_launch  # noqa: F401  (re-exported for callers)
 
 
+def adam_state_dict(trainer):
+    """the fused trainer's Adam moments as a `torch.optim.Adam.state_dict()` of this model's parameters -- what the
+    reference stores under 'optimizer_state_dict' (train_cglow_reverse_kl.py:281-289) and feeds to
+    `optimizer.load_state_dict` on resume: per-parameter exp_avg / exp_avg_sq / step sliced out of the flat buffers
+    (built through a real torch.optim.Adam, so the layout is the installed torch's own)"""
+    m = trainer.model
+    opt = torch.optim.Adam(m._params, lr=trainer.lr, betas=trainer.betas, eps=trainer.eps, weight_decay=trainer.wd)
+    if trainer.step_count > 0:
+        for p, off in zip(m._params, m._offsets):
+            n = p.numel()
+            opt.state[p] = {'step': torch.tensor(float(trainer.step_count)),
+                            'exp_avg': trainer.exp_avg[off:off + n].view(p.shape).detach().cpu().clone(),
+                            'exp_avg_sq': trainer.exp_avg_sq[off:off + n].view(p.shape).detach().cpu().clone()}
+    return opt.state_dict()
+
+
+def load_adam_state(trainer, sd):
+    """restore the flat moments / step count from an 'optimizer_state_dict': a torch.optim.Adam state_dict (the
+    reference's, --mode dropin's and, since round 3, --mode fused's) or the flat {'exp_avg', 'exp_avg_sq', 'step'} that
+    round-2 fused checkpoints hold.  Returns True when the state was restored; raises on a state of another model."""
+    m = trainer.model
+    if 'exp_avg' in sd and 'state' not in sd:                        # round-2 fused format
+        if sd['exp_avg'].numel() != trainer.exp_avg.numel():
+            raise ValueError('optimizer_state_dict belongs to another model (flat moment buffer of another size)')
+        trainer.exp_avg.copy_(sd['exp_avg'])
+        trainer.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        trainer.step_count = int(sd['step'])
+        return True
+    state = sd.get('state', {})
+    if not state:
+        return False                                                 # an optimizer that never stepped
+    if len(state) != len(m._params):
+        raise ValueError(f'optimizer_state_dict has {len(state)} parameter states, the model {len(m._params)} parameters')
+    steps = set()
+    for i, (p, off) in enumerate(zip(m._params, m._offsets)):
+        st = state[i] if i in state else state[str(i)]
+        n = p.numel()
+        if st['exp_avg'].numel() != n:
+            raise ValueError(f'optimizer_state_dict: state {i} has {st["exp_avg"].numel()} elements, parameter {i} {n}')
+        trainer.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+        trainer.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+        steps.add(int(st['step']))
+    if len(steps) != 1:
+        raise ValueError(f'optimizer_state_dict: parameters at different step counts {sorted(steps)} (one flat Adam step '
+                         'keeps a single count)')
+    trainer.step_count = steps.pop()
+    return True
+
+
+def to_torch_adam_state(sd, model):
+    """an 'optimizer_state_dict' in either format -> something torch.optim.Adam(model.parameters()).load_state_dict
+    accepts (the flat round-2 format is sliced per parameter; a torch state_dict is returned as is)"""
+    if 'state' in sd or 'exp_avg' not in sd:
+        return sd
+
+    class _T:                                   # the four attributes adam_state_dict reads
+        pass
+    t = _T()
+    t.model, t.exp_avg, t.exp_avg_sq, t.step_count = model, sd['exp_avg'], sd['exp_avg_sq'], int(sd['step'])
+    t.lr, t.betas, t.eps, t.wd = 1e-3, (0.9, 0.999), 1e-8, 0.0      # the loading optimizer keeps its own hyper-parameters...
+    out = adam_state_dict(t)
+    return out
+
+
 class MixedResidualTrainer:
     def __init__(self, model, batch_size, imsize=64, lr=1e-3, weight_decay=0.0, weight_bound=10.0,
                  betas=(0.9, 0.999), eps=1e-8, device=None, process_group=None, use_graph=False,
@@ -73,9 +137,24 @@ class MixedResidualTrainer:
         self._hook = None
         self.host_prof = None             # a dict: host seconds per phase of _step are accumulated into it (bench.py)
         self.overlap_allreduce = os.environ.get('PDES_DP_OVERLAP', '1') != '0'
+        self._rccl = None
         if self.world > 1 or process_group is not None:
             self._hook_fn = _lib.BUCKET_FN(self._on_bucket)          # keep the callback object alive
             self._hook = _lib.BucketHook(self._hook_fn, None)
+            # the per-step exchange: ncclAllReduce enqueued by pointer on a dedicated stream (parallel.DirectRccl);
+            # torch.distributed's all_reduce (the only choice over gloo, and the fallback when the direct communicator
+            # cannot be made; PDES_DP_DIRECT=0 selects it) costs the host ~0.3 ms per call
+            if os.environ.get('PDES_DP_DIRECT', '1') != '0' and torch.distributed.get_backend(process_group) == 'nccl':
+                try:
+                    with _lib.device_guard(self.dev):
+                        self._rccl = parallel.DirectRccl(process_group, self.dev)
+                        self._comm_stream = torch.cuda.Stream(self.dev, priority=-1)
+                    self._ev_a, self._ev_b, self._ev_done = (torch.cuda.Event() for _ in range(3))
+                except Exception as e:
+                    import warnings
+                    warnings.warn(f'direct RCCL communicator unavailable ({type(e).__name__}: {e}); the gradient exchange '
+                                  'goes through torch.distributed.all_reduce')
+                    self._rccl = None
             # what the early bucket relies on (checked once, here): the convolution weights sit in LAYER ORDER at the
             # tail of the flat buffer, so "layers >= first_layer" is exactly the slice gflat[_conv_off[first_layer]:]
             off, end = model._conv_off, self.gflat.numel()
@@ -90,9 +169,17 @@ class MixedResidualTrainer:
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
         try:
             off = self.model._conv_off[first_layer]
-            with torch.cuda.stream(self.eng._side_stream()):
-                self._bucket_work = torch.distributed.all_reduce(self.gflat[off:], op=torch.distributed.ReduceOp.SUM,
-                                                                 group=self.pg, async_op=True)
+            if self._rccl is not None:
+                # bucket A on the communication stream, behind everything the weight-gradient stream has enqueued so far
+                self._ev_a.record(self.eng._side_stream())
+                self._comm_stream.wait_event(self._ev_a)
+                self._rccl.all_reduce_sum_(self.gflat.data_ptr() + 4 * off, self.gflat.numel() - off,
+                                           self._comm_stream.cuda_stream)
+                self._bucket_work = True
+            else:
+                with torch.cuda.stream(self.eng._side_stream()):
+                    self._bucket_work = torch.distributed.all_reduce(self.gflat[off:], op=torch.distributed.ReduceOp.SUM,
+                                                                     group=self.pg, async_op=True)
             self._bucket_off = off
             return 0
         except Exception as e:                                  # never let an exception cross the C ABI
@@ -178,14 +265,7 @@ class MixedResidualTrainer:
             self._compute()
         self.n_accum += 1
         if self._hook is not None:                            # data parallel (a group of ONE rank still runs the path)
-            work, off = self._bucket_work, self._bucket_off
-            self._bucket_work = None
-            if work is not None:                              # bucket A is in flight since the middle of the backward pass
-                if off:
-                    torch.distributed.all_reduce(self.gflat[:off], op=torch.distributed.ReduceOp.SUM, group=self.pg)
-                work.wait()                                   # the main stream waits for bucket A
-            else:
-                torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self._exchange_rest()
         if self.use_graph:
             rc = self._L.pdes_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
                                         self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), 1.0 / self.world,
@@ -203,6 +283,34 @@ class MixedResidualTrainer:
         if prof is not None:
             prof['step'] = prof.get('step', 0.0) + (time.perf_counter() - ts)
             prof['n'] = prof.get('n', 0) + 1
+
+    def _exchange_rest(self):
+        """finish the gradient exchange of this step: what the early bucket (if the hook ran) did not cover, then the
+        main stream waits for all of it"""
+        work, off = self._bucket_work, self._bucket_off
+        self._bucket_work = None
+        if self._rccl is not None:
+            n = self.gflat.numel() if work is None else off   # no early bucket: everything; else the head of the buffer
+            main = torch.cuda.current_stream(self.dev)
+            if n:
+                self._ev_b.record(main)                        # the end-of-step launch has finished the BatchNorm gradients
+                self._comm_stream.wait_event(self._ev_b)
+                self._rccl.all_reduce_sum_(self.gflat.data_ptr(), n, self._comm_stream.cuda_stream)
+            self._ev_done.record(self._comm_stream)            # in stream order behind bucket A as well
+            main.wait_event(self._ev_done)
+            return
+        if work is not None:                                  # bucket A is in flight since the middle of the backward pass
+            if off:
+                torch.distributed.all_reduce(self.gflat[:off], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            work.wait()                                       # the main stream waits for bucket A
+        else:
+            torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def exchange_standalone(self):
+        """the whole gradient buffer through the step's exchange path with nothing to overlap (bench.py: what the step
+        would pay for the all-reduce if it were not hidden under the backward pass)"""
+        self._bucket_work, self._bucket_off = None, 0
+        self._exchange_rest()
 
     def _capture(self):
         # warm the allocator / lazy inits on a side stream, then capture the compute part once

@@ -214,7 +214,10 @@ def _dp2_worker(rank, world, port, out, cfg):
     if cfg == 'default_b32':
         assert len(res['1'][2]) == 3
         assert 0 < res['1'][3] < res['1'][4]                   # bucket A is a proper tail slice of the gradient buffer
-    assert torch.equal(res['1'][0], res['0'][0]), 'two-bucket overlapped exchange != one all-reduce after the backward pass'
+    if cfg == 'default_b32':    # (the small net's 8- and 16-channel layers run on the VALU kernels, whose weight gradients are
+        #                         fp32 atomics: not bit-reproducible from run to run, with or without buckets)
+        assert torch.equal(res['1'][0], res['0'][0]), 'two-bucket overlapped exchange != one all-reduce after the backward pass'
+    assert rel_l2(res['1'][0].numpy(), res['0'][0].numpy()) < 1e-5
     out[rank] = (res['1'][0], res['1'][1], res['1'][3] / res['1'][4])
     dist.barrier()
     dist.destroy_process_group()

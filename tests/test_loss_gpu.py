@@ -215,6 +215,8 @@ def test_generic_kernel_vs_oracle(dev, n, B, flags):
     from pde_surrogate_amd.models import darcy
     if n == 64 and flags == 0:
         pytest.skip('64 with correct=True is the specialised kernel (tested above)')
+    if n == 2 and flags & 2:
+        pytest.skip('use_tb=False on a 2-row field: a mean over ZERO rows (nan in the reference too, darcy.py:224)')
     K, y, Kd, yd = _fields(B, n, 1000 + n + flags, dev)
     w = (0.7, 1.3, 9.0, 11.0)
     nl, tb, correct = bool(flags & 1), not (flags & 2), not (flags & 4)

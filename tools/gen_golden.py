@@ -57,44 +57,10 @@ def ref_loss(K, y, sobel, wb, nonlinear=False, b1=0.0, b2=0.0):
     return lc + lt + (ld + ln) * wb, lc, lt, ld, ln
 
 
-def gen_round2():
-    """fixtures added in round 2; every section owns its rng so that G1..G10 stay bit-identical"""
-    sob = SobelFilter(64, correct=True)
-
-    # ---- G11: the HEADLINE configuration: default DenseED from manual_seed(1), B = 32 GRF-KLE512 fields (the build's
-    # synthetic generator; the fields are stored), reference forward + loss + backward, ALL 82 gradient tensors
-    from pde_surrogate_amd.utils.data import grf_kle_fields
-    torch.manual_seed(1)
-    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
-    xb = grf_kle_fields(32, seed=11, cache_dir='/tmp')
-    net.train()
-    xt = torch.from_numpy(xb)
-    yo = net(xt)
-    terms = ref_loss(xt, yo, sob, 10.0)
-    terms[0].backward()
-    g11 = {'x': xb, 'y0': yo.detach().numpy()[0], 'y_slice': yo.detach().numpy()[:, :, ::8, ::8],
-           'terms': np.array([float(t) for t in terms], np.float64),
-           'param_names': np.array([k for k, _ in net.named_parameters()])}
-    for k, p in net.named_parameters():
-        g11['grad/' + k] = p.grad.numpy()
-    # rounding floor of the REFERENCE itself: its fp32 gradients against the fp64 oracle (same weights, same input).
-    # A few BatchNorm-bias gradients are sums with heavy cancellation and sit at 0.6e-3 .. 1.6e-3 in the reference's
-    # own fp32 arithmetic; for those the fp64 gradient is stored too, so a test can tell "differs from the reference
-    # by the reference's rounding error" from "wrong".
+def gen_g13():
+    """G13 (its own rng / seeds: regenerating it alone reproduces the round-2 file bit for bit, plus the round-3 keys)"""
     from oracle import codec as ocodec, train as otrain
-    torch.manual_seed(1)
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in ocodec.densed_init(1, 3, [6, 8, 6], 16, 48).items()}
-    tr64 = otrain.CpuTrainer(sd64, [6, 8, 6])
-    _, l64, _ = tr64.forward_loss(xt.double(), True)
-    l64.backward()
-    floor = np.array([float(np.linalg.norm(g11['grad/' + k].astype(np.float64) - sd64[k].grad.numpy())
-                            / np.linalg.norm(sd64[k].grad.numpy())) for k in tr64.keys])
-    g11['ref_fp32_vs_fp64_floor'] = floor
-    for k, f in zip(tr64.keys, floor):
-        if f > 3e-4:
-            g11['grad64/' + k] = sd64[k].grad.numpy()
-    np.savez_compressed(os.path.join(OUT, 'G11_densed_default_b32.npz'), **g11)
-
+    sob = SobelFilter(64, correct=True)
     # ---- G13: --upsample bilinear (reference codec.py:33-40, align_corners=True): tiny net with every tensor,
     # default net (B = 4) with output, loss terms, every gradient norm and the tensors next to the upsampling layers
     rng = np.random.default_rng(20190613)
@@ -133,6 +99,11 @@ def gen_round2():
     for k, p in net.named_parameters():
         if k.startswith('features.TransUp1.') or (k.startswith('features.LastTransUp.') and 'conv1' not in k):
             g13['grad/' + k] = p.grad.numpy()
+        elif 'norm' in k:
+            # round 3: EVERY BatchNorm gradient tensor (26 KB in all).  These are the sums with cancellation where one ReLU
+            # mask that differs between two fp32 implementations shows: a test can then tell "one element of one tensor
+            # moved by one term of its sum" (a flip) from an error spread over the tensor (a bug)
+            g13['grad/' + k] = p.grad.numpy()
     # the same pass on the fp64 oracle: where the reference's own fp32 norm is off by ~1e-3 (BatchNorm-bias sums with
     # heavy cancellation) a test may accept the fp64 value instead
     torch.manual_seed(1)
@@ -142,6 +113,48 @@ def gen_round2():
     l64.backward()
     g13['grad_norms_fp64'] = np.array([float(sd64[k].grad.norm()) for k in tr64.keys])
     np.savez_compressed(os.path.join(OUT, 'G13_bilinear.npz'), **g13)
+
+
+
+def gen_round2():
+    """fixtures added in round 2; every section owns its rng so that G1..G10 stay bit-identical"""
+    sob = SobelFilter(64, correct=True)
+
+    # ---- G11: the HEADLINE configuration: default DenseED from manual_seed(1), B = 32 GRF-KLE512 fields (the build's
+    # synthetic generator; the fields are stored), reference forward + loss + backward, ALL 82 gradient tensors
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    xb = grf_kle_fields(32, seed=11, cache_dir='/tmp')
+    net.train()
+    xt = torch.from_numpy(xb)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob, 10.0)
+    terms[0].backward()
+    g11 = {'x': xb, 'y0': yo.detach().numpy()[0], 'y_slice': yo.detach().numpy()[:, :, ::8, ::8],
+           'terms': np.array([float(t) for t in terms], np.float64),
+           'param_names': np.array([k for k, _ in net.named_parameters()])}
+    for k, p in net.named_parameters():
+        g11['grad/' + k] = p.grad.numpy()
+    # rounding floor of the REFERENCE itself: its fp32 gradients against the fp64 oracle (same weights, same input).
+    # A few BatchNorm-bias gradients are sums with heavy cancellation and sit at 0.6e-3 .. 1.6e-3 in the reference's
+    # own fp32 arithmetic; for those the fp64 gradient is stored too, so a test can tell "differs from the reference
+    # by the reference's rounding error" from "wrong".
+    from oracle import codec as ocodec, train as otrain
+    torch.manual_seed(1)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in ocodec.densed_init(1, 3, [6, 8, 6], 16, 48).items()}
+    tr64 = otrain.CpuTrainer(sd64, [6, 8, 6])
+    _, l64, _ = tr64.forward_loss(xt.double(), True)
+    l64.backward()
+    floor = np.array([float(np.linalg.norm(g11['grad/' + k].astype(np.float64) - sd64[k].grad.numpy())
+                            / np.linalg.norm(sd64[k].grad.numpy())) for k in tr64.keys])
+    g11['ref_fp32_vs_fp64_floor'] = floor
+    for k, f in zip(tr64.keys, floor):
+        if f > 3e-4:
+            g11['grad64/' + k] = sd64[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'G11_densed_default_b32.npz'), **g11)
+
+    gen_g13()
 
     # ---- G14: conv_continuity_constraint(use_tb=False) (darcy.py:224) value + gradient; 5x5 Sobel fields
     rng = np.random.default_rng(20190614)
@@ -670,6 +683,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'glow':      # only the conditional-Glow fixtures (G18-G20)
         torch.set_num_threads(8)
         gen_glow()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'g13':
+        torch.set_num_threads(8)
+        gen_g13()
     elif len(sys.argv) > 1 and sys.argv[1] == 'round3':  # only G21 (any field size, correct=False through the loss)
         torch.set_num_threads(8)
         gen_round3()
