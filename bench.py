@@ -410,7 +410,7 @@ def dp1_rccl_timing(dev, data, perm, B, steps, warmup):
         h = host_enqueue_timing(tr, load, 50)
         return {'dp1_rccl_ms_per_step': round(1e3 * (t2 - t0) / steps, 4),
                 'dp1_rccl_host_enqueue_ms_per_step': h['host_enqueue_ms_per_step'], 'steps': steps,
-                'exchange': 'ncclAllReduce by pointer on a dedicated stream (parallel.DirectRccl)' if tr._rccl is not None
+                'exchange': 'ncclAllReduce by pointer on the weight-gradient / main stream (parallel.DirectRccl)' if tr._rccl is not None
                             else 'torch.distributed.all_reduce',
                 'buckets': 2 if tr.overlap_allreduce else 1, 'bucket_a_bytes': int(tr.gflat.numel() - tr._bucket_off) * 4,
                 'bytes_per_step': int(tr.gflat.numel()) * 4}

@@ -9,7 +9,7 @@ The reference has no distributed code at all; data parallelism is what this buil
   * parameters start identical (same seed, checked/enforced by `broadcast_parameters`).
 Rendezvous, broadcasts and the once-per-epoch scalar means go through `torch.distributed` (backend `nccl` = RCCL on
 ROCm; the CPU tests run them over `gloo` with world_size 2).  The PER-STEP gradient exchange does not: `DirectRccl`
-holds its own RCCL communicator and enqueues `ncclAllReduce` on a HIP stream by pointer (ctypes into the librccl.so
+holds its own RCCL communicator and enqueues `ncclAllReduce` by pointer on the stream where the data becomes final (ctypes into the librccl.so
 torch ships) -- a `torch.distributed.all_reduce` costs the host ~0.3 ms per call (Work objects, stream guards, event
 bookkeeping: 1.63 vs 0.97 ms of host time per step measured with two buckets on one rank), the direct call a few
 microseconds, and the step of an 8-rank job must not become host-bound.

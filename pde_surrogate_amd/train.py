@@ -141,15 +141,18 @@ class MixedResidualTrainer:
         if self.world > 1 or process_group is not None:
             self._hook_fn = _lib.BUCKET_FN(self._on_bucket)          # keep the callback object alive
             self._hook = _lib.BucketHook(self._hook_fn, None)
-            # the per-step exchange: ncclAllReduce enqueued by pointer on a dedicated stream (parallel.DirectRccl);
-            # torch.distributed's all_reduce (the only choice over gloo, and the fallback when the direct communicator
-            # cannot be made; PDES_DP_DIRECT=0 selects it) costs the host ~0.3 ms per call
+            # the per-step exchange: ncclAllReduce enqueued by pointer (parallel.DirectRccl) where the data becomes final:
+            # bucket A on the weight-gradient stream right behind the early split-K reduce, the rest on the main stream
+            # behind the end-of-step launch -- no extra stream, no events of our own (RCCL orders two collectives of one
+            # communicator that are issued on different streams itself; pdes_backward2's final join puts the main stream
+            # behind bucket A).  A dedicated high-priority communication stream joined by three events was measured at
+            # 5.05 ms per step on one rank (1.75 without the exchange): rejected.  torch.distributed's all_reduce (the only
+            # choice over gloo, and the fallback when the direct communicator cannot be made; PDES_DP_DIRECT=0 selects
+            # it) costs the host ~0.3 ms per call.
             if os.environ.get('PDES_DP_DIRECT', '1') != '0' and torch.distributed.get_backend(process_group) == 'nccl':
                 try:
                     with _lib.device_guard(self.dev):
                         self._rccl = parallel.DirectRccl(process_group, self.dev)
-                        self._comm_stream = torch.cuda.Stream(self.dev, priority=-1)
-                    self._ev_a, self._ev_b, self._ev_done = (torch.cuda.Event() for _ in range(3))
                 except Exception as e:
                     import warnings
                     warnings.warn(f'direct RCCL communicator unavailable ({type(e).__name__}: {e}); the gradient exchange '
@@ -165,16 +168,13 @@ class MixedResidualTrainer:
                 raise RuntimeError('flat gradient layout: convolution weights are not contiguous in layer order at the tail '
                                    '(the early all-reduce bucket would cover the wrong slice)')
 
-    def _on_bucket(self, _user, first_layer, _stream):
+    def _on_bucket(self, _user, first_layer, stream):
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
         try:
             off = self.model._conv_off[first_layer]
             if self._rccl is not None:
-                # bucket A on the communication stream, behind everything the weight-gradient stream has enqueued so far
-                self._ev_a.record(self.eng._side_stream())
-                self._comm_stream.wait_event(self._ev_a)
-                self._rccl.all_reduce_sum_(self.gflat.data_ptr() + 4 * off, self.gflat.numel() - off,
-                                           self._comm_stream.cuda_stream)
+                # bucket A on the weight-gradient stream itself, behind the early split-K reduce just enqueued there
+                self._rccl.all_reduce_sum_(self.gflat.data_ptr() + 4 * off, self.gflat.numel() - off, stream)
                 self._bucket_work = True
             else:
                 with torch.cuda.stream(self.eng._side_stream()):
@@ -291,13 +291,8 @@ class MixedResidualTrainer:
         self._bucket_work = None
         if self._rccl is not None:
             n = self.gflat.numel() if work is None else off   # no early bucket: everything; else the head of the buffer
-            main = torch.cuda.current_stream(self.dev)
-            if n:
-                self._ev_b.record(main)                        # the end-of-step launch has finished the BatchNorm gradients
-                self._comm_stream.wait_event(self._ev_b)
-                self._rccl.all_reduce_sum_(self.gflat.data_ptr(), n, self._comm_stream.cuda_stream)
-            self._ev_done.record(self._comm_stream)            # in stream order behind bucket A as well
-            main.wait_event(self._ev_done)
+            if n:                                             # on the main stream: behind the end-of-step launch, in front of Adam
+                self._rccl.all_reduce_sum_(self.gflat.data_ptr(), n, _lib.stream_ptr(self.dev))
             return
         if work is not None:                                  # bucket A is in flight since the middle of the backward pass
             if off:
