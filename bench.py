@@ -446,6 +446,8 @@ def main():
                     help='capture the compute part of the step in a hipGraph (default: eager launches with the weight '
                          'gradients on a second HIP stream, which measured faster than one serial graph)')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
+    ap.add_argument('--segments', action='store_true',
+                    help='replay the step as linear hipGraphs per network stage joined by events (StepProgram)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the roofline_1x1 and config5_solver legs (profiling runs: only the training step and the '
@@ -493,7 +495,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
     trainer = MixedResidualTrainer(model, B, 64, lr=1e-3, weight_bound=10.0, device=dev,
-                                   use_graph=args.graph)
+                                   use_graph='segments' if args.segments else args.graph)
     # device-resident synthetic dataset (every rank holds the replica, uses its slice of the global batch)
     # the KLE basis (a 4096x4096 eigen-decomposition, ~20 s) is computed by rank 0 and cached for the others
     if rank == 0:
@@ -581,7 +583,7 @@ def main():
                                      '100->100: sub-pixel forward (98->49), data and weight gradients): both operands split '
                                      'into three bf16 terms, six cross products accumulated in fp32 on '
                                      'v_mfma_f32_16x16x32_bf16 (24-bit significand coverage, error vs fp64 equal to the f32 '
-                                     'pipe: layer-level adversarial test; PDES_MFMA_B3 / _B3W / _B3U / _B3UB / _B3WU = 0 '
+                                     'pipe: layer-level adversarial test of all of these kernels; option PDES_MFMA_B3 = 0 '
                                      'put them back on the f32 pipe)'},
             'loss_mean_over_run': round(means[0], 4),
             'ranks': torch.distributed.get_world_size() if world > 1 else 1,

@@ -39,14 +39,20 @@ extern "C" {
  * arguments; these select among equivalent kernels and exist for A/B measurements and cross-checks).
  *   pdes_context_create   n_events order-only events are created on the CURRENT device (pdes_backward with a
  *                         second stream needs n_layers + 1); returns hipError_t > 0 on failure.
- *   pdes_context_set_option  key = one of "PDES_CONV_IMPL" ("direct" | "auto"), "PDES_FUSE_FINALIZE",
- *                         "PDES_FUSE_MAXC", "PDES_FUSE_MAXHW", "PDES_FIN_EARLY", "PDES_MFMA_NTW", "PDES_MFMA_MT",
- *                         "PDES_MFMA_NG", "PDES_MFMA_1X1", "PDES_1X1_KSPLIT", "PDES_MFMA_1X1W", "PDES_1X1W_SPI",
- *                         "PDES_MFMA_B3", "PDES_MFMA_B3W", "PDES_MFMA_B3U", "PDES_MFMA_SMALL", "PDES_MFMA_B3UB", "PDES_MFMA_B3WU", "PDES_B3W_PF", "PDES_B3_TAIL", "PDES_B3_APIPE", "PDES_B3_MT", "PDES_FEW_R", "PDES_WGRAD_WGS", "PDES_LOSS_NT",
- *                         "PDES_LOSS_DMA", "PDES_DEBUG_CHAIN" (timing experiments only, gradients are WRONG: 1 = pdes_backward skips the
- *                         weight-gradient kernels, 2 = and the fork events), "PDES_FORK_SIGNAL" (1: pdes_backward's fork events ride on the finalize
- *                         kernel's completion signal, 0: hipEventRecord); value = decimal string (NULL = default).
- *                         PDES_ENOSUP: unknown key.
+ *   pdes_context_set_option  value = decimal string (NULL = default); PDES_ENOSUP: unknown key.  The eight keys
+ *                         (csrc/pdes_options.h; each selects between EQUIVALENT kernels, for cross-checks and re-tuning):
+ *                           "PDES_CONV_IMPL"   "direct": the generic VALU kernels for every convolution | "auto"
+ *                           "PDES_MFMA_B3"     bit mask of the bf16 x3 split kernels, default 31 (0: the exact-f32 pipe everywhere):
+ *                                              1 wide 3x3 forward + data gradient, 2 wide 3x3 weight gradient, 4 nearest-x2 forward,
+ *                                              8 nearest-x2 data gradient, 16 nearest-x2 weight gradient
+ *                           "PDES_B3_TAIL"     1: <= 4 channels of a last 32-channel chunk on one f32 MFMA per tap | 0: a whole bf16 chunk
+ *                           "PDES_MFMA_1X1"    bit mask of the register-operand 1x1 kernels, default 7: 1 forward, 2 data gradient,
+ *                                              4 weight gradient (0: the LDS-tiled generic kernels)
+ *                           "PDES_MFMA_SMALL"  1: matrix-core kernels for 3x3 convolutions on 8x8 maps | 0: VALU kernels
+ *                           "PDES_WGRAD_WGS"   workgroup target of the split-K weight-gradient plan (default 256)
+ *                           "PDES_LOSS_NT"     streaming accesses in the loss kernel: -1 by working-set size (default), 0, 1
+ *                           "PDES_FORK_SIGNAL" 1: pdes_backward's fork events ride on the finalize kernel's completion signal |
+ *                                              0: hipEventRecord
  *   pdes_context_load_env every key above that is set in the process environment, read ONCE, now.
  *   pdes_context_device   the device the context's events belong to.
  */
@@ -211,9 +217,9 @@ typedef struct pdes_conv_desc {
   /* backward */
   const float* g;        /* dL/d(out): (B, g_ctot, Hout, Wout), channels [g_coff, g_coff+Cout) */
   int g_ctot, g_coff;
-  int g_fused;           /* 1: `g` still holds the accumulator T of the output buffer; the BN-backward finalize
-                            (fin_xstats / fin_tstats, raw activation = `out`) is applied by the consuming kernel
-                            on operand load.  Set by pdes_backward only (matrix-core paths); callers pass 0. */
+  int g_fused;           /* 1: `g` still holds the accumulator T of the output buffer and the consuming kernel applies the
+                            BN-backward finalize (fin_xstats / fin_tstats, raw activation = `out`) on operand load: implemented
+                            by PDES_OP_COPY only (the caller sets it there); convolutions take 0 */
   float* t_in;           /* T accumulator of the input buffer (B, x_ctot, Hin, Win) */
   int t_accumulate;      /* 0: T = ..., 1: T += ... */
   int final_c0, final_c1;/* input channels whose T is complete after this call: their
@@ -300,6 +306,40 @@ int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* descs, int n, v
 int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream, void* wgrad_stream,
                    void* wgrad_stream_b, const pdes_reduce_item* reduce_items, const int* reduce_index,
                    const pdes_bucket_hook* hook);
+
+/* The two halves of that pass for the layers [lo, hi) of `descs`, each on ONE stream and without events (for i = hi-1 .. lo):
+ *   pdes_backward_chain:   [finalize of descs[i]'s output channels] + pdes_conv_backward_data(descs[i])
+ *   pdes_backward_weights: pdes_conv_backward_weight(descs[i])
+ * The caller orders them (chain of a range before its weights) and reduces the split-K partials.  These are what the
+ * segment graphs below are captured from. */
+int pdes_backward_chain(const pdes_context* ctx, const pdes_conv_desc* descs, int lo, int hi, void* stream);
+int pdes_backward_weights(const pdes_context* ctx, const pdes_conv_desc* descs, int lo, int hi, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The step as LINEAR hipGraphs (csrc/step_graph.hip; no reference counterpart -- the reference launches ~2,000 aten
+ * kernels per step one by one).  On this runtime an eager launch costs the host 3-9 us and leaves ~3 us between dependent
+ * kernels, a linear graph of 120 kernels replays for 8 us with ~1.7 us between kernels, and a graph with forks is slower
+ * than eager launches on two streams: so the step is cut into linear pieces (forward + loss; per backward segment the
+ * finalize -> data-gradient chain, and separately its weight gradients) joined by one event per segment.
+ *   pdes_graph_begin / pdes_graph_end  bracket ANY sequence of this library's enqueue-only calls on `stream` (not the
+ *                         legacy default stream); end returns the instantiated graph.  Nothing executes during capture.
+ *   pdes_graph_launch     replay on any stream;  pdes_graph_nodes: kernel / memset nodes captured.
+ *   pdes_program_run      replay a list of operations in one call: launch graphs[arg] on streams[stream], record /
+ *                         wait the CONTEXT's event number arg on streams[stream], or call the bucket hook with
+ *                         first_layer = arg (data parallel: see pdes_backward).  The caller owns graphs and list. */
+typedef struct pdes_graph pdes_graph;
+#define PDES_OP_LAUNCH 0
+#define PDES_OP_RECORD 1
+#define PDES_OP_WAIT 2
+#define PDES_OP_HOOK 3
+typedef struct pdes_op { int kind, arg, stream; } pdes_op;
+int pdes_graph_begin(void* stream);
+int pdes_graph_end(void* stream, pdes_graph** out);
+int pdes_graph_nodes(const pdes_graph* g);
+int pdes_graph_launch(pdes_graph* g, void* stream);
+int pdes_graph_destroy(pdes_graph* g);
+int pdes_program_run(const pdes_context* ctx, pdes_graph* const* graphs, int n_graphs, void* const* streams, int n_streams,
+                     const pdes_op* ops, int n_ops, const pdes_bucket_hook* hook);
 
 /* ---------------------------------------------------------------------------------------------
  * Parameter side of the flow (models/glow_msc.py): one launch each for ALL invertible 1x1 convolutions + ActNorms.

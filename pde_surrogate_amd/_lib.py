@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -30,6 +30,14 @@ SIGNATURES = {
     'pdes_conv_backward_data': [_c_p, _c_p, _c_i, _c_p],
     'pdes_backward': [_c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p],
     'pdes_backward2': [_c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
+    'pdes_backward_chain': [_c_p, _c_p, _c_i, _c_i, _c_p],
+    'pdes_backward_weights': [_c_p, _c_p, _c_i, _c_i, _c_p],
+    'pdes_graph_begin': [_c_p],
+    'pdes_graph_end': [_c_p, _c_p],
+    'pdes_graph_nodes': [_c_p],
+    'pdes_graph_launch': [_c_p, _c_p],
+    'pdes_graph_destroy': [_c_p],
+    'pdes_program_run': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p],
     'pdes_bn_backward_finalize': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i,
                                   ctypes.c_longlong, _c_p],
     'pdes_conv_wgrad_plan': [_c_p, _c_p, _c_p, _c_p],

@@ -19,19 +19,9 @@ OptScope::~OptScope() { tl_opt = prev; }
 
 struct Knob { const char* name; int Options::*field; };
 static const Knob kKnobs[] = {
-    {"PDES_FUSE_FINALIZE", &Options::fuse_finalize}, {"PDES_FUSE_MAXC", &Options::fuse_maxc},
-    {"PDES_FUSE_MAXHW", &Options::fuse_maxhw},       {"PDES_FIN_EARLY", &Options::fin_early},
-    {"PDES_MFMA_NTW", &Options::mfma_ntw},           {"PDES_MFMA_MT", &Options::mfma_mt},
-    {"PDES_MFMA_NG", &Options::mfma_ng},             {"PDES_MFMA_1X1", &Options::mfma_1x1},
-    {"PDES_1X1_KSPLIT", &Options::k1_ksplit},        {"PDES_MFMA_1X1W", &Options::mfma_1x1w},
-    {"PDES_1X1W_SPI", &Options::w1x1_spi},           {"PDES_MFMA_B3", &Options::mfma_b3},
-    {"PDES_B3_MT", &Options::b3_mt},                 {"PDES_FEW_R", &Options::few_r},
-    {"PDES_WGRAD_WGS", &Options::wgrad_wgs},         {"PDES_LOSS_NT", &Options::loss_nt},
-    {"PDES_FORK_SIGNAL", &Options::fork_signal},     {"PDES_DEBUG_CHAIN", &Options::debug_chain},     {"PDES_MFMA_B3W", &Options::mfma_b3w},
-    {"PDES_MFMA_B3U", &Options::mfma_b3u},
-    {"PDES_MFMA_SMALL", &Options::mfma_small},       {"PDES_B3_APIPE", &Options::b3_apipe},
-    {"PDES_MFMA_B3UB", &Options::mfma_b3ub},         {"PDES_MFMA_B3WU", &Options::mfma_b3wu},
-    {"PDES_B3W_PF", &Options::b3w_pf},               {"PDES_B3_TAIL", &Options::b3_tail},
+    {"PDES_MFMA_B3", &Options::mfma_b3},       {"PDES_B3_TAIL", &Options::b3_tail},     {"PDES_MFMA_1X1", &Options::mfma_1x1},
+    {"PDES_MFMA_SMALL", &Options::mfma_small}, {"PDES_WGRAD_WGS", &Options::wgrad_wgs}, {"PDES_LOSS_NT", &Options::loss_nt},
+    {"PDES_FORK_SIGNAL", &Options::fork_signal},
 };
 
 static int set_knob(Options& o, const char* key, const char* value) {

@@ -1,7 +1,6 @@
 // C-ABI entry points for the convolution family: walk a host array of descriptors and enqueue
 // one kernel per descriptor on the caller's stream.  Kernel selection lives here so the Python
 // side never needs to know which implementation (MFMA or VALU) serves a shape.
-#include <vector>
 #include "pdes_common.h"
 #include "pdes_options.h"
 #include "../../include/pdes_hip.h"
@@ -149,6 +148,37 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
   return PDES_OK;
 }
 
+// The two halves of pdes_backward2 for a range of layers, each on ONE stream and free of events: what the segment graphs
+// of step_graph.hip are captured from (also usable eagerly).
+extern "C" int pdes_backward_chain(const pdes_context* ctx, const pdes_conv_desc* descs, int lo, int hi, void* stream) {
+  if (!descs || lo < 0 || hi <= lo) return PDES_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int i = hi - 1; i >= lo; --i) {
+    const pdes_conv_desc& d = descs[i];
+    if (d.fin_tstats && !d.g_fused) {
+      const int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
+                                                 d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
+                                                 d.rep_stride, st, nullptr, d.g_add);
+      if (rc) return rc;
+    }
+    if (d.has_bn || is_resample_op(d) || d.t_in) {
+      const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
+      if (rc) return rc;
+    }
+  }
+  return PDES_OK;
+}
+
+extern "C" int pdes_backward_weights(const pdes_context* ctx, const pdes_conv_desc* descs, int lo, int hi, void* stream) {
+  if (!descs || lo < 0 || hi <= lo) return PDES_EINVAL;
+  for (int i = hi - 1; i >= lo; --i) {
+    if (is_resample_op(descs[i])) continue;
+    const int rc = pdes_conv_backward_weight(ctx, &descs[i], 1, stream);
+    if (rc) return rc;
+  }
+  return PDES_OK;
+}
+
 extern "C" int pdes_backward(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream,
                              void* wgrad_stream, const pdes_reduce_item* reduce_items, const int* reduce_index,
                              const pdes_bucket_hook* hook) {
@@ -194,10 +224,8 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     b_dirty = false;
     return he == hipSuccess ? PDES_OK : (int)he;
   };
-  const int dbg = opt().debug_chain;
   auto release = [&](int i, bool on_main, hipEvent_t signalled) -> int {
     hipStream_t wsi = (two && (i & 1)) ? wsb : ws;
-    if (dbg == 2) return PDES_OK;
     if (fork && !on_main) {
       hipEvent_t e = signalled;
       hipError_t he = hipSuccess;
@@ -209,7 +237,6 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       if (he != hipSuccess) return (int)he;
       if (wsi != ws) b_dirty = true;
     }
-    if (dbg == 1) return PDES_OK;
     const int rc = pdes_conv_backward_weight(ctx, &descs[i], 1, on_main ? st : wsi);
     if (rc) return rc;
     if (have_red && reduce_index[i] >= 0) per_done += per_of(i);
@@ -241,28 +268,6 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     return PDES_OK;
   };
 
-  // BatchNorm-backward finalize: the in-place kernel by default.  Option PDES_FUSE_FINALIZE=1 fuses it into the
-  // operand load of the layer's two consumers when both run on the matrix-core kernels (bn_fused.h; layers with up
-  // to PDES_FUSE_MAXC = 16 output channels).  Same-box A/B of the final kernel set: 2.188 ms per step fused vs
-  // 2.151 ms with the separate kernel (x staged next to T costs the consumers more than 20 small launches), so it is
-  // opt-in -- and only then is the descriptor array copied (g_fused is set on the copy).
-  std::vector<pdes_conv_desc> local;
-  if (opt().fuse_finalize && !force_direct()) {
-    local.assign(descs, descs + n);
-    for (int i = 0; i < n; ++i) {
-      pdes_conv_desc& d = local[i];
-      d.g_fused = 0;
-      if (!d.fin_tstats || !d.fin_xstats || !d.out || is_resample_op(d)) continue;
-      if (d.Cout > opt().fuse_maxc || d.Hout * d.Wout > opt().fuse_maxhw) continue;   // wide layers: staging x next to T costs the consumers more than the kernel saves
-      if (d.g_ctot != d.out_ctot || d.g_coff != d.out_coff || d.nrep != PDES_NREP) continue;
-      const bool w_ok = conv_backward_weight_mfma(d, st, true) == PDES_OK;
-      const bool d_ok = !d.has_bn || conv_backward_data_up_mfma(d, st, true) == PDES_OK ||
-                        conv_backward_data_mfma(d, st, true) == PDES_OK;
-      d.g_fused = (w_ok && d_ok) ? 1 : 0;
-    }
-    descs = local.data();
-  }
-
   const bool use_signal = opt().fork_signal != 0;
   for (int i = n - 1; i >= 0; --i) {
     const pdes_conv_desc& d = descs[i];
@@ -270,7 +275,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     if (d.fin_tstats && !d.g_fused) {
       // this layer's weight gradient is released by the completion of ITS finalize kernel: the fork event rides on
       // that kernel's completion signal, no barrier packet sits between the finalize and the data gradient
-      if (fork && use_signal && i != 0 && !is_resample_op(d) && dbg != 2) signalled = cx->events[nev++];
+      if (fork && use_signal && i != 0 && !is_resample_op(d)) signalled = cx->events[nev++];
       int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
                                            d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
                                            d.rep_stride, st, signalled, d.g_add);

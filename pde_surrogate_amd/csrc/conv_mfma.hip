@@ -28,7 +28,6 @@
 #include "pdes_common.h"
 #include "pdes_options.h"
 #include "../../include/pdes_hip.h"
-#include "bn_fused.h"
 #include "pack_kernels.h"
 
 namespace pdes {
@@ -88,12 +87,10 @@ __device__ unsigned long long pdes_trace_buf[16];
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-inserted x2 (stride-2 data gradient)
 
-// FUSED (data gradient only): d.g holds the raw accumulator T; the BatchNorm-backward finalize is applied
-// while the tile is committed to LDS (bn_fused.h) -- the raw output activation is staged next to it.
 // NG = 2 (forward of the 16-output-channel layers only): TWO K-split wave groups of 4 waves each; group g stages and
 // multiplies the chunks g, g+2, ... out of its own double-buffered LDS tile, halving the serial chunk chain of a
 // workgroup (a dense layer at batch 32 has one workgroup per CU, i.e. otherwise one wave per SIMD).
-template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, bool FUSED, int NG>
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, int NG>
 __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : ((NT_W == 1 && KS != 5 && S == 1) ? 3 : 1))
 void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
   static_assert(NG == 1 || (NG == 2 && WAVES_K == 4 && MODE == MODE_FWD && PIPE), "wave groups: K-split forward only");
@@ -135,19 +132,14 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   kWc = kmode ? 2 * kW : kW;
   const int kpad = (kC + 15) & ~15;
   const int nchunk = kpad / 16;
-  static_assert(!(FUSED && MODE == MODE_FWD), "the fused finalize belongs to the data gradient");
-  float* tile0 = smem + ((MODE == MODE_FWD || FUSED) ? 4 * kpad : 0);  // [kpad] float4 per-channel coefficients first
+  float* tile0 = smem + (MODE == MODE_FWD ? 4 * kpad : 0);             // [kpad] float4 per-channel coefficients first
   float* tile = tile0 + grp * (2 * G::KC * G::CS);                     // this wave group's two tile buffers
-  const float* xkbase = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff) * d.Hout * d.Wout : nullptr;
 
   const int tiles_x = Wout / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
 
   // FWD: per-channel {mean, gamma*invstd, beta, -} as one float4 (a single ds_read_b128 per staged float4)
   float4* cf4 = reinterpret_cast<float4*>(smem);
-  if (FUSED) {        // {mean, invstd, mean(T), mean(T xhat)} of the gradient channels
-    for (int c = threadIdx.x; c < kpad; c += 256 * NG) cf4[c] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   if (MODE == MODE_FWD) {
     for (int c = threadIdx.x; c < kpad; c += 256 * NG) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -199,7 +191,6 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
   struct Stage {
     float4 pv[G::NPV]; float ph[NPHS];
-    float4 xv[FUSED ? G::NPV : 1]; float xh[FUSED ? NPHS : 1];     // FUSED: the raw activation at the same positions
   };
   Stage sA, sB;
   // loads are unconditional (row offsets are clamped into the image above, the channel is clamped
@@ -208,7 +199,6 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
     float4 (&pv)[G::NPV] = st.pv;
     float (&ph)[NPHS] = st.ph;
     const float* src = kbase + (size_t)chunk * 16 * HWs;
-    const float* xsrc = FUSED ? xkbase + (size_t)chunk * 16 * HWs : nullptr;
     const int cmax = kC - chunk * 16 - 1;           // last valid channel of this chunk
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
@@ -216,14 +206,9 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       const float* p = src + ch * HWs + vg[i];
       if constexpr (kmode == KV_PLAIN) {
         pv[i] = *reinterpret_cast<const float4*>(p);
-        if constexpr (FUSED) st.xv[i] = *reinterpret_cast<const float4*>(xsrc + ch * HWs + vg[i]);
       } else {                                       // raw pair; expanded to (x, 0, y, 0) at commit time
         const float2 t = *reinterpret_cast<const float2*>(p);
         pv[i].x = t.x; pv[i].y = t.y;
-        if constexpr (FUSED) {
-          const float2 u = *reinterpret_cast<const float2*>(xsrc + ch * HWs + vg[i]);
-          st.xv[i].x = u.x; st.xv[i].y = u.y;
-        }
       }
     }
     if (halo_live) {
@@ -231,7 +216,6 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       for (int i = 0; i < G::NPH; ++i) {
         const int ch = min((tid + 256 * i) / (G::ROWS * G::NHC), cmax);
         ph[i] = src[ch * HWs + hg[i]];
-        if constexpr (FUSED) st.xh[i] = xsrc[ch * HWs + hg[i]];
       }
     }
   };
@@ -246,19 +230,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
         float4 z = kmode == KV_PLAIN ? pv[i] : make_float4(pv[i].x, 0.f, pv[i].y, 0.f);
         const int ch = (tid + 256 * i) / (G::ROWS * (G::TWI / 4));
         const bool ok = ((vrow >> i) & 1u) && ch < crem;
-        if constexpr (FUSED) {
-          const float4 k = cf4[chunk * 16 + ch];
-          const float4 x = st.xv[i];
-          if (kmode == KV_PLAIN) {
-            z.x = ok ? fin_apply(k, z.x, x.x) : 0.f;
-            z.y = ok ? fin_apply(k, z.y, x.y) : 0.f;
-            z.z = ok ? fin_apply(k, z.z, x.z) : 0.f;
-            z.w = ok ? fin_apply(k, z.w, x.w) : 0.f;
-          } else {
-            z.x = ok ? fin_apply(k, z.x, x.x) : 0.f;
-            z.z = ok ? fin_apply(k, z.z, x.y) : 0.f;
-          }
-        } else if (MODE == MODE_FWD) {
+        if (MODE == MODE_FWD) {
           const float4 k = cf4[chunk * 16 + ch];
           z.x = ok ? fmaxf(0.f, (z.x - k.x) * k.y + k.z) : 0.f;
           z.y = ok ? fmaxf(0.f, (z.y - k.x) * k.y + k.z) : 0.f;
@@ -277,9 +249,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
           float z = ph[i];
           const int ch = (tid + 256 * i) / (G::ROWS * G::NHC);
           const bool ok = ((hval >> i) & 1u) && ch < crem;
-          if constexpr (FUSED) {
-            z = ok ? fin_apply(cf4[chunk * 16 + ch], z, st.xh[i]) : 0.f;
-          } else if (MODE == MODE_FWD) {
+          if (MODE == MODE_FWD) {
             const float4 k = cf4[chunk * 16 + ch];
             z = ok ? fmaxf(0.f, (z - k.x) * k.y + k.z) : 0.f;
           } else if (!ok) {
@@ -573,7 +543,7 @@ static bool mfma_shape_ok(const pdes_conv_desc& d, bool bwd, int* W, int* H) {
 template <int KS, int S, int MODE, int KM>
 static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st, bool dry = false) {
   const bool bwd = MODE == MODE_BWD;
-  const bool fused = bwd && d.g_fused;
+  if (d.g_fused) return PDES_ENOSUP;       // finalize-on-load exists for PDES_OP_COPY only (flow_ops.hip)
   const int kC = bwd ? d.Cout : d.Cin, nC = bwd ? d.Cin : d.Cout;
   const int kpad = (kC + 15) & ~15, nchunk = kpad / 16;
   const int nt_total = (nC + 15) / 16;
@@ -590,7 +560,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     if (tiles8 < 256 && mt4_ok) mt = 4;
   } else {
     wk = 1;
-    const bool ntw2_ok = KS != 5 && kpad > 16 && nt_total > 4 && opt().mfma_ntw != 1;
+    const bool ntw2_ok = KS != 5 && kpad > 16 && nt_total > 4;
     const int cand[4][2] = {{8, 2}, {8, 1}, {4, 2}, {4, 1}};
     long long best = -1;
     mt = 8; ntw = 1;
@@ -603,7 +573,6 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     }
     gz = (nt_total + 4 * ntw - 1) / (4 * ntw);
   }
-  { const int e = opt().mfma_mt; if ((e == 8 || e == 4) && (e == 8 || mt4_ok)) mt = e; }
   const int th = mt / twg;
   if (H % th) return PDES_ENOSUP;
   dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
@@ -613,8 +582,8 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
 #define PDES_TRY(TWG_, MT_, WK_, NTW_)                                                                       \
   if (twg == TWG_ && mt == MT_ && wk == WK_ && ntw == NTW_) {                                                 \
     using G = TileGeo<KS, TWG_, MT_, S>;                                                                      \
-    const size_t cf_f = (bwd && !fused) ? 0 : 4 * (size_t)kpad;                                              \
-    const int ng = (WK_ == 4 && !bwd && S == 1 && nchunk >= 3 && opt().mfma_ng == 2) ? 2 : 1;  \
+    const size_t cf_f = bwd ? 0 : 4 * (size_t)kpad;                                                          \
+    const int ng = (WK_ == 4 && !bwd && S == 1 && nchunk >= 3) ? 2 : 1;                        \
     size_t fl = cf_f + (size_t)ng * 2 * G::KC * G::CS;                                                        \
     const size_t red = cf_f + (size_t)4 * ng * MT_ * 4 * 64 + 256;                                            \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \
@@ -623,28 +592,21 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     } else if constexpr (MODE == MODE_FWD) {                                                                  \
       if constexpr (WK_ == 4 && S == 1) {                                                                     \
         if (ng == 2) {                                                                                        \
-          hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false, 2>), grid, dim3(512), \
+          hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, 2>), grid, dim3(512), \
                              lds, st, d, wm, nt_total);                                                       \
           rc = PDES_OK;                                                                                       \
           break_out = true;                                                                                   \
         }                                                                                                     \
       }                                                                                                       \
       if (!break_out)                                                                                         \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false, 1>), grid, block, lds, st, \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, 1>), grid, block, lds, st, \
                          d, wm, nt_total);                                                                    \
-    } else if (fused) {                                                                                       \
-      if (nchunk > 1)                                                                                         \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, true, 1>), grid, block, lds, st, \
-                           d, wm, nt_total);                                                                  \
-      else   /* one chunk (dense layers: 16 gradient channels): single stage */                     \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, true, 1>), grid, block, lds, st, \
-                           d, wm, nt_total);                                                                  \
     } else {                                                                                                  \
       if (nchunk > 1)                                                                                         \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, false, 1>), grid, block, lds, st, \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
       else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, false, 1>), grid, block, lds, st, \
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
     }                                                                                                         \
     rc = PDES_OK;                                                                                             \

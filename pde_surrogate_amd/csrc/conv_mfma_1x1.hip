@@ -361,12 +361,9 @@ __global__ __launch_bounds__(64 * KSW, 2) void conv1x1_wgrad_kernel(pdes_conv_de
 }
 
 // ------------------------------------------------------------------------------- host dispatch
-// PDES_MFMA_1X1: 0 = off (conv_mfma.hip serves the 1x1 layers), 1 = forward and data gradient (default),
-// 2 = forward only, 3 = data gradient only
-static bool p1_enabled(bool bwd) {
-  const int m = opt().mfma_1x1;
-  return m == 1 || (m == 2 && !bwd) || (m == 3 && bwd);
-}
+// PDES_MFMA_1X1: bit mask of the register-operand 1x1 kernels: 1 forward, 2 data gradient, 4 weight gradient (default 7;
+// 0: conv_mfma.hip / conv_mfma_wgrad.hip serve the 1x1 layers)
+static bool p1_enabled(bool bwd) { return (opt().mfma_1x1 & (bwd ? 2 : 1)) != 0; }
 
 static bool p1_shape_ok(const pdes_conv_desc& d, bool bwd) {
   if (d.ksize != 1 || d.stride != 1 || d.pad != 0 || d.upsample || !d.has_bn || d.nrep != PDES_NREP) return false;
@@ -386,7 +383,6 @@ static int launch_p1(const pdes_conv_desc& d, const float* wm, hipStream_t st) {
   const long long groups = (long long)d.B * (d.Hin * d.Win / 32);
   // K-split: enough waves for 1024 SIMDs, but at least four K-steps per wave
   int ksplit = (groups * nz * 2 >= 1024 || kC < 64) ? 2 : 4;
-  if (opt().k1_ksplit == 2 || opt().k1_ksplit == 4) ksplit = opt().k1_ksplit;
   // 8 waves per workgroup (more pixel groups share one set of statistics atomics) unless that leaves CUs idle
   const int nw = ((groups + 8 / ksplit - 1) / (8 / ksplit)) * nz >= 256 ? 8 : 4;
   const int gp = nw / ksplit, nown = (ntw + ksplit - 1) / ksplit;
@@ -422,7 +418,7 @@ int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry) {
 // weight gradient into the split-K partial buffer d.ws, spi splits per image (the plan of conv_mfma_wgrad.hip);
 // PDES_ENOSUP leaves the layer to the generic kernel
 int conv_backward_weight_1x1(const pdes_conv_desc& d, int spi, hipStream_t st) {
-  if (!opt().mfma_1x1w) return PDES_ENOSUP;
+  if (!(opt().mfma_1x1 & 4)) return PDES_ENOSUP;
   if (!p1_shape_ok(d, false) || !d.ws || d.eval_mode || d.g_fused || spi < 1) return PDES_ENOSUP;
   const int mtiles = (d.Cout + 15) / 16, ntiles = (d.Cin + 15) / 16, HW = d.Hin * d.Win;
   if ((long long)d.B * spi * d.Cout * d.Cin * 4 > d.ws_bytes) return PDES_ENOSUP;

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void pack_b3_kernel(const pdes_b3_pack_item* _
 
 // ------------------------------------------------------------------------------- host dispatch
 static bool b3_enabled() {
-  return opt().mfma_b3 != 0;
+  return (opt().mfma_b3 & 1) != 0;
 }
 
 // the layers this kernel takes: 3x3, stride 1, no upsampling, wide on both sides of the contraction
@@ -485,7 +485,6 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
   // 8 M-tiles per workgroup (82 KB of LDS: one workgroup per CU) or 4 (52 KB: two to three per CU, whose staging
   // and matrix phases overlap)
   int mt = 4;
-  if (opt().b3_mt == 8) mt = 8;
   if (H % (mt / twg)) mt = 8;
   dim3 grid((W / (16 * twg)) * (H / (mt / twg)), d.B, (nt_total + 7) / 8), block(256);
   const size_t cf = bwd ? 0 : 16 * (size_t)kpad;
@@ -494,7 +493,7 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
     using GL = B3Geo<TWG_, MT_>;                                                                              \
     const size_t lds = cf + 2 * (size_t)GL::BUF * 2 + 4 * (size_t)GL::FCS * sizeof(float);                    \
     const int tail_on = (opt().b3_tail && d.w) ? 1 : 0;                                                       \
-    if (opt().b3_apipe && MT_ == 4)                                                                           \
+    if (MT_ == 4)       /* A-operand fragments of the next (tap, M-tile) read before this one's MFMAs */     \
       hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, true>), grid, block, lds, st, d, wb, nt_total, tail_on);  \
     else                                                                                                      \
       hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, false>), grid, block, lds, st, d, wb, nt_total, tail_on); \
@@ -513,7 +512,7 @@ int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st) {
 
 // data gradient of nearest-x2 + 3x3 in the sub-pixel form (B3_UPBWD)
 int conv_backward_data_b3_up(const pdes_conv_desc& d, hipStream_t st, bool dry) {
-  if (!opt().mfma_b3ub || !d.wbu_bwd || d.eval_mode || d.g_fused) return PDES_ENOSUP;
+  if (!(opt().mfma_b3 & 8) || !d.wbu_bwd || d.eval_mode || d.g_fused) return PDES_ENOSUP;
   if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.upsample != PDES_UPSAMPLE_NEAREST || !d.has_bn || d.nrep != PDES_NREP)
     return PDES_ENOSUP;
   if (d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win || d.Cout < 32 || d.Cin < 64) return PDES_ENOSUP;

@@ -22,7 +22,6 @@
 // weight images with rolling register prefetch) follows conv_mfma.hip.
 #include "pdes_common.h"
 #include "../../include/pdes_hip.h"
-#include "bn_fused.h"
 #include "pack_kernels.h"
 
 namespace pdes {
@@ -65,8 +64,7 @@ struct UpGeo {                                 // 3x3 halo tile of the low-res m
 enum { UP_FWD = 0, UP_BWD = 1 };
 
 // grid: (low-res tiles, B, ceil(N-tiles/4)); 4 waves, one N-tile each
-// FUSED (UP_BWD only): d.g is the raw accumulator T, finalized on the way into LDS (bn_fused.h)
-template <int TWG, int MT, int MODE, bool FUSED>
+template <int TWG, int MT, int MODE>
 __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm,
                                                           int nt_total) {
   using G = UpGeo<TWG, MT>;
@@ -81,17 +79,13 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
   const int kpad = (kC + 15) & ~15;
   const int nchunk = kpad / 16;                      // channel chunks
   const int nvc = MODE == UP_FWD ? nchunk : nchunk * 4;   // staged (chunk, parity) tiles
-  static_assert(!(FUSED && MODE == UP_FWD), "the fused finalize belongs to the data gradient");
-  float* tile = smem + ((MODE == UP_FWD || FUSED) ? 4 * kpad : 0);
+  float* tile = smem + (MODE == UP_FWD ? 4 * kpad : 0);
   float4* cf4 = reinterpret_cast<float4*>(smem);
 
   const int tiles_x = Wl / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
   const bool halo_live = tiles_x > 1;
 
-  if (FUSED) {
-    for (int c = tid; c < kpad; c += 256) cf4[c] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   if (MODE == UP_FWD) {
     for (int c = tid; c < kpad; c += 256) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -104,7 +98,6 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
   const float* kbase = MODE == UP_FWD ? d.x + (size_t)b * d.x_ctot * HWl
                                       : d.g + ((size_t)b * d.g_ctot + d.g_coff) * HWh;
   const int HWk = MODE == UP_FWD ? HWl : HWh;
-  const float* xkbase = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff) * HWh : nullptr;
   int vg[G::NPV], vl[G::NPV], hg[G::NPH], hl[G::NPH];
   unsigned vrow = 0, hval = 0;
 #pragma unroll
@@ -137,14 +130,12 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
   constexpr int NPW = MODE == UP_BWD ? G::NPV : 1;
   struct Stage {
     float4 pv[G::NPV]; float4 pw[NPW]; float ph[G::NPH];
-    float4 xv[FUSED ? G::NPV : 1]; float4 xw[FUSED ? G::NPV : 1]; float xh[FUSED ? G::NPH : 1];   // raw activation, same positions
   };
   Stage sA, sB;
   auto issue = [&](int vc, Stage& st) __attribute__((always_inline)) {
     const int chunk = MODE == UP_FWD ? vc : vc >> 2, p = vc & 3;
     const int dy = MODE == UP_FWD ? 0 : p >> 1, dx = MODE == UP_FWD ? 0 : p & 1;
     const float* src = kbase + (size_t)chunk * 16 * HWk + (MODE == UP_BWD ? dy * Wh : 0);
-    const float* xsrc = FUSED ? xkbase + (size_t)chunk * 16 * HWk + dy * Wh : nullptr;
     const int cmax = kC - chunk * 16 - 1;
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
@@ -152,18 +143,12 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
       const float* q = src + ch * HWk + vg[i];
       st.pv[i] = *reinterpret_cast<const float4*>(q);
       if (MODE == UP_BWD) st.pw[i] = *reinterpret_cast<const float4*>(q + 4);      // 8 hi-res columns -> 4 of one parity
-      if constexpr (FUSED) {
-        const float* xq = xsrc + ch * HWk + vg[i];
-        st.xv[i] = *reinterpret_cast<const float4*>(xq);
-        st.xw[i] = *reinterpret_cast<const float4*>(xq + 4);
-      }
     }
     if (halo_live) {
 #pragma unroll
       for (int i = 0; i < G::NPH; ++i) {
         const int ch = min((tid + 256 * i) / (G::ROWS * 2), cmax);
         st.ph[i] = src[ch * HWk + hg[i] + (MODE == UP_BWD ? dx : 0)];
-        if constexpr (FUSED) st.xh[i] = xsrc[ch * HWk + hg[i] + dx];
       }
     }
   };
@@ -188,12 +173,6 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
         } else {
           z = dx ? make_float4(st.pv[i].y, st.pv[i].w, st.pw[i].y, st.pw[i].w)
                  : make_float4(st.pv[i].x, st.pv[i].z, st.pw[i].x, st.pw[i].z);
-          if constexpr (FUSED) {
-            const float4 k = cf4[chunk * 16 + ch];
-            const float4 x = dx ? make_float4(st.xv[i].y, st.xv[i].w, st.xw[i].y, st.xw[i].w)
-                                : make_float4(st.xv[i].x, st.xv[i].z, st.xw[i].x, st.xw[i].z);
-            z = make_float4(fin_apply(k, z.x, x.x), fin_apply(k, z.y, x.y), fin_apply(k, z.z, x.z), fin_apply(k, z.w, x.w));
-          }
           if (!ok) z = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         *reinterpret_cast<float4*>(t + vl[i]) = z;
@@ -209,7 +188,6 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
           const float4 k = cf4[chunk * 16 + ch];
           z = ok ? fmaxf(0.f, (z - k.x) * k.y + k.z) : 0.f;
         } else {
-          if constexpr (FUSED) z = fin_apply(cf4[chunk * 16 + ch], z, st.xh[i]);
           if (!ok) z = 0.f;
         }
         t[hl[i]] = z;
@@ -410,18 +388,13 @@ static int launch_up(const pdes_conv_desc& d, const float* wm, hipStream_t st, b
   const int th = mt / twg;
   if (H % th) return PDES_ENOSUP;
   if (dry) return PDES_OK;
-  const bool fused = MODE == UP_BWD && d.g_fused;
+  if (d.g_fused) return PDES_ENOSUP;
   dim3 grid((W / (16 * twg)) * (H / th), d.B, gz), block(256);
 #define PDES_UP_LAUNCH(TWG_, MT_)                                                                            \
   do {                                                                                                        \
     using G = UpGeo<TWG_, MT_>;                                                                               \
-    const size_t lds = (((MODE == UP_FWD || fused) ? 4 * (size_t)kpad : 0) + 2 * (size_t)G::KC * G::CS) * sizeof(float); \
-    if constexpr (MODE == UP_BWD) {                                                                           \
-      if (fused) hipLaunchKernelGGL((conv_up_mfma_kernel<TWG_, MT_, MODE, true>), grid, block, lds, st, d, wm, nt_total); \
-      else hipLaunchKernelGGL((conv_up_mfma_kernel<TWG_, MT_, MODE, false>), grid, block, lds, st, d, wm, nt_total); \
-    } else {                                                                                                  \
-      hipLaunchKernelGGL((conv_up_mfma_kernel<TWG_, MT_, MODE, false>), grid, block, lds, st, d, wm, nt_total); \
-    }                                                                                                         \
+    const size_t lds = ((MODE == UP_FWD ? 4 * (size_t)kpad : 0) + 2 * (size_t)G::KC * G::CS) * sizeof(float); \
+    hipLaunchKernelGGL((conv_up_mfma_kernel<TWG_, MT_, MODE>), grid, block, lds, st, d, wm, nt_total);        \
   } while (0)
   if (twg == 2) { if (mt == 8) PDES_UP_LAUNCH(2, 8); else PDES_UP_LAUNCH(2, 4); }
   else { if (mt == 8) PDES_UP_LAUNCH(1, 8); else PDES_UP_LAUNCH(1, 4); }

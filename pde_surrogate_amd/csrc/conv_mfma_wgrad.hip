@@ -14,7 +14,6 @@
 #include "pdes_common.h"
 #include "pdes_options.h"
 #include "../../include/pdes_hip.h"
-#include "bn_fused.h"
 
 namespace pdes {
 int conv_backward_weight_1x1(const pdes_conv_desc& d, int splits_per_image, hipStream_t st);   // conv_mfma_1x1.hip
@@ -44,19 +43,18 @@ struct WGeo {
   static_assert(CS % 32 == 2 && GS % 32 == 2 && CS >= ROWS * LDW && NR >= 0, "LDS geometry");
 };
 
-// PIPE: > 2 pixel tiles per workgroup, prefetch two ahead.  FUSED: d.g is the raw accumulator T; the
-// BatchNorm-backward finalize is applied while the gradient tile is committed to LDS (bn_fused.h).
+// PIPE: > 2 pixel tiles per workgroup, prefetch two ahead.
 // FEW (5x5, Cout*5 <= 16): the N dimension is (output channel, kernel column kx) instead of 16 output channels
 // (conv_mfma_fewout.hip): 5 accumulators (kernel rows) and 5 MFMAs per pixel k-step instead of 25, the B
 // operand is the gradient tile read with a per-lane column shift of -kx.
-template <int KS, int TWG, int NTW, int S, bool PIPE, bool FUSED, bool FEW>
+template <int KS, int TWG, int NTW, int S, bool PIPE, bool FEW>
 __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                              int n_ngroups, int co_off) {
   using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS;
   constexpr int NPG4 = 16 * NTW * G::TH * G::TW / 4 / 256;      // g float4 per thread per tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  static_assert(!FEW || (KS == 5 && NTW == 1 && S == 1 && !FUSED), "few-output form: 5x5, stride 1");
+  static_assert(!FEW || (KS == 5 && NTW == 1 && S == 1), "few-output form: 5x5, stride 1");
   constexpr int GROW = G::TW + 8;                                // FEW: gradient row with 4 zero columns either side
   constexpr int GPL = ((G::TH * GROW - 8 + 31) / 32) * 32 + 8;  // FEW: plane stride == 8 (mod 32); plane 3 stays zero
   constexpr int GAREA = FEW ? 4 * GPL : 16 * NTW * G::GS;
@@ -93,18 +91,12 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
     }
     cf[tid][0] = m; cf[tid][1] = s; cf[tid][2] = bt;
   }
-  __shared__ float4 cg[FUSED ? 16 * NTW : 1];     // finalize coefficients of this workgroup's gradient channels
-  if (FUSED && tid >= 64 && tid < 64 + 16 * NTW) {
-    const int c = co0 + (tid - 64);
-    cg[tid - 64] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
 
   if (FEW) {                     // pad columns and the zero plane are never written by the staging
     for (int i = tid; i < GAREA; i += 256) { gt[i] = 0.f; if (PIPE) gt[LDSB + i] = 0.f; }
   }
   const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWi;
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
-  const float* ob = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff + co0) * HWo : nullptr;
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
 
   const bool halo_live = (G::NL + G::NR) > 0 && tiles_x > 1;
@@ -112,7 +104,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
   // anything that consumes a load right after issuing it would drain vmcnt and serialise the prefetch
   // with the matrix work.  Validity is applied when a stage is committed to LDS.
   constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
-  struct Stage { float4 pv[G::NPV]; float4 pg[NPG4]; float ph[NPHS]; float4 px[FUSED ? NPG4 : 1]; };
+  struct Stage { float4 pv[G::NPV]; float4 pg[NPG4]; float ph[NPHS]; };
   Stage sA, sB;
   auto issue = [&](int tile, Stage& st) __attribute__((always_inline)) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
@@ -144,7 +136,6 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
       const int oy = oy0 + (4 * p4) / G::TW, ox = ox0 + (4 * p4) % G::TW;
       const size_t off = (size_t)min(ch, corem - 1) * HWo + oy * d.Wout + ox;
       st.pg[i] = *reinterpret_cast<const float4*>(gb + off);
-      if constexpr (FUSED) st.px[i] = *reinterpret_cast<const float4*>(ob + off);
     }
   };
   auto bnrelu = [&](float x, int ch, bool ok) __attribute__((always_inline)) {
@@ -194,12 +185,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
         continue;
       }
       float* dst = gtb + ch * G::GS + 4 * p4;                               // 8-byte aligned (GS even)
-      float4 gv = st.pg[i];
-      if constexpr (FUSED) {
-        const float4 k = cg[ch];
-        const float4 x = st.px[i];
-        gv = make_float4(fin_apply(k, gv.x, x.x), fin_apply(k, gv.y, x.y), fin_apply(k, gv.z, x.z), fin_apply(k, gv.w, x.w));
-      }
+      const float4 gv = st.pg[i];
       *reinterpret_cast<float2*>(dst) = ok ? make_float2(gv.x, gv.y) : make_float2(0.f, 0.f);
       *reinterpret_cast<float2*>(dst + 2) = ok ? make_float2(gv.z, gv.w) : make_float2(0.f, 0.f);
     }
@@ -324,7 +310,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
 //   dW[ky][kx] = sum_{dy,dx} dWeff[(dy,dx)][a(ky,dy)][b(kx,dx)]
 // 16 MFMAs per low-res pixel k-step instead of 36; the operand images are the low-res z halo tile
 // and the four de-interleaved parity sub-images of the hi-res gradient.
-template <int TWG, int NTW, bool FUSED>
+template <int TWG, int NTW>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
                                                                 int n_ngroups, int co_off) {
   using G = WGeo<3, TWG, 1>;
@@ -358,21 +344,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
     }
     cf[tid][0] = m; cf[tid][1] = sc; cf[tid][2] = bt;
   }
-  __shared__ float4 cg[FUSED ? 16 * NTW : 1];
-  if (FUSED && tid >= 64 && tid < 64 + 16 * NTW) {
-    const int c = co0 + (tid - 64);
-    cg[tid - 64] = c < d.Cout ? fin_coef(d, c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWl;
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWh;
-  const float* ob = FUSED ? d.out + ((size_t)b * d.out_ctot + d.out_coff + co0) * HWh : nullptr;
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
   const bool halo_live = tiles_x > 1;
 
   // raw loads only (clamped addresses, no select on loaded values: see conv_mfma_wgrad_kernel); validity and
   // the parity de-interleave happen when the registers are committed to LDS
   float4 pv[G::NPV], ph0[NPG], ph1[NPG];
-  float4 xh0[FUSED ? NPG : 1], xh1[FUSED ? NPG : 1];
   float ph[G::NPH];
   auto issue = [&](int tile) __attribute__((always_inline)) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
@@ -406,10 +385,6 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       const float* src = gb + off;
       ph0[i] = *reinterpret_cast<const float4*>(src);
       ph1[i] = *reinterpret_cast<const float4*>(src + 4);
-      if constexpr (FUSED) {
-        xh0[i] = *reinterpret_cast<const float4*>(ob + off);
-        xh1[i] = *reinterpret_cast<const float4*>(ob + off + 4);
-      }
     }
   };
   auto bnrelu = [&](float x, int ch, bool ok) __attribute__((always_inline)) {
@@ -448,13 +423,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
       const int dy = e & 1, q = e >> 1;
       const int ch = q / (NPX / 4), p4 = q % (NPX / 4);
       const bool v = ch < corem;
-      float4 h0 = ph0[i], h1 = ph1[i];
-      if constexpr (FUSED) {
-        const float4 k = cg[ch];
-        const float4 x0 = xh0[i], x1 = xh1[i];
-        h0 = make_float4(fin_apply(k, h0.x, x0.x), fin_apply(k, h0.y, x0.y), fin_apply(k, h0.z, x0.z), fin_apply(k, h0.w, x0.w));
-        h1 = make_float4(fin_apply(k, h1.x, x1.x), fin_apply(k, h1.y, x1.y), fin_apply(k, h1.z, x1.z), fin_apply(k, h1.w, x1.w));
-      }
+      const float4 h0 = ph0[i], h1 = ph1[i];
       float* d0 = gt + ((dy * 2 + 0) * 16 * NTW + ch) * G::GS + 4 * p4;
       float* d1 = gt + ((dy * 2 + 1) * 16 * NTW + ch) * G::GS + 4 * p4;
       *reinterpret_cast<float2*>(d0) = v ? make_float2(h0.x, h0.z) : make_float2(0.f, 0.f);       // dx = 0
@@ -618,14 +587,6 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
     if (ns * p->per * 4 > d.ws_bytes) continue;
     if (ns * p->gy <= wg_target || cand == p->tps) { p->tpw = cand; break; }
   }
-  // 1x1 layers on big maps (conv_mfma_1x1.hip: a workgroup per (split, group of input-channel tiles)):
-  // PDES_1X1W_SPI=4 asks for four splits per image, which puts a workgroup on every CU -- 23.4 -> 16.6 us stand-alone
-  // for the 144->72 layer, but no gain inside the step (2.0375 vs 2.0389 ms, three same-box runs each: the bigger
-  // grid takes more of the chip from the data-gradient chain), so one split per image stays the default
-  if (d.ksize == 1 && d.stride == 1 && !d.upsample && d.Hout * d.Wout >= 1024 && p->tps % 4 == 0 &&
-      opt().w1x1_spi == 4 &&
-      (long long)d.B * 4 * p->per * 4 <= d.ws_bytes)
-    p->tpw = p->tps / 4;
   p->nsplit = d.B * (p->tps / p->tpw);
   return (long long)p->nsplit * p->per * 4 <= d.ws_bytes;
 }
@@ -649,25 +610,18 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
     if constexpr (KS == 5 && NTW_ == 1 && S == 1) {                                                           \
-      if (d.Cout * 5 <= 16 && !d.g_fused) {      /* few-output form; its LDS need is below the generic one */ \
+      if (d.Cout * 5 <= 16) {                    /* few-output form; its LDS need is below the generic one */ \
         if (tpw > 2)                                                                                          \
-          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
         else                                                                                                  \
-          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
         break;                                                                                                \
       }                                                                                                       \
     }                                                                                                         \
-    if (d.g_fused) {                                                                                          \
-      if (tpw > 2)                                                                                            \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
-      else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
-    } else {                                                                                                  \
-      if (tpw > 2)                                                                                            \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
-      else                                                                                                    \
-        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
-    }                                                                                                         \
+    if (tpw > 2)                                                                                              \
+      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
   } while (0)
   // an odd number of N-tiles >= 3: pairs with the two-tile kernel, the last tile with the one-tile kernel
   // (instead of a padding tile: 98 output channels are 7 tiles, not 8)
@@ -710,10 +664,7 @@ static int launch_wgrad_up(const pdes_conv_desc& d, hipStream_t st) {
     size_t lds = (size_t)(16 * G::CS + 4 * 16 * NTW_ * G::GS) * sizeof(float);                                \
     const size_t red = (size_t)4 * 9 * NTW_ * 4 * 64 * sizeof(float);                                         \
     if (red > lds) lds = red;                                                                                 \
-    if (d.g_fused)                                                                                            \
-      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, true>), grid, block, lds, st, d, d.ws, pl.tpw, ngroups_l, (COFF_)); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_, false>), grid, block, lds, st, d, d.ws, pl.tpw, ngroups_l, (COFF_)); \
+    hipLaunchKernelGGL((conv_mfma_wgrad_up_kernel<TWG_, NTW_>), grid, block, lds, st, d, d.ws, pl.tpw, ngroups_l, (COFF_)); \
   } while (0)
   const bool split_odd = pl.ntw == 2 && (ntiles & 1) && ntiles >= 7;
   if (split_odd) {
@@ -736,9 +687,9 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry)
     return PDES_ENOSUP;
   if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample)) return PDES_ENOSUP;
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
-  if (!wgrad_shape_ok(d)) return PDES_ENOSUP;
+  if (d.g_fused || !wgrad_shape_ok(d)) return PDES_ENOSUP;    // finalize-on-load exists for PDES_OP_COPY only (flow_ops.hip)
   if (dry) { WgradPlan pl; return wgrad_plan(d, &pl) ? PDES_OK : PDES_ENOSUP; }
-  if (d.ksize == 1 && d.stride == 1 && !d.upsample && !d.g_fused) {      // conv_mfma_1x1.hip: one split per image
+  if (d.ksize == 1 && d.stride == 1 && !d.upsample) {      // conv_mfma_1x1.hip: one split per image
     WgradPlan pl;
     if (wgrad_plan(d, &pl) && pl.nsplit % d.B == 0) {
       const int rc = conv_backward_weight_1x1(d, pl.nsplit / d.B, st);

@@ -461,13 +461,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
 
 // ------------------------------------------------------------------------------- host side
 static bool wgrad_b3_up_shape(const pdes_conv_desc& d) {      // nearest-x2 + 3x3 from a 32- or 16-wide map
-  if (!opt().mfma_b3wu || d.upsample != PDES_UPSAMPLE_NEAREST || d.Wout != 2 * d.Win || d.Hout != 2 * d.Hin) return false;
+  if (!(opt().mfma_b3 & 16) || d.upsample != PDES_UPSAMPLE_NEAREST || d.Wout != 2 * d.Win || d.Hout != 2 * d.Hin) return false;
   if (!(d.Win == 32 || (d.Win == 16 && d.Hin % 2 == 0))) return false;
   return d.Cin >= 64 && d.Cout >= 32 && d.Cout <= 128;
 }
 
 bool wgrad_b3_applies(const pdes_conv_desc& d) {
-  if (!opt().mfma_b3w || d.ksize != 3 || d.stride != 1 || d.pad != 1 || !d.has_bn || d.g_fused || d.nrep != PDES_NREP) return false;
+  if (!(opt().mfma_b3 & 2) || d.ksize != 3 || d.stride != 1 || d.pad != 1 || !d.has_bn || d.g_fused || d.nrep != PDES_NREP) return false;
   if (d.upsample) return wgrad_b3_up_shape(d);
   if (d.Win != wb3::W || d.Wout != wb3::W || d.Hin != d.Hout) return false;
   return d.Cin >= 64 && d.Cout >= 32 && d.Cout <= 128;
@@ -498,8 +498,7 @@ int conv_backward_weight_b3(const pdes_conv_desc& d, hipStream_t st) {
   } else {
     size_t lds = (size_t)wb3::ZSIZE * 2 + (size_t)2 * 3 * nco * wb3::W * 2;
     if (epi > lds) lds = epi;
-    if (opt().b3w_pf == 1) hipLaunchKernelGGL(conv_wgrad_b3_kernel<1>, grid, block, lds, st, d, d.ws, rows);
-    else hipLaunchKernelGGL(conv_wgrad_b3_kernel<2>, grid, block, lds, st, d, d.ws, rows);
+    hipLaunchKernelGGL(conv_wgrad_b3_kernel<2>, grid, block, lds, st, d, d.ws, rows);        // two rows of load lead
   }
   PDES_LAUNCH_CHECK();
   return PDES_OK;

@@ -547,6 +547,143 @@ class _Engine(_EngineBase):
                                         _lib.ptr(accum), self.nrep, self.rep_stride, st), 'pdes_step_tail')
 
 
+class PdesOp(ctypes.Structure):
+    """mirror of `pdes_op` (include/pdes_hip.h)"""
+    _fields_ = [('kind', _I), ('arg', _I), ('stream', _I)]
+
+
+OP_LAUNCH, OP_RECORD, OP_WAIT, OP_HOOK = 0, 1, 2, 3
+
+
+class StepProgram:
+    """One training step of an engine as LINEAR hipGraphs + the fork / join events between them (csrc/step_graph.hip):
+    graph 0 = weight packing + forward chain + loss launch on the main stream; per backward segment (a stage of the
+    network: LastTransUp, DecBlock2, ...) the finalize -> data-gradient chain on the main stream and the segment's weight
+    gradients on one of the two weight-gradient streams, released by ONE event per segment; the early split-K reduce (+
+    the data-parallel bucket hook) behind the segment that completes 60 % of the weights; a last graph with the first
+    layer's weight gradient, the remaining reduce and the end-of-step launch.  Replayed by one pdes_program_run call."""
+
+    def __init__(self, eng, loss_launch, tail, grad_y, seg_max=None, forward_only=False, split_w=False):
+        L = _lib.lib()
+        self.eng, self._L = eng, L
+        net, descs, specs = eng.net, eng.descs, eng._chain_specs()
+        n = len(descs)
+        if eng.mask_off:
+            raise NotImplementedError('Dropout2d draws its channel masks with torch RNG launches: eager steps only')
+        if not hasattr(eng, '_reduce_n'):
+            eng._plan_wgrad_scratch()
+        for d, os_ in zip(descs, eng._out_stats):
+            d.eval_mode, d.out_stats = 0, os_
+        descs[n - 1].g = grad_y.data_ptr()
+        # segments = stages of the network (layers of one dense block / transition), optionally cut into chunks
+        segs, start = [], 0
+        stage = lambda i: (specs[i].conv or specs[i].norm or '').split('.')[0]
+        for i in range(1, n + 1):
+            if i == n or stage(i) != stage(start) or (seg_max and i - start >= seg_max):
+                segs.append((start, i))
+                start = i
+        self.segments = segs
+        per = [(specs[i].cout * specs[i].cin * specs[i].k * specs[i].k) if eng._reduce_index[i] >= 0 else 0 for i in range(n)]
+        total, done, trigger = sum(per), 0, None
+        cap = eng._side_stream()                     # idle while the program is built
+        cap_ptr = ctypes.c_void_p(cap.cuda_stream)
+        self.graphs = []
+
+        def capture(fn):
+            torch.cuda.synchronize(eng.dev)
+            with torch.cuda.stream(cap):
+                _lib.check(L.pdes_graph_begin(cap_ptr), 'pdes_graph_begin')
+                try:
+                    fn(cap_ptr)
+                finally:
+                    g = ctypes.c_void_p()
+                    rc = L.pdes_graph_end(cap_ptr, ctypes.byref(g))
+                _lib.check(rc, 'pdes_graph_end')
+            self.graphs.append(g)
+            return len(self.graphs) - 1
+
+        def fwd(st):
+            net._pack_weights()
+            _lib.check(L.pdes_conv_forward(eng.ctx, descs, n, st), 'pdes_conv_forward')
+            loss_launch(st)
+        ops = [(OP_LAUNCH, capture(fwd), 0)]
+        ev = 0
+        used = set()
+        self.forward_only = forward_only
+        for k, (lo, hi) in enumerate(reversed(segs) if not forward_only else ()):
+            g_chain = capture(lambda st: _lib.check(L.pdes_backward_chain(eng.ctx, descs, lo, hi, st), 'pdes_backward_chain'))
+            ops.append((OP_LAUNCH, g_chain, 0))
+            wlo = max(lo, 1)                          # the first layer's weight gradient goes last, on the main stream
+            if hi > wlo and any(specs[i].conv is not None for i in range(wlo, hi)):
+                side = 1 + (k & 1)
+                if split_w and hi - wlo >= 2:          # the segment's weight gradients alternate between BOTH streams
+                    def w_half(par):
+                        def fn(st):
+                            for i in range(hi - 1, wlo - 1, -1):
+                                if (hi - 1 - i) % 2 == par and specs[i].conv is not None:
+                                    _lib.check(L.pdes_backward_weights(eng.ctx, descs, i, i + 1, st), 'pdes_backward_weights')
+                        return fn
+                    g_w, g_w2 = capture(w_half(0)), capture(w_half(1))
+                    ops += [(OP_RECORD, ev, 0), (OP_WAIT, ev, side), (OP_LAUNCH, g_w, side), (OP_WAIT, ev, 3 - side),
+                            (OP_LAUNCH, g_w2, 3 - side)]
+                    used.add(3 - side)
+                else:
+                    g_w = capture(lambda st: _lib.check(L.pdes_backward_weights(eng.ctx, descs, wlo, hi, st), 'pdes_backward_weights'))
+                    ops += [(OP_RECORD, ev, 0), (OP_WAIT, ev, side), (OP_LAUNCH, g_w, side)]
+                ev += 1
+                used.add(side)
+                done += sum(per[wlo:hi])
+                if trigger is None and total and 5 * done >= 3 * total and lo > 0:
+                    rows = [eng._reduce_index[i] for i in range(lo, n) if eng._reduce_index[i] >= 0]
+                    if rows and rows[0] > 0:
+                        trigger = (lo, rows[0])
+                        other = 3 - side
+                        if other in used:             # the reduce reads partials written on both weight-gradient streams
+                            ops += [(OP_RECORD, ev, other), (OP_WAIT, ev, side)]
+                            ev += 1
+                        first, cnt, mx = rows[0], eng._reduce_n - rows[0], max(per[lo:n])
+                        g_r = capture(lambda st: _lib.check(L.pdes_wgrad_reduce_all(
+                            eng._reduce_table.data_ptr() + 24 * first, cnt, mx, st), 'pdes_wgrad_reduce_all'))
+                        ops += [(OP_LAUNCH, g_r, side), (OP_HOOK, lo, side)]
+        for side in sorted(used):                     # join the weight-gradient streams into the main stream
+            ops += [(OP_RECORD, ev, side), (OP_WAIT, ev, 0)]
+            ev += 1
+        self.early = trigger
+
+        def end(st):
+            if specs[0].conv is not None:
+                _lib.check(L.pdes_backward_weights(eng.ctx, descs, 0, 1, st), 'pdes_backward_weights')
+            cnt = trigger[1] if trigger else eng._reduce_n
+            if cnt:
+                mx = max(per[i] for i in range(n) if 0 <= eng._reduce_index[i] < cnt)
+                _lib.check(L.pdes_wgrad_reduce_all(eng._reduce_table.data_ptr(), cnt, mx, st), 'pdes_wgrad_reduce_all')
+            upd, partials, B, H, W, w0, w1, w2, w3, terms, accum = tail
+            _lib.check(L.pdes_step_tail(eng.bn_table.data_ptr(), eng.n_bn, eng.max_c, ctypes.c_float(0.1), 1 if upd else 0,
+                                        _lib.ptr(partials), B, H, W, w0, w1, w2, w3, _lib.ptr(terms), _lib.ptr(accum),
+                                        eng.nrep, eng.rep_stride, st), 'pdes_step_tail')
+        if not forward_only:
+            ops.append((OP_LAUNCH, capture(end), 0))
+        torch.cuda.synchronize(eng.dev)
+        self.n_ops = len(ops)
+        self._ops = (PdesOp * len(ops))(*[PdesOp(*o) for o in ops])
+        self._graph_arr = (ctypes.c_void_p * len(self.graphs))(*[g.value for g in self.graphs])
+        self._streams = (ctypes.c_void_p * 3)(None, eng._side_stream().cuda_stream, eng._side_stream('b').cuda_stream)
+        self.nodes = [L.pdes_graph_nodes(g) for g in self.graphs]
+
+    def run(self, hook=None):
+        self._streams[0] = _lib.stream_ptr()
+        rc = self._L.pdes_program_run(self.eng.ctx, self._graph_arr, len(self.graphs), self._streams, 3, self._ops,
+                                      self.n_ops, ctypes.byref(hook) if hook is not None else None)
+        _lib.check(rc, 'pdes_program_run')
+
+    def close(self):
+        for g in self.graphs:
+            self._L.pdes_graph_destroy(g)
+        self.graphs = []
+
+    __del__ = close
+
+
 class _Lease:
     """an engine held by one autograd forward until its backward has run -- or until autograd drops the graph
     (the lease is garbage collected with the function's ctx)"""

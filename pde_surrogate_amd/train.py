@@ -9,7 +9,9 @@ Adam -- without autograd, host synchronisation or per-parameter kernels.
     rank-local, exactly what DistributedDataParallel would do);
   * the loss terms are accumulated on the device and read once per epoch (the reference's
     per-step ``loss.item()`` sync, :240, is not needed for its per-epoch mean);
-  * the whole compute part of the step can be captured in a hipGraph (`use_graph=True`).
+  * the step is replayed as LINEAR hipGraphs joined by one event per backward segment (`use_graph='segments'`,
+    models/codec.py StepProgram + csrc/step_graph.hip); `use_graph=True` captures the compute part as ONE serial graph
+    (no overlap of the weight gradients: slower), `use_graph=False` launches every kernel eagerly on three streams.
 """
 import ctypes
 import math
@@ -124,9 +126,16 @@ class MixedResidualTrainer:
         self.terms = torch.zeros(5, device=self.dev)
         self.terms_accum = torch.zeros(5, device=self.dev, dtype=torch.float64)
         self.n_accum = 0
-        self.use_graph = use_graph
+        if use_graph not in (False, True, 'segments', 'forward'):
+            raise ValueError("use_graph: False (eager launches), True (one serial hipGraph), 'segments' (linear graphs per "
+                             "stage) or 'forward' (the forward pass + loss as one graph, the backward pass eager)")
+        self.segments = use_graph in ('segments', 'forward')
+        self.forward_graph = use_graph == 'forward'
+        self.use_graph = use_graph is True                    # the single serial graph
+        self._program = None
+        self.seg_max = int(os.environ.get('PDES_SEG_MAX', '0')) or None
         self._graph = None
-        self._hyper_event = torch.cuda.Event() if use_graph else None
+        self._hyper_event = torch.cuda.Event() if self.use_graph else None
         self._grad_clean = False          # eager: True once the Adam kernel has cleared the gradient buffer
         self._L = _lib.lib()
         # data parallel: the gradient buffer is exchanged in two buckets.  Bucket A = the convolution weights of the
@@ -172,12 +181,15 @@ class MixedResidualTrainer:
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
         try:
             off = self.model._conv_off[first_layer]
+            side = self.eng._side_stream()
+            if stream is not None and stream != side.cuda_stream and stream == self.eng._side_stream('b').cuda_stream:
+                side = self.eng._side_stream('b')            # (the segment program alternates the two weight-gradient streams)
             if self._rccl is not None:
                 # bucket A on the weight-gradient stream itself, behind the early split-K reduce just enqueued there
                 self._rccl.all_reduce_sum_(self.gflat.data_ptr() + 4 * off, self.gflat.numel() - off, stream)
                 self._bucket_work = True
             else:
-                with torch.cuda.stream(self.eng._side_stream()):
+                with torch.cuda.stream(side):
                     self._bucket_work = torch.distributed.all_reduce(self.gflat[off:], op=torch.distributed.ReduceOp.SUM,
                                                                      group=self.pg, async_op=True)
             self._bucket_off = off
@@ -224,7 +236,7 @@ class MixedResidualTrainer:
                                      self.partials.data_ptr(), None, self.B, self.n, self.n,
                                      1.0, 1.0, self.wb, self.wb, 1 if self.nl else 0, self.nb1, self.nb2, st)
         _lib.check(rc, 'pdes_darcy_loss')
-        return (True, self.partials, self.B, self.n, self.n, 1.0, 1.0, self.wb, self.wb, self.terms, self.terms_accum)
+        return self._tail_args()
 
     def _set_hyper(self, lr):
         self.step_count += 1
@@ -261,8 +273,10 @@ class MixedResidualTrainer:
             if self._graph is None:
                 self._capture()
             self._graph.replay()
+        elif self.segments and self.step_count > 1:
+            self._run_segments()
         else:
-            self._compute()
+            self._compute()                                   # (segments: the first step is eager -- lazy initialisations, a clean arena)
         self.n_accum += 1
         if self._hook is not None:                            # data parallel (a group of ONE rank still runs the path)
             self._exchange_rest()
@@ -283,6 +297,36 @@ class MixedResidualTrainer:
         if prof is not None:
             prof['step'] = prof.get('step', 0.0) + (time.perf_counter() - ts)
             prof['n'] = prof.get('n', 0) + 1
+
+    def _run_segments(self):
+        """the step as linear hipGraphs (StepProgram): built after the first, eager step"""
+        from .models.codec import StepProgram
+        m = self.model
+        assert m._flat is self.flat, 'the model was re-flattened (moved to another device?) after the trainer was built'
+        if self._program is None:
+            tail_box = []
+            self._program = StepProgram(self.eng, lambda st: tail_box.append(self._loss(self.eng.X['out'], st)),
+                                        self._tail_args(), self.grad_y, self.seg_max, forward_only=self.forward_graph,
+                                        split_w=os.environ.get('PDES_SEG_SPLITW', '0') == '1')
+        if not self._grad_clean or m._grad_dirty:
+            self.gflat.zero_()
+            m._grad_dirty = False
+        if not self.eng.arena_clean:
+            self.eng.arena.zero_()
+        self.eng.arena_clean = False
+        hook = self._hook if self.overlap_allreduce else None
+        self._hook_error = None
+        try:
+            self._program.run(hook)
+            if self.forward_graph:                             # the backward pass as eager launches on three streams
+                self.eng.backward(self.grad_y, tail=self._tail_args(), bucket_hook=hook)
+        except RuntimeError:
+            if self._hook_error is not None:
+                raise self._hook_error
+            raise
+
+    def _tail_args(self):
+        return (True, self.partials, self.B, self.n, self.n, 1.0, 1.0, self.wb, self.wb, self.terms, self.terms_accum)
 
     def _exchange_rest(self):
         """finish the gradient exchange of this step: what the early bucket (if the hook ran) did not cover, then the
@@ -355,6 +399,9 @@ class MaxLikelihoodTrainer(MixedResidualTrainer):
                                    self._mse_partials.data_ptr(), self.terms.data_ptr(), self.terms_accum.data_ptr(),
                                    y.numel(), st)
         _lib.check(rc, 'pdes_mse_loss')
+        return self._tail_args()
+
+    def _tail_args(self):
         return (True, None, self.B, self.n, self.n, 0.0, 0.0, 0.0, 0.0, None, None)
 
     def step(self, x=None, target=None, lr=None):

@@ -3,7 +3,7 @@ conv_mfma_wgrad_b3.hip: the wide 3x3 layers on v_mfma_f32_16x16x32_bf16, both op
 six of the nine cross products kept; forward, data gradient and weight gradient, plain and sub-pixel forms, with and
 without the f32 K-tail path) against fp64 convolutions -- VERDICT r1 weak #4, r2 weak #2.  The claim under test: each
 kernel is fp32-EQUIVALENT, i.e. its error against fp64 is of the size of the exact-f32 pipe's
-(v_mfma_f32_16x16x4_f32, the kernel's option = 0) on the same data, also where the dropped cross terms could matter:
+(v_mfma_f32_16x16x4_f32: the kernel's bit of PDES_MFMA_B3 cleared) on the same data, also where the dropped cross terms could matter:
   * wide dynamic range across the 196 * 9 = 1764-long contraction (1e-6 .. 1e3 in the activations, 1e-2 .. 1e2 in
     the weights),
   * post-ReLU sparsity (90 % exact zeros),
@@ -29,16 +29,16 @@ LAYERS = {           # name -> (convolution, Cin, Cout, input map size, nearest-
     'up32': ('LastTransUp.conv2', 98, 49, 32, True),
     'up16': ('TransUp1.conv2', 100, 100, 16, True),
 }
-# every kernel of the bf16 x3 family: (layer, pass, the option that moves it to the exact-f32 pipe)
+# every kernel of the bf16 x3 family: (layer, pass, its bit of the option PDES_MFMA_B3 -- cleared, the exact-f32 pipe runs)
 KERNELS = {
-    'conv_mfma_b3_kernel<FWD> 196->98': ('wide', 'fwd', 'PDES_MFMA_B3'),
-    'conv_mfma_b3_kernel<BWD> 196->98': ('wide', 'dgrad', 'PDES_MFMA_B3'),
-    'conv_wgrad_b3_kernel 196->98': ('wide', 'wgrad', 'PDES_MFMA_B3W'),
-    'conv_b3_up_fwd_kernel 98->49': ('up32', 'fwd', 'PDES_MFMA_B3U'),
-    'conv_mfma_b3_kernel<UPBWD> 98->49': ('up32', 'dgrad', 'PDES_MFMA_B3UB'),
-    'conv_mfma_b3_kernel<UPBWD> 100->100': ('up16', 'dgrad', 'PDES_MFMA_B3UB'),
-    'conv_wgrad_b3_up_kernel<32> 98->49': ('up32', 'wgrad', 'PDES_MFMA_B3WU'),
-    'conv_wgrad_b3_up_kernel<16> 100->100': ('up16', 'wgrad', 'PDES_MFMA_B3WU'),
+    'conv_mfma_b3_kernel<FWD> 196->98': ('wide', 'fwd', 1),
+    'conv_mfma_b3_kernel<BWD> 196->98': ('wide', 'dgrad', 1),
+    'conv_wgrad_b3_kernel 196->98': ('wide', 'wgrad', 2),
+    'conv_b3_up_fwd_kernel 98->49': ('up32', 'fwd', 4),
+    'conv_mfma_b3_kernel<UPBWD> 98->49': ('up32', 'dgrad', 8),
+    'conv_mfma_b3_kernel<UPBWD> 100->100': ('up16', 'dgrad', 8),
+    'conv_wgrad_b3_up_kernel<32> 98->49': ('up32', 'wgrad', 16),
+    'conv_wgrad_b3_up_kernel<16> 100->100': ('up16', 'wgrad', 16),
 }
 B = 2
 
@@ -156,7 +156,7 @@ def test_bf16x3_kernels_are_fp32_equivalent(option, kernel, kind, tail):
     """all six kernels of the bf16 x3 family (eight layer / pass combinations) x four adversarial input families x the
     f32 K-tail path on and off: error against fp64 within 2x of the exact-f32 pipe's on the same data, and at most 4
     fp32 rounding units of sum |w| |x| componentwise"""
-    layer, what, knob = KERNELS[kernel]
+    layer, what, bit = KERNELS[kernel]
     if tail == '0' and (what == 'wgrad' or layer == 'up16'):
         pytest.skip('no K tail in this kernel (the weight gradients contract over pixels; 100 = 3 x 32 + 4 goes through '
                     'PDES_B3_TAIL only in the forward / data-gradient kernels of the 98- and 196-channel layers)')
@@ -172,8 +172,8 @@ def test_bf16x3_kernels_are_fp32_equivalent(option, kernel, kind, tail):
     mask = (x > 0) if what == 'dgrad' else 1.0
     res, raw = {}, {}
     option('PDES_B3_TAIL', tail)
-    for tag, v in (('b3', '1'), ('f32', '0')):
-        option(knob, v)
+    for tag, v in (('b3', '31'), ('f32', str(31 - bit))):
+        option('PDES_MFMA_B3', v)
         rig = _rig(layer)
         raw[tag] = _run_kernel(rig, what, x, w, g)
         res[tag] = _errors(raw[tag] * mask, refs[k] * mask, scales[k])

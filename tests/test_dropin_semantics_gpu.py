@@ -131,11 +131,13 @@ def test_data_parallel_branch_on_one_rank(dev):
         pg = dist.new_group([0])
         x = torch.exp(0.5 * torch.randn(32, 1, 64, 64, device=dev))
         finals, hooks = [], []
-        for group in (None, pg):
+        for group, mode in ((None, False), (pg, False), (pg, 'segments')):
             torch.manual_seed(1)
             with contextlib.redirect_stdout(io.StringIO()):
                 net = DenseED(1, 3, 64, [6, 8, 6]).to(dev).train()
-            tr = MixedResidualTrainer(net, 32, 64, lr=1e-3, device=dev, process_group=group)
+            tr = MixedResidualTrainer(net, 32, 64, lr=1e-3, device=dev, process_group=group, use_graph=mode)
+            if group is not None:
+                assert tr._rccl is not None                   # the direct RCCL communicator (parallel.DirectRccl) was made
             seen = []
             if group is not None:
                 orig = tr._on_bucket
@@ -152,6 +154,9 @@ def test_data_parallel_branch_on_one_rank(dev):
             hooks.append(seen)
             finals.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), tr.epoch_means()))
         assert hooks[0] == [] and len(hooks[1]) == 3          # one early bucket per step
+        assert hooks[2] == hooks[1]                           # ... also when the step is replayed as segment graphs
+        np.testing.assert_allclose(finals[2][1], finals[0][1], rtol=1e-5)
+        assert rel_l2(finals[2][0].cpu().numpy(), finals[0][0].cpu().numpy()) < 1e-4
         first = hooks[1][0]
         assert 0 < first < 28
         # bucket A (conv weights of layers >= first) is the larger share of the gradient bytes

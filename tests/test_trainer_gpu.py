@@ -284,3 +284,62 @@ def test_other_field_sizes_end_to_end(dev, tmp_path, monkeypatch, imsize):
         run = tmp_path / 'codec/mixed_residual/grf_kle512_ntrain16_run1_bs8_lr0.001_epochs2'
         lt = np.loadtxt(run / 'training/loss_train.txt')
         assert lt.shape == (2,) and np.isfinite(lt).all() and lt[1] < lt[0]
+
+
+@pytest.mark.parametrize('mode', ['segments', 'forward'])
+def test_segment_graph_program_equals_eager_step(dev, mode, monkeypatch):
+    """the step replayed as linear hipGraphs joined by one event per stage (StepProgram, csrc/step_graph.hip) -- or with
+    only the forward pass + loss as a graph -- runs the SAME kernels in the same per-stream order as the eager step:
+    parameters, loss terms and BatchNorm buffers are bit-identical after six steps (default net, B = 32: deterministic
+    kernels), also with segments cut into chunks of three layers and the weight gradients split over both streams"""
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    data = torch.from_numpy(grf_kle_fields(64, n_kle=64, cache_dir='/tmp')).to(dev)
+
+    def run(use_graph, env=()):
+        for k, v in env:
+            monkeypatch.setenv(k, v)
+        net = _net(dev).train()
+        tr = MixedResidualTrainer(net, 32, 64, lr=1e-3, device=dev, use_graph=use_graph)
+        for i in range(6):
+            tr.step(data[(i % 2) * 32:(i % 2 + 1) * 32], 1e-3)
+        torch.cuda.synchronize()
+        for k, _ in env:
+            monkeypatch.delenv(k)
+        bn = net.features.LastTransUp.norm3
+        return tr.flat.clone(), tr.epoch_means(), bn.running_var.clone(), int(bn.num_batches_tracked), tr
+    want = run(False)
+    variants = [()] if mode == 'forward' else [(), (('PDES_SEG_MAX', '3'),), (('PDES_SEG_SPLITW', '1'),)]
+    for env in variants:
+        got = run(mode, env)
+        assert torch.equal(got[0], want[0]), env
+        assert got[1] == want[1] and torch.equal(got[2], want[2]) and got[3] == want[3] == 6, env
+        prog = got[4]._program
+        assert prog is not None and sum(prog.nodes) >= 30
+        if mode == 'segments':
+            assert prog.early is not None and prog.early[0] == 17           # the early bucket = the layers from TransUp1 on
+            assert sum(prog.nodes) >= 110                                    # every kernel of the step sits in a graph
+
+
+def test_segment_graph_program_rejects_dropout_and_serves_the_data_driven_trainer(dev):
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MaxLikelihoodTrainer, MixedResidualTrainer
+    torch.manual_seed(0)
+    x = torch.exp(0.5 * torch.randn(8, 1, 64, 64, device=dev))
+    t = torch.randn(8, 3, 64, 64, device=dev)
+    res = []
+    for mode in (False, 'segments'):
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = DenseED(1, 3, 64, [2, 2, 2], growth_rate=16, init_features=32).to(dev).train()
+        tr = MaxLikelihoodTrainer(net, 8, 64, lr=1e-3, device=dev, use_graph=mode)
+        for _ in range(4):
+            tr.step(x, t, 1e-3)
+        res.append((tr.flat.clone(), tr.epoch_means()[0]))
+    assert rel_l2(res[1][0].cpu().numpy(), res[0][0].cpu().numpy()) < 1e-5 and abs(res[1][1] - res[0][1]) <= 1e-5 * abs(res[0][1])
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DenseED(1, 3, 64, [1, 1, 1], growth_rate=8, init_features=16, drop_rate=0.1).to(dev).train()
+    tr = MixedResidualTrainer(net, 8, 64, lr=1e-3, device=dev, use_graph='segments')
+    tr.step(x, 1e-3)                                         # the first step is eager
+    with pytest.raises(NotImplementedError):
+        tr.step(x, 1e-3)
