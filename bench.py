@@ -178,23 +178,29 @@ def conv1x1_timing(dev, B, iters=200):
     eng = net._engine(x)
     L, st = _lib.lib(), _lib.stream_ptr()
     out = []
+    if not hasattr(eng, '_reduce_n'):
+        eng._plan_wgrad_scratch()
     for i, s in enumerate(net._specs):
         if s.k != 1:
             continue
         ref = ctypes.byref(eng.descs[i])
-        for _ in range(20):
-            L.pdes_conv_forward(eng.ctx, ref, 1, st)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            L.pdes_conv_forward(eng.ctx, ref, 1, st)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        us = e0.elapsed_time(e1) * 1e3 / iters
         d = eng.descs[i]
         flop = 2.0 * s.cout * s.cin * d.Hout * d.Wout * B
-        out.append({'layer': s.conv, 'gemm': f'M={s.cout} K={s.cin} N={d.Hout * d.Wout}x{B}', 'us_per_launch': round(us, 2),
-                    'achieved': round(flop / us / 1e6, 2), 'frac': round(flop / us / 1e6 / 157.3, 4)})
+        row = {'layer': s.conv, 'gemm': f'M={s.cout} K={s.cin} N={d.Hout * d.Wout}x{B}'}
+        for tag, fn in (('forward', L.pdes_conv_forward), ('data_gradient', L.pdes_conv_backward_data),
+                        ('weight_gradient', L.pdes_conv_backward_weight)):
+            for _ in range(20):
+                fn(eng.ctx, ref, 1, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn(eng.ctx, ref, 1, st)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            row[tag] = {'us_per_launch': round(us, 2), 'achieved': round(flop / us / 1e6, 2), 'frac': round(flop / us / 1e6 / 157.3, 4)}
+        row.update(row['forward'])                     # (round-2 keys: the forward kernel's figures at the top level)
+        out.append(row)
     return out
 
 
@@ -418,6 +424,41 @@ def dp1_rccl_timing(dev, data, perm, B, steps, warmup):
         torch.distributed.destroy_process_group()
 
 
+def segments_timing(dev, data, perm, B, steps=100):
+    """the same step replayed as linear hipGraphs joined by one event per network stage (use_graph='segments',
+    models/codec.py StepProgram): what the host pays when it must be cheap (0.2 ms instead of 0.5), and what that costs on
+    the GPU (coarser release of the weight gradients).  Indicative -- a second trainer's streams share hardware queues
+    with the first one's; the per-process A/B is profiles/r03_e_launch_modes_ab.log."""
+    import contextlib
+    import io
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
+    tr = MixedResidualTrainer(model, B, 64, lr=1e-3, weight_bound=10.0, device=dev, use_graph='segments')
+    n = data.shape[0]
+
+    def load(i):
+        lo = (i * B) % (n - B + 1)
+        tr.load_batch(data, perm[lo:lo + B])
+    for i in range(20):
+        load(i)
+        tr.step(None, 1e-3)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        load(i)
+        tr.step(None, 1e-3)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    h = host_enqueue_timing(tr, load, 50)
+    pr = tr._program
+    return {'ms_per_step': round(dt * 1e3, 4), 'host_enqueue_ms_per_step': h['host_enqueue_ms_per_step'],
+            'graphs': len(pr.graphs), 'kernel_nodes': int(sum(pr.nodes)), 'operations_per_step': pr.n_ops,
+            'segments': [list(s_) for s_ in pr.segments]}
+
+
 def allreduce_timing(trainer, iters=50):
     """stand-alone cost of the gradient exchange (both buckets back to back, nothing to overlap with): what the step
     would pay for the all-reduce if it were NOT hidden under the backward pass"""
@@ -547,6 +588,12 @@ def main():
         except Exception as e:                                # the headline line must still be printed
             dp1 = {'dp1_rccl_ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
 
+    seg = None
+    if world == 1 and not args.no_extras and not args.graph and not args.segments:
+        try:
+            seg = segments_timing(dev, data, perm, B)
+        except Exception as e:
+            seg = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
     if rank == 0:
         traffic, traffic_src = None, None
         import glob
@@ -568,7 +615,9 @@ def main():
                                    'growth 16 init 48 (740,091 params), fp32, Adam + one-cycle LR'
                                    % ('configs[1]' if world == 1 else 'configs[2] (global batch %d = %d x %d, weak-scaled '
                                       'points of its 8-GPU run)' % (GB, world, B), args.ntrain, B),
-                       'global_batch': GB, 'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph), 'wgrad_stream': not args.graph,
+                       'global_batch': GB, 'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph),
+                       'launch_mode': 'segments' if args.segments else ('one serial hipGraph' if args.graph else 'eager, three streams'),
+                       'wgrad_stream': not args.graph,
                        'ranks': torch.distributed.get_world_size() if world > 1 else 1,
                        'collective': None if world == 1 else {
                            'backend': 'nccl (RCCL over xGMI)', 'bytes_per_step': int(trainer.gflat.numel()) * 4,
@@ -606,8 +655,11 @@ def main():
         if dp1 is not None:
             out['dp1_rccl_ms_per_step'] = dp1['dp1_rccl_ms_per_step']
             out['dp1_rccl'] = dp1
+        if seg is not None:
+            out['segment_graphs'] = seg
         if world == 1 and not args.no_extras:
-            out['roofline_1x1'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'kernel': 'conv1x1_mfma_kernel (forward)',
+            out['roofline_1x1'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s',
+                                   'kernel': 'conv1x1_mfma_kernel (forward, data gradient), conv1x1_wgrad_kernel',
                                    'layers': conv1x1_timing(dev, B),
                                    'note': 'the 1x1 channel-halving layers, HIP-event timed stand-alone at the training '
                                            'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}

@@ -565,7 +565,7 @@ class StepProgram:
 
     def __init__(self, eng, loss_launch, tail, grad_y, seg_max=None, forward_only=False, split_w=False):
         L = _lib.lib()
-        self.eng, self._L = eng, L
+        self.eng, self._L, self.graphs = eng, L, []
         net, descs, specs = eng.net, eng.descs, eng._chain_specs()
         n = len(descs)
         if eng.mask_off:
@@ -587,7 +587,6 @@ class StepProgram:
         total, done, trigger = sum(per), 0, None
         cap = eng._side_stream()                     # idle while the program is built
         cap_ptr = ctypes.c_void_p(cap.cuda_stream)
-        self.graphs = []
 
         def capture(fn):
             torch.cuda.synchronize(eng.dev)

@@ -204,28 +204,47 @@ def test_g13_bilinear_upsampling(dev):
     loss.backward()
     assert [k for k, _ in net.named_parameters()] == [str(s) for s in g['param_names']]
     norms = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
-    # 1e-3 of the reference on every norm and on every stored tensor (round 3: ALL 54 BatchNorm gradient tensors are in the
-    # fixture besides the layers around the upsampling stages) -- except that a ReLU whose pre-activation lies within fp32
-    # rounding of zero may take the other side in this implementation: the gradient of every layer UPSTREAM of it then
-    # moves by ~1e-3 (spread over those tensors, not confined to a channel: a per-channel "flip detector" was tried in
-    # round 3 and does not hold upstream), and the bilinear resampling's backward accumulates with fp32 atomics, so WHICH
-    # unit flips changes from run to run (round 3, three runs: features.DecBlock1.denselayer3.norm1.bias at 1.02e-3 in one,
-    # features.EncBlock1.denselayer3.norm1.bias at 1.10e-3 in another, a third beyond a "two tensors / 2e-3" bound; the
-    # reference's own fp32 agrees with the fp64 oracle to 1e-6 on this input).  Hence round 2's allowance stays: all within
-    # 3e-3, at most 3 of 82 norms -- and now also at most 3 of the 60+ stored tensors -- beyond 1e-3.
+    # 1e-3 of the reference on every norm and every stored tensor (round 3: ALL 54 BatchNorm gradient tensors are in the
+    # fixture besides the layers around the upsampling stages) -- except for the consequences of ONE ReLU flip, which round 3
+    # pinned down on the GPU (tools/debug_g13.py / debug_g13b.py, profiles/r03_g_g13_flip.log; deterministic: 12 identical
+    # runs): at one pixel, channel 51 of DecBlock1's input equals its batch mean to within fp32 rounding; with the fresh
+    # BatchNorms (gamma 1, beta 0) EVERY layer of the block thresholds that channel at exactly the mean, so the unit takes the
+    # other side of all eight ReLUs at once.  Signature, as measured: (b) the eight DecBlock1 BatchNorm-BIAS gradients differ
+    # in that ONE channel by one term of its 1,024-term sum (tensor rel-L2 1.8e-3 .. 7.6e-3, <= 5.4e-4 without the channel;
+    # the weight gradients do not move: the term carries xhat = 0); (c) two tensors upstream differ by 1.0e-3 .. 1.1e-3,
+    # spread.  The reference's own fp32 agrees with the fp64 oracle to 4e-6 on every one of these tensors (no flip there).
+    # The check: a tensor beyond 1e-3 is either (b) a BatchNorm gradient whose deviation sits in <= 2 channels (< 1e-3
+    # without them, < 2e-2 with) -- and all such tensors name the SAME channels -- or (c) spread below 2e-3, at most 3 of
+    # those.  An error spread over a tensor beyond 2e-3, or concentrated in different channels per layer, fails.
     dev_n = np.abs(norms - g['grad_norms']) / g['grad_norms']
     assert dev_n.max() < 3e-3 and int((dev_n > 1e-3).sum()) <= 3, np.sort(dev_n)[-5:]
     gr = dict(net.named_parameters())
-    n_full, beyond = 0, []
+    n_full, flipped, spread, worst = 0, [], [], set()
     for k in g.files:
-        if k.startswith('grad/'):
-            n_full += 1
-            e = rel_l2(gr[k[5:]].grad.cpu().numpy(), g[k])
-            assert e < 3e-3, (k, e)
-            if e >= 1e-3:
-                beyond.append((k, float(e)))
-    print('G13 tensors beyond 1e-3:', beyond)
-    assert len(beyond) <= 3, beyond
+        if not k.startswith('grad/'):
+            continue
+        n_full += 1
+        got, want = gr[k[5:]].grad.cpu().numpy(), g[k]
+        e = rel_l2(got, want)
+        if e < 1e-3:
+            continue
+        rest = None
+        if 'norm' in k and got.ndim == 1:
+            d = np.abs(got - want)
+            top = np.argsort(-d)[:2]
+            keep = np.ones(d.shape, bool)
+            keep[top] = False
+            rest = float(np.linalg.norm((got - want)[keep]) / np.linalg.norm(want))
+        if rest is not None and rest < 1e-3 and e >= 1.5e-3:
+            assert e < 2e-2, (k, e)
+            flipped.append((k, float(e), rest))
+            worst.add(int(top[0]))
+        else:
+            assert e < 2e-3, (k, e, rest)
+            spread.append((k, float(e)))
+    print('G13 beyond 1e-3 -- one flipped unit (concentrated):', flipped, 'worst channels', sorted(worst), '; upstream (spread):', spread)
+    assert len(spread) <= 3, spread
+    assert len(worst) <= 2, (sorted(worst), flipped)                 # every concentrated deviation names the same unit(s)
     assert n_full >= 60
 
 
