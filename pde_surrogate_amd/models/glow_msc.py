@@ -797,6 +797,7 @@ class MultiScaleCondGlow(_HipNet):
 
     def _flatten(self, device):
         super()._flatten(device)
+        self._fwd_engines = {}                          # the y -> z engines hold pointers into the OLD flat buffer / images
         for m in self.modules():                       # p, sign_s, masks: the kernels read them through device pointers
             for name, buf in m._buffers.items():
                 if buf is not None and buf.device != device:
@@ -870,10 +871,21 @@ class MultiScaleCondGlow(_HipNet):
         elif n_samples != eps_list[-1].shape[0] or x.shape[0] != eps_list[-1].shape[1]:
             raise AssertionError('eps_list: (n_samples, B, ...) tensors')
         ys = []
+        # the reference runs the conditioning encoder ONCE for all samples (glow_msc.py:860-862); here every sample is a
+        # full generate(), so in train() mode only the first one may move the BatchNorm running statistics
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)] if (self.training and n_samples > 1) else []
+        snap = None
         with torch.no_grad():
             for i in range(n_samples):
                 el = [e[i] * temperature for e in eps_list[:-1]] + [eps_list[-1][i]]
                 ys.append(self.generate(x, el)[0])
+                if i == 0 and bns:
+                    snap = [(m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for m in bns]
+            if snap is not None:
+                for m, (rm, rv, nb) in zip(bns, snap):
+                    m.running_mean.copy_(rm)
+                    m.running_var.copy_(rv)
+                    m.num_batches_tracked.copy_(nb)
         return torch.stack(ys, 0)
 
     def predict(self, x_test, n_samples=20, temperature=1.0):

@@ -74,12 +74,13 @@ def _grid(ax, field, plot_fn, cmap, **kw):
 
 def plot_prediction_bayes2(save_dir, target, pred_mean, pred_var, epoch, index, plot_fn='imshow', cmap='jet',
                            same_scale=False):
-    """4 rows (simulation, predictive mean, error of the mean, predictive variance) x n_fields columns"""
+    """the reference's figure (utils/plot.py:181-258 there): 4 rows -- Simulation, Pred Mean, Pred Std (the SQUARE ROOT of
+    the predictive variance), Sim - Pred Mean -- x n_fields columns; the first two rows of a column share a colour scale"""
     plt = _plt()
-    target, pred_mean, pred_var = to_numpy(target), to_numpy(pred_mean), to_numpy(pred_var)
+    target, pred_mean, pred_std = to_numpy(target), to_numpy(pred_mean), np.sqrt(to_numpy(pred_var))
     nf = target.shape[0]
-    rows = ['Simulation', 'Predictive Mean', r'Simulation $-$ Mean', 'Predictive Variance']
-    fields = np.concatenate((target, pred_mean, target - pred_mean, pred_var), axis=0)
+    rows = ['Simulation', 'Pred Mean', 'Pred Std', r'Sim $-$ Pred Mean']
+    fields = np.concatenate((target, pred_mean, pred_std, target - pred_mean), axis=0)
     fig, axes = plt.subplots(4, nf, figsize=(3.75 * nf, 12))
     for j, ax in enumerate(np.atleast_1d(axes).ravel()):
         kw = {}

@@ -445,3 +445,35 @@ def test_clamped_log_stddev_values_and_gradients(dev):
     # the clamped channels of the split prior's bias receive exactly no gradient
     gb = params['flow.revblock2.split.latent_encoder.conv2d.conv.bias'].grad
     assert float(gb[6:12].abs().max()) == 0.0 and float(sd['flow.revblock2.split.latent_encoder.conv2d.conv.bias'].grad[6:12].abs().max()) == 0.0
+
+
+def test_other_field_size_against_the_cpu_oracle(dev):
+    """--imsize 48 (levels of 48 / 24 / 12 pixels: none of them one of the specialised map sizes; the loss through the
+    any-size kernel of csrc/darcy_loss_generic.hip) against oracle/glow.py on the CPU, batch 4"""
+    from oracle import glow as oglow
+    from pde_surrogate_amd.models.glow_msc import MultiScaleCondGlow
+    torch.manual_seed(31)
+    np.random.seed(31)
+    net = MultiScaleCondGlow(48, 1, 3, [2, 2, 2], [2, 2, 2], LUdecompose=True)
+    perturb_glow(net, torch.Generator().manual_seed(32), 0.7)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(33)
+    x = torch.exp(0.5 * torch.randn(4, 1, 48, 48, generator=gen))
+    eps = [torch.randn((4,) + s, generator=gen) for s in net._z_shapes()]
+    assert [tuple(e.shape[1:]) for e in eps] == oglow.latent_shapes(sd, 3, 48)
+    keys = oglow.param_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    loss_o, _, _, y_o = oglow.reverse_kl_loss(sd, x, eps, 150.0, 50.0, True)
+    loss_o.backward()
+    net = net.to(dev).train()
+    loss, _, _, y, logp = reverse_kl(net, x.to(dev), [e.to(dev) for e in eps], 150.0, 50.0)
+    loss.backward()
+    assert tuple(y.shape) == (4, 3, 48, 48)
+    assert rel_l2(y.detach().cpu().numpy(), y_o.detach().numpy()) < 2e-5
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 5e-5 * abs(float(loss_o.detach()))
+    gmax = max(float(sd[k].grad.norm()) for k in keys)
+    dev_rel = sorted(((float((p.grad.cpu() - sd[k].grad).norm()) / (float(sd[k].grad.norm()) + 1e-6 * gmax), k)
+                      for k, p in net.named_parameters() if not k.endswith('in_conv.bias')), reverse=True)
+    assert float(np.median([d for d, _ in dev_rel])) < 1e-4, dev_rel[:5]
+    assert dev_rel[0][0] < 3e-2 and sum(d > 2e-3 for d, _ in dev_rel) <= 8, dev_rel[:10]
