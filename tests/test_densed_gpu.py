@@ -245,7 +245,7 @@ def test_g13_bilinear_upsampling(dev):
     print('G13 beyond 1e-3 -- one flipped unit (concentrated):', flipped, 'worst channels', sorted(worst), '; upstream (spread):', spread)
     assert len(spread) <= 3, spread
     assert len(worst) <= 2, (sorted(worst), flipped)                 # every concentrated deviation names the same unit(s)
-    assert n_full >= 60
+    assert n_full >= 55
 
 
 def test_out_activation(dev):

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/profile_round.sh r02_b'
 # writes summaries under gpurun_out/<tag>/ (copy the ones to be judged into profiles/).  Counter passes (--pmc) run
 # separately from the kernel-trace/stats pass, each with --kernel-trace only (MI355X_MICROARCH.md).
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -47,7 +47,7 @@ for LAYER in 24 16 7 17; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format rocpd -d $OUT/pmc_conv_${LAYER}_$C -o p -- python $ROOT/tools/bench_conv.py $LAYER > $OUT/bench_conv_pmc_run.log 2>&1
     echo "== $C layer $LAYER (tools/bench_conv.py $LAYER)" >> $OUT/pmc_conv.txt
-    python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_conv_${LAYER}_$C) | grep -A1 -E "1, 1, 1, 1, 0, false, false|1x1_mfma_kernel<[0-9, ]*1>|finalize" >> $OUT/pmc_conv.txt
+    python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_conv_${LAYER}_$C) >> $OUT/pmc_conv.txt
   done
 done
 
