@@ -72,7 +72,12 @@ if os.path.exists(cp):
         c, layer = m.group(1), int(m.group(2))
         # the kernel of the layer under test = the one with the most dispatches (bench_conv.py repeats it; every other
         # kernel ran once in the warm-up pass); median per dispatch
-        cand = [(cs[c][2], k, cs[c][1]) for k, cs in ks.items() if 'finalize' not in k and c in cs]
+        # (bench_conv.py also runs the layer's forward and weight-gradient kernels as often: keep the data-gradient ones --
+        #  conv_mfma_kernel<KS, TWG, MT, S, WK, NTW, MODE = 1, ...> / conv1x1_mfma_kernel<..., MODE = 1>)
+        isdg = lambda k: re.search(r'conv_mfma_kernel<\d+, \d+, \d+, \d+, \d+, \d+, 1,', k) or re.search(r'conv1x1_mfma_kernel<[\d, ]*, 1>', k)
+        cand = [(cs[c][2], k, cs[c][1]) for k, cs in ks.items() if isdg(k) and c in cs]
+        if not cand:
+            continue
         n, k, med = max(cand)
         per.setdefault(layer, {})[c] = med
         per[layer]['kernel'] = k[:90]
