@@ -65,15 +65,16 @@ class DeviceLoader:
     """Device-resident replacement for DataLoader(shuffle=True, drop_last=True): the whole dataset
     lives in HBM (4096 x 16 KiB = 64 MiB), a minibatch is one index_select.  With world_size > 1 every
     rank holds the replica and takes its contiguous slice of each global batch from a permutation
-    that is identical on all ranks (same generator seed)."""
+    that is identical on all ranks (same generator seed).  Like the reference's loader (utils/load.py:34-35 there:
+    drop_last=True) samples beyond the last full global batch of an epoch's permutation are dropped."""
 
     def __init__(self, *tensors, batch_size, device, shuffle=True, seed=0, rank=0, world_size=1):
         self.tensors = [t.to(device) for t in tensors]
         self.n = self.tensors[0].shape[0]
         self.batch_size, self.rank, self.world = batch_size, rank, world_size
         self.global_batch = batch_size * world_size
-        if self.n % self.global_batch:
-            raise ValueError(f'{self.n} samples are not a multiple of the global batch {self.global_batch}')
+        if self.n < self.global_batch:
+            raise ValueError(f'{self.n} samples are fewer than one global batch of {self.global_batch}')
         self.shuffle = shuffle
         self.gen = torch.Generator(device='cpu').manual_seed(seed)
         self.device = device

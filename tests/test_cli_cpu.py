@@ -153,7 +153,7 @@ def test_cglow_parser_contract(tmp_path):
                               'batch32_lr0.0015_epochs400')
     b = cli.Parser().parse(['--exp-dir', str(tmp_path), '--enc-blocks', '211', '--flow-blocks', '221', '--no-LU-decompose'])
     assert b.enc_blocks == [2, 1, 1] and b.flow_blocks == [2, 2, 1] and not b.LU_decompose
-    for bad in (['--imsize', '50'], ['--enc-blocks', '34'], ['--ntrain', '100'], ['--imsize', '16', '--enc-blocks', '33333',
+    for bad in (['--imsize', '50'], ['--enc-blocks', '34'], ['--ntrain', '20'], ['--imsize', '16', '--enc-blocks', '33333',
                                                                                   '--flow-blocks', '33333']):
         with pytest.raises(SystemExit):
             cli.Parser().parse(['--exp-dir', str(tmp_path)] + bad)

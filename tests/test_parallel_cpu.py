@@ -138,3 +138,20 @@ def _worker_mean(rank, world, port, out):
     assert float(bn.running_mean[0]) == 1.0
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_device_loader_drops_the_last_partial_batch_like_the_reference():
+    """utils/load.py:34-35 of the reference: DataLoader(shuffle=True, drop_last=True) -- 22 samples at batch 4 are 5
+    batches per epoch; under two ranks (global batch 8) 2 steps, and the ranks' slices never overlap"""
+    from pde_surrogate_amd.utils.load import DeviceLoader
+    x = torch.arange(22, dtype=torch.float32).reshape(22, 1)
+    dl = DeviceLoader(x, batch_size=4, device='cpu', seed=0)
+    batches = [b[0].reshape(-1) for b in dl]
+    assert len(dl) == 5 and len(batches) == 5 and len(set(torch.cat(batches).tolist())) == 20
+    a = DeviceLoader(x, batch_size=4, device='cpu', seed=1, rank=0, world_size=2)
+    b = DeviceLoader(x, batch_size=4, device='cpu', seed=1, rank=1, world_size=2)
+    assert len(a) == len(b) == 2
+    for (ba,), (bb,) in zip(a, b):
+        assert not set(ba.reshape(-1).tolist()) & set(bb.reshape(-1).tolist())
+    with pytest.raises(ValueError):
+        DeviceLoader(x[:3], batch_size=4, device='cpu')

@@ -70,10 +70,11 @@ def validate_args(args, world):
         raise SystemExit(f'--imsize {args.imsize} cannot be squeezed {levels - 1} times')
     if args.x_channels != 1 or args.y_channels != 3:
         raise SystemExit('the Darcy loss is defined for 1 input field and the 3 output fields (pressure, two fluxes)')
-    if args.ntrain % (args.batch_size * world):
-        raise SystemExit(f'--ntrain {args.ntrain} is not a multiple of the global batch {args.batch_size} x {world} ranks')
-    if args.ntest % args.test_batch_size:
-        raise SystemExit(f'--ntest {args.ntest} is not a multiple of --test-batch-size {args.test_batch_size}')
+    # (no multiple-of-the-batch requirement: the reference's loaders drop the last partial batch, utils/load.py:34-35)
+    if args.ntrain < args.batch_size * world:
+        raise SystemExit(f'--ntrain {args.ntrain} is less than one global batch of {args.batch_size} x {world} ranks')
+    if args.ntest < args.test_batch_size:
+        raise SystemExit(f'--ntest {args.ntest} is less than --test-batch-size {args.test_batch_size}')
 
 
 class Parser(argparse.ArgumentParser):
