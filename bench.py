@@ -621,6 +621,8 @@ def main():
                        'ranks': torch.distributed.get_world_size() if world > 1 else 1,
                        'collective': None if world == 1 else {
                            'backend': 'nccl (RCCL over xGMI)', 'bytes_per_step': int(trainer.gflat.numel()) * 4,
+                           'exchange': 'ncclAllReduce by pointer on the weight-gradient / main stream (parallel.DirectRccl)'
+                                       if trainer._rccl is not None else 'torch.distributed.all_reduce',
                            'buckets': 2 if trainer.overlap_allreduce and not args.graph else 1,
                            'overlapped_with_backward': bool(trainer.overlap_allreduce and not args.graph),
                            'allreduce_us_standalone': round(ar_us, 1),

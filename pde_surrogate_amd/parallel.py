@@ -72,6 +72,35 @@ class DirectRccl:
             self._comm = None
 
 
+def make_direct_rccl(group, device):
+    """a DirectRccl over `group` for the per-step gradient exchange, or None (-> torch.distributed.all_reduce): when the
+    backend is not nccl, when PDES_DP_DIRECT=0, or when ANY rank failed to build or probe its communicator -- the ranks
+    agree on the outcome over torch.distributed, so that all of them take the same path"""
+    if os.environ.get('PDES_DP_DIRECT', '1') == '0' or dist.get_backend(group) != 'nccl':
+        return None
+    device = torch.device(device)
+    comm, err = None, None
+    try:
+        with torch.cuda.device(device):
+            comm = DirectRccl(group, device)
+            probe = torch.ones(4, device=device)      # one small all-reduce: every rank must read back the number of ranks
+            comm.all_reduce_sum_(probe.data_ptr(), 4, torch.cuda.current_stream(device).cuda_stream)
+            if float(probe[0].item()) != float(comm.world):
+                raise RuntimeError(f'probe all-reduce returned {float(probe[0].item())}, expected {comm.world}')
+    except Exception as e:                           # noqa: BLE001  (any failure means: use the torch path, on every rank)
+        err = e
+    ok = torch.tensor([0.0 if err is not None else 1.0], device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if float(ok.item()) == 1.0:
+        return comm
+    if comm is not None and err is None:
+        comm.close()
+    import warnings
+    warnings.warn('direct RCCL communicator unavailable (' + (f'{type(err).__name__}: {err}' if err else 'on another rank')
+                  + '); the gradient exchange goes through torch.distributed.all_reduce')
+    return None
+
+
 def init_from_env(backend=None):
     """torchrun-style rendezvous: returns (rank, local_rank, world_size); world 1 = no process group"""
     world = int(os.environ.get('WORLD_SIZE', '1'))

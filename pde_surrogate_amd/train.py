@@ -158,24 +158,7 @@ class MixedResidualTrainer:
             # 5.05 ms per step on one rank (1.75 without the exchange): rejected.  torch.distributed's all_reduce (the only
             # choice over gloo, and the fallback when the direct communicator cannot be made; PDES_DP_DIRECT=0 selects
             # it) costs the host ~0.3 ms per call.
-            if os.environ.get('PDES_DP_DIRECT', '1') != '0' and torch.distributed.get_backend(process_group) == 'nccl':
-                try:
-                    with _lib.device_guard(self.dev):
-                        self._rccl = parallel.DirectRccl(process_group, self.dev)
-                except Exception as e:
-                    import warnings
-                    warnings.warn(f'direct RCCL communicator unavailable ({type(e).__name__}: {e}); the gradient exchange '
-                                  'goes through torch.distributed.all_reduce')
-                    self._rccl = None
-            # what the early bucket relies on (checked once, here): the convolution weights sit in LAYER ORDER at the
-            # tail of the flat buffer, so "layers >= first_layer" is exactly the slice gflat[_conv_off[first_layer]:]
-            off, end = model._conv_off, self.gflat.numel()
-            convs = [i for i, sp in enumerate(model._specs) if sp.conv is not None]
-            sizes = [sp.cout * sp.cin * sp.k * sp.k for sp in model._specs if sp.conv is not None]
-            if any(off[a] + n != off[b] for a, b, n in zip(convs, convs[1:], sizes)) or off[convs[-1]] + sizes[-1] != end \
-                    or any(off[i] > off[i + 1] for i in range(len(off) - 1)):
-                raise RuntimeError('flat gradient layout: convolution weights are not contiguous in layer order at the tail '
-                                   '(the early all-reduce bucket would cover the wrong slice)')
+            self._rccl = parallel.make_direct_rccl(process_group, self.dev)
 
     def _on_bucket(self, _user, first_layer, stream):
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
@@ -441,8 +424,10 @@ class ReverseKLTrainer:
         self.x_static = self.eng.X['in']
         self.x_static.zero_()
         self.flat, self.gflat = model._flat, model._gscratch
+        self._rccl = None
         if self.dp:
             parallel.broadcast_parameters(self.flat, process_group)
+            self._rccl = parallel.make_direct_rccl(process_group, self.dev)      # ncclAllReduce by pointer (or None: torch's)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self._hyper_args = (ctypes.c_float * 8)()
@@ -492,7 +477,9 @@ class ReverseKLTrainer:
             self.gflat.zero_()
             m._grad_dirty = False
         eng.backward(self.grad_y, eng.glogp)
-        if self.dp:
+        if self._rccl is not None:
+            self._rccl.all_reduce_sum_(self.gflat.data_ptr(), self.gflat.numel(), st)
+        elif self.dp:
             torch.distributed.all_reduce(self.gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         self.step_count += 1
         b1, b2 = self.betas
