@@ -149,17 +149,18 @@ def _run_kernel(rig, what, x, w, g):
     return gw.cpu().numpy().copy()
 
 
+# the f32 K-tail path exists in the forward / data-gradient kernels of the 196- and 98-channel layers only (196 = 6 x 32 + 4,
+# 98 = 3 x 32 + 2; the weight gradients contract over pixels, and the 100 -> 100 data gradient has K = 100 output channels...)
+CASES = [(k, '1') for k in KERNELS] + [(k, '0') for k, (layer, what, _) in KERNELS.items() if what != 'wgrad' and layer != 'up16']
+
+
 @pytest.mark.parametrize('kind', ['wide', 'sparse', 'boundary', 'cancel'])
-@pytest.mark.parametrize('kernel', list(KERNELS))
-@pytest.mark.parametrize('tail', ['1', '0'])
+@pytest.mark.parametrize('kernel,tail', CASES)
 def test_bf16x3_kernels_are_fp32_equivalent(option, kernel, kind, tail):
     """all six kernels of the bf16 x3 family (eight layer / pass combinations) x four adversarial input families x the
     f32 K-tail path on and off: error against fp64 within 2x of the exact-f32 pipe's on the same data, and at most 4
     fp32 rounding units of sum |w| |x| componentwise"""
     layer, what, bit = KERNELS[kernel]
-    if tail == '0' and (what == 'wgrad' or layer == 'up16'):
-        pytest.skip('no K tail in this kernel (the weight gradients contract over pixels; 100 = 3 x 32 + 4 goes through '
-                    'PDES_B3_TAIL only in the forward / data-gradient kernels of the 98- and 196-channel layers)')
     conv_name, cin, cout, hw, up = LAYERS[layer]
     ho = 2 * hw if up else hw
     rng = np.random.default_rng({'wide': 1, 'sparse': 2, 'boundary': 3, 'cancel': 4}[kind] + 10 * list(KERNELS).index(kernel))

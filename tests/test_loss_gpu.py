@@ -140,8 +140,7 @@ def test_fused_loss_vs_oracle(dev, n, B, nl):
     np.testing.assert_allclose(terms.cpu().numpy(), terms2.cpu().numpy(), rtol=1e-6)
 
 
-@pytest.mark.parametrize('n', [20, 48, 65, 128])
-@pytest.mark.parametrize('correct', [True, False])
+@pytest.mark.parametrize('n,correct', [(20, True), (20, False), (48, True), (48, False), (65, True), (65, False), (128, True)])
 def test_g21_any_field_size_fixture(dev, n, correct):
     """field sizes other than 16 / 32 / 64 and SobelFilter(correct=False) through the drop-in loss functions, against
     the REAL reference (G21: image_gradient.py:26-92 for any imsize, darcy.py:162-233)"""
@@ -149,8 +148,6 @@ def test_g21_any_field_size_fixture(dev, n, correct):
     from pde_surrogate_amd.utils.image_gradient import SobelFilter
     g = golden('G21_any_size.npz')
     sfx = '' if correct else '_nocorrect'
-    if f'terms{n}{sfx}' not in g:
-        pytest.skip('not recorded')
     sob = SobelFilter(n, correct=correct, device=dev)
     img = torch.from_numpy(g[f'img{n}']).to(dev)
     np.testing.assert_allclose(sob.grad_h(img).cpu().numpy(), g[f'gh{n}{sfx}'], rtol=1e-5, atol=1e-4)
@@ -205,18 +202,19 @@ def test_g21_variants_at_65(dev):
             assert rel_l2(img.grad.cpu().numpy(), g[f'adj65_f{fs}{sfx}']) < 1e-5, (correct, fs)
 
 
-@pytest.mark.parametrize('n,B', [(2, 3), (3, 2), (5, 4), (33, 3), (64, 2), (96, 2), (130, 2), (300, 1), (20, 300)])
-@pytest.mark.parametrize('flags', [0, 4, 3])
+# (64 with correct=True is the specialised kernel, tested above; use_tb=False on a 2-row field is a mean over ZERO rows:
+#  nan in the reference too, darcy.py:224)
+GENERIC_CASES = [(n, B, f) for n, B in [(2, 3), (3, 2), (5, 4), (33, 3), (64, 2), (96, 2), (130, 2), (300, 1), (20, 300)]
+                 for f in (0, 4, 3) if not (n == 64 and f == 0) and not (n == 2 and f & 2)]
+
+
+@pytest.mark.parametrize('n,B,flags', GENERIC_CASES)
 def test_generic_kernel_vs_oracle(dev, n, B, flags):
     """the tiled any-size kernel (csrc/darcy_loss_generic.hip) against the fp64 oracle: smallest fields, one tile,
     several row tiles (n = 96, 130), column tiles too (n = 300), a grid of 300 images; correct=False (flag 4) and
     nonlinear + use_tb=False (flags 3) also route n = 64 to it"""
     from oracle import darcy as od
     from pde_surrogate_amd.models import darcy
-    if n == 64 and flags == 0:
-        pytest.skip('64 with correct=True is the specialised kernel (tested above)')
-    if n == 2 and flags & 2:
-        pytest.skip('use_tb=False on a 2-row field: a mean over ZERO rows (nan in the reference too, darcy.py:224)')
     K, y, Kd, yd = _fields(B, n, 1000 + n + flags, dev)
     w = (0.7, 1.3, 9.0, 11.0)
     nl, tb, correct = bool(flags & 1), not (flags & 2), not (flags & 4)
