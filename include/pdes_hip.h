@@ -78,7 +78,9 @@ int pdes_stat_replicas(void);
  *   K        (B,1,H,W)  permeability ("input")
  *   y        (B,3,H,W)  network output: u, sigma1, sigma2
  *   grad_y   (B,3,H,W)  OUT, d(total)/dy; NULL = forward only (eval)
- *   partials (B,4)      OUT workspace: per-image sums {sum r1^2+r2^2, sum c^2, dirichlet, neumann}
+ *   partials (rows,4)   OUT workspace: partial sums {sum r1^2+r2^2, sum c^2, dirichlet, neumann}; rows =
+ *                       pdes_darcy_loss_partial_rows(B, H, W, flags): one per image for the specialised kernel, one per
+ *                       (image, tile) for the tiled kernel (reduced in a fixed order: deterministic)
  *   loss_out (5)        OUT {total, L_const, L_cont, L_dir, L_neu}; NULL = skip the final reduce
  *   total = w_const*L_const + w_cont*L_cont + w_dir*L_dir + w_neu*L_neu
  *           (the reference's loss is w = (1, 1, weight_bound, weight_bound))
@@ -98,6 +100,8 @@ int pdes_stat_replicas(void);
 int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
                     int B, int H, int W, float w_const, float w_cont, float w_dir, float w_neu,
                     int flags, float beta1, float beta2, void* stream);
+/* rows of `partials` the call above writes for these arguments (> 0), or PDES_ENOSUP */
+int pdes_darcy_loss_partial_rows(int B, int H, int W, int flags);
 
 /* Stand-alone Sobel gradients of `nimg` single-channel images (either output may be NULL); correct = the
  * SobelFilter's flag.  Any square H == W >= 2.
@@ -461,7 +465,8 @@ int pdes_adam_step_host2(float* param, float* grad, float* exp_avg, float* exp_a
  * per-image loss partials of pdes_darcy_loss (called with loss_out = NULL) into terms[5] = {total,
  * const, cont, dirichlet, neumann} (nullable) and terms_accum[5] += terms (fp64, nullable): the
  * per-epoch loss sums of train_codec_mixed_residual.py:240 without a host sync or extra launches.
- * The weights are those given to pdes_darcy_loss. */
+ * The weights are those given to pdes_darcy_loss; `partials` holds pdes_darcy_loss_partial_rows(B, H, W, flags) rows of a
+ * launch whose flags had neither PDES_LOSS_NO_TB nor PDES_LOSS_UNCORRECTED. */
 int pdes_step_tail(const pdes_bn_item* items, int n, int max_c, float momentum, int update_running,
                    const float* partials, int B, int H, int W, float w_const, float w_cont, float w_dir,
                    float w_neu, float* terms, double* terms_accum, int nrep, long long rep_stride,

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -21,6 +21,7 @@ SIGNATURES = {
     'pdes_context_load_env': [_c_p],
     'pdes_context_device': [_c_p],
     'pdes_darcy_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_p],
+    'pdes_darcy_loss_partial_rows': [_c_i, _c_i, _c_i, _c_i],
     'pdes_sobel_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
     'pdes_sobel_grad_adjoint': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
     'pdes_sobel5_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
@@ -148,6 +149,14 @@ def destroy_contexts():
     for h in _contexts.values():
         lib().pdes_context_destroy(h)
     _contexts.clear()
+
+
+def loss_partial_rows(B, H, W, flags=0):
+    """rows of the `partials` workspace of pdes_darcy_loss for these arguments"""
+    rows = lib().pdes_darcy_loss_partial_rows(B, H, W, flags)
+    if rows <= 0:
+        check(rows if rows < 0 else -2, 'pdes_darcy_loss_partial_rows')
+    return rows
 
 
 def check(rc, what):

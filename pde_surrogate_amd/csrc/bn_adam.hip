@@ -342,7 +342,9 @@ extern "C" int pdes_step_tail(const pdes_bn_item* items, int n, int max_c, float
   if (!items || n <= 0 || max_c <= 0 || nrep != PDES_NREP) return PDES_EINVAL;
   if (partials && (B <= 0 || H <= 0 || W <= 0 || !aligned16(partials))) return PDES_EINVAL;
   LossTail lt;
-  lt.partials = partials; lt.terms = terms; lt.accum = terms_accum; lt.B = B;
+  lt.partials = partials; lt.terms = terms; lt.accum = terms_accum;
+  lt.B = partials ? pdes_darcy_loss_partial_rows(B, H, W, 0) : 0;       // rows of the loss launch (flags without NO_TB / UNCORRECTED)
+  if (partials && lt.B <= 0) return PDES_ENOSUP;
   lt.inv_n = partials ? 1.0 / ((double)B * H * W) : 0.0;
   lt.inv_dir = partials ? 1.0 / ((double)B * H) : 0.0;
   lt.inv_neu = partials ? 1.0 / (2.0 * B * W) : 0.0;

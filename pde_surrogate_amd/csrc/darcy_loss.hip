@@ -35,6 +35,7 @@ namespace pdes {
 // darcy_loss_generic.hip: any square n >= 2, SobelFilter(correct=False), filter_size = 5
 int launch_loss_generic(const float* K, const float* y, float* gy, float* partials, int B, int n, LossParams p,
                         int flags, hipStream_t st);
+int loss_generic_tiles(int n);
 int launch_sobel_generic(const float* img, float* gh, float* gv, int nimg, int n, int correct, int five, hipStream_t st);
 int launch_sobel_adjoint_generic(const float* ghb, const float* gvb, float* out, int nimg, int n, int correct, int five,
                                  hipStream_t st);
@@ -461,6 +462,16 @@ static int launch_loss(const float* K, const float* y, float* gy, float* partial
 using namespace pdes;
 
 static bool fast_size(int H) { return H == 16 || H == 32 || H == 64; }
+static bool loss_fast(int H, int flags) {
+  return fast_size(H) && !(flags & PDES_LOSS_UNCORRECTED) && !((flags & PDES_LOSS_NONLINEAR) && (flags & PDES_LOSS_NO_TB));
+}
+
+extern "C" int pdes_darcy_loss_partial_rows(int B, int H, int W, int flags) {
+  if (B <= 0 || H != W || H < 2) return PDES_ENOSUP;
+  if (loss_fast(H, flags)) return B;
+  const int t = loss_generic_tiles(H);
+  return t > 0 ? B * t : PDES_ENOSUP;
+}
 
 extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
                                float* loss_out, int B, int H, int W, float w_const, float w_cont,
@@ -470,7 +481,9 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
   const int nonlinear = flags & PDES_LOSS_NONLINEAR, no_tb = (flags & PDES_LOSS_NO_TB) ? 1 : 0;
   if (H != W || H < 2) return PDES_ENOSUP;       // SobelFilter has ONE imsize x imsize modifier: square fields (image_gradient.py:43-46)
   // the specialised kernel: 16 / 32 / 64, correct=True, not (nonlinear and no top/bottom rows); everything else: generic
-  const bool fast = fast_size(H) && !(flags & PDES_LOSS_UNCORRECTED) && !(nonlinear && no_tb);
+  const bool fast = loss_fast(H, flags);
+  const int rows = pdes_darcy_loss_partial_rows(B, H, W, flags);
+  if (rows <= 0) return PDES_ENOSUP;
   if (!aligned16(partials)) return PDES_EALIGN;
   if (fast && (!aligned16(K) || !aligned16(y) || (grad_y && !aligned16(grad_y)))) return PDES_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -496,7 +509,7 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
   else launch_loss<16>(K, y, grad_y, partials, B, p, nonlinear, no_tb, st);
   PDES_LAUNCH_CHECK();
   if (loss_out) {
-    hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partials, B, loss_out, 1.0 / ntot, 1.0 / ncont,
+    hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partials, rows, loss_out, 1.0 / ntot, 1.0 / ncont,
                        1.0 / ((double)B * H), 1.0 / (2.0 * B * W), w_const, w_cont, w_dir, w_neu);
     PDES_LAUNCH_CHECK();
   }
@@ -561,4 +574,4 @@ extern "C" int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar
   return PDES_OK;
 }
 
-extern "C" int pdes_abi_version(void) { return 17; }
+extern "C" int pdes_abi_version(void) { return 18; }

@@ -5,13 +5,14 @@
 // Reference: utils/image_gradient.py:24-92 (SobelFilter(imsize) for any imsize, correct=True/False, filter_size 3/5),
 // models/darcy.py:162-233 (its docstrings use 65 x 65 fields), train_codec_mixed_residual.py:52 (--imsize).
 //
-// Fused loss: ONE workgroup (1024 threads) per image walks the image in tiles; per tile the three fields (own region
-// +-3), the three adjoint sources (own region +-2) and the direct part of dL/dy (own region) live in 128 KiB of LDS, so
-// every field value is read from HBM once per tile that touches it (the +-3 halo of neighbouring tiles of the same
-// image comes out of L2), the gradient is written once, and the per-image loss sums stay in the workgroup: partials
-// keep the (B, 4) contract of the specialised kernel and its fixed-order reductions.  Accesses are scalar (rows of an
-// odd width are not 16-byte aligned) but coalesced along the row.  HBM-bound like the specialised kernel; the
-// per-pixel arithmetic is shared with the CPU emulation the tests check against the oracle (darcy_generic.h).
+// Fused loss: one workgroup (256 threads) per TILE of an image (rows -- for wide images also columns -- split so that a tile's planes fit 40 KiB of LDS:
+// the three fields on the own region +-3, the three adjoint sources +-2, the direct part of dL/dy); every field value is
+// read from HBM once per tile that touches it (the halo of neighbouring tiles comes out of L2 / Infinity Cache), the
+// gradient is written once.  Away from the image border a thread handles a 1 x 4 strip with 16-byte LDS accesses and
+// branch-free stencils (the adjoints there are minus the forward operators); the two outermost rows / columns take the
+// per-pixel path that follows the reference's order of operations.  Per-(image, tile) partial sums, reduced in a fixed
+// order (pdes_darcy_loss_partial_rows tells the caller how many rows).  The whole tile procedure is ONE function shared
+// with the CPU emulation the tests check against the oracle (darcy_generic.h: process_tile).
 //
 // Stand-alone Sobel / adjoint kernels (3x3 and 5x5): one thread per pixel straight from global memory (the 9..50
 // taps of a pixel hit L1/L2); these are the autograd-facing SobelFilter.grad_h / grad_v of fields the fused loss does
@@ -23,74 +24,34 @@ namespace pdes {
 
 using namespace gen;
 
-constexpr int GEN_NT = 1024;
-constexpr int GEN_LDSF = 32768;          // floats of tile planes (128 KiB)
+// 256 threads and 40 KiB of tile planes per workgroup: four workgroups per CU, whose load / stencil / store phases
+// overlap (one 1024-thread workgroup with 128 KiB per CU ran its phases back to back: 0.10 of 8 TB/s)
+constexpr int GEN_NT = 256;
+constexpr int GEN_LDSF = 10240;
 
+struct BlockExec {
+  int tid, nthreads;
+  __device__ __forceinline__ void barrier() const { __syncthreads(); }
+};
+
+// grid = (tiles of an image, images); partials: one row {const, cont, dir, neu} per (image, tile), reduced in a fixed
+// order by darcy_loss_finalize / the end-of-step launch (deterministic)
 template <bool BWD>
 __global__ __launch_bounds__(GEN_NT) void darcy_loss_generic_kernel(const float* __restrict__ Kp,
                                                                     const float* __restrict__ yp,
                                                                     float* __restrict__ gyp,
                                                                     float* __restrict__ partials, LossParams p, int n,
-                                                                    int tr, int tc, int flags) {
-  __shared__ float lds[GEN_LDSF];
+                                                                    int tr, int tc, int ntc, int flags) {
+  __shared__ __attribute__((aligned(16))) float lds[GEN_LDSF];
   __shared__ float red[(GEN_NT / 64) * 4];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const size_t nn = (size_t)n * n;
-  const float* Kb = Kp + (size_t)b * nn;
-  const float* yb = yp + (size_t)b * 3 * nn;
-  float* gb = BWD ? gyp + (size_t)b * 3 * nn : nullptr;
-  const bool correct = !(flags & kUncorrected);
-  const int ntr = cdiv(n, tr), ntc = cdiv(n, tc);
-  float s_const = 0.f, s_cont = 0.f, s_dir = 0.f, s_neu = 0.f;
-
-  for (int ti = 0; ti < ntr; ++ti)
-    for (int tj = 0; tj < ntc; ++tj) {
-      const TileGeo g = tile_geo(n, tr, tc, ti, tj);
-      const int ih = g.ir1 - g.ir0, iw = g.ic1 - g.ic0, sh = g.sr1 - g.sr0, sw = g.sc1 - g.sc0;
-      const int oh = g.r1 - g.r0, ow = g.c1 - g.c0;
-      const int ni = ih * iw, ns = sh * sw, no = oh * ow;
-      float* F = lds;                  // fields u, sigma1, sigma2
-      float* S = F + 3 * ni;           // adjoint sources a_const K r1, a_const K r2, a_cont c
-      float* D = S + 3 * ns;           // direct part of dL/du, dL/dsigma1, dL/dsigma2
-      for (int i = tid; i < ni; i += GEN_NT) {
-        const int rr = i / iw, cc = i - rr * iw;
-        const size_t o = (size_t)(g.ir0 + rr) * n + (g.ic0 + cc);
-        F[i] = yb[o];
-        F[ni + i] = yb[nn + o];
-        F[2 * ni + i] = yb[2 * nn + o];
-      }
-      __syncthreads();
-      const Plane U{F, g.ir0, g.ic0, iw, n}, X1{F + ni, g.ir0, g.ic0, iw, n}, X2{F + 2 * ni, g.ir0, g.ic0, iw, n};
-      for (int i = tid; i < ns; i += GEN_NT) {
-        const int rr = i / sw, cc = i - rr * sw;
-        const int r = g.sr0 + rr, c = g.sc0 + cc;
-        const PixelTerms t = loss_pixel(U, X1, X2, Kb[(size_t)r * n + c], r, c, p, flags);
-        if (r >= g.r0 && r < g.r1 && c >= g.c0 && c < g.c1) {
-          s_const += t.s_const; s_cont += t.s_cont; s_dir += t.s_dir; s_neu += t.s_neu;
-          if (BWD) {
-            const int k = (r - g.r0) * ow + (c - g.c0);
-            D[k] = t.d_u; D[no + k] = t.d_s1; D[2 * no + k] = t.d_s2;
-          }
-        }
-        if (BWD) { S[i] = t.src_p1; S[ns + i] = t.src_p2; S[2 * ns + i] = t.src_cc; }
-      }
-      __syncthreads();
-      if (BWD) {
-        const Plane G1{S, g.sr0, g.sc0, sw, n}, G2{S + ns, g.sr0, g.sc0, sw, n}, GC{S + 2 * ns, g.sr0, g.sc0, sw, n};
-        for (int i = tid; i < no; i += GEN_NT) {
-          const int rr = i / ow, cc = i - rr * ow;
-          const int r = g.r0 + rr, c = g.c0 + cc;
-          const float du = D[i] + sobel_adj<true>(G1, r, c, correct) + sobel_adj<false>(G2, r, c, correct);
-          const float d1 = D[no + i] + sobel_adj<true>(GC, r, c, correct);
-          const float d2 = D[2 * no + i] + sobel_adj<false>(GC, r, c, correct);
-          const size_t o = (size_t)r * n + c;
-          gb[o] = du; gb[nn + o] = d1; gb[2 * nn + o] = d2;
-        }
-        __syncthreads();               // the next tile's loads overwrite the planes
-      }
-    }
-
-  const float t0 = wave_sum(s_const), t1 = wave_sum(s_cont), t2 = wave_sum(s_dir), t3 = wave_sum(s_neu);
+  const TileGeo g = tile_geo(n, tr, tc, tile / ntc, tile % ntc);
+  float sums[4] = {0.f, 0.f, 0.f, 0.f};
+  BlockExec ex{tid, GEN_NT};
+  process_tile<BWD>(Kp + (size_t)b * nn, yp + (size_t)b * 3 * nn, BWD ? gyp + (size_t)b * 3 * nn : nullptr, n, g, p, flags,
+                    lds, ex, sums);
+  const float t0 = wave_sum(sums[0]), t1 = wave_sum(sums[1]), t2 = wave_sum(sums[2]), t3 = wave_sum(sums[3]);
   if ((tid & 63) == 0) {
     const int w = tid >> 6;
     red[w * 4 + 0] = t0; red[w * 4 + 1] = t1; red[w * 4 + 2] = t2; red[w * 4 + 3] = t3;
@@ -100,7 +61,7 @@ __global__ __launch_bounds__(GEN_NT) void darcy_loss_generic_kernel(const float*
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < GEN_NT / 64; ++w) t += red[w * 4 + tid];     // fixed order: deterministic
-    partials[(size_t)b * 4 + tid] = t;
+    partials[((size_t)b * gridDim.x + tile) * 4 + tid] = t;
   }
 }
 
@@ -138,12 +99,20 @@ __global__ __launch_bounds__(256) void sobel_adjoint_generic_kernel(const float*
 }
 
 // ---- launchers (darcy_loss.hip's entry points validate the arguments) -----------------------------------------------
+int loss_generic_tiles(int n) {       // tiles per image (<= 0: size not supported)
+  int tr = 0, tc = 0;
+  if (n < 2 || !choose_tile(n, GEN_LDSF, tr, tc)) return 0;
+  return cdiv(n, tr) * cdiv(n, tc);
+}
+
 int launch_loss_generic(const float* K, const float* y, float* gy, float* partials, int B, int n, LossParams p,
                         int flags, hipStream_t st) {
   int tr = 0, tc = 0;
   if (n < 2 || !choose_tile(n, GEN_LDSF, tr, tc)) return PDES_ENOSUP;
-  if (gy) hipLaunchKernelGGL(darcy_loss_generic_kernel<true>, dim3(B), dim3(GEN_NT), 0, st, K, y, gy, partials, p, n, tr, tc, flags);
-  else hipLaunchKernelGGL(darcy_loss_generic_kernel<false>, dim3(B), dim3(GEN_NT), 0, st, K, y, gy, partials, p, n, tr, tc, flags);
+  const int ntc = cdiv(n, tc);
+  const dim3 grid(cdiv(n, tr) * ntc, B), block(GEN_NT);
+  if (gy) hipLaunchKernelGGL(darcy_loss_generic_kernel<true>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
+  else hipLaunchKernelGGL(darcy_loss_generic_kernel<false>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
   return PDES_OK;
 }
 

@@ -50,15 +50,15 @@ def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta
         K = torch.zeros((B, 1, H, W), device=y.device, dtype=torch.float32)
     K = K.detach().contiguous()
     y = y.detach().contiguous()
-    partials = torch.empty((B, 4), device=y.device, dtype=torch.float32)
+    flags = (1 if nonlinear else 0) | (0 if use_tb else 2) | (0 if correct else 4)
+    partials = torch.empty((_lib.loss_partial_rows(B, H, W, flags), 4), device=y.device, dtype=torch.float32)
     terms = torch.empty(5, device=y.device, dtype=torch.float32)
     grad = torch.empty_like(y) if want_grad else None
     w = [float(v) for v in weights]
     with _lib.device_guard(y.device):
         rc = _lib.lib().pdes_darcy_loss(_lib.context(y.device), _lib.ptr(K), _lib.ptr(y), _lib.ptr(grad),
                                         _lib.ptr(partials), _lib.ptr(terms), B, H, W, w[0], w[1], w[2], w[3],
-                                        (1 if nonlinear else 0) | (0 if use_tb else 2) | (0 if correct else 4),
-                                        float(beta1), float(beta2),
+                                        flags, float(beta1), float(beta2),
                                         _lib.stream_ptr(y.device))
     _lib.check(rc, 'pdes_darcy_loss')
     return terms, grad

@@ -25,7 +25,7 @@ class ResidualClosure:
         B, _, H, W = self.K.shape
         self.B, self.n = B, H
         self.grad_y = torch.empty((B, 3, H, W), device=self.dev)
-        self.partials = torch.empty((B, 4), device=self.dev)
+        self.partials = torch.empty((_lib.loss_partial_rows(B, H, W, 1 if nonlinear else 0), 4), device=self.dev)
         self.terms = torch.zeros(5, device=self.dev)      # {total, const, cont, dirichlet, neumann} of the last call
         self.gflat = model._gscratch
         for p, off in zip(model._params, model._offsets):  # .grad aliases the flat gradient buffer (what LBFGS gathers)

@@ -122,7 +122,7 @@ class MixedResidualTrainer:
         self._hyper_args = (ctypes.c_float * 8)()                 # eager mode: passed to the kernel by value
         self.step_count = 0
         self.grad_y = torch.empty((batch_size, 3, imsize, imsize), device=self.dev)
-        self.partials = torch.empty((batch_size, 4), device=self.dev)
+        self.partials = torch.empty((_lib.loss_partial_rows(batch_size, imsize, imsize, 1 if nonlinear else 0), 4), device=self.dev)
         self.terms = torch.zeros(5, device=self.dev)
         self.terms_accum = torch.zeros(5, device=self.dev, dtype=torch.float64)
         self.n_accum = 0
@@ -434,7 +434,7 @@ class ReverseKLTrainer:
         self.step_count = 0
         C = model.y_channels
         self.grad_y = torch.empty((batch_size, C, imsize, imsize), device=self.dev)
-        self.partials = torch.empty((batch_size, 4), device=self.dev)
+        self.partials = torch.empty((_lib.loss_partial_rows(batch_size, imsize, imsize, 0), 4), device=self.dev)
         self.terms = torch.zeros(5, device=self.dev)              # {beta * loss_pde, constitutive, continuity, dirichlet, neumann}
         self.terms_accum = torch.zeros(6, device=self.dev, dtype=torch.float64)     # ... + sum_b log p(y_b|x_b)
         self.n_accum = 0
