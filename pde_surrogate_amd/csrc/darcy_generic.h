@@ -344,12 +344,12 @@ inline bool choose_tile(int n, long long budget, int& tr, int& tc) {
   return false;
 }
 
-// ---- one tile, start to finish ---------------------------------------------------------------------------------------
+// ---- one tile, start to finish: the per-pixel form (tiny images, n < 8) ---------------------------------------------------------------------------------------
 // The SAME code runs as a HIP workgroup (Exec: tid / nthreads of the block, barrier = __syncthreads) and as a serial
 // loop on the host (tests/emu: one "thread", barrier a no-op).  Phases: fields -> LDS | sources + direct terms + sums |
 // adjoint + stores.  sums[4] are this thread's contributions {const, cont, dir, neu}.
 template <bool BWD, class Exec>
-PDES_HD void process_tile(const float* Kb, const float* yb, float* gb, int n, const TileGeo& g, const LossParams& p, int flags,
+PDES_HD void process_tile_pixelwise(const float* Kb, const float* yb, float* gb, int n, const TileGeo& g, const LossParams& p, int flags,
                           float* lds, Exec& ex, float* sums) {
   const size_t nn = (size_t)n * n;
   const bool correct = !(flags & kUncorrected);
@@ -476,6 +476,318 @@ PDES_HD void process_tile(const float* Kb, const float* yb, float* gb, int n, co
         gb[2 * nn + o] = D[2 * L.nd + ldd] + sobel_adj<false>(GC, r, c, correct);
       }
     }
+  }
+}
+
+// ---- one tile, start to finish: the strip form (n >= 8) ----------------------------------------------------------------
+// Every pixel -- border or not -- goes through the SAME branch-free code: along an axis of length n the corrected
+// (or uncorrected) clamped central difference, its adjoint, and the replicate-edge smoothing are 5- resp. 3-point
+// stencils whose coefficients depend on the index only (tables below, derived from image_gradient.py:26-47 as in the
+// header comment: rows 0-2 and n-3..n-1 of the adjoint carry the modifier's couplings), and the LDS planes are ZEROED
+// before they are filled, so a stencil may touch cells outside the image with a zero coefficient.  A thread owns a 1 x 4
+// strip (16-byte LDS accesses, columns c0-2 .. c0+5 of a row in registers); waves do not diverge on border strips.
+struct Ax5 { float c[5]; };                 // weights of x[k-2 .. k+2]
+struct Ax3 { float c[3]; };                 // weights of x[k-1 .. k+1]
+struct Row8 { float v[8]; };                // columns c0-2 .. c0+5
+
+PDES_HD Ax5 axis_diff(int k, int n, bool correct) {
+  Ax5 t = {{0.f, -0.5f, 0.f, 0.5f, 0.f}};
+  if (k == 0) { if (correct) t = {{0.f, 0.f, -1.5f, 2.f, -0.5f}}; else t = {{0.f, 0.f, -0.5f, 0.5f, 0.f}}; }
+  else if (k == n - 1) { if (correct) t = {{0.5f, -2.f, 1.5f, 0.f, 0.f}}; else t = {{0.f, -0.5f, 0.5f, 0.f, 0.f}}; }
+  return t;
+}
+PDES_HD Ax5 axis_diff_adj(int k, int n, bool correct) {      // n >= 6: the cases are distinct
+  Ax5 t = {{0.f, 0.5f, 0.f, -0.5f, 0.f}};
+  if (correct) {
+    if (k == 0) t = {{0.f, 0.f, -1.5f, -0.5f, 0.f}};
+    else if (k == 1) t = {{0.f, 2.f, 0.f, -0.5f, 0.f}};
+    else if (k == 2) t = {{-0.5f, 0.5f, 0.f, -0.5f, 0.f}};
+    else if (k == n - 3) t = {{0.f, 0.5f, 0.f, -0.5f, 0.5f}};
+    else if (k == n - 2) t = {{0.f, 0.5f, 0.f, -2.f, 0.f}};
+    else if (k == n - 1) t = {{0.f, 0.5f, 1.5f, 0.f, 0.f}};
+  } else {
+    if (k == 0) t = {{0.f, 0.f, -0.5f, -0.5f, 0.f}};
+    else if (k == n - 1) t = {{0.f, 0.5f, 0.5f, 0.f, 0.f}};
+  }
+  return t;
+}
+PDES_HD Ax3 axis_smooth(int k, int n) {
+  Ax3 t = {{0.25f, 0.5f, 0.25f}};
+  if (k == 0) t = {{0.f, 0.75f, 0.25f}};
+  else if (k == n - 1) t = {{0.25f, 0.75f, 0.f}};
+  return t;
+}
+
+// a plane of a strip tile: rows [r_lo, r_hi), row stride w, LDS column 0 = image column c_org (a multiple of 4, possibly
+// negative); every cell of the allocation is zero or a field / source value
+struct SPlane {
+  const float* p;
+  int r_lo, r_hi, c_org, w;
+};
+PDES_HD Row8 load8(const SPlane& P, int r, int c0) {       // r clamped into the plane (callers pass a zero weight then)
+  const int rr = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
+  const float* q = P.p + (rr - P.r_lo) * P.w + (c0 - P.c_org);
+  Row8 o;
+  o.v[0] = q[-2]; o.v[1] = q[-1];
+  ld4(q, &o.v[2]);
+  o.v[6] = q[4]; o.v[7] = q[5];
+  return o;
+}
+// n * sum_q colt[j][q] * (sum_p rows[p] * P(r+p-1, c0+j+q-2)): grad_h with (axis_diff, axis_smooth), grad_h^T with
+// (axis_diff_adj, axis_smooth)
+PDES_HD void strip_h(const SPlane& P, int r, int c0, const Ax3& rows, const Ax5* colt, float fn, float* out) {
+  const Row8 a = load8(P, r - 1, c0), b = load8(P, r, c0), d = load8(P, r + 1, c0);
+  float sv[8];
+  for (int k = 0; k < 8; ++k) sv[k] = rows.c[0] * a.v[k] + rows.c[1] * b.v[k] + rows.c[2] * d.v[k];
+  for (int j = 0; j < 4; ++j)
+    out[j] = fn * (colt[j].c[0] * sv[j] + colt[j].c[1] * sv[j + 1] + colt[j].c[2] * sv[j + 2] + colt[j].c[3] * sv[j + 3] +
+                   colt[j].c[4] * sv[j + 4]);
+}
+// n * sum_p cols[j][p] * (sum_q rowt[q] * P(r+q-2, c0+j+p-1)): grad_v with (axis_diff, axis_smooth), grad_v^T with the adjoint table
+PDES_HD void strip_v(const SPlane& P, int r, int c0, const Ax5& rowt, const Ax3* cols, float fn, float* out) {
+  float dv[8];
+  {
+    const Row8 a = load8(P, r - 1, c0), d = load8(P, r + 1, c0);
+    for (int k = 0; k < 8; ++k) dv[k] = rowt.c[1] * a.v[k] + rowt.c[3] * d.v[k];
+  }
+  if (rowt.c[2] != 0.f) { const Row8 b = load8(P, r, c0); for (int k = 0; k < 8; ++k) dv[k] += rowt.c[2] * b.v[k]; }
+  if (rowt.c[0] != 0.f) { const Row8 b = load8(P, r - 2, c0); for (int k = 0; k < 8; ++k) dv[k] += rowt.c[0] * b.v[k]; }
+  if (rowt.c[4] != 0.f) { const Row8 b = load8(P, r + 2, c0); for (int k = 0; k < 8; ++k) dv[k] += rowt.c[4] * b.v[k]; }
+  for (int j = 0; j < 4; ++j)
+    out[j] = fn * (cols[j].c[0] * dv[j + 1] + cols[j].c[1] * dv[j + 2] + cols[j].c[2] * dv[j + 3]);
+}
+
+struct StripGeo {
+  int r0, r1, c0, c1;          // own pixels; c0 a multiple of 4
+  int sr0, sr1, sc0, sc1;      // source strips: rows, columns [sc0, sc1) in whole strips (sc1 may exceed n: zero cells)
+  int fr0, fr1;                // field rows
+  int fo, wf, so, ws, wd;      // plane column origins (multiples of 4) and row strides
+  int nf, ns, nd;              // floats per plane
+};
+PDES_HD StripGeo strip_geo(int n, int tr, int tc, int ti, int tj) {
+  StripGeo g;
+  const int na = (n + 3) & ~3;
+  g.r0 = ti * tr; g.r1 = imin(g.r0 + tr, n);
+  g.c0 = tj * tc; g.c1 = imin(g.c0 + tc, n);
+  const int c1a = (g.c1 + 3) & ~3;
+  g.sr0 = imax(g.r0 - 2, 0); g.sr1 = imin(g.r1 + 2, n);
+  g.sc0 = imax(g.c0 - 4, 0); g.sc1 = imin(c1a + 4, na);
+  g.fr0 = imax(g.sr0 - 1, 0); g.fr1 = imin(g.sr1 + 1, n);
+  g.fo = g.sc0 - 4; g.wf = g.sc1 + 4 - g.fo;
+  g.so = g.sc0 - 4; g.ws = g.sc1 + 4 - g.so;
+  g.wd = c1a - g.c0;
+  g.nf = (g.fr1 - g.fr0) * g.wf; g.ns = (g.sr1 - g.sr0) * g.ws; g.nd = (g.r1 - g.r0) * g.wd;
+  return g;
+}
+PDES_HD long long strip_tile_floats(int tr, int tc, int n) {       // upper bound over the tiles of an image
+  const long long w = imin(tc, (n + 3) & ~3) + 16;
+  return 3 * ((long long)imin(tr + 6, n) * w + (long long)imin(tr + 4, n) * w + (long long)imin(tr, n) * (w - 12));
+}
+inline bool choose_strip_tile(int n, long long budget, int& tr, int& tc) {
+  for (int ntc = 1; ntc <= n; ++ntc) {
+    tc = (((n + ntc - 1) / ntc) + 3) & ~3;
+    int best = 0;
+    for (int t = 1; t <= n; ++t) {
+      if (strip_tile_floats(t, tc, n) > budget) break;
+      best = t;
+    }
+    if (best >= 8 || (best >= 1 && tc <= 16)) {
+      const int ntr = (n + best - 1) / best;
+      tr = (n + ntr - 1) / ntr;
+      return true;
+    }
+  }
+  return false;
+}
+
+struct StripCtx {
+  const float* Kb;
+  float* gb;
+  int n, flags;
+  bool correct, vec;
+  float fn;
+  size_t nn;
+  StripGeo g;
+  LossParams p;
+  SPlane U, X1, X2, G1, G2, GC;
+  float* F;
+  float* S;
+  float* D;
+};
+
+// the residuals of the four pixels of a strip from their gradients: sums, adjoint sources, direct terms (phase B, both paths)
+// the conductivities of a strip (global memory: issued ahead of the field staging for a thread's first strips)
+PDES_HD void load_k(const StripCtx& x, int r, int c0, float* kk) {
+  const float* kp = x.Kb + (size_t)r * x.n + c0;
+  if (x.vec) ld4(kp, kk);
+  else for (int j = 0; j < 4; ++j) kk[j] = (c0 + j < x.n) ? kp[j] : 0.f;
+}
+
+template <bool BWD>
+PDES_HD void strip_residuals(const StripCtx& x, int r, int c0, const float* kk, const float* ghu, const float* gvu, const float* gh1,
+                             const float* gv2, float* sums) {
+  const StripGeo& g = x.g;
+  const LossParams& p = x.p;
+  const int n = x.n;
+  float u4[4], v14[4], v24[4];
+  const int fl = (r - g.fr0) * g.wf + (c0 - g.fo);
+  ld4(x.F + fl, u4); ld4(x.F + g.nf + fl, v14); ld4(x.F + 2 * g.nf + fl, v24);
+  const bool tb = (r == 0) || (r == n - 1);
+  const bool own_row = r >= g.r0 && r < g.r1;
+  float sp1[4], sp2[4], scc[4], d1[4], d2[4], du[4];
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    const bool in = c < n;
+    const float K = kk[j], v1 = v14[j], v2 = v24[j];
+    float r1 = v1 + K * ghu[j], r2 = v2 + K * gvu[j], q1 = 1.f, q2 = 1.f;
+    if (x.flags & kNonlinear) {               // darcy.py:179-191
+      const float sq = sqrt_f(K);
+      r1 += p.beta1 * sq * v1 * v1 + p.beta2 * K * v1 * v1 * v1;
+      r2 += p.beta1 * sq * v2 * v2 + p.beta2 * K * v2 * v2 * v2;
+      q1 += 2.f * p.beta1 * sq * v1 + 3.f * p.beta2 * K * v1 * v1;
+      q2 += 2.f * p.beta1 * sq * v2 + 3.f * p.beta2 * K * v2 * v2;
+    }
+    const float cc = ((x.flags & kNoTB) && tb) ? 0.f : gh1[j] + gv2[j];
+    sp1[j] = in ? p.a_const * K * r1 : 0.f;
+    sp2[j] = in ? p.a_const * K * r2 : 0.f;
+    scc[j] = in ? p.a_cont * cc : 0.f;
+    d1[j] = p.a_const * r1 * q1;
+    d2[j] = p.a_const * r2 * q2 + (tb ? p.b_neu * v2 : 0.f);
+    float e = 0.f, dd = 0.f;
+    if (c == 0) { e = u4[j] - 1.f; dd = p.b_dir * e; }
+    if (c == n - 1) { e = u4[j]; dd = p.b_dir * e; }
+    du[j] = dd;
+    if (own_row && in && c >= g.c0 && c < g.c1) {
+      sums[0] += r1 * r1 + r2 * r2;
+      sums[1] += cc * cc;
+      sums[2] += e * e;
+      if (tb) sums[3] += v2 * v2;
+    }
+  }
+  if (BWD) {
+    const int ls = (r - g.sr0) * g.ws + (c0 - g.so);
+    st4(x.S + ls, sp1); st4(x.S + g.ns + ls, sp2); st4(x.S + 2 * g.ns + ls, scc);
+    if (own_row && c0 >= g.c0 && c0 < g.c1) {
+      const int ldd = (r - g.r0) * g.wd + (c0 - g.c0);
+      st4(x.D + ldd, du); st4(x.D + g.nd + ldd, d1); st4(x.D + 2 * g.nd + ldd, d2);
+    }
+  }
+}
+
+template <bool BWD>
+PDES_HD void phase_b_strip(const StripCtx& x, int r, int c0, const float* kk, float* sums) {
+  float ghu[4], gvu[4], gh1[4], gv2[4];
+  Ax5 colf[4];
+  Ax3 cols[4];
+  for (int j = 0; j < 4; ++j) { colf[j] = axis_diff(c0 + j, x.n, x.correct); cols[j] = axis_smooth(c0 + j, x.n); }
+  const Ax5 rowf = axis_diff(r, x.n, x.correct);
+  const Ax3 rows = axis_smooth(r, x.n);
+  strip_h(x.U, r, c0, rows, colf, x.fn, ghu);
+  strip_v(x.U, r, c0, rowf, cols, x.fn, gvu);
+  strip_h(x.X1, r, c0, rows, colf, x.fn, gh1);
+  strip_v(x.X2, r, c0, rowf, cols, x.fn, gv2);
+  strip_residuals<BWD>(x, r, c0, kk, ghu, gvu, gh1, gv2, sums);
+}
+
+PDES_HD void phase_c_strip(const StripCtx& x, int r, int c0) {
+  const StripGeo& g = x.g;
+  float a1[4], a2[4], ac1[4], ac2[4], du[4], d1[4], d2[4];
+  Ax5 cola[4];
+  Ax3 cols[4];
+  for (int j = 0; j < 4; ++j) { cola[j] = axis_diff_adj(c0 + j, x.n, x.correct); cols[j] = axis_smooth(c0 + j, x.n); }
+  const Ax5 rowa = axis_diff_adj(r, x.n, x.correct);
+  const Ax3 rows = axis_smooth(r, x.n);
+  strip_h(x.G1, r, c0, rows, cola, x.fn, a1);
+  strip_v(x.G2, r, c0, rowa, cols, x.fn, a2);
+  strip_h(x.GC, r, c0, rows, cola, x.fn, ac1);
+  strip_v(x.GC, r, c0, rowa, cols, x.fn, ac2);
+  const int ldd = (r - g.r0) * g.wd + (c0 - g.c0);
+  ld4(x.D + ldd, du); ld4(x.D + g.nd + ldd, d1); ld4(x.D + 2 * g.nd + ldd, d2);
+  for (int j = 0; j < 4; ++j) { du[j] += a1[j] + a2[j]; d1[j] += ac1[j]; d2[j] += ac2[j]; }
+  float* o = x.gb + (size_t)r * x.n + c0;
+  if (x.vec) { st4(o, du); st4(o + x.nn, d1); st4(o + 2 * x.nn, d2); }
+  else for (int j = 0; j < 4; ++j) if (c0 + j < x.n) { o[j] = du[j]; o[x.nn + j] = d1[j]; o[2 * x.nn + j] = d2[j]; }
+}
+
+template <bool BWD, class Exec>
+PDES_HD void process_tile_strips(const float* Kb, const float* yb, float* gb, int n, const StripGeo& g, const LossParams& p,
+                                 int flags, float* lds, Exec& ex, float* sums) {
+  StripCtx x;
+  x.Kb = Kb; x.gb = gb; x.n = n; x.flags = flags; x.g = g; x.p = p;
+  x.nn = (size_t)n * n;
+  x.correct = !(flags & kUncorrected);
+  x.vec = (n & 3) == 0;
+  x.fn = (float)n;
+  x.F = lds; x.S = x.F + 3 * g.nf; x.D = x.S + 3 * g.ns;
+  // ---- zero the planes (stencils may touch cells outside the image / the tile with a zero weight)
+  {
+    const int tot = 3 * (g.nf + g.ns + g.nd);
+    const float zz[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 4 * ex.tid; i < tot; i += 4 * ex.nthreads) st4(lds + i, zz);
+  }
+  ex.barrier();
+  // the conductivities of this thread's first strip: their latency hides behind the field staging
+  const int sw = (g.sc1 - g.sc0) >> 2, nslots_b = (g.sr1 - g.sr0) * sw;
+  float kk[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ex.tid < nslots_b) { const int rr = ex.tid / sw; load_k(x, g.sr0 + rr, g.sc0 + 4 * (ex.tid - rr * sw), kk); }
+  // ---- phase A: the three fields on the source strips +- one strip, rows fr0 .. fr1; loads issued in batches (one
+  // round trip to memory per batch, not per element)
+  {
+    const int rows = g.fr1 - g.fr0;
+    if (x.vec) {
+      const int ca = imax(g.sc0 - 4, 0), cb = imin(g.sc1 + 4, n), qw = (cb - ca) >> 2, per = rows * qw, ni = 3 * per;
+      for (int base = ex.tid; base < ni; base += 4 * ex.nthreads) {
+        float v[4][4];
+        int dst[4];
+        for (int u = 0; u < 4; ++u) {
+          const int i = base + u * ex.nthreads;
+          dst[u] = -1;
+          if (i < ni) {
+            const int pl = i / per, rem = i - pl * per, rr = rem / qw, cc = ca + 4 * (rem - rr * qw);
+            ld4(yb + pl * x.nn + (size_t)(g.fr0 + rr) * n + cc, v[u]);
+            dst[u] = pl * g.nf + rr * g.wf + (cc - g.fo);
+          }
+        }
+        for (int u = 0; u < 4; ++u) if (dst[u] >= 0) st4(x.F + dst[u], v[u]);
+      }
+    } else {
+      const int ca = imax(g.sc0 - 2, 0), cb = imin(g.sc1 + 2, n), iw = cb - ca, per = rows * iw, ni = 3 * per;
+      for (int base = ex.tid; base < ni; base += 8 * ex.nthreads) {
+        float v[8];
+        int dst[8];
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * ex.nthreads;
+          dst[u] = -1;
+          if (i < ni) {
+            const int pl = i / per, rem = i - pl * per, rr = rem / iw, cc = ca + (rem - rr * iw);
+            v[u] = yb[pl * x.nn + (size_t)(g.fr0 + rr) * n + cc];
+            dst[u] = pl * g.nf + rr * g.wf + (cc - g.fo);
+          }
+        }
+        for (int u = 0; u < 8; ++u) if (dst[u] >= 0) x.F[dst[u]] = v[u];
+      }
+    }
+  }
+  ex.barrier();
+  x.U = SPlane{x.F, g.fr0, g.fr1, g.fo, g.wf};
+  x.X1 = SPlane{x.F + g.nf, g.fr0, g.fr1, g.fo, g.wf};
+  x.X2 = SPlane{x.F + 2 * g.nf, g.fr0, g.fr1, g.fo, g.wf};
+  // ---- phase B: the residuals on the source strips
+  for (int i = ex.tid; i < nslots_b; i += ex.nthreads) {
+    const int rr = i / sw, r = g.sr0 + rr, c0 = g.sc0 + 4 * (i - rr * sw);
+    if (i != ex.tid) load_k(x, r, c0, kk);
+    phase_b_strip<BWD>(x, r, c0, kk, sums);
+  }
+  if (!BWD) return;
+  ex.barrier();
+  // ---- phase C: dL/dy on the own strips
+  x.G1 = SPlane{x.S, g.sr0, g.sr1, g.so, g.ws};
+  x.G2 = SPlane{x.S + g.ns, g.sr0, g.sr1, g.so, g.ws};
+  x.GC = SPlane{x.S + 2 * g.ns, g.sr0, g.sr1, g.so, g.ws};
+  const int ow = g.wd >> 2, nslots_c = (g.r1 - g.r0) * ow;
+  for (int i = ex.tid; i < nslots_c; i += ex.nthreads) {
+    const int rr = i / ow;
+    phase_c_strip(x, g.r0 + rr, g.c0 + 4 * (i - rr * ow));
   }
 }
 

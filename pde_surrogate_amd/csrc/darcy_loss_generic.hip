@@ -49,8 +49,8 @@ __global__ __launch_bounds__(GEN_NT) void darcy_loss_generic_kernel(const float*
   const TileGeo g = tile_geo(n, tr, tc, tile / ntc, tile % ntc);
   float sums[4] = {0.f, 0.f, 0.f, 0.f};
   BlockExec ex{tid, GEN_NT};
-  process_tile<BWD>(Kp + (size_t)b * nn, yp + (size_t)b * 3 * nn, BWD ? gyp + (size_t)b * 3 * nn : nullptr, n, g, p, flags,
-                    lds, ex, sums);
+  process_tile_pixelwise<BWD>(Kp + (size_t)b * nn, yp + (size_t)b * 3 * nn, BWD ? gyp + (size_t)b * 3 * nn : nullptr, n, g, p,
+                              flags, lds, ex, sums);
   const float t0 = wave_sum(sums[0]), t1 = wave_sum(sums[1]), t2 = wave_sum(sums[2]), t3 = wave_sum(sums[3]);
   if ((tid & 63) == 0) {
     const int w = tid >> 6;
@@ -61,6 +61,34 @@ __global__ __launch_bounds__(GEN_NT) void darcy_loss_generic_kernel(const float*
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < GEN_NT / 64; ++w) t += red[w * 4 + tid];     // fixed order: deterministic
+    partials[((size_t)b * gridDim.x + tile) * 4 + tid] = t;
+  }
+}
+
+// the strip form (n >= 8): every pixel through the same branch-free code (darcy_generic.h: process_tile_strips)
+template <bool BWD>
+__global__ __launch_bounds__(GEN_NT) void darcy_loss_strips_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
+                                                                   float* __restrict__ gyp, float* __restrict__ partials,
+                                                                   LossParams p, int n, int tr, int tc, int ntc, int flags) {
+  __shared__ __attribute__((aligned(16))) float lds[GEN_LDSF];
+  __shared__ float red[(GEN_NT / 64) * 4];
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const size_t nn = (size_t)n * n;
+  const StripGeo g = strip_geo(n, tr, tc, tile / ntc, tile % ntc);
+  float sums[4] = {0.f, 0.f, 0.f, 0.f};
+  BlockExec ex{tid, GEN_NT};
+  process_tile_strips<BWD>(Kp + (size_t)b * nn, yp + (size_t)b * 3 * nn, BWD ? gyp + (size_t)b * 3 * nn : nullptr, n, g, p, flags,
+                           lds, ex, sums);
+  const float t0 = wave_sum(sums[0]), t1 = wave_sum(sums[1]), t2 = wave_sum(sums[2]), t3 = wave_sum(sums[3]);
+  if ((tid & 63) == 0) {
+    const int w = tid >> 6;
+    red[w * 4 + 0] = t0; red[w * 4 + 1] = t1; red[w * 4 + 2] = t2; red[w * 4 + 3] = t3;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < GEN_NT / 64; ++w) t += red[w * 4 + tid];
     partials[((size_t)b * gridDim.x + tile) * 4 + tid] = t;
   }
 }
@@ -99,20 +127,32 @@ __global__ __launch_bounds__(256) void sobel_adjoint_generic_kernel(const float*
 }
 
 // ---- launchers (darcy_loss.hip's entry points validate the arguments) -----------------------------------------------
+constexpr int STRIP_MIN_N = 8;        // below: the per-pixel kernel (the adjoint tables of the strip form need n >= 6)
+
 int loss_generic_tiles(int n) {       // tiles per image (<= 0: size not supported)
   int tr = 0, tc = 0;
-  if (n < 2 || !choose_tile(n, GEN_LDSF, tr, tc)) return 0;
+  if (n < 2) return 0;
+  if (n >= STRIP_MIN_N) {
+    if (!choose_strip_tile(n, GEN_LDSF, tr, tc)) return 0;
+  } else if (!choose_tile(n, GEN_LDSF, tr, tc)) return 0;
   return cdiv(n, tr) * cdiv(n, tc);
 }
 
 int launch_loss_generic(const float* K, const float* y, float* gy, float* partials, int B, int n, LossParams p,
                         int flags, hipStream_t st) {
   int tr = 0, tc = 0;
-  if (n < 2 || !choose_tile(n, GEN_LDSF, tr, tc)) return PDES_ENOSUP;
+  if (n < 2) return PDES_ENOSUP;
+  const bool strips = n >= STRIP_MIN_N;
+  if (strips ? !choose_strip_tile(n, GEN_LDSF, tr, tc) : !choose_tile(n, GEN_LDSF, tr, tc)) return PDES_ENOSUP;
   const int ntc = cdiv(n, tc);
   const dim3 grid(cdiv(n, tr) * ntc, B), block(GEN_NT);
-  if (gy) hipLaunchKernelGGL(darcy_loss_generic_kernel<true>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
-  else hipLaunchKernelGGL(darcy_loss_generic_kernel<false>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
+  if (strips) {
+    if (gy) hipLaunchKernelGGL(darcy_loss_strips_kernel<true>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
+    else hipLaunchKernelGGL(darcy_loss_strips_kernel<false>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
+  } else {
+    if (gy) hipLaunchKernelGGL(darcy_loss_generic_kernel<true>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
+    else hipLaunchKernelGGL(darcy_loss_generic_kernel<false>, grid, block, 0, st, K, y, gy, partials, p, n, tr, tc, ntc, flags);
+  }
   return PDES_OK;
 }
 

@@ -23,21 +23,34 @@ struct SerialExec {                     // one "thread" runs every slot; the pha
 int emu_darcy_loss(const float* Kp, const float* yp, float* gyp, float* partials, int B, int n, float a_const,
                    float a_cont, float b_dir, float b_neu, float beta1, float beta2, int flags, int tr, int tc,
                    long long budget) {
+  const bool strips = n >= 8;                                  // = STRIP_MIN_N of darcy_loss_generic.hip
   if (tr <= 0 || tc <= 0) {
-    if (!choose_tile(n, budget, tr, tc)) return 0;
+    if (strips ? !choose_strip_tile(n, budget, tr, tc) : !choose_tile(n, budget, tr, tc)) return 0;
   }
-  if (tile_floats(tr, tc, n) > budget) return 0;
+  if (strips) tc = (tc + 3) & ~3;                              // tile columns start on strip boundaries
+  const long long need = strips ? strip_tile_floats(tr, tc, n) : tile_floats(tr, tc, n);
+  if (need > budget) return 0;
   LossParams p{a_const, a_cont, b_dir, b_neu, beta1, beta2, 0};
   const size_t nn = (size_t)n * n;
   const int ntr = (n + tr - 1) / tr, ntc = (n + tc - 1) / tc;
   for (int b = 0; b < B; ++b)
     for (int tile = 0; tile < ntr * ntc; ++tile) {
-      const TileGeo g = tile_geo(n, tr, tc, tile / ntc, tile % ntc);
-      std::vector<float> lds((size_t)tile_floats(tr, tc, n), -12345.f);     // poison: a read outside what was written shows
+      std::vector<float> lds((size_t)need + 8, -12345.f);     // poison: a read outside what was written / zeroed shows
       float sums[4] = {0, 0, 0, 0};
       SerialExec ex;
-      if (gyp) process_tile<true>(Kp + b * nn, yp + b * 3 * nn, gyp + b * 3 * nn, n, g, p, flags, lds.data(), ex, sums);
-      else process_tile<false>(Kp + b * nn, yp + b * 3 * nn, nullptr, n, g, p, flags, lds.data(), ex, sums);
+      const float* Kb = Kp + b * nn;
+      const float* yb = yp + b * 3 * nn;
+      float* gb = gyp ? gyp + b * 3 * nn : nullptr;
+      if (strips) {
+        const StripGeo g = strip_geo(n, tr, tc, tile / ntc, tile % ntc);
+        if (3ll * (g.nf + g.ns + g.nd) > need) return 0;       // the bound the tile choice relies on
+        if (gb) process_tile_strips<true>(Kb, yb, gb, n, g, p, flags, lds.data(), ex, sums);
+        else process_tile_strips<false>(Kb, yb, nullptr, n, g, p, flags, lds.data(), ex, sums);
+      } else {
+        const TileGeo g = tile_geo(n, tr, tc, tile / ntc, tile % ntc);
+        if (gb) process_tile_pixelwise<true>(Kb, yb, gb, n, g, p, flags, lds.data(), ex, sums);
+        else process_tile_pixelwise<false>(Kb, yb, nullptr, n, g, p, flags, lds.data(), ex, sums);
+      }
       for (int k = 0; k < 4; ++k) partials[((size_t)b * ntr * ntc + tile) * 4 + k] = sums[k];
     }
   return ntr * ntc;
@@ -73,7 +86,9 @@ void emu_sobel_adjoint(const float* ghb, const float* gvb, float* out, int nimg,
   }
 }
 
-int emu_choose_tile(int n, long long budget, int* tr, int* tc) { return choose_tile(n, budget, *tr, *tc) ? 1 : 0; }
-long long emu_tile_floats(int tr, int tc, int n) { return tile_floats(tr, tc, n); }
+int emu_choose_tile(int n, long long budget, int* tr, int* tc) {
+  return (n >= 8 ? choose_strip_tile(n, budget, *tr, *tc) : choose_tile(n, budget, *tr, *tc)) ? 1 : 0;
+}
+long long emu_tile_floats(int tr, int tc, int n) { return n >= 8 ? strip_tile_floats(tr, tc, n) : tile_floats(tr, tc, n); }
 
 }  // extern "C"

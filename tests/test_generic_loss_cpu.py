@@ -87,7 +87,8 @@ def test_loss_tiled_equals_oracle(emu, n, tr, tc, flags):
     ref_t, ref_g = _oracle(K, y, w, flags, 0.1, 0.2)
     np.testing.assert_allclose(terms, ref_t, rtol=1e-5)
     assert rel_l2(gy, ref_g) < 1e-5
-    assert nt == -(-n // tr) * -(-n // tc)
+    tce = (tc + 3) // 4 * 4 if n >= 8 else tc            # the strip form (n >= 8) cuts columns on strip boundaries
+    assert nt == -(-n // tr) * -(-n // tce)
 
 
 @pytest.mark.parametrize('n', [17, 64, 65, 96, 128, 130, 300, 1000])
@@ -96,7 +97,7 @@ def test_loss_kernel_tile_choice(emu, n):
     tr, tc = I(0), I(0)
     assert emu.emu_choose_tile(n, BUDGET, ctypes.byref(tr), ctypes.byref(tc)) == 1
     assert emu.emu_tile_floats(tr.value, tc.value, n) <= BUDGET
-    assert 1 <= tr.value <= n and 1 <= tc.value <= n
+    assert 1 <= tr.value <= n and tc.value >= 1
     if n > 130:
         return                                    # geometry only (the fp64 oracle at 300 x 300 is slow)
     K, y = _fields(1, n, n)
@@ -106,6 +107,7 @@ def test_loss_kernel_tile_choice(emu, n):
     np.testing.assert_allclose(terms, ref_t, rtol=1e-5)
     assert rel_l2(gy, ref_g) < 1e-5
     assert nt == -(-n // tr.value) * -(-n // tc.value)
+    assert tc.value % 4 == 0 or tc.value >= n
 
 
 def test_forward_only_leaves_no_gradient(emu):
