@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -14,6 +14,7 @@ _c_p = ctypes.c_void_p
 # name -> argtypes; mirrors include/pdes_hip.h one to one (tests check every symbol is exported)
 SIGNATURES = {
     'pdes_abi_version': [],
+    'pdes_sizeof': [_c_i],
     'pdes_stat_replicas': [],
     'pdes_context_create': [_c_p, _c_i],
     'pdes_context_destroy': [_c_p],
@@ -48,6 +49,9 @@ SIGNATURES = {
     'pdes_pack_weights_up': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_all': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
     'pdes_pack_all2': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
+    'pdes_pack_all3': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
+    'pdes_mirror_image_floats': [_c_i, _c_i, _c_i, _c_p, _c_p],
+    'pdes_mirror_check': [_c_p, _c_i],
     'pdes_pack_weights_b3': [_c_p, _c_i, _c_i, _c_p],
     'pdes_b3_image_elems': [_c_i, _c_i, _c_p, _c_p],
     'pdes_pack_weights_b3up': [_c_p, _c_i, _c_i, _c_p],

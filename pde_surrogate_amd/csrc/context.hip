@@ -21,7 +21,8 @@ struct Knob { const char* name; int Options::*field; };
 static const Knob kKnobs[] = {
     {"PDES_MFMA_B3", &Options::mfma_b3},       {"PDES_B3_TAIL", &Options::b3_tail},     {"PDES_MFMA_1X1", &Options::mfma_1x1},
     {"PDES_MFMA_SMALL", &Options::mfma_small}, {"PDES_WGRAD_WGS", &Options::wgrad_wgs}, {"PDES_LOSS_NT", &Options::loss_nt},
-    {"PDES_FORK_SIGNAL", &Options::fork_signal},
+    {"PDES_FORK_SIGNAL", &Options::fork_signal}, {"PDES_DENSE_MIRROR", &Options::dense_mirror},
+    {"PDES_WGRAD_LDS_KB", &Options::wgrad_lds_kb},
 };
 
 static int set_knob(Options& o, const char* key, const char* value) {
@@ -84,4 +85,21 @@ extern "C" int pdes_context_load_env(pdes_context* ctx) {
 
 extern "C" int pdes_context_device(const pdes_context* ctx) {
   return ctx ? reinterpret_cast<const Context*>(ctx)->device : PDES_EINVAL;
+}
+
+// sizeof of the structures that cross the boundary (the ctypes mirrors are checked against it: tests/test_cabi.py)
+extern "C" int pdes_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(pdes_conv_desc);
+    case 1: return (int)sizeof(pdes_pack_item);
+    case 2: return (int)sizeof(pdes_mfma_pack_item);
+    case 3: return (int)sizeof(pdes_up_pack_item);
+    case 4: return (int)sizeof(pdes_b3_pack_item);
+    case 5: return (int)sizeof(pdes_b3up_pack_item);
+    case 6: return (int)sizeof(pdes_mir_pack_item);
+    case 7: return (int)sizeof(pdes_reduce_item);
+    case 8: return (int)sizeof(pdes_bn_item);
+    case 9: return (int)sizeof(pdes_op);
+    default: return -1;
+  }
 }
