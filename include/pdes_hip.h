@@ -66,8 +66,8 @@ int pdes_context_device(const pdes_context* ctx);
 /* ABI version of this header; bumped on any signature change. */
 int pdes_abi_version(void);
 /* sizeof of a boundary structure: 0 pdes_conv_desc, 1 pdes_pack_item, 2 pdes_mfma_pack_item, 3 pdes_up_pack_item,
- * 4 pdes_b3_pack_item, 5 pdes_b3up_pack_item, 6 pdes_mir_pack_item, 7 pdes_reduce_item, 8 pdes_bn_item, 9 pdes_op; -1 otherwise
- * (a binding checks its own mirrors against it) */
+ * 4 pdes_b3_pack_item, 5 pdes_b3up_pack_item, 6 pdes_reduce_item, 7 pdes_bn_item, 8 pdes_op; -1 otherwise (a binding checks
+ * its own mirrors against it) */
 int pdes_sizeof(int which);
 /* number of replicas of the fp64 accumulator arena the kernels are compiled for (see pdes_conv_desc.nrep) */
 int pdes_stat_replicas(void);
@@ -257,12 +257,6 @@ typedef struct pdes_conv_desc {
   /* appended in ABI 15 */
   const unsigned short* wbu_bwd; /* nearest-x2 + 3x3 layers: split image of the effective sub-pixel weights for the DATA gradient
                                     (pdes_pack_weights_b3up), or NULL */
-  /* appended in ABI 19: the write-once ("mirror") data gradient of a dense block (csrc/conv_mfma_mirror.hip).  Set on
-     EVERY layer of a block or on none: with it, pdes_backward / pdes_backward_chain replace the layer's data gradient by
-     one launch that completes T of channels [final_c0, final_c1) from this layer and the mir_nj - 1 that follow it */
-  const float* wm_mir;   /* image packed by pdes_pack_all3 (pdes_mir_pack_item), or NULL */
-  int mir_nj;            /* this layer and the later layers of its block: descs[i .. i + mir_nj) */
-  int mir_ntp;           /* N-tiles per (k-step, tap) of the image: 1 for one N-tile, else padded to a multiple of 8 */
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.
@@ -325,8 +319,7 @@ int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* descs, int n, 
  *   pdes_backward_chain:   [finalize of descs[i]'s output channels] + pdes_conv_backward_data(descs[i])
  *   pdes_backward_weights: pdes_conv_backward_weight(descs[i])
  * The caller orders them (chain of a range before its weights) and reduces the split-K partials.  These are what the
- * segment graphs below are captured from.  `descs` is the WHOLE chain, not a slice of it: the mirror data gradient of a
- * dense-block layer i (wm_mir) reads descs[i .. i + mir_nj), which may lie beyond `hi`. */
+ * segment graphs below are captured from. */
 int pdes_backward_chain(const pdes_context* ctx, const pdes_conv_desc* descs, int lo, int hi, void* stream);
 int pdes_backward_weights(const pdes_context* ctx, const pdes_conv_desc* descs, int lo, int hi, void* stream);
 
@@ -427,27 +420,10 @@ int pdes_b3up_image_elems(int Cout, int Cin, long long* fwd_elems, long long* bw
 int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
                   const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
                   int max_elems, void* stream);
-#define PDES_MIRROR_MAX 16   /* layers of a dense block one mirror launch can sum over */
-typedef struct pdes_mir_pack_item {
-  float* dst;                         /* [(kstep*9 + tap)*ntp + nt][kq*16 + n] = W_k[4 (kstep%4) + kq][n0 + 16 nt + n][8 - tap], k = kstep / 4 */
-  const float* w[PDES_MIRROR_MAX];    /* (16, cin[k], 3, 3): the weights of the block's layers j .. j + nj - 1 */
-  int cin[PDES_MIRROR_MAX];
-  int nj, n0, n1, ntp;
-} pdes_mir_pack_item;
-/* floats of one mirror image, and its N-tile pitch */
-int pdes_mirror_image_floats(int nj, int n0, int n1, long long* floats, int* ntp);
-/* PDES_OK when descs[0 .. nj) (a block's layers from some layer to its last, wm_mir / mir_* filled in) can run as one
- * mirror launch; PDES_ENOSUP otherwise (the caller then leaves wm_mir NULL on the whole block) */
-int pdes_mirror_check(const pdes_conv_desc* descs, int nj);
 /* The same with a fifth table: the split effective-weight images of the sub-pixel layers (pdes_pack_weights_b3up). */
 int pdes_pack_all2(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
                    const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
                    const pdes_b3up_pack_item* buitems, int nbu, int max_elems, void* stream);
-/* ... and a sixth: the mirror images of the dense blocks (work items: elements). */
-int pdes_pack_all3(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
-                   const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
-                   const pdes_b3up_pack_item* buitems, int nbu, const pdes_mir_pack_item* ritems, int nr,
-                   int max_elems, void* stream);
 
 typedef struct pdes_bn_item {    /* one BatchNorm layer */
   const double* x_stats;  /* (>=C, 2) batch sums of its input channels */

@@ -49,9 +49,6 @@ SIGNATURES = {
     'pdes_pack_weights_up': [_c_p, _c_i, _c_i, _c_p],
     'pdes_pack_all': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
     'pdes_pack_all2': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
-    'pdes_pack_all3': [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
-    'pdes_mirror_image_floats': [_c_i, _c_i, _c_i, _c_p, _c_p],
-    'pdes_mirror_check': [_c_p, _c_i],
     'pdes_pack_weights_b3': [_c_p, _c_i, _c_i, _c_p],
     'pdes_b3_image_elems': [_c_i, _c_i, _c_p, _c_p],
     'pdes_pack_weights_b3up': [_c_p, _c_i, _c_i, _c_p],

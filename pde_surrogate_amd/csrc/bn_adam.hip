@@ -87,15 +87,13 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const pdes_pack_item* __r
                                                        const pdes_mfma_pack_item* __restrict__ m, int nm,
                                                        const pdes_up_pack_item* __restrict__ u, int nu,
                                                        const pdes_b3_pack_item* __restrict__ b3, int nb,
-                                                       const pdes_b3up_pack_item* __restrict__ bu, int nbu,
-                                                       const pdes_mir_pack_item* __restrict__ mr) {
+                                                       const pdes_b3up_pack_item* __restrict__ bu) {
   const int y = blockIdx.y;
   if (y < na) pack_direct_item(a[y], blockIdx.x, gridDim.x);
   else if (y < na + nm) pack_mfma_item(m[y - na], blockIdx.x, gridDim.x);
   else if (y < na + nm + nu) pack_up_item(u[y - na - nm], blockIdx.x, gridDim.x);
   else if (y < na + nm + nu + nb) pack_b3_item(b3[y - na - nm - nu], blockIdx.x, gridDim.x);
-  else if (y < na + nm + nu + nb + nbu) pack_b3up_item(bu[y - na - nm - nu - nb], blockIdx.x, gridDim.x);
-  else pack_mir_item(mr[y - na - nm - nu - nb - nbu], blockIdx.x, gridDim.x);
+  else pack_b3up_item(bu[y - na - nm - nu - nb], blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void bn_update_running_kernel(const pdes_bn_item* __restrict__ items, float momentum,
@@ -271,23 +269,14 @@ extern "C" int pdes_pack_all(const pdes_pack_item* items, int n, const pdes_mfma
 extern "C" int pdes_pack_all2(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
                               const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
                               const pdes_b3up_pack_item* buitems, int nbu, int max_elems, void* stream) {
-  return pdes_pack_all3(items, n, mitems, nm, uitems, nu, bitems, nb, buitems, nbu, nullptr, 0, max_elems, stream);
-}
-
-extern "C" int pdes_pack_all3(const pdes_pack_item* items, int n, const pdes_mfma_pack_item* mitems, int nm,
-                              const pdes_up_pack_item* uitems, int nu, const pdes_b3_pack_item* bitems, int nb,
-                              const pdes_b3up_pack_item* buitems, int nbu, const pdes_mir_pack_item* ritems, int nr,
-                              int max_elems, void* stream) {
-  if (n < 0 || nm < 0 || nu < 0 || nb < 0 || nbu < 0 || nr < 0 || n + nm + nu + nb + nbu + nr <= 0 || max_elems <= 0)
-    return PDES_EINVAL;
-  if ((n && !items) || (nm && !mitems) || (nu && !uitems) || (nb && !bitems) || (nbu && !buitems) || (nr && !ritems))
-    return PDES_EINVAL;
+  if (n < 0 || nm < 0 || nu < 0 || nb < 0 || nbu < 0 || n + nm + nu + nb + nbu <= 0 || max_elems <= 0) return PDES_EINVAL;
+  if ((n && !items) || (nm && !mitems) || (nu && !uitems) || (nb && !bitems) || (nbu && !buitems)) return PDES_EINVAL;
   // one element per thread per iteration is a dependent div/mod + gather chain: enough blocks that the
   // largest image (~0.5 M elements) needs 4 iterations, the small ones exit after one
   int gx = cdiv(max_elems, 256);
   gx = gx > 512 ? 512 : gx;
-  hipLaunchKernelGGL(pack_all_kernel, dim3(gx, n + nm + nu + nb + nbu + nr), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     items, n, mitems, nm, uitems, nu, bitems, nb, buitems, nbu, ritems);
+  hipLaunchKernelGGL(pack_all_kernel, dim3(gx, n + nm + nu + nb + nbu), dim3(256), 0, static_cast<hipStream_t>(stream), items, n,
+                     mitems, nm, uitems, nu, bitems, nb, buitems);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }

@@ -18,7 +18,6 @@ int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st);         // 5x5
 int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st);             // wide 3x3 layers: bf16 x3 split (conv_mfma_b3.hip)
 int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st);          // nearest-x2 + 3x3, sub-pixel form, bf16 x3 split
 int conv_backward_data_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
-int conv_backward_data_mirror(const pdes_conv_desc* ds, int nj, hipStream_t st, bool dry = false);   // conv_mfma_mirror.hip
 int conv_backward_data_b3_up(const pdes_conv_desc& d, hipStream_t st, bool dry = false);     // sub-pixel data gradient, bf16 x3 split
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_forward_small(const pdes_conv_desc& d, hipStream_t st);          // 3x3 on 8x8 maps (conv_small.hip)
@@ -149,19 +148,6 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
   return PDES_OK;
 }
 
-// the data gradient of layer i inside a chain of n descriptors: the layer's own kernel, or -- when the caller planned the
-// block for it (wm_mir) and the option allows it for this map size -- the mirror launch over layers [i, i + mir_nj)
-static int chain_backward_data(const pdes_context* ctx, const pdes_conv_desc* descs, int i, int n, hipStream_t st) {
-  const pdes_conv_desc& d = descs[i];
-  if (d.wm_mir && !is_resample_op(d)) {
-    if (d.mir_nj < 1 || i + d.mir_nj > n) return PDES_EINVAL;
-    OptScope scope(ctx);
-    const int bit = d.Win >= 32 ? 1 : 2;
-    if ((opt().dense_mirror & bit) && !force_direct()) return conv_backward_data_mirror(&descs[i], d.mir_nj, st);
-  }
-  return pdes_conv_backward_data(ctx, &d, 1, st);
-}
-
 // The two halves of pdes_backward2 for a range of layers, each on ONE stream and free of events: what the segment graphs
 // of step_graph.hip are captured from (also usable eagerly).
 extern "C" int pdes_backward_chain(const pdes_context* ctx, const pdes_conv_desc* descs, int lo, int hi, void* stream) {
@@ -176,7 +162,7 @@ extern "C" int pdes_backward_chain(const pdes_context* ctx, const pdes_conv_desc
       if (rc) return rc;
     }
     if (d.has_bn || is_resample_op(d) || d.t_in) {
-      const int rc = chain_backward_data(ctx, descs, i, 0x7fffffff, st)     /* `descs` is the whole chain: see the header */;
+      const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
       if (rc) return rc;
     }
   }
@@ -303,7 +289,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     }
     // (a convolution without a BatchNorm in front has a data gradient only when the caller gave it somewhere to go)
     if (d.has_bn || is_resample_op(d) || d.t_in) {
-      const int rc = chain_backward_data(ctx, descs, i, n, st);
+      const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
       if (rc) return rc;
     }
   }

@@ -609,7 +609,6 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     size_t lds = (size_t)(tpw > 2 ? 2 : 1) * (16 * G::CS + 16 * NTW_ * G::GS) * sizeof(float);                \
     const size_t red = (size_t)4 * KS * KS * NTW_ * 4 * 64 * sizeof(float);                                   \
     if (red > lds) lds = red;                                                                                 \
-    if ((size_t)opt().wgrad_lds_kb * 1024 > lds) lds = (size_t)opt().wgrad_lds_kb * 1024;                       \
     if constexpr (KS == 5 && NTW_ == 1 && S == 1) {                                                           \
       if (d.Cout * 5 <= 16) {                    /* few-output form; its LDS need is below the generic one */ \
         if (tpw > 2)                                                                                          \

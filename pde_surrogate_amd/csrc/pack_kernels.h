@@ -41,19 +41,6 @@ __device__ __forceinline__ void pack_mfma_item(const pdes_mfma_pack_item& it, in
   }
 }
 
-// mirror image of a dense block's group (conv_mfma_mirror.hip): the tap-flipped, transposed weights of the layers
-// j .. j + nj - 1 restricted to input channels [n0, n1), k-steps of successive layers back to back
-__device__ __forceinline__ void pack_mir_item(const pdes_mir_pack_item& it, int bx, int nbx) {
-  const int ntr = (it.n1 - it.n0 + 15) / 16;
-  const int total = 4 * it.nj * 9 * ntr * 64;
-  for (int i = bx * 256 + threadIdx.x; i < total; i += nbx * 256) {
-    const int l = i & 63, nt = (i >> 6) % ntr, t = ((i >> 6) / ntr) % 9, ks = (i >> 6) / (ntr * 9);
-    const int k = ks >> 2, co = 4 * (ks & 3) + (l >> 4), ci = it.n0 + nt * 16 + (l & 15);
-    const float v = it.w[k][((size_t)co * it.cin[k] + min(ci, it.n1 - 1)) * 9 + (8 - t)];
-    it.dst[((size_t)(ks * 9 + t) * it.ntp + nt) * 64 + l] = ci < it.n1 ? v : 0.f;
-  }
-}
-
 // R(d, i): the 3x3 taps that land on position i of the 2x2 kernel of parity d.  Rows (and, likewise, columns): parity 0:
 // position 0 <- {0}, 1 <- {1, 2}; parity 1: position 0 <- {0, 1}, 1 <- {2}.  Branch free: the nine loads are
 // unconditional and independent (with data-dependent loop bounds every tap was a serial round trip to L2, and the

@@ -2,7 +2,7 @@
 // Nothing in the library reads the environment on its own: pdes_context_load_env() does, once, when the caller
 // asks for it; every other read goes through opt(), which resolves to the options of the context the running
 // entry point was called with (or to the compiled-in defaults for a NULL context).
-// Ten options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
+// Eight options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
 // parts; the A/B measurements that settled the defaults, and the knobs that went with them, are in EXPERIMENTS.md.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -19,12 +19,8 @@ struct Options {
   int mfma_1x1 = 7;             // PDES_MFMA_1X1  : bit mask of the register-operand 1x1 kernels: 1 forward, 2 data gradient, 4 weight gradient
   int mfma_small = 1;           // PDES_MFMA_SMALL: matrix-core kernels for 3x3 convolutions on 8x8 maps (conv_small.hip)
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS : workgroup target of the split-K weight-gradient plan
-  int wgrad_lds_kb = 0;         // PDES_WGRAD_LDS_KB: LDS request of the narrow layers' weight-gradient workgroups, padded up to this many KiB:
-                                //                  caps how many of them share a CU, so that a workgroup of the main chain always finds room
   int loss_nt = -1;             // PDES_LOSS_NT   : streaming loads / stores in the loss kernel: -1 = by working-set size, 0, 1
   int fork_signal = 1;          // PDES_FORK_SIGNAL: fork events ride on the finalize kernel's completion signal (0: hipEventRecord)
-  int dense_mirror = 0;         // PDES_DENSE_MIRROR: write-once data gradient of the dense blocks (conv_mfma_mirror.hip): bit 1 maps
-                                //                  >= 32 wide, bit 2 narrower maps; 0 = one read-modify-write of T per layer
 };
 
 struct Context {

@@ -43,7 +43,6 @@ class ConvDesc(ctypes.Structure):
         ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong), ('wbu_fwd', _P),
         ('g_add', _P), ('x2', _P), ('x2_ctot', _I), ('t2', _P), ('p0', _P), ('p1', _P), ('acc', _P), ('flags', _I),
         ('wbu_bwd', _P),
-        ('wm_mir', _P), ('mir_nj', _I), ('mir_ntp', _I),
     ]
 
 
@@ -66,14 +65,6 @@ class B3PackItem(ctypes.Structure):
 
 class B3UpPackItem(ctypes.Structure):
     _fields_ = [('w', _P), ('wbu_fwd', _P), ('wbu_bwd', _P), ('Cout', _I), ('Cin', _I)]
-
-
-MIRROR_MAX = 16                     # PDES_MIRROR_MAX
-
-
-class MirPackItem(ctypes.Structure):
-    """mirror of `pdes_mir_pack_item`"""
-    _fields_ = [('dst', _P), ('w', _P * MIRROR_MAX), ('cin', _I * MIRROR_MAX), ('nj', _I), ('n0', _I), ('n1', _I), ('ntp', _I)]
 
 
 class ReduceItem(ctypes.Structure):
@@ -111,27 +102,6 @@ class _ConvSpec:
     def bn(self):
         """the kernels apply a BatchNorm+ReLU on operand load (a real module's, or the identity one)"""
         return self.norm is not None or self.fake_bn
-
-
-def _dense_runs(specs):
-    """index runs of CONSECUTIVE plain dense layers of one block (3x3, stride 1, 16 outputs appended to their own input
-    buffer right behind their inputs): the layers whose data gradients the mirror kernel can sum (>= 2, <= MIRROR_MAX)"""
-    def dense(s):
-        if getattr(s, 'kind', None) is not None:         # the flow networks' operator specs (glow_msc.py)
-            return False
-        return (s.conv is not None and s.norm is not None and s.k == 3 and s.stride == 1 and s.pad == 1 and not s.up
-                and s.cout == 16 and s.src == s.dst and s.dst_coff == s.cin)
-    runs, cur = [], []
-    for i, s in enumerate(specs):
-        if dense(s) and (not cur or (specs[cur[-1]].src == s.src and specs[cur[-1]].cin + 16 == s.cin)):
-            cur.append(i)
-            continue
-        if len(cur) >= 2:
-            runs.append(cur)
-        cur = [i] if dense(s) else []
-    if len(cur) >= 2:
-        runs.append(cur)
-    return [r for r in runs if len(r) <= MIRROR_MAX]
 
 
 def _plan_dropout(specs, bufs, drop):
@@ -485,16 +455,6 @@ class _Engine(_EngineBase):
             else:
                 d.out_stats = None
                 d.g, d.g_ctot, d.g_coff = None, bufs[s.dst][0], 0
-        # mirror data gradient of the dense blocks: every layer of a block or none (include/pdes_hip.h: wm_mir)
-        for run in _dense_runs(specs):
-            for p, i in enumerate(run):
-                img, nj, ntp = net._packed_mir[specs[i].conv]
-                self.descs[i].wm_mir, self.descs[i].mir_nj, self.descs[i].mir_ntp = img.data_ptr(), nj, ntp
-            ok = all(_lib.lib().pdes_mirror_check(ctypes.byref(self.descs, i * ctypes.sizeof(ConvDesc)), len(run) - p) == 0
-                     for p, i in enumerate(run))
-            if not ok:
-                for i in run:
-                    self.descs[i].wm_mir, self.descs[i].mir_nj, self.descs[i].mir_ntp = None, 0, 0
         self._out_stats = [d.out_stats for d in self.descs]
         # BatchNorm table (device) for running statistics and fp32 gamma/beta gradients
         items = []
@@ -958,29 +918,6 @@ class _HipNet(nn.Module):
         if buitems:
             arr = (B3UpPackItem * len(buitems))(*buitems)
             self._bupack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        # mirror images of the dense blocks (conv_mfma_mirror.hip): for layer p of a block, the weights of layers p .. L
-        # restricted to the channels whose accumulator T the launch at p completes
-        self._packed_mir, ritems, rmx = {}, [], 0
-        for run in _dense_runs(self._specs):
-            c0 = self._specs[run[0]].cin
-            for p, i in enumerate(run):
-                s, nj = self._specs[i], len(run) - p
-                n0, n1 = (0 if p == 0 else s.cin - s.cout), s.cin
-                fl, ntp = ctypes.c_longlong(0), _I(0)
-                _lib.check(_lib.lib().pdes_mirror_image_floats(nj, n0, n1, ctypes.byref(fl), ctypes.byref(ntp)), 'pdes_mirror_image_floats')
-                img = torch.zeros(fl.value, device=device)
-                self._packed_mir[s.conv] = (img, nj, ntp.value)
-                it = MirPackItem()
-                it.dst, it.nj, it.n0, it.n1, it.ntp = img.data_ptr(), nj, n0, n1, ntp.value
-                for k in range(nj):
-                    sk = self._specs[run[p + k]]
-                    it.w[k], it.cin[k] = _get(self._root, sk.conv).weight.data_ptr(), sk.cin
-                ritems.append(it)
-                rmx = max(rmx, 4 * nj * 9 * ((n1 - n0 + 15) // 16) * 64)
-        self._rpack_n, self._rpack_max = len(ritems), rmx
-        if ritems:
-            arr = (MirPackItem * len(ritems))(*ritems)
-            self._rpack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._ws = torch.empty(8 << 20, device=device)       # 32 MiB split-K scratch (weight gradients)
         if mitems:
             arr = (MfmaPackItem * len(mitems))(*mitems)
@@ -1000,16 +937,14 @@ class _HipNet(nn.Module):
     def _pack_weights(self):
         """rebuild every packed weight image from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables)"""
         mx = max(self._pack_max, self._mpack_max if self._mpack_n else 0, self._upack_max if self._upack_n else 0,
-                 self._bpack_max if self._bpack_n else 0, self._bupack_max if self._bupack_n else 0,
-                 self._rpack_max if self._rpack_n else 0)
-        rc = _lib.lib().pdes_pack_all3(self._pack_table.data_ptr(), self._pack_n,
+                 self._bpack_max if self._bpack_n else 0, self._bupack_max if self._bupack_n else 0)
+        rc = _lib.lib().pdes_pack_all2(self._pack_table.data_ptr(), self._pack_n,
                                        self._mpack_table.data_ptr() if self._mpack_n else None, self._mpack_n,
                                        self._upack_table.data_ptr() if self._upack_n else None, self._upack_n,
                                        self._bpack_table.data_ptr() if self._bpack_n else None, self._bpack_n,
                                        self._bupack_table.data_ptr() if self._bupack_n else None, self._bupack_n,
-                                       self._rpack_table.data_ptr() if self._rpack_n else None, self._rpack_n,
                                        mx, _lib.stream_ptr())
-        _lib.check(rc, 'pdes_pack_all3')
+        _lib.check(rc, 'pdes_pack_all2')
 
     def _is_flat(self, device):
         if self._flat is None or self._flat.device != device:

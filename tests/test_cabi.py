@@ -61,23 +61,7 @@ def test_ctypes_mirrors_have_the_size_of_the_c_structures():
     from pde_surrogate_amd.models import codec
     L = _lib.lib()
     mirrors = {0: codec.ConvDesc, 1: codec.PackItem, 2: codec.MfmaPackItem, 3: codec.UpPackItem, 4: codec.B3PackItem,
-               5: codec.B3UpPackItem, 6: codec.MirPackItem, 7: codec.ReduceItem, 8: codec.BnItem, 9: codec.PdesOp}
+               5: codec.B3UpPackItem, 6: codec.ReduceItem, 7: codec.BnItem, 8: codec.PdesOp}
     for which, cls in mirrors.items():
         assert L.pdes_sizeof(which) == ctypes.sizeof(cls), (which, cls.__name__, L.pdes_sizeof(which), ctypes.sizeof(cls))
     assert L.pdes_sizeof(99) == -1
-
-
-def test_dense_runs_of_the_default_network():
-    """the layers the mirror data gradient sums over: the three dense blocks of the default DenseED, nothing else; none
-    with dropout between the layers or bottleneck layers"""
-    from pde_surrogate_amd.models import codec
-    specs, _ = codec._plan_densed([6, 8, 6], 16, 48, 1, 3, 64)
-    runs = codec._dense_runs(specs)
-    assert [len(r) for r in runs] == [6, 8, 6]
-    assert [specs[r[0]].cin for r in runs] == [48, 72, 100]
-    for r in runs:
-        assert all(specs[b].cin == specs[a].cin + 16 and specs[a].src == specs[b].src for a, b in zip(r, r[1:]))
-    specs, _ = codec._plan_densed([3, 4, 3], 16, 48, 1, 3, 64, drop=True)
-    assert codec._dense_runs(specs) == []
-    specs, _ = codec._plan_densed([6, 8, 6], 16, 48, 1, 3, 64, bottleneck=True, bn_size=4)
-    assert all(specs[i].cin <= 64 for r in codec._dense_runs(specs) for i in r)

@@ -468,9 +468,6 @@ VARIANTS = {   # name -> (option or environment variable, value A, value B): pai
     '1x1_all': ('PDES_MFMA_1X1', '0', '7'),
     '1x1_wgrad': ('PDES_MFMA_1X1', '3', '7'),
     'fork_signal': ('PDES_FORK_SIGNAL', '0', '1'),
-    'dense_mirror': ('PDES_DENSE_MIRROR', '0', '3'),         # one read-modify-write of T per layer vs the write-once form
-    'dense_mirror_wide_maps': ('PDES_DENSE_MIRROR', '2', '3'),
-    'dense_mirror_small_maps': ('PDES_DENSE_MIRROR', '1', '3'),
 }
 
 
