@@ -493,6 +493,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the roofline_1x1 and config5_solver legs (profiling runs: only the training step and the '
                          'loss-kernel roofline launches)')
+    ap.add_argument('--leg', default=None, choices=['cglow'],
+                    help='internal: run ONE extra leg in this (fresh) process and print its JSON object')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='initialise the process group (gloo when there is no GPU), count the ranks with one '
                          'all-reduce, print it and exit: exercises the launch contract without touching a kernel')
@@ -508,6 +510,9 @@ def main():
     def emit(obj):
         os.write(real_stdout, (json.dumps(obj) + '\n').encode())
 
+    if args.leg == 'cglow':
+        emit(cglow_timing(torch.device('cuda:0'), cpu_steps=0 if args.no_cpu_baseline else 3))
+        return
     rank, local, world, dev = rendezvous(args.gpus)
     if args.ntrain is None:
         args.ntrain = 4096 if world == 1 else 8192         # configs[2]: ntrain 8192, global batch 256 = 8 x 32
@@ -666,9 +671,15 @@ def main():
                                    'note': 'the 1x1 channel-halving layers, HIP-event timed stand-alone at the training '
                                            'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}
         if world == 1 and not args.no_extras:
-            # (before the solver leg: after its hipGraph captures every later eager step in this process runs ~14 %
-            #  slower -- 6.0 -> 6.85 ms for this one, measured by reordering; the legs are independent)
-            out['cglow_reverse_kl'] = cglow_timing(dev, cpu_steps=0 if args.no_cpu_baseline else 3)
+            # in a process of its own: after a hipGraph capture (the segment-graph leg above, the solver leg below) every
+            # later eager step of the same process runs ~14-18 % slower (5.33 -> 6.30 ms for this one); the legs are independent
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), '--leg', 'cglow'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else [])
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=600, check=True)
+                out['cglow_reverse_kl'] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            except Exception as e:                      # noqa: BLE001  (the headline line must not depend on an extra leg)
+                out['cglow_reverse_kl'] = {'error': f'{type(e).__name__}: {e}'}
         if world == 1 and not args.no_extras:
             out['config5_solver'] = config5_timing(dev)
         if world == 1 and not args.no_cpu_baseline:
