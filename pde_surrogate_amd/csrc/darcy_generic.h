@@ -231,13 +231,7 @@ PDES_HD PixelTerms loss_pixel(const Plane& U, const Plane& S1, const Plane& S2, 
   return o;
 }
 
-// ---- interior fast path: 1 x 4 strips ---------------------------------------------------------------------------------
-// Away from the image border neither the replicate clamping nor the modifier acts, and both Sobel operators reduce to
-// [1,2,1]/4 across x central difference along; their adjoints are the NEGATIVES of the same operators (the central
-// difference is skew-symmetric).  A thread then handles four consecutive pixels of a row from three 6-wide row segments
-// (columns c0-1 .. c0+4; c0 a multiple of 4, the LDS planes are laid out so that such a strip is 16-byte aligned).
-struct Row6 { float v[6]; };
-
+// ---- 16-byte accesses of four consecutive floats (LDS planes / image rows that are laid out 16-byte aligned) ----------
 PDES_HD void ld4(const float* q, float* o) {
 #ifdef __HIP_DEVICE_COMPILE__
   const float4 t = *reinterpret_cast<const float4*>(q);
@@ -253,30 +247,7 @@ PDES_HD void st4(float* q, const float* v) {
   q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
 #endif
 }
-PDES_HD Row6 load6(const Plane& P, int r, int c0) {
-  const float* q = P.p + (r - P.r_lo) * P.stride + (c0 - P.c_lo);
-  Row6 o;
-  o.v[0] = q[-1];
-  ld4(q, &o.v[1]);
-  o.v[5] = q[4];
-  return o;
-}
-// n/2 (sv[c+1] - sv[c-1]), sv = [1,2,1]/4 down the rows a (r-1), b (r), d (r+1)
-PDES_HD void strip_grad_h(const Row6& a, const Row6& b, const Row6& d, float n, float* out) {
-  float sv[6];
-  for (int k = 0; k < 6; ++k) sv[k] = 0.25f * a.v[k] + 0.5f * b.v[k] + 0.25f * d.v[k];
-  for (int i = 0; i < 4; ++i) out[i] = 0.5f * n * (sv[i + 2] - sv[i]);
-}
-// n/2 (sh[r+1] - sh[r-1]), sh = [1,2,1]/4 along the row
-PDES_HD void strip_grad_v(const Row6& a, const Row6& d, float n, float* out) {
-  for (int i = 0; i < 4; ++i) {
-    const float lo = 0.25f * a.v[i] + 0.5f * a.v[i + 1] + 0.25f * a.v[i + 2];
-    const float hi = 0.25f * d.v[i] + 0.5f * d.v[i + 1] + 0.25f * d.v[i + 2];
-    out[i] = 0.5f * n * (hi - lo);
-  }
-}
-
-// ---- tile geometry of the fused kernel -------------------------------------------------------------------------------
+// ---- tile geometry of the per-pixel form (n < 8) ------------------------------------------------------------------------
 // One workgroup processes one tile of one image.  A tile OWNS [r0, r1) x [c0, c1); the adjoint stencils at its pixels read
 // the sources within +-2 of them, and the sources' forward stencils read the fields within +-1 (+-2 where the
 // modifier couples the two outermost rows / columns): sources on the own region +-2, fields on it +-3, clipped.
@@ -353,12 +324,10 @@ PDES_HD void process_tile_pixelwise(const float* Kb, const float* yb, float* gb,
                           float* lds, Exec& ex, float* sums) {
   const size_t nn = (size_t)n * n;
   const bool correct = !(flags & kUncorrected);
-  const bool vec = (n & 3) == 0;                    // image rows are 16-byte aligned in global memory
   const TileLayout L = tile_layout(g);
   float* F = lds + 4;                               // (4 floats of slack: a strip at the plane's first column reads q[-1])
   float* S = F + 3 * L.nf;
   float* D = S + 3 * L.ns;
-  const float fn = (float)n;
   // ---- phase A: the three fields of the tile (+-3)
   {
     const int iw = g.ic1 - g.ic0, ni = (g.ir1 - g.ir0) * iw;
@@ -379,50 +348,6 @@ PDES_HD void process_tile_pixelwise(const float* Kb, const float* yb, float* gb,
     for (int i = ex.tid; i < nslots; i += ex.nthreads) {
       const int rr = i / nq, r = g.sr0 + rr, c0 = 4 * (q0 + i - rr * nq);
       const bool own_row = r >= g.r0 && r < g.r1;
-      const bool fast = r >= 1 && r <= n - 2 && c0 >= 4 && c0 + 3 <= n - 2 && c0 >= g.sc0 && c0 + 3 < g.sc1;
-      if (fast) {
-        const Row6 ua = load6(U, r - 1, c0), ub = load6(U, r, c0), ud = load6(U, r + 1, c0);
-        float ghu[4], gvu[4], gh1[4], gv2[4], kk[4];
-        strip_grad_h(ua, ub, ud, fn, ghu);
-        strip_grad_v(ua, ud, fn, gvu);
-        const Row6 xb = load6(X1, r, c0);
-        strip_grad_h(load6(X1, r - 1, c0), xb, load6(X1, r + 1, c0), fn, gh1);
-        strip_grad_v(load6(X2, r - 1, c0), load6(X2, r + 1, c0), fn, gv2);
-        float x2[4];
-        ld4(X2.p + (r - X2.r_lo) * X2.stride + (c0 - X2.c_lo), x2);
-        const float* kp = Kb + (size_t)r * n + c0;
-        if (vec) ld4(kp, kk); else { kk[0] = kp[0]; kk[1] = kp[1]; kk[2] = kp[2]; kk[3] = kp[3]; }
-        float sp1[4], sp2[4], scc[4], d1[4], d2[4], du[4];
-        for (int j = 0; j < 4; ++j) {
-          const float K = kk[j], v1 = xb.v[j + 1], v2 = x2[j], cc = gh1[j] + gv2[j];
-          float r1 = v1 + K * ghu[j], r2 = v2 + K * gvu[j], q1 = 1.f, q2 = 1.f;
-          if (flags & kNonlinear) {               // darcy.py:179-191
-            const float sq = sqrt_f(K);
-            r1 += p.beta1 * sq * v1 * v1 + p.beta2 * K * v1 * v1 * v1;
-            r2 += p.beta1 * sq * v2 * v2 + p.beta2 * K * v2 * v2 * v2;
-            q1 += 2.f * p.beta1 * sq * v1 + 3.f * p.beta2 * K * v1 * v1;
-            q2 += 2.f * p.beta1 * sq * v2 + 3.f * p.beta2 * K * v2 * v2;
-          }
-          sp1[j] = p.a_const * K * r1; sp2[j] = p.a_const * K * r2; scc[j] = p.a_cont * cc;
-          d1[j] = p.a_const * r1 * q1; d2[j] = p.a_const * r2 * q2; du[j] = 0.f;
-          if (own_row && c0 + j >= g.c0 && c0 + j < g.c1) { sums[0] += r1 * r1 + r2 * r2; sums[1] += cc * cc; }
-        }
-        if (BWD) {
-          const int ls = rr * L.ws + (c0 - L.ls);
-          st4(S + ls, sp1); st4(S + L.ns + ls, sp2); st4(S + 2 * L.ns + ls, scc);
-          if (own_row && c0 >= g.c0 && c0 + 3 < g.c1) {
-            const int ldd = (r - g.r0) * L.wd + (c0 - L.ld);
-            st4(D + ldd, du); st4(D + L.nd + ldd, d1); st4(D + 2 * L.nd + ldd, d2);
-          } else if (own_row) {
-            for (int j = 0; j < 4; ++j)
-              if (c0 + j >= g.c0 && c0 + j < g.c1) {
-                const int ldd = (r - g.r0) * L.wd + (c0 + j - L.ld);
-                D[ldd] = du[j]; D[L.nd + ldd] = d1[j]; D[2 * L.nd + ldd] = d2[j];
-              }
-          }
-        }
-        continue;
-      }
       for (int j = 0; j < 4; ++j) {
         const int c = c0 + j;
         if (c < g.sc0 || c >= g.sc1) continue;
@@ -449,23 +374,6 @@ PDES_HD void process_tile_pixelwise(const float* Kb, const float* yb, float* gb,
     const int q0 = g.c0 >> 2, nq = ((g.c1 + 3) >> 2) - q0, nslots = (g.r1 - g.r0) * nq;
     for (int i = ex.tid; i < nslots; i += ex.nthreads) {
       const int rr = i / nq, r = g.r0 + rr, c0 = 4 * (q0 + i - rr * nq);
-      const bool fast = correct ? (r >= 3 && r <= n - 4 && c0 >= 4 && c0 + 3 <= n - 4 && c0 >= g.c0 && c0 + 3 < g.c1)
-                                : (r >= 1 && r <= n - 2 && c0 >= 4 && c0 + 3 <= n - 2 && c0 >= g.c0 && c0 + 3 < g.c1);
-      if (fast) {            // interior: the adjoints are minus the forward operators applied to the sources
-        float a1[4], a2[4], ac1[4], ac2[4], du[4], d1[4], d2[4];
-        const Row6 ca = load6(GC, r - 1, c0), cd = load6(GC, r + 1, c0);
-        strip_grad_h(load6(G1, r - 1, c0), load6(G1, r, c0), load6(G1, r + 1, c0), fn, a1);
-        strip_grad_v(load6(G2, r - 1, c0), load6(G2, r + 1, c0), fn, a2);
-        strip_grad_h(ca, load6(GC, r, c0), cd, fn, ac1);
-        strip_grad_v(ca, cd, fn, ac2);
-        const int ldd = rr * L.wd + (c0 - L.ld);
-        ld4(D + ldd, du); ld4(D + L.nd + ldd, d1); ld4(D + 2 * L.nd + ldd, d2);
-        for (int j = 0; j < 4; ++j) { du[j] -= a1[j] + a2[j]; d1[j] -= ac1[j]; d2[j] -= ac2[j]; }
-        float* o = gb + (size_t)r * n + c0;
-        if (vec) { st4(o, du); st4(o + nn, d1); st4(o + 2 * nn, d2); }
-        else for (int j = 0; j < 4; ++j) { o[j] = du[j]; o[nn + j] = d1[j]; o[2 * nn + j] = d2[j]; }
-        continue;
-      }
       for (int j = 0; j < 4; ++j) {
         const int c = c0 + j;
         if (c < g.c0 || c >= g.c1) continue;
