@@ -264,7 +264,10 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   if (!halo_live && (G::NL + G::NR) > 0) {
 #pragma unroll
     for (int i = 0; i < G::NPH; ++i)
-      if (hl[i] >= 0) { tile[hl[i]] = 0.f; tile[G::KC * G::CS + hl[i]] = 0.f; }
+      if (hl[i] >= 0) {
+        tile[hl[i]] = 0.f;
+        if constexpr (PIPE) tile[G::KC * G::CS + hl[i]] = 0.f;      // !PIPE: one chunk, one buffer (the launch allocates one)
+      }
   }
 
   v4f acc[MT][NT_W];
@@ -600,7 +603,9 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     using G = TileGeo<KS, TWG_, MT_, S>;                                                                      \
     const size_t cf_f = bwd ? 0 : 4 * (size_t)kpad;                                                          \
     const int ng = (WK_ == 4 && !bwd && S == 1 && nchunk >= 3) ? 2 : 1;                        \
-    size_t fl = cf_f + (size_t)ng * 2 * G::KC * G::CS;                                                        \
+    /* one chunk needs ONE tile buffer: half the LDS -> the 1024 workgroups of the 3 -> 49 channel 5x5 data gradient  \
+       are resident at once instead of running a second, quarter-full round */                                       \
+    size_t fl = cf_f + (size_t)ng * ((bwd && nchunk == 1) ? 1 : 2) * G::KC * G::CS;   /* (= the !PIPE instantiation) */ \
     const size_t red = cf_f + (size_t)4 * ng * MT_ * 4 * 64 + 256;                                            \
     if (WK_ == 4 && red > fl) fl = red;                                                                       \
     lds = fl * sizeof(float);                                                                                 \
