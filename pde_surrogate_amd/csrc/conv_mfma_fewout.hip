@@ -11,7 +11,9 @@
 // (B: gathered straight from the (Cout,Cin,5,5) weight tensor, 5 loads per k-step), K = 4 input channels.
 // Workgroup = R output rows of one sample, full width; its 4 waves split K (one k-step of every 16-channel
 // chunk each) and are summed through LDS before the shift-add.  Staging is the straight-line, two-stage
-// register pipeline of conv_mfma.hip.
+// register pipeline of conv_mfma.hip, but through ONE LDS tile (two barriers per chunk): with two tile buffers and the
+// whole exchange area a workgroup held 69 KB and the 1024 workgroups of the 64 x 64 layer ran as two rounds of two per
+// CU; with 35 KB four are resident and cover each other's barriers.
 #include <stdlib.h>
 #include "pdes_common.h"
 #include "pdes_options.h"
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
   const int H = d.Hin, HW = H * W;
   const int kpad = (d.Cin + 15) & ~15, nchunk = kpad / 16, ksteps = kpad / 4;
   float4* cf4 = reinterpret_cast<float4*>(smem);            // [kpad] {mean, gamma*invstd, beta, -}
-  float* tile = smem + 4 * kpad;                            // 2 x [16][CS]
+  float* tile = smem + 4 * kpad;                            // [16][CS]
 
   for (int c = tid; c < kpad; c += 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
     cf4[c] = v;
   }
   // pad columns (x' < 0 and x' >= W) are never written by the staging: zero both buffers once
-  for (int i = tid; i < 2 * 16 * G::CS; i += 256) tile[i] = 0.f;
+  for (int i = tid; i < 16 * G::CS; i += 256) tile[i] = 0.f;
 
   // ---- staging geometry (chunk independent)
   const float* xb = d.x + (size_t)b * d.x_ctot * HW;
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
       st.pv[i] = *reinterpret_cast<const float4*>(src + ch * HW + vg[i]);
     }
   };
-  auto commit = [&](int chunk, int buf, const Stage& st) __attribute__((always_inline)) {
-    float* t = tile + buf * (16 * G::CS);
+  auto commit = [&](int chunk, const Stage& st) __attribute__((always_inline)) {
+    float* t = tile;
     const int crem = d.Cin - chunk * 16;
 #pragma unroll
     for (int i = 0; i < G::NPV; ++i) {
@@ -133,15 +135,14 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
   issue(0, sA);
   issue(min(1, nchunk - 1), sB);
   __syncthreads();                 // cf4 and the zeroed pads are visible
-  commit(0, 0, sA);
+  commit(0, sA);
   __syncthreads();
 
   const int a_lane = (lane >> 4) * G::CS + 2 + (lane & 15);
   auto step = [&](int chunk, Stage& sfree, const Stage& snext, float (&b0)[5], float (&b1)[5]) __attribute__((always_inline)) {
-    const int buf = chunk & 1;
     load_b((chunk + 1) * 4 + wave, b1);
     issue(min(chunk + 2, nchunk - 1), sfree);
-    const float* tk = tile + buf * (16 * G::CS) + wave * 4 * G::CS + a_lane;
+    const float* tk = tile + wave * 4 * G::CS + a_lane;
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
       const float bw = b0[ky] * bmask;
@@ -151,8 +152,11 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
         for (int j = 0; j < NMT; ++j)
           acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tk[(r + ky) * G::LDW + 16 * j], bw, acc[r][j], 0, 0, 0);
     }
-    if (chunk + 1 < nchunk) commit(chunk + 1, buf ^ 1, snext);
-    __syncthreads();
+    __syncthreads();                                   // every wave is done with this chunk's tile
+    if (chunk + 1 < nchunk) {
+      commit(chunk + 1, snext);
+      __syncthreads();
+    }
   };
   {
     int chunk = 0;
@@ -160,28 +164,30 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
     if (chunk < nchunk) step(chunk, sA, sB, bA, bB);
   }
 
-  // ---- sum the 4 K-split waves and shift-add the kernel columns.  Exchange layout red[w][r][p][n] with a
-  // pixel pitch of 17 floats: the readers below walk consecutive pixels p (stride 17 -> 32 distinct banks)
+  // ---- sum the 4 K-split waves and shift-add the kernel columns, one output row at a time.  Exchange layout
+  // red[w][p][n] with a pixel pitch of 17 floats: the readers below walk consecutive pixels p (stride 17 -> 32 distinct banks)
   float* red = tile;
   constexpr int PP = 17, NPX = 16 * NMT;
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int r = 0; r < R; ++r) {
+    if (r) __syncthreads();                            // the previous row's readers are done
 #pragma unroll
     for (int j = 0; j < NMT; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        red[((wave * R + r) * NPX + 16 * j + (lane >> 4) * 4 + q) * PP + (lane & 15)] = acc[r][j][q];
-  __syncthreads();
-  const int nout = R * d.Cout * W;
-  for (int o = tid; o < nout; o += 256) {
-    const int x = o % W, co = (o / W) % d.Cout, r = o / (W * d.Cout);
-    float s = 0.f;
+        red[(wave * NPX + 16 * j + (lane >> 4) * 4 + q) * PP + (lane & 15)] = acc[r][j][q];
+    __syncthreads();
+    const int nout = d.Cout * W;
+    for (int o = tid; o < nout; o += 256) {
+      const int x = o % W, co = o / W;
+      float s = 0.f;
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {
+      for (int kx = 0; kx < 5; ++kx) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) s += red[((w * R + r) * NPX + x + kx) * PP + co * 5 + kx];   // P index = x' + 2 = x + kx
+        for (int w = 0; w < 4; ++w) s += red[(w * NPX + x + kx) * PP + co * 5 + kx];   // P index = x' + 2 = x + kx
+      }
+      d.out[((size_t)b * d.out_ctot + d.out_coff + co) * HW + (size_t)(oy0 + r) * W + x] = s;
     }
-    d.out[((size_t)b * d.out_ctot + d.out_coff + co) * HW + (size_t)(oy0 + r) * W + x] = s;
   }
 }
 
@@ -197,8 +203,8 @@ int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st) {
 #define PDES_FEW_LAUNCH(NMT_, R_)                                                                    \
   do {                                                                                                \
     using G = FewGeo<NMT_, R_>;                                                                       \
-    size_t fl = 2 * (size_t)16 * G::CS;                                                               \
-    const size_t red = (size_t)4 * R_ * 16 * NMT_ * 17;                                                \
+    size_t fl = (size_t)16 * G::CS;                                                                   \
+    const size_t red = (size_t)4 * 16 * NMT_ * 17;                                                     \
     if (red > fl) fl = red;                                                                           \
     hipLaunchKernelGGL((conv5_fewout_fwd_kernel<NMT_, R_>), grid, block, (4 * (size_t)kpad + fl) * sizeof(float), st, d); \
   } while (0)
