@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
     xv0 = reinterpret_cast<const float4*>(x + base)[i0];
   }
   if (threadIdx.x < 64) {
-    // 4 quantities x PDES_NREP(=16) replicas: one load per lane, then a 16-lane shuffle reduction
+    // 4 quantities x PDES_NREP (<= 16) replicas: one load per lane, then a 16-lane shuffle reduction
     const int q = threadIdx.x >> 4, r = threadIdx.x & 15;
     const double* src = (q < 2 ? x_stats : t_stats) + (long long)r * rs + 2 * c + (q & 1);
-    double v = *src;
+    double v = r < PDES_NREP ? *src : 0.0;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
     if (r == 0) sums[q] = v;

@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void flow_copy_bwd_kernel(const float* __restr
   __shared__ float sc[4];
   __shared__ double sums[4];
   if (FUSED) {
-    if (threadIdx.x < 64) {          // 4 quantities x PDES_NREP(=16) replicas: one load per lane, 16-lane shuffle reduction
+    if (threadIdx.x < 64) {          // 4 quantities x PDES_NREP (<= 16) replicas: one load per lane, 16-lane shuffle reduction
       const int q = threadIdx.x >> 4, r = threadIdx.x & 15;
-      double v = (q < 2 ? x_stats : t_stats)[(long long)r * rs + 2 * (g_coff + c) + (q & 1)];
+      double v = r < PDES_NREP ? (q < 2 ? x_stats : t_stats)[(long long)r * rs + 2 * (g_coff + c) + (q & 1)] : 0.0;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
       if (r == 0) sums[q] = v;

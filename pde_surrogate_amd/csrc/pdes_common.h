@@ -54,7 +54,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 // doubles) to keep same-address atomic contention low; readers sum the replicas.
 // The replica count is a compile-time constant (descriptors must carry nrep == PDES_NREP) so the
 // loads below are issued back to back and their latency is paid once, not nrep times.
-#define PDES_NREP 16
+// 8 replicas (round 3, same process alternated on one box: 1.712-1.713 ms per step against 1.725-1.740 with 16 and
+// 1.740-1.757 with 4: every reader sums the replicas in its prologue, every writer queues behind the atomics of its
+// replica; rounds 1-2 ran 16).  At most 16: bn_bwd_finalize / the flow finalize reduce them with a 16-lane shuffle.
+#ifndef PDES_NREP
+#define PDES_NREP 8
+#endif
+static_assert(PDES_NREP >= 1 && PDES_NREP <= 16, "replica count");
 __device__ __forceinline__ double rep_sum(const double* p, int idx, int /*nrep*/, long long stride) {
   double a[PDES_NREP];
 #pragma unroll
