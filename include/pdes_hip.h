@@ -257,6 +257,11 @@ typedef struct pdes_conv_desc {
   /* appended in ABI 15 */
   const unsigned short* wbu_bwd; /* nearest-x2 + 3x3 layers: split image of the effective sub-pixel weights for the DATA gradient
                                     (pdes_pack_weights_b3up), or NULL */
+  /* appended in ABI 20 */
+  float* coef;           /* (x_ctot, 2) {batch mean, invstd} of the input buffer's channels, or NULL.  The caller zeroes it together
+                            with the statistics at the start of every step; a kernel that sums the replicas of a channel
+                            publishes the result here (invstd > 0 marks a valid entry), the kernels after it read 8 bytes
+                            instead of 2 x nrep doubles.  Train mode only */
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.

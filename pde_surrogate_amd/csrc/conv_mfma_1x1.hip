@@ -28,18 +28,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 enum { P1_FWD = 0, P1_BWD = 1 };
 
 struct BnP { float mean, invstd, gamma, beta; };
-__device__ __forceinline__ BnP bn_coef_p(const pdes_conv_desc& d, int c) {
+__device__ __forceinline__ BnP bn_coef_p(const pdes_conv_desc& d, int c, bool publish = false) {
   BnP o;
   if (d.eval_mode) {
     o.mean = d.run_mean[c];
     o.invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
   } else {
-    const double n = (double)d.B * d.Hin * d.Win;
-    const double m = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-    double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - m * m;
-    var = var < 0.0 ? 0.0 : var;
-    o.mean = (float)m;
-    o.invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+    const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * d.Hin * d.Win, d.eps, c, publish);
+    o.mean = mi.mean;
+    o.invstd = mi.invstd;
   }
   o.gamma = d.gamma[c];
   o.beta = d.beta[c];
@@ -77,7 +74,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_mfma_kernel(pdes_conv_desc
 
   if (MODE == P1_FWD) {
     for (int c = tid; c < kC; c += 64 * NW) {
-      const BnP k = bn_coef_p(d, c);
+      const BnP k = bn_coef_p(d, c, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
       cf4[c] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
     }
   }

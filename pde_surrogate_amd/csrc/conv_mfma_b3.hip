@@ -50,18 +50,15 @@ struct B3Geo {
 };
 
 struct BnB { float mean, invstd, gamma, beta; };
-__device__ __forceinline__ BnB bn_coef_b3(const pdes_conv_desc& d, int c) {
+__device__ __forceinline__ BnB bn_coef_b3(const pdes_conv_desc& d, int c, bool publish = false) {
   BnB o;
   if (d.eval_mode) {
     o.mean = d.run_mean[c];
     o.invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
   } else {
-    const double n = (double)d.B * d.Hin * d.Win;
-    const double m = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-    double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - m * m;
-    var = var < 0.0 ? 0.0 : var;
-    o.mean = (float)m;
-    o.invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+    const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * d.Hin * d.Win, d.eps, c, publish);
+    o.mean = mi.mean;
+    o.invstd = mi.invstd;
   }
   o.gamma = d.gamma[c];
   o.beta = d.beta[c];
@@ -116,7 +113,7 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   if (MODE == B3_FWD) {
     for (int c = tid; c < kpad; c += 256) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < d.Cin) { const BnB k = bn_coef_b3(d, c); v = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f); }
+      if (c < d.Cin) { const BnB k = bn_coef_b3(d, c, (blockIdx.x | blockIdx.y | blockIdx.z) == 0); v = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f); }
       cf4[c] = v;
     }
   }

@@ -55,12 +55,9 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
         mean = d.run_mean[c];
         invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
       } else {
-        const double n = (double)d.B * HW;
-        const double m = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        mean = (float)m;
-        invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+        const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * HW, d.eps, c, (blockIdx.x | blockIdx.y) == 0);
+        mean = mi.mean;
+        invstd = mi.invstd;
       }
       v = make_float4(mean, d.gamma[c] * invstd, d.beta[c], 0.f);
     }

@@ -29,18 +29,15 @@ namespace pdes {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct BnU { float mean, invstd, gamma, beta; };
-__device__ __forceinline__ BnU bn_coef_u(const pdes_conv_desc& d, int c) {
+__device__ __forceinline__ BnU bn_coef_u(const pdes_conv_desc& d, int c, bool publish = false) {
   BnU o;
   if (d.eval_mode) {
     o.mean = d.run_mean[c];
     o.invstd = (float)(1.0 / sqrt((double)d.run_var[c] + (double)d.eps));
   } else {
-    const double n = (double)d.B * d.Hin * d.Win;
-    const double m = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-    double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - m * m;
-    var = var < 0.0 ? 0.0 : var;
-    o.mean = (float)m;
-    o.invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+    const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * d.Hin * d.Win, d.eps, c, publish);
+    o.mean = mi.mean;
+    o.invstd = mi.invstd;
   }
   o.gamma = d.gamma[c];
   o.beta = d.beta[c];
@@ -89,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_up_mfma_kernel(pdes_conv_desc d, con
   if (MODE == UP_FWD) {
     for (int c = tid; c < kpad; c += 256) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < d.Cin) { const BnU k = bn_coef_u(d, c); v = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f); }
+      if (c < d.Cin) { const BnU k = bn_coef_u(d, c, (blockIdx.x | blockIdx.y | blockIdx.z) == 0); v = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f); }
       cf4[c] = v;
     }
   }

@@ -80,12 +80,9 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
     if (c < d.Cin) {
       double mean, invstd;
       if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
-      else {
-        const double n = (double)d.B * HWi;
-        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        invstd = 1.0 / sqrt(var + (double)d.eps);
+      else {           // (the table entry, or the replica sums; published by the workgroups of the first pixel split)
+        const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * HWi, d.eps, c, blockIdx.x == 0);
+        mean = mi.mean; invstd = mi.invstd;
       }
       m = (float)mean; s = d.gamma[c] * (float)invstd; bt = d.beta[c];
     }
@@ -333,12 +330,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_up_kernel(pdes_conv_desc 
     if (c < d.Cin) {
       double mean, invstd;
       if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
-      else {
-        const double n = (double)d.B * HWl;
-        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        invstd = 1.0 / sqrt(var + (double)d.eps);
+      else {           // (the table entry, or the replica sums; published by the workgroups of the first pixel split)
+        const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * HWl, d.eps, c, blockIdx.x == 0);
+        mean = mi.mean; invstd = mi.invstd;
       }
       m = (float)mean; sc = d.gamma[c] * (float)invstd; bt = d.beta[c];
     }

@@ -64,12 +64,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_kernel(pdes_conv_desc d,
     if (c < d.Cin) {
       double mean, invstd;
       if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
-      else {
-        const double n = (double)d.B * HW;
-        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        invstd = 1.0 / sqrt(var + (double)d.eps);
+      else {           // (the table entry, or the replica sums; published by the workgroups of the first pixel split)
+        const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * HW, d.eps, c, blockIdx.x == 0);
+        mean = mi.mean; invstd = mi.invstd;
       }
       m = (float)mean; s = d.gamma[c] * (float)invstd; bt = d.beta[c];
     }
@@ -275,12 +272,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b3_up_kernel(pdes_conv_desc
     if (c < d.Cin) {
       double mean, invstd;
       if (d.eval_mode) { mean = d.run_mean[c]; invstd = 1.0 / sqrt((double)d.run_var[c] + (double)d.eps); }
-      else {
-        const double n = (double)d.B * HW;
-        mean = rep_sum(d.x_stats, 2 * c, d.nrep, d.rep_stride) / n;
-        double var = rep_sum(d.x_stats, 2 * c + 1, d.nrep, d.rep_stride) / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        invstd = 1.0 / sqrt(var + (double)d.eps);
+      else {           // (the table entry, or the replica sums; published by the workgroups of the first pixel split)
+        const MeanInv mi = batch_mean_invstd(d.coef, d.x_stats, d.rep_stride, (double)d.B * HW, d.eps, c, blockIdx.x == 0);
+        mean = mi.mean; invstd = mi.invstd;
       }
       m = (float)mean; s = d.gamma[c] * (float)invstd; bt = d.beta[c];
     }

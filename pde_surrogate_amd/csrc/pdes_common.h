@@ -70,6 +70,27 @@ __device__ __forceinline__ double rep_sum(const double* p, int idx, int /*nrep*/
   for (int r = 0; r < PDES_NREP; ++r) s += a[r];
   return s;
 }
+// Batch mean / inverse standard deviation of channel `c` of a buffer.  `coef` (may be NULL) is the per-channel {mean,
+// invstd} table of the buffer, zeroed with the statistics arena at the start of every step: an entry with invstd > 0 was
+// published earlier in THIS step from the completed sums (same expression, same bits), otherwise the replicas are summed
+// here and -- from one workgroup of the launch (`publish`) -- the entry is written for the kernels that follow.  One
+// 8-byte access per entry: no torn reads.
+struct MeanInv { float mean, invstd; };
+__device__ __forceinline__ MeanInv batch_mean_invstd(float* coef, const double* x_stats, long long rs, double n, float eps,
+                                                     int c, bool publish) {
+  MeanInv o;
+  if (coef) {
+    const float2 e = reinterpret_cast<const float2*>(coef)[c];
+    if (e.y > 0.f) { o.mean = e.x; o.invstd = e.y; return o; }
+  }
+  const double m = rep_sum(x_stats, 2 * c, PDES_NREP, rs) / n;
+  double var = rep_sum(x_stats, 2 * c + 1, PDES_NREP, rs) / n - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  o.mean = (float)m;
+  o.invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (coef && publish) reinterpret_cast<float2*>(coef)[c] = make_float2(o.mean, o.invstd);
+  return o;
+}
 __device__ __forceinline__ int rep_of_block(int nrep) {
   return (int)((blockIdx.x + 7u * blockIdx.y + 3u * blockIdx.z) % (unsigned)nrep);
 }

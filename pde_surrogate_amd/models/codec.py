@@ -43,6 +43,7 @@ class ConvDesc(ctypes.Structure):
         ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong), ('wbu_fwd', _P),
         ('g_add', _P), ('x2', _P), ('x2_ctot', _I), ('t2', _P), ('p0', _P), ('p1', _P), ('acc', _P), ('flags', _I),
         ('wbu_bwd', _P),
+        ('coef', _P),
     ]
 
 
@@ -369,8 +370,11 @@ class _Engine(_EngineBase):
                 n_bn += 2 * s.cin
         # NREP replicas of the whole arena spread same-address fp64 atomics (readers sum them)
         self.nrep, self.rep_stride = _lib.lib().pdes_stat_replicas(), 2 * n_stat + n_bn
-        self.arena = torch.zeros(self.nrep * self.rep_stride, device=dev, dtype=torch.float64)
+        # ... followed by the {mean, invstd} table of every buffer channel (float2 = one double slot per channel): cleared
+        # with the arena, filled by the first kernel of a step that sums a channel's replicas (pdes_conv_desc.coef)
+        self.arena = torch.zeros(self.nrep * self.rep_stride + n_stat // 2, device=dev, dtype=torch.float64)
         a0 = self.arena.data_ptr()
+        cf = lambda k: a0 + 8 * (self.nrep * self.rep_stride + self.stat_off[k] // 2)
         xs = lambda k: a0 + 8 * self.stat_off[k]
         ts = lambda k: a0 + 8 * (n_stat + self.stat_off[k])
         bg = lambda nm: a0 + 8 * (2 * n_stat + bn_off[nm])
@@ -430,6 +434,7 @@ class _Engine(_EngineBase):
                     one, zero, var = net._identity_bn(dev, s.cin)
                     d.gamma, d.beta, d.run_mean, d.run_var = one.data_ptr(), zero.data_ptr(), zero.data_ptr(), var.data_ptr()
                 d.x_stats = xs(s.src)
+                d.coef = cf(s.src)
                 d.t_in = self.T[s.src].data_ptr()
                 d.t_stats = ts(s.src)
                 d.bn_grad = bg(s.norm or ('identity:' + s.conv))
