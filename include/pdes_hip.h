@@ -262,6 +262,9 @@ typedef struct pdes_conv_desc {
                             with the statistics at the start of every step; a kernel that sums the replicas of a channel
                             publishes the result here (invstd > 0 marks a valid entry), the kernels after it read 8 bytes
                             instead of 2 x nrep doubles.  Train mode only */
+  /* appended in ABI 21 */
+  const float* fin_coef; /* the same table of the OUTPUT buffer (next to fin_xstats), for the finalize of this layer's output
+                            channels; NULL: the finalize sums the replicas of x itself */
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.

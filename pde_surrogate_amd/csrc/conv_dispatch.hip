@@ -32,7 +32,7 @@ int channel_mask_backward(const pdes_conv_desc& d, hipStream_t st);
 // descriptors that are not convolutions: no weights, their own forward / backward kernels
 int bn_backward_finalize_launch(const pdes_context* ctx, float* t, const float* x, const double* x_stats,
                                 const double* t_stats, int B, int ctot, int c0, int c1, int HW, float eps, int nrep,
-                                long long rep_stride, hipStream_t st, hipEvent_t done, const float* add);
+                                long long rep_stride, hipStream_t st, hipEvent_t done, const float* add, const float* coef);
 // flow operators of the conditional Glow (flow_ops.hip)
 int flow_copy_forward(const pdes_conv_desc& d, hipStream_t st);
 int flow_copy_backward(const pdes_conv_desc& d, hipStream_t st);
@@ -158,7 +158,7 @@ extern "C" int pdes_backward_chain(const pdes_context* ctx, const pdes_conv_desc
     if (d.fin_tstats && !d.g_fused) {
       const int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
                                                  d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
-                                                 d.rep_stride, st, nullptr, d.g_add);
+                                                 d.rep_stride, st, nullptr, d.g_add, d.fin_coef);
       if (rc) return rc;
     }
     if (d.has_bn || is_resample_op(d) || d.t_in) {
@@ -278,7 +278,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       if (fork && use_signal && i != 0 && !is_resample_op(d)) signalled = cx->events[nev++];
       int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
                                            d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
-                                           d.rep_stride, st, signalled, d.g_add);
+                                           d.rep_stride, st, signalled, d.g_add, d.fin_coef);
       if (rc) return rc;
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream

@@ -43,7 +43,7 @@ class ConvDesc(ctypes.Structure):
         ('ws_defer', _I), ('nrep', _I), ('rep_stride', ctypes.c_longlong), ('wbu_fwd', _P),
         ('g_add', _P), ('x2', _P), ('x2_ctot', _I), ('t2', _P), ('p0', _P), ('p1', _P), ('acc', _P), ('flags', _I),
         ('wbu_bwd', _P),
-        ('coef', _P),
+        ('coef', _P), ('fin_coef', _P),
     ]
 
 
@@ -449,6 +449,7 @@ class _Engine(_EngineBase):
             if s.dst != 'out':
                 d.out_stats = xs(s.dst)
                 d.fin_xstats, d.fin_tstats = xs(s.dst), ts(s.dst)
+                d.fin_coef = cf(s.dst)
                 d.g = self.T[s.dst].data_ptr()      # finalised in place before use
                 d.g_ctot, d.g_coff = bufs[s.dst][0], s.dst_coff
                 if s.up == UP_BILINEAR_OP:          # its consumer's BatchNorm is the identity: T IS dL/d(out)
