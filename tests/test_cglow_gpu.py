@@ -114,8 +114,9 @@ def test_g19_default_net_from_seeded_initial_values(dev):
     for k, v in net.named_parameters():
         h.update(k.encode())
         h.update(v.detach().numpy().tobytes())
-    if h.hexdigest() != str(g['param_sha256']):
-        pytest.skip('local torch / numpy RNG streams differ from the fixture generator')
+    if h.hexdigest() != str(g['param_sha256']):     # other RNG streams: the stored (perturbed) parameters and buffers
+        from conftest import load_seeded
+        load_seeded(net, 'cglow_g19', 'cglow_g19_buffers')
     net = net.to(dev).train()
     x = torch.from_numpy(g['x']).to(dev)
     loss, loss_pde, neg_ent, y, logp = reverse_kl(net, x, _eps(g, dev), float(g['beta']), float(g['weight_bound']))

@@ -83,8 +83,9 @@ def test_g15_max_likelihood_fused_and_dropin_steps(dev):
         for k, v in n.state_dict().items():
             h.update(k.encode())
             h.update(v.numpy().tobytes())
-        if h.hexdigest() != str(g6['sha256']):
-            pytest.skip('local torch RNG stream differs from the fixture generator')
+        if h.hexdigest() != str(g6['sha256']):      # a torch with another RNG stream: the stored initial values
+            from conftest import load_seeded
+            load_seeded(n, 'densed_seed1')
         return n.to(dev).train()
 
     sched = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)

@@ -11,6 +11,7 @@ whether the local torch reproduces it).
     python tools/gen_golden.py            # rewrites tests/golden/*.npz
     python tools/gen_golden.py glow       # only G18-G20 (conditional Glow)
     python tools/gen_golden.py round3     # only G21 (any field size; correct=False through the loss functions)
+    python tools/gen_golden.py round4     # only W_seeded (seeded initial parameters) and G22 (DenseED at B = 64 / 128 / 256)
 """
 import hashlib
 import io
@@ -263,6 +264,111 @@ def gen_round3():
                 out[f'gh65_f5{sfx}'], out[f'gv65_f5{sfx}'] = gh.detach().numpy(), gv.detach().numpy()
             out[f'adj65_f{fs}{sfx}'] = it.grad.numpy()
     np.savez_compressed(os.path.join(OUT, 'G21_any_size.npz'), **out)
+
+
+def fixed_projection(shape, tag):
+    """an RNG-free projection direction for a gradient tensor (tests rebuild it bit for bit): cos of a ramp"""
+    n = int(np.prod(shape))
+    return np.cos(0.37 * np.arange(n, dtype=np.float64) + 0.11 * tag).reshape(shape)
+
+
+def gen_round4():
+    """round 4.  (1) W_seeded.npz: the seeded INITIAL parameters the G6/G10/G11/G12/G13/G15/G19 fixtures were made
+    from (default DenseED from torch.manual_seed(1), Decoder(1,3,[8,6]) from manual_seed(3), the default conditional
+    Glow of G19 after its perturbation) -- SURVEY 8(c) G6 fallback: a torch whose RNG stream differs loads these instead
+    of skipping.  (2) G22: the default DenseED ABOVE the training batch: train mode at B = 256 and B = 128 (config 3's
+    strong-scaled points; output, loss terms, running statistics, gradient norms + projections of all 82 tensors, a
+    handful of tensors in full) and eval mode at B = 64 (the reference's default test() batch,
+    train_codec_mixed_residual.py:63,166-206) -- the kernel plans are chosen by batch size."""
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    sob = SobelFilter(64, correct=True)
+    w = {}
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    g6 = np.load(os.path.join(OUT, 'G6_densed_default.npz'))
+    assert sd_sha(net.state_dict()) == str(g6['sha256'])
+    for k, v in net.state_dict().items():
+        w['densed_seed1/' + k] = v.numpy().copy()
+    torch.manual_seed(3)
+    dec = Decoder(1, 3, [8, 6])
+    assert sd_sha(dec.state_dict()) == str(np.load(os.path.join(OUT, 'G10_decoder.npz'))['sha256'])
+    for k, v in dec.state_dict().items():
+        w['decoder_seed3/' + k] = v.numpy().copy()
+    G = _glow_module()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    gl = quiet(G.MultiScaleCondGlow, 32, 1, 3, [3, 4, 4], [6, 6, 6], LUdecompose=True, squeeze_factor=2)
+    g19 = np.load(os.path.join(OUT, 'G19_cglow_default.npz'))
+    assert sd_sha({k: v for k, v in gl.named_parameters()}) == str(g19['init_sha256'])
+    pn = {k for k, _ in gl.named_parameters()}
+    for k, v in gl.state_dict().items():            # buffers only (BatchNorm running statistics, permutations, masks)
+        if k not in pn:
+            w['cglow_g19_buffers/' + k] = v.detach().numpy().copy()
+    _perturb_glow(gl, torch.Generator().manual_seed(13), 0.4)
+    assert sd_sha({k: v for k, v in gl.named_parameters()}) == str(g19['param_sha256'])
+    for k, v in gl.named_parameters():
+        w['cglow_g19/' + k] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'W_seeded.npz'), **w)
+
+    # ---- G22
+    x = grf_kle_fields(256, seed=22, cache_dir='/tmp')
+    g = {'x': x}
+    full = ['features.In_conv.weight', 'features.EncBlock1.denselayer3.conv1.weight',
+            'features.TransDown1.conv1.weight', 'features.TransDown1.conv2.weight',
+            'features.DecBlock1.denselayer5.conv1.weight', 'features.DecBlock1.denselayer5.norm1.bias',
+            'features.TransUp1.conv1.weight', 'features.TransUp1.conv2.weight',
+            'features.DecBlock2.denselayer6.conv1.weight', 'features.DecBlock2.denselayer2.norm1.weight',
+            'features.LastTransUp.conv1.weight', 'features.LastTransUp.conv2.weight',
+            'features.LastTransUp.conv3.weight', 'features.LastTransUp.norm3.bias']
+    names = [k for k, _ in net.named_parameters()]
+    g['param_names'] = np.array(names)
+    from oracle import codec as ocodec, train as otrain
+    for B in (256, 128):
+        net.train()
+        net.zero_grad()
+        xt = torch.from_numpy(x[:B])
+        yo = net(xt)
+        terms = ref_loss(xt, yo, sob, 10.0)
+        terms[0].backward()
+        t = 'b%d/' % B
+        yn = yo.detach().numpy()
+        g[t + 'y_first'], g[t + 'y_last'], g[t + 'y_slice'] = yn[0], yn[B - 1], yn[:, :, ::8, ::8]
+        g[t + 'terms'] = np.array([float(v) for v in terms], np.float64)
+        grads = {k: p.grad.numpy().copy() for k, p in net.named_parameters()}
+        g[t + 'grad_norms'] = np.array([float(np.linalg.norm(grads[k].astype(np.float64))) for k in names])
+        g[t + 'grad_proj'] = np.array([float((grads[k].astype(np.float64) * fixed_projection(grads[k].shape, i)).sum())
+                                       for i, k in enumerate(names)])
+        for k in full:
+            g[t + 'grad/' + k] = grads[k]
+        for k, v in net.state_dict().items():
+            if 'running' in k:
+                g[t + 'sd/' + k] = v.numpy().copy()
+        # the reference's own fp32 rounding floor against the fp64 oracle (same weights, same input), as for G11
+        sd64 = {k: (torch.from_numpy(w['densed_seed1/' + k]).double() if w['densed_seed1/' + k].dtype == np.float32
+                    else torch.from_numpy(w['densed_seed1/' + k]).clone()) for k in net.state_dict().keys()}
+        tr64 = otrain.CpuTrainer(sd64, [6, 8, 6])
+        _, l64, _ = tr64.forward_loss(xt.double(), True)
+        l64.backward()
+        assert list(tr64.keys) == names
+        g[t + 'ref_fp32_vs_fp64_floor'] = np.array(
+            [float(np.linalg.norm(grads[k].astype(np.float64) - sd64[k].grad.numpy()) / np.linalg.norm(sd64[k].grad.numpy()))
+             for k in names])
+        g[t + 'grad_norms64'] = np.array([float(sd64[k].grad.norm()) for k in names])
+        g[t + 'grad_proj64'] = np.array([float((sd64[k].grad.numpy() * fixed_projection(grads[k].shape, i)).sum())
+                                         for i, k in enumerate(names)])
+        print('G22 B=%d loss %.6f  floor max %.2e' % (B, float(terms[0]), g[t + 'ref_fp32_vs_fp64_floor'].max()))
+    # eval mode at the default test batch, with the running statistics the two training forwards left behind
+    net.eval()
+    with torch.no_grad():
+        xt = torch.from_numpy(x[:64])
+        yo = net(xt)
+        terms = ref_loss(xt, yo, sob, 10.0)
+    g['e64/y_head'] = yo.numpy()[:4]
+    g['e64/y_slice'] = yo.numpy()[:, :, ::4, ::4]
+    g['e64/terms'] = np.array([float(v) for v in terms], np.float64)
+    np.savez_compressed(os.path.join(OUT, 'G22_densed_batches.npz'), **g)
+    for f in ('W_seeded.npz', 'G22_densed_batches.npz'):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
 def gen_dropout():
@@ -675,6 +781,7 @@ def main():
     gen_bottleneck()
     gen_glow()
     gen_round3()
+    gen_round4()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
@@ -689,5 +796,8 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'round3':  # only G21 (any field size, correct=False through the loss)
         torch.set_num_threads(8)
         gen_round3()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round4':  # only W_seeded (initial parameters) and G22 (B = 64 / 128 / 256)
+        torch.set_num_threads(8)
+        gen_round4()
     else:
         main()
