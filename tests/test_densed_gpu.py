@@ -182,13 +182,19 @@ def test_g22_above_the_training_batch_train_256_128_then_eval_64(dev):
     (train_codec_mixed_residual.py:63,166-206), config 3's strong-scaled per-GPU batches are 128 and 256.  The same
     sequence as the generator: train-mode forward + loss + backward at B = 256, then at B = 128 (outputs, loss terms
     1e-5; the norm and a fixed projection of ALL 82 gradient tensors, fourteen tensors element by element; the running
-    statistics after each), then eval mode at B = 64 on those running statistics (outputs, loss terms)."""
-    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    statistics after each), then eval mode at B = 64 on those running statistics (outputs, loss terms), then the
+    train-mode step at B = 64."""
     g = golden('G22_densed_batches.npz')
     net = _default_net(dev)
     x = torch.from_numpy(g['x']).to(dev)
     _check_g22_train(net, g, x, 256, dev)
     _check_g22_train(net, g, x, 128, dev)
+    _eval64(net, g, x)
+    _check_g22_train(net, g, x, 64, dev)         # train mode at 64 too (the generator's order)
+
+
+def _eval64(net, g, x):
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
     net.eval()
     with torch.no_grad():
         xb = x[:64]

@@ -323,7 +323,8 @@ def gen_round4():
     names = [k for k, _ in net.named_parameters()]
     g['param_names'] = np.array(names)
     from oracle import codec as ocodec, train as otrain
-    for B in (256, 128):
+
+    def train_case(B):
         net.train()
         net.zero_grad()
         xt = torch.from_numpy(x[:B])
@@ -357,6 +358,9 @@ def gen_round4():
         g[t + 'grad_proj64'] = np.array([float((sd64[k].grad.numpy() * fixed_projection(grads[k].shape, i)).sum())
                                          for i, k in enumerate(names)])
         print('G22 B=%d loss %.6f  floor max %.2e' % (B, float(terms[0]), g[t + 'ref_fp32_vs_fp64_floor'].max()))
+
+    for B in (256, 128):
+        train_case(B)
     # eval mode at the default test batch, with the running statistics the two training forwards left behind
     net.eval()
     with torch.no_grad():
@@ -366,6 +370,7 @@ def gen_round4():
     g['e64/y_head'] = yo.numpy()[:4]
     g['e64/y_slice'] = yo.numpy()[:, :, ::4, ::4]
     g['e64/terms'] = np.array([float(v) for v in terms], np.float64)
+    train_case(64)          # and the train-mode step at 64 (after the eval case: the entries above stay what they were)
     np.savez_compressed(os.path.join(OUT, 'G22_densed_batches.npz'), **g)
     for f in ('W_seeded.npz', 'G22_densed_batches.npz'):
         print(f, os.path.getsize(os.path.join(OUT, f)))
