@@ -33,25 +33,36 @@ class DirectRccl:
     def __init__(self, group=None, device=None):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != 'nccl':
             raise RuntimeError('DirectRccl needs an initialised torch.distributed process group with backend nccl (RCCL)')
-        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-        L = ctypes.CDLL(path)                                # the library torch itself loaded: the same RCCL, the same HIP runtime
-        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
-        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
-        L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                                    ctypes.c_void_p, ctypes.c_void_p]
-        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-        L.ncclGetErrorString.argtypes = [ctypes.c_int]
-        L.ncclGetErrorString.restype = ctypes.c_char_p
-        self._L = L
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        uid = _NcclUniqueId()
-        if self.rank == 0:
-            self._check(L.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-        payload = [bytes(bytearray(uid)) if self.rank == 0 else None]
-        src = dist.get_global_rank(group, 0) if group is not None else 0
-        dist.broadcast_object_list(payload, src=src, group=group, device=self.device)      # 128 bytes, once
-        ctypes.memmove(ctypes.byref(uid), payload[0], 128)
+        self._comm = None
+        # 1. everything that can fail on ONE rank only (loading the library, ncclGetUniqueId on rank 0) happens before any
+        #    collective, and its outcome is exchanged together with the id: either every rank goes on to
+        #    ncclCommInitRank or every rank raises -- no rank is left waiting in a collective the others never enter
+        uid, err = _NcclUniqueId(), None
+        try:
+            path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            L = ctypes.CDLL(path)                            # the library torch itself loaded: the same RCCL, the same HIP runtime
+            L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+            L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+            L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p]
+            L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            L.ncclGetErrorString.argtypes = [ctypes.c_int]
+            L.ncclGetErrorString.restype = ctypes.c_char_p
+            self._L = L
+            if self.rank == 0:
+                self._check(L.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        except Exception as e:                               # noqa: BLE001
+            err = e
+        status = [None] * self.world
+        dist.all_gather_object(status, (None if err is None else f'{type(err).__name__}: {err}',
+                                        bytes(bytearray(uid)) if self.rank == 0 and err is None else None), group=group)
+        failed = [(r, s[0]) for r, s in enumerate(status) if s[0] is not None]
+        if failed:
+            raise RuntimeError('DirectRccl: local setup failed on rank(s) ' + ', '.join(f'{r} ({m})' for r, m in failed))
+        ctypes.memmove(ctypes.byref(uid), status[0][1], 128)
+        # 2. the collective part
         comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             self._check(L.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
@@ -67,15 +78,23 @@ class DirectRccl:
             self._check(rc, 'ncclAllReduce')
 
     def close(self):
+        """destroy the communicator (idempotent; MixedResidualTrainer.close / __del__ call it)"""
         if getattr(self, '_comm', None):
             self._L.ncclCommDestroy(self._comm)
             self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                    # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def make_direct_rccl(group, device):
     """a DirectRccl over `group` for the per-step gradient exchange, or None (-> torch.distributed.all_reduce): when the
     backend is not nccl, when PDES_DP_DIRECT=0, or when ANY rank failed to build or probe its communicator -- the ranks
-    agree on the outcome over torch.distributed, so that all of them take the same path"""
+    agree on the outcome over torch.distributed, so that all of them take the same path (DirectRccl's constructor fails
+    on every rank or on none before it enters RCCL; the probe's verdict is exchanged below)"""
     if os.environ.get('PDES_DP_DIRECT', '1') == '0' or dist.get_backend(group) != 'nccl':
         return None
     device = torch.device(device)

@@ -73,9 +73,11 @@ def load_adam_state(trainer, sd):
     return True
 
 
-def to_torch_adam_state(sd, model):
+def to_torch_adam_state(sd, model, optimizer=None):
     """an 'optimizer_state_dict' in either format -> something torch.optim.Adam(model.parameters()).load_state_dict
-    accepts (the flat round-2 format is sliced per parameter; a torch state_dict is returned as is)"""
+    accepts (the flat round-2 format is sliced per parameter; a torch state_dict is returned as is).  The flat format
+    carries no hyper-parameters and torch's load_state_dict INSTALLS the param_groups it is handed, so pass the
+    `optimizer` that will load the result: its own param_groups (--weight-decay, betas, eps, lr) go into the result."""
     if 'state' in sd or 'exp_avg' not in sd:
         return sd
 
@@ -83,8 +85,13 @@ def to_torch_adam_state(sd, model):
         pass
     t = _T()
     t.model, t.exp_avg, t.exp_avg_sq, t.step_count = model, sd['exp_avg'], sd['exp_avg_sq'], int(sd['step'])
-    t.lr, t.betas, t.eps, t.wd = 1e-3, (0.9, 0.999), 1e-8, 0.0      # the loading optimizer keeps its own hyper-parameters...
+    t.lr, t.betas, t.eps, t.wd = 1e-3, (0.9, 0.999), 1e-8, 0.0      # placeholders: replaced by the loader's groups below
     out = adam_state_dict(t)
+    if optimizer is not None:
+        own = optimizer.state_dict()['param_groups']
+        if [len(g['params']) for g in own] != [len(g['params']) for g in out['param_groups']]:
+            raise ValueError('to_torch_adam_state: the optimizer does not hold the model\'s parameters as one group')
+        out['param_groups'] = own
     return out
 
 
@@ -126,7 +133,11 @@ class MixedResidualTrainer:
         self.terms = torch.zeros(5, device=self.dev)
         self.terms_accum = torch.zeros(5, device=self.dev, dtype=torch.float64)
         self.n_accum = 0
-        if use_graph not in (False, True, 'segments', 'forward'):
+        if isinstance(use_graph, int) and not isinstance(use_graph, bool):
+            if use_graph not in (0, 1):
+                raise ValueError(f'use_graph: {use_graph!r} is neither a bool nor one of the named modes')
+            use_graph = bool(use_graph)              # 1 == True passes a membership test but not `is True`
+        if not (isinstance(use_graph, bool) or use_graph in ('segments', 'forward')):
             raise ValueError("use_graph: False (eager launches), True (one serial hipGraph), 'segments' (linear graphs per "
                              "stage) or 'forward' (the forward pass + loss as one graph, the backward pass eager)")
         self.segments = use_graph in ('segments', 'forward')
@@ -159,6 +170,18 @@ class MixedResidualTrainer:
             # choice over gloo, and the fallback when the direct communicator cannot be made; PDES_DP_DIRECT=0 selects
             # it) costs the host ~0.3 ms per call.
             self._rccl = parallel.make_direct_rccl(process_group, self.dev)
+
+    def close(self):
+        """release what the trainer holds outside torch's allocator: the direct RCCL communicator (idempotent)"""
+        r, self._rccl = getattr(self, '_rccl', None), None
+        if r is not None:
+            r.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                    # noqa: BLE001
+            pass
 
     def _on_bucket(self, _user, first_layer, stream):
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
@@ -443,6 +466,9 @@ class ReverseKLTrainer:
         self._eps_bufs = [self.eng.X[name] for _, name in sorted(model._meta['eps'].items())]
         self._grad_clean = False
         self._L = _lib.lib()
+
+    close = MixedResidualTrainer.close
+    __del__ = MixedResidualTrainer.__del__
 
     def load_batch(self, data, index):
         torch.index_select(data, 0, index, out=self.x_static)

@@ -311,6 +311,9 @@ def test_g13_bilinear_upsampling(dev):
             keep[top] = False
             rest = float(np.linalg.norm((got - want)[keep]) / np.linalg.norm(want))
         if rest is not None and rest < 1e-3 and e >= 1.5e-3:
+            # pinned to the measured signature: only DecBlock1's eight BatchNorm BIAS gradients, channel 51
+            assert k.startswith('grad/features.DecBlock1.denselayer') and k.endswith('.norm1.bias'), (k, e)
+            assert int(top[0]) == 51, (k, top, e)
             assert e < 2e-2, (k, e)
             flipped.append((k, float(e), rest))
             worst.add(int(top[0]))
@@ -319,7 +322,7 @@ def test_g13_bilinear_upsampling(dev):
             spread.append((k, float(e)))
     print('G13 beyond 1e-3 -- one flipped unit (concentrated):', flipped, 'worst channels', sorted(worst), '; upstream (spread):', spread)
     assert len(spread) <= 3, spread
-    assert len(worst) <= 2, (sorted(worst), flipped)                 # every concentrated deviation names the same unit(s)
+    assert worst <= {51}, (sorted(worst), flipped)                   # every concentrated deviation names the same unit
     assert n_full >= 55
 
 

@@ -204,7 +204,7 @@ def main(argv=None):
                 say('WARNING: the checkpoint holds no optimizer_state_dict: Adam restarts from zero moments')
             else:
                 model._engine(torch.zeros((args.batch_size, args.x_channels, args.imsize, args.imsize), device=device))   # flat layout
-                optimizer.load_state_dict(to_torch_adam_state(checkpoint['optimizer_state_dict'], model))
+                optimizer.load_state_dict(to_torch_adam_state(checkpoint['optimizer_state_dict'], model, optimizer))
     metrics = TestMetrics(3, device) if have_targets else None
 
     def test(epoch):
