@@ -341,6 +341,24 @@ def rendezvous(gpus):
     return rank, local, world, dev
 
 
+def batch_offset(i, global_batch, rank, b, ntrain):
+    """offset into the shared permutation of rank `rank`'s `b` samples of global step i (contiguous split of the global
+    batch, parallel.shard_indices; wraps around the dataset)"""
+    return (i * global_batch + rank * b) % (ntrain - b + 1)
+
+
+def pin_host(dev, local, world):
+    """each rank onto its share of the cores of its GPU's NUMA node (parallel.pin_rank_to_gpu_numa); all ranks' plans are
+    gathered for the line"""
+    from pde_surrogate_amd import parallel
+    info = parallel.pin_rank_to_gpu_numa(dev, local, world)
+    if world > 1:
+        got = [None] * world
+        torch.distributed.all_gather_object(got, info)
+        return got
+    return [info]
+
+
 def host_enqueue_timing(trainer, load, k=50):
     """wall time the host needs to ENQUEUE a training step (no synchronisation inside the timed region) against the
     time until the GPU has finished it, and where the host time goes (per-phase perf_counter deltas inside
@@ -481,6 +499,12 @@ def main():
     ap.add_argument('--steps', type=int, default=256, help='timed steps (default: two epochs of config 2, SURVEY 8(d))')
     ap.add_argument('--warmup', type=int, default=128, help='untimed steps before them (default: one epoch)')
     ap.add_argument('--batch-size', type=int, default=32, help='per-GPU minibatch')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='STRONG scaling: a fixed global minibatch split over the ranks (configs[2]: 256 = 8 x 32; per-rank '
+                         'batch = global / ranks).  Default: weak scaling, --batch-size per rank')
+    ap.add_argument('--launch-mode', default='auto', choices=['auto', 'eager', 'forward'],
+                    help="auto (default): eager launches unless the warm-up finds the host enqueue time above 0.8 x the "
+                         "step time, then the forward pass is replayed as a hipGraph ('forward': less host work per step)")
     ap.add_argument('--ntrain', type=int, default=None,
                     help='dataset size (default: 4096 = configs[1] on one GPU, 8192 = configs[2] under torchrun)')
     ap.add_argument('--graph', action='store_true',
@@ -520,9 +544,22 @@ def main():
         t = torch.ones(1, device=dev if dev.type == 'cuda' else 'cpu')
         if world > 1:
             torch.distributed.all_reduce(t)
+        line = {'rendezvous': 'ok', 'ranks': int(t.item()), 'world_size': world,
+                'backend': torch.distributed.get_backend() if world > 1 else None}
+        if args.global_batch is not None:                  # the strong-scaled split, as the timed run would take it
+            if args.global_batch % world:
+                raise SystemExit(f'--global-batch {args.global_batch} is not a multiple of the {world} ranks')
+            b = args.global_batch // world
+            mine = [batch_offset(i, args.global_batch, rank, b, args.ntrain) for i in range(3)]
+            got = [None] * world
+            if world > 1:
+                torch.distributed.all_gather_object(got, mine)
+            else:
+                got = [mine]
+            line.update({'scaling': 'strong', 'global_batch': args.global_batch, 'per_rank_batch': b, 'first_offsets': got,
+                         'host_affinity': pin_host(dev, local, world)})
         if rank == 0:
-            emit({'rendezvous': 'ok', 'ranks': int(t.item()), 'world_size': world,
-                  'backend': torch.distributed.get_backend() if world > 1 else None})
+            emit(line)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -537,6 +574,11 @@ def main():
     import io
 
     B = args.batch_size
+    if args.global_batch is not None:
+        if args.global_batch % world:
+            raise SystemExit(f'--global-batch {args.global_batch} is not a multiple of the {world} ranks')
+        B = args.global_batch // world
+    pins = pin_host(dev, local, world)
     torch.manual_seed(1)                                   # identical init on every rank
     with contextlib.redirect_stdout(io.StringIO()):
         model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
@@ -558,7 +600,7 @@ def main():
     GB = B * world
 
     def batch(i):
-        lo = (i * GB + rank * B) % (args.ntrain - B + 1)
+        lo = batch_offset(i, GB, rank, B, args.ntrain)
         trainer.load_batch(data, perm[lo:lo + B])          # the minibatch gather lands in the trainer's input buffer
         return None
 
@@ -567,18 +609,52 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
+    # warm-up; inside it (auto mode, eager launches) ONE burst of 10 steps is timed behind a device synchronise: how long the
+    # host needs to enqueue a step against how long the GPU needs to finish it.  Eight ranks share one host: where the host
+    # side comes within 0.8 of the step, the remaining steps replay the forward pass as a hipGraph (bit-identical kernels,
+    # ~0.1 ms less host work per step, +0.6 % GPU time on an unconstrained host).  The ranks decide together (MAX).
+    probe, i = None, 0
+    can_probe = args.launch_mode == 'auto' and not args.graph and not args.segments and args.warmup >= 16
+    while i < args.warmup:
+        if can_probe and probe is None and i >= min(args.warmup // 2, 24) and args.warmup - i >= 14:
+            torch.cuda.synchronize(dev)
+            p0 = time.perf_counter()
+            for _ in range(10):
+                trainer.step(batch(i), sched.step((i + 1) / total))
+                i += 1
+            p1 = time.perf_counter()
+            torch.cuda.synchronize(dev)
+            p2 = time.perf_counter()
+            ratio = (p1 - p0) / max(p2 - p0, 1e-9)
+            if world > 1:
+                t = torch.tensor([ratio], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                ratio = float(t.item())
+            probe = {'host_enqueue_ms': round((p1 - p0) * 100, 4), 'until_gpu_done_ms': round((p2 - p0) * 100, 4),
+                     'host_over_step_max_over_ranks': round(ratio, 3), 'threshold': 0.8, 'switched_to': None}
+            if ratio > 0.8:
+                trainer.set_launch_mode('forward')
+                probe['switched_to'] = 'forward'
+            continue
         trainer.step(batch(i), sched.step((i + 1) / total))
+        i += 1
+    if args.launch_mode == 'forward' and not args.graph and not args.segments:
+        trainer.set_launch_mode('forward')
+        for i in range(3):                                 # builds the program (the step after next is the first replay)
+            trainer.step(batch(i), sched.step(1 / total))
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         trainer.step(batch(i), sched.step((i + 1) / total))
     sync()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = dt
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in t.tolist()]
+        dt = float(t.max().item())
     means = trainer.epoch_means()
     ar_us = allreduce_timing(trainer) if world > 1 else None
     host = None
@@ -611,17 +687,24 @@ def main():
         us32, gb32 = loss_kernel_timing(dev, B, 200)
         usL, gbL, gbBurst = loss_kernel_timing(dev, 16384, 100, warmup=100, burst=True)
         out = {
-            'metric': 'training samples/sec (64x64 GRF-KLE512, bs=32 per GPU)',
+            'metric': 'training samples/sec (64x64 GRF-KLE512, bs=%d per GPU)' % B,
             'value': round(GB * args.steps / dt, 1), 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'strong' if args.global_batch is not None else 'weak', 'vs_baseline': None,
+            'dtype': 'f32',
             'data': 'synthetic GRF-KLE512 (exp. covariance ell=0.25, 512 KLE terms), random-init DenseED',
             'config': {'workload': '%s: GRF KLE512 64x64, ntrain=%d, bs=%d per GPU, DenseED blocks [6,8,6] '
                                    'growth 16 init 48 (740,091 params), fp32, Adam + one-cycle LR'
-                                   % ('configs[1]' if world == 1 else 'configs[2] (global batch %d = %d x %d, weak-scaled '
-                                      'points of its 8-GPU run)' % (GB, world, B), args.ntrain, B),
+                                   % ('configs[1]' if world == 1 and args.global_batch is None else
+                                      ('configs[2] STRONG-scaled (--global-batch %d = %d ranks x %d)' % (GB, world, B)
+                                       if args.global_batch is not None else
+                                       'configs[2] (global batch %d = %d x %d, weak-scaled points of its 8-GPU run)' % (GB, world, B)),
+                                      args.ntrain, B),
                        'global_batch': GB, 'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph),
-                       'launch_mode': 'segments' if args.segments else ('one serial hipGraph' if args.graph else 'eager, three streams'),
+                       'launch_mode': 'segments' if args.segments else ('one serial hipGraph' if args.graph else (
+                           'forward pass as one hipGraph, backward eager on three streams' if trainer.launch_mode == 'forward'
+                           else 'eager, three streams')),
+                       'launch_mode_probe': probe,
                        'wgrad_stream': not args.graph,
                        'ranks': torch.distributed.get_world_size() if world > 1 else 1,
                        'collective': None if world == 1 else {
@@ -643,6 +726,11 @@ def main():
                                      'put them back on the f32 pipe)'},
             'loss_mean_over_run': round(means[0], 4),
             'ranks': torch.distributed.get_world_size() if world > 1 else 1,
+            'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 4), 'max': round(max(per_rank_ms), 4),
+                                     'all': [round(v, 4) for v in per_rank_ms]},
+            'exchange_path': None if world == 1 else ('DirectRccl (ncclAllReduce by pointer)' if trainer._rccl is not None
+                                                      else 'torch.distributed.all_reduce'),
+            'host_affinity': pins,
             'allreduce_us_standalone': None if ar_us is None else round(ar_us, 1),
             'host': host,
             'roofline': {'bound': 'hbm', 'kernel': 'darcy_loss_kernel<64,bwd> (fused Sobel+Darcy residual+boundary, fwd+bwd)',

@@ -183,6 +183,25 @@ class MixedResidualTrainer:
         except Exception:                                    # noqa: BLE001
             pass
 
+    def set_launch_mode(self, use_graph):
+        """switch BETWEEN steps among eager launches (False), 'forward' (the forward pass + loss as one hipGraph, eager
+        backward) and 'segments' (linear graphs per stage): the three replay the same kernels and are bit-identical; the
+        program of a graph mode is (re)built lazily by the next steps.  The single serial graph (True) is a constructor
+        choice only.  bench.py uses this to leave eager mode on a host-constrained node."""
+        if self.use_graph or use_graph is True:
+            raise ValueError('the single serial graph is chosen at construction; set_launch_mode switches False / '
+                             "'forward' / 'segments'")
+        if use_graph not in (False, 'forward', 'segments'):
+            raise ValueError("set_launch_mode: False, 'forward' or 'segments'")
+        segments, forward = use_graph in ('segments', 'forward'), use_graph == 'forward'
+        if self._program is not None and (not segments or forward != self.forward_graph):
+            self._program = None
+        self.segments, self.forward_graph = segments, forward     # (a trainer's first two steps are eager in any mode, _step)
+
+    @property
+    def launch_mode(self):
+        return True if self.use_graph else ('forward' if self.forward_graph else ('segments' if self.segments else False))
+
     def _on_bucket(self, _user, first_layer, stream):
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
         try:

@@ -55,6 +55,13 @@ def test_round2_flat_format_still_loads_and_converts():
     opt.load_state_dict(to_torch_adam_state(flat, tr.model))
     p, off = tr.model._params[0], tr.model._offsets[0]
     assert torch.equal(opt.state[p]['exp_avg'].reshape(-1), tr.exp_avg[off:off + p.numel()])
+    # the flat format carries no hyper-parameters and load_state_dict installs the groups it is handed: with the loading
+    # optimizer passed in, ITS --weight-decay / betas / eps survive the resume
+    opt = torch.optim.Adam(tr.model._params, lr=3e-4, weight_decay=1e-2, betas=(0.8, 0.99), eps=1e-6)
+    opt.load_state_dict(to_torch_adam_state(flat, tr.model, opt))
+    g = opt.param_groups[0]
+    assert (g['lr'], g['weight_decay'], tuple(g['betas']), g['eps']) == (3e-4, 1e-2, (0.8, 0.99), 1e-6)
+    assert torch.equal(opt.state[p]['exp_avg'].reshape(-1), tr.exp_avg[off:off + p.numel()])
 
 
 def test_unstepped_and_foreign_states():

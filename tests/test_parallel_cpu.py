@@ -119,6 +119,55 @@ def test_bench_launch_contract_rendezvous_world2_gloo():
     assert p.returncode != 0 and 'WORLD_SIZE=1' in (p.stderr + p.stdout)
 
 
+def test_bench_global_batch_strong_scaling_split_world2_gloo():
+    """bench.py --global-batch 256 (configs[2] strong-scaled) under the launch contract with two ranks:
+    per-rank batch = 256 / 2, the two ranks' slices of every global step are disjoint, contiguous and cover the global
+    batch; a global batch the ranks do not divide is refused"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE='2')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rendezvous-only',
+                                       '--global-batch', '256'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line['scaling'] == 'strong' and line['global_batch'] == 256 and line['per_rank_batch'] == 128
+    r0, r1 = line['first_offsets']
+    assert r0 == [0, 256, 512] and r1 == [128, 384, 640]            # ntrain 8192: rank r takes [i*256 + r*128, +128)
+    assert [p['pinned'] for p in line['host_affinity']] == [False, False]      # no GPU here: nothing to pin to
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--rendezvous-only',
+                        '--global-batch', '255', '--ntrain', '4096'], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0                                         # one rank divides anything
+    import bench
+    assert bench.batch_offset(31, 256, 7, 32, 8192) == 31 * 256 + 7 * 32
+    assert 0 <= bench.batch_offset(40, 256, 7, 32, 8192) <= 8192 - 32         # wraps inside the dataset
+
+
+def test_affinity_plan_shares_a_numa_node_between_its_ranks():
+    """parallel.plan_affinity: eight GPUs on two sockets -> four disjoint slices per socket, inside the allowed set"""
+    from pde_surrogate_amd.parallel import plan_affinity, _parse_cpulist, _cpulist_str
+    n0 = _parse_cpulist('0-63,128-191')
+    n1 = _parse_cpulist('64-127,192-255')
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    lists = [n0] * 4 + [n1] * 4
+    allowed = set(range(256))
+    plans = [plan_affinity(r, nodes, lists, allowed) for r in range(8)]
+    assert all(len(p) == 32 for p in plans)
+    assert sorted(c for p in plans[:4] for c in p) == sorted(n0) and sorted(c for p in plans[4:] for c in p) == sorted(n1)
+    assert _cpulist_str(plans[0]) == '0-31' and _cpulist_str(plans[5]) == '96-127'
+    # a container that allows only 8 CPUs of node 0: the node's ranks share what is allowed, node 1's ranks are left alone
+    few = set(range(8))
+    assert [len(plan_affinity(r, nodes, lists, few)) for r in range(8)] == [2, 2, 2, 2, 0, 0, 0, 0]
+    assert plan_affinity(0, [0], [n0], allowed) == n0
+
+
 def test_mean_over_ranks_and_buffer_broadcast_world2_gloo():
     world, port = 2, _free_port()
     mgr = mp.Manager()

@@ -177,6 +177,9 @@ def main(argv=None):
     torch.cuda.set_device(device)
     is_main = rank == 0
     say = print if is_main else (lambda *a, **k: None)
+    if world > 1:                 # each rank onto its share of the cores of its GPU's NUMA node (PDES_PIN=0 disables)
+        pin = parallel.pin_rank_to_gpu_numa(device, local_rank, world)
+        say('host affinity (rank 0):', pin)
 
     args.train_dir = args.run_dir + '/training'
     args.pred_dir = args.train_dir + '/predictions'
