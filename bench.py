@@ -445,8 +445,7 @@ def dp1_rccl_timing(dev, data, perm, B, steps, warmup):
 def segments_timing(dev, data, perm, B, steps=100):
     """the same step replayed as linear hipGraphs joined by one event per network stage (use_graph='segments',
     models/codec.py StepProgram): what the host pays when it must be cheap (0.2 ms instead of 0.5), and what that costs on
-    the GPU (coarser release of the weight gradients).  Indicative -- a second trainer's streams share hardware queues
-    with the first one's; the per-process A/B is profiles/r03_e_launch_modes_ab.log."""
+    the GPU (coarser release of the weight gradients).  (The per-process A/B is profiles/r03_e_launch_modes_ab.log.)"""
     import contextlib
     import io
     from pde_surrogate_amd.models.codec import DenseED
@@ -759,8 +758,10 @@ def main():
                                    'note': 'the 1x1 channel-halving layers, HIP-event timed stand-alone at the training '
                                            'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}
         if world == 1 and not args.no_extras:
-            # in a process of its own: after a hipGraph capture (the segment-graph leg above, the solver leg below) every
-            # later eager step of the same process runs ~14-18 % slower (5.33 -> 6.30 ms for this one); the legs are independent
+            # in a process of its own, so that a failure of the leg cannot take the headline line with it.  (Round 3 ran it
+            # apart because a trainer built late in a process was 14-18 % slower, 5.33 -> 6.30 ms: its side streams came from
+            # torch's pool and shared hardware queues -- the weight-gradient streams are per device since round 4,
+            # profiles/r04_a_late_trainer_streams.log.)
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--leg', 'cglow'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else [])
             try:

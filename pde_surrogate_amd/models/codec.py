@@ -318,15 +318,27 @@ class _EngineBase:
         workgroup slots go to the finalize -> data-gradient chain on the main stream first, the weight gradients fill
         what is left"""
         key = self.dev if which == 'a' else (self.dev, which)
-        side = self.net._side_streams.get(key)
+        side = self.net._side_streams.get(key)             # (a per-network override, tools/ab_cumask.py)
+        if side is None:
+            side = _DEVICE_SIDE_STREAMS.get(key)
         if side is None:
             try:
                 least = torch.cuda.Stream.priority_range()[0]
             except Exception:
                 least = 0
-            side = self.net._side_streams[key] = torch.cuda.Stream(self.dev, priority=least)
+            side = _DEVICE_SIDE_STREAMS[key] = torch.cuda.Stream(self.dev, priority=least)
         return side
 
+
+
+# The two weight-gradient streams are PER DEVICE, shared by every network / engine / trainer of the process.  Each new
+# torch.cuda.Stream is another HIP stream, and the runtime multiplexes HIP streams onto a handful of hardware queues: a
+# trainer built late in a process (after other trainers, solvers, torch's own pool streams) used to draw side streams that
+# share a hardware queue with each other or with the main stream, and ran 4-16 % slower for it (5.21-5.34 vs 6.16 ms for the
+# conditional-Glow step, 1.695 vs 1.768 ms for the DenseED step: tools/post_capture.py, profiles/r04_a_late_trainer_streams.log
+# -- this, not the hipGraph capture before it, was the "slow after a capture" effect of round 3).  The first pair of a
+# process is the one every benchmark of this repository has measured.
+_DEVICE_SIDE_STREAMS = {}
 
 
 class _Engine(_EngineBase):
