@@ -233,7 +233,7 @@ extern "C" int pdes_stat_replicas(void) { return PDES_NREP; }
 namespace pdes {
 // `done` (nullable): an event that completes WITH this kernel -- it rides on the dispatch packet's own completion signal
 // (hipExtLaunchKernelGGL stop event) instead of a barrier packet behind it.  pdes_backward forks its weight-gradient
-// stream from it: measured with tools/proto/event_gap.hip, hipEventRecord costs the NEXT kernel of the recording
+// stream from it: measured with tools/archive/proto/event_gap.hip, hipEventRecord costs the NEXT kernel of the recording
 // stream 3-5 us (27 times per step on the finalize -> data-gradient chain), the completion-signal form costs nothing.
 int bn_backward_finalize_launch(const pdes_context* ctx, float* t, const float* x, const double* x_stats,
                                 const double* t_stats, int B, int ctot, int c0, int c1, int HW, float eps, int nrep,

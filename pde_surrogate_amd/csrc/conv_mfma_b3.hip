@@ -5,7 +5,7 @@
 //     am*bm + al*bh + ah*bl + am*bh + ah*bm + ah*bh                          (small terms first)
 // with v_mfma_f32_16x16x32_bf16 (K = 32 channels per instruction, ~17 cycles) instead of v_mfma_f32_16x16x4_f32
 // (K = 4, 32 cycles): 6 instructions replace 8 at about half their cost each.  Stand-alone measurement
-// (tools/proto/bf16x3_mfma.hip): 212 vs 104 fp32-equivalent TFLOP/s, rel-L2 error vs fp64 1.5e-7 vs 2.0e-7.
+// (tools/archive/proto/bf16x3_mfma.hip): 212 vs 104 fp32-equivalent TFLOP/s, rel-L2 error vs fp64 1.5e-7 vs 2.0e-7.
 //
 // GEMM roles as in conv_mfma.hip (M = 16 pixels of an image row, N = 16 output channels, K = input channels),
 // but the LDS tile is pixel-major / channel-minor -- [plane hi|mid|lo][row][pixel][32 channels] bf16 -- so that the
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   // ds_read_b128 is serviced in four NON-contiguous 16-lane groups (MI355X_MICROARCH.md), and with the linear layout pixels
   // i and i + 12 (resp. i + 4) of one group fall on the same 16 banks -- a 2-way conflict on EVERY fragment read, 50-58 % of
   // the LDS cycles of this kernel in the SQ counters.  XOR-ing bit 1 of the octet index with bit 2 of the pixel's tile column
-  // makes all four groups conflict free for every tap offset (exhaustive check in tools/lds_swizzle_check.py); the writers
+  // makes all four groups conflict free for every tap offset (exhaustive check in tools/archive/lds_swizzle_check.py); the writers
   // below use the same map.
   auto swz_oct = [](int col, int oct) __attribute__((always_inline)) { return oct ^ (((col >> 2) & 1) << 1); };
 

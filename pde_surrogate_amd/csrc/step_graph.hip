@@ -1,6 +1,6 @@
 // The training step as a handful of LINEAR hipGraphs replayed on the step's streams.
 //
-// Why (tools/proto/launch_cost.hip, round 3): one eager launch costs the host 3.0-3.5 us (4.1 with a completion-signal
+// Why (tools/archive/proto/launch_cost.hip, round 3): one eager launch costs the host 3.0-3.5 us (4.1 with a completion-signal
 // event, 9.1 with an event record + cross-stream wait) and leaves ~3.0 us between dependent kernels on the GPU; a
 // linear graph of 120 kernel nodes replays for 8 us of host time with ~1.7 us between kernels -- while a graph WITH
 // forks runs 37 % slower than the same launches issued eagerly on two streams (the runtime serialises branches).  So
