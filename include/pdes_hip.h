@@ -96,11 +96,15 @@ int pdes_stat_replicas(void);
  *   Any square field, H == W >= 2 (SobelFilter(imsize) holds one imsize x imsize modifier for both axes; the
  *   reference's docstrings use 65 x 65, models/darcy.py:165-167).  H in {16, 32, 64} with correct=True runs the
  *   specialised one-image-per-workgroup kernel (16-byte aligned K / y / grad_y required); every other size or flag
- *   combination the tiled kernel of csrc/darcy_loss_generic.hip (same results, same (B, 4) partials, scalar accesses).
+ *   combination the any-size kernels of csrc/darcy_loss_generic.hip: for 8 <= H <= 256 the ROW-BAND kernel (the same
+ *   strip / LDS / neighbour-lane structure without the compile-time size, csrc/darcy_band.h; 16-byte accesses when H is a
+ *   multiple of 4 and the pointers are 16-byte aligned), otherwise tiles with halos.  Same results, (rows, 4) partials.
  */
 #define PDES_LOSS_NONLINEAR 1
 #define PDES_LOSS_NO_TB 2
 #define PDES_LOSS_UNCORRECTED 4
+#define PDES_LOSS_GENERIC 16     /* cross-checks: never the 16 / 32 / 64 specialisation (the any-size kernels at those sizes too) */
+#define PDES_LOSS_TILED 8        /* cross-checks: the tile kernel instead of the row-band kernel (implies PDES_LOSS_GENERIC) */
 int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
                     int B, int H, int W, float w_const, float w_cont, float w_dir, float w_neu,
                     int flags, float beta1, float beta2, void* stream);

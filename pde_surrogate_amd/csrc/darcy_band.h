@@ -1,0 +1,352 @@
+// The fused Darcy mixed-residual loss for any square field of 8 .. 256 pixels as ROW BANDS: the structure of the
+// 16 / 32 / 64 kernels of darcy_loss.hip (whole rows of 1 x 4 strips in consecutive lanes, vertical neighbours by 16-byte
+// LDS reads, horizontal neighbours from the adjacent lane, the three LDS planes reused for the adjoint sources) without
+// their compile-time size.  Host/device code: darcy_loss_generic.hip runs it as a workgroup (neighbour lanes by DPP wave
+// shifts), tests/emu/darcy_generic_emu.cpp as a lane-by-lane emulation (neighbour lanes from arrays) that the CPU tests
+// compare with the oracle before any GPU run.
+//
+// Reference (file:line relative to the reference repository): utils/image_gradient.py:26-92 (SobelFilter for any imsize,
+// correct=True/False), models/darcy.py:162-233 (the loss functions; their docstrings use 65 x 65 fields).
+//
+// Geometry.  An image row is SPR = ceil(n / 4) strips; the last strip holds jl + 1 = ((n - 1) & 3) + 1 real columns.  A wave
+// takes RPP = 64 / SPR whole rows per pass (lanes beyond RPP * SPR idle), so a strip's left / right neighbour is the
+// adjacent lane and never another wave.  A workgroup of `waves` waves owns a BAND of rows [r0, r1) of one image: it computes
+// the residuals ("sources") on [r0 - 1, r1 + 1) in `npass` passes from the fields on [r0 - 2, r1 + 2) (three LDS planes of
+// row stride 4 * SPR floats), keeps the direct terms of its own rows in registers, overwrites the planes with the
+// sources and applies the adjoint stencils on its own rows.  Rows 0 .. 2 and n-3 .. n-1 couple through the reference's
+// boundary `modifier` (one-sided differences): bands are at least 3 rows, so those sit in the first / last band together.
+//
+// Arithmetic: S = replicate-edge [1,2,1]/4 smoother, A = clamped central difference (x modifier when `correct`):
+// grad_h = n S_rows(.) A_cols, grad_v = n A_rows(.) S_cols, adjoints with A^T.  The column operators are written as the
+// interior stencil on (replicate- resp. zero-) extended strips plus border terms that are per-lane CONSTANTS
+// (LaneConst): waves never diverge on border strips.
+#pragma once
+
+#include "darcy_generic.h"
+
+namespace pdes {
+namespace band {
+
+using gen::imax;
+using gen::imin;
+using gen::kNoTB;
+using gen::kNonlinear;
+using gen::kUncorrected;
+using gen::ld4;
+using gen::sqrt_f;
+using gen::st4;
+
+constexpr int kMinN = 8, kMaxN = 256;
+
+struct V4 { float v[4]; };
+
+// ---- the plan of a field size ---------------------------------------------------------------------------------------
+struct Plan {
+  int n, spr, jl, rpp, w;      // strips per row, last real column of the last strip, rows per wave and pass, LDS row stride
+  int waves, npass, cap;       // workgroup: waves, passes, source rows it can hold = waves * rpp * npass
+  int nbands, rows_f;          // bands per image; field rows of the tallest band
+  long long lds_floats;        // 3 * rows_f * w
+};
+
+PDES_HD int band_lo(int band, int nbands, int n) { return (int)(((long long)band * n) / nbands); }
+
+// waves in {1,2,4,8}, passes in {1,2}: the most strip slots doing own work; ties -> the larger workgroup (fewer bands,
+// less halo).  False: size not served by the band kernel.
+inline bool choose_plan(int n, long long lds_floats_max, Plan& best) {
+  if (n < kMinN || n > kMaxN) return false;
+  const int spr = (n + 3) >> 2, rpp = 64 / spr;
+  bool found = false;
+  double best_eff = -1.0;
+  for (int waves = 1; waves <= 8; waves *= 2)
+    for (int npass = 1; npass <= 2; ++npass) {
+      Plan p;
+      p.n = n; p.spr = spr; p.jl = (n - 1) & 3; p.rpp = rpp; p.w = 4 * spr;
+      p.waves = waves; p.npass = npass; p.cap = waves * rpp * npass;
+      if (p.cap >= n) p.nbands = 1;
+      else {
+        if (p.cap < 5) continue;
+        p.nbands = (n + (p.cap - 2) - 1) / (p.cap - 2);
+        if (n / p.nbands < 3) continue;
+      }
+      const int own_max = (n + p.nbands - 1) / p.nbands;
+      p.rows_f = imin(own_max + 4, n);
+      p.lds_floats = 3ll * p.rows_f * p.w;
+      if (p.lds_floats > lds_floats_max) continue;
+      const double eff = (double)n / ((double)p.nbands * p.cap);
+      if (!found || eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && waves * npass >= best.waves * best.npass)) {
+        best = p; best_eff = eff; found = true;
+      }
+    }
+  return found;
+}
+
+struct BandGeo {
+  int r0, r1;       // own rows
+  int sr0, sr1;     // source rows
+  int fr0, fr1;     // field rows
+};
+PDES_HD BandGeo band_geo(const Plan& p, int band) {
+  BandGeo g;
+  g.r0 = band_lo(band, p.nbands, p.n); g.r1 = band_lo(band + 1, p.nbands, p.n);
+  g.sr0 = imax(g.r0 - 1, 0); g.sr1 = imin(g.r1 + 1, p.n);
+  g.fr0 = imax(g.sr0 - 1, 0); g.fr1 = imin(g.sr1 + 1, p.n);
+  return g;
+}
+
+// ---- rows: clamped neighbours and the coefficients of the vertical difference / its adjoint ---------------------------
+struct RowGeom {
+  int up, dn, farF, farA;
+  float f_own, f_up, f_dn, f_far;   // forward:  f_own x[r] + f_up x[up] + f_dn x[dn] + f_far x[farF]
+  float a_own, a_up, a_dn, a_far;   // adjoint:  a_own g[r] + a_up g[up] + a_dn g[dn] + a_far g[farA]
+};
+PDES_HD RowGeom row_geom(int r, int n, bool correct) {
+  RowGeom g;
+  g.up = r > 0 ? r - 1 : 0;
+  g.dn = r < n - 1 ? r + 1 : n - 1;
+  g.farF = r; g.farA = r;
+  g.f_own = 0.f; g.f_up = -0.5f; g.f_dn = 0.5f; g.f_far = 0.f;
+  g.a_own = 0.f; g.a_up = 0.5f; g.a_dn = -0.5f; g.a_far = 0.f;
+  if (r == 0) {
+    if (correct) { g.f_own = -1.5f; g.f_up = 0.f; g.f_dn = 2.f; g.f_far = -0.5f; g.farF = 2; g.a_own = -1.5f; }
+    else { g.f_own = -0.5f; g.f_up = 0.f; g.a_own = -0.5f; }
+    g.a_up = 0.f;
+  } else if (r == n - 1) {
+    if (correct) { g.f_own = 1.5f; g.f_up = -2.f; g.f_dn = 0.f; g.f_far = 0.5f; g.farF = n - 3; g.a_own = 1.5f; }
+    else { g.f_own = 0.5f; g.f_dn = 0.f; g.a_own = 0.5f; }
+    g.a_dn = 0.f;
+  } else if (correct) {
+    if (r == 1) g.a_up = 2.f;
+    if (r == n - 2) g.a_dn = -2.f;
+    if (r == 2) { g.a_far = -0.5f; g.farA = 0; }
+    if (r == n - 3) { g.a_far = 0.5f; g.farA = n - 1; }      // (n >= 8: the four cases are distinct rows)
+  }
+  return g;
+}
+
+// ---- what a lane knows about its strip column (constant over the passes) ---------------------------------------------
+struct LaneConst {
+  int cs;                  // strip of the row
+  bool active;             // lane < rpp * spr
+  bool first, last;
+  bool valid[4];           // column < n
+  float cl[4], cr[4];      // adjoint of the column difference: border terms cl[j] g[0] + cr[j] g[n-1]
+};
+PDES_HD LaneConst lane_const(const Plan& p, int lane, bool correct) {
+  LaneConst c;
+  c.active = lane < p.rpp * p.spr;
+  c.cs = lane % p.spr;
+  c.first = c.cs == 0;
+  c.last = c.cs == p.spr - 1;
+  for (int j = 0; j < 4; ++j) {
+    const int col = 4 * c.cs + j;
+    c.valid[j] = col < p.n;
+    c.cl[j] = 0.f; c.cr[j] = 0.f;
+    if (correct) {
+      if (col == 0) c.cl[j] = -1.5f;
+      if (col == 1) c.cl[j] = 1.5f;
+      if (col == 2) c.cl[j] = -0.5f;
+      if (col == p.n - 1) c.cr[j] = 1.5f;
+      if (col == p.n - 2) c.cr[j] = -1.5f;
+      if (col == p.n - 3) c.cr[j] = 0.5f;
+    } else {
+      if (col == 0) c.cl[j] = -0.5f;
+      if (col == p.n - 1) c.cr[j] = 0.5f;
+    }
+  }
+  return c;
+}
+
+// ---- strips -----------------------------------------------------------------------------------------------------------
+// An LDS plane of a band: rows [fr0, fr1) of the image, row stride w; strip (r, cs) = 4 floats at (r - fr0) * w + 4 cs.
+struct BPlane {
+  const float* p;
+  int fr0, fr1, w;
+};
+PDES_HD V4 ldrow(const BPlane& P, int r, int cs) {       // r clamped into the plane (the caller masks what it must)
+  const int rr = r < P.fr0 ? P.fr0 : (r >= P.fr1 ? P.fr1 - 1 : r);
+  V4 o;
+  ld4(P.p + (rr - P.fr0) * P.w + 4 * cs, o.v);
+  return o;
+}
+PDES_HD V4 vsmooth3(const V4& up, const V4& own, const V4& dn) {
+  V4 o;
+  for (int i = 0; i < 4; ++i) o.v[i] = 0.25f * up.v[i] + 0.5f * own.v[i] + 0.25f * dn.v[i];
+  return o;
+}
+PDES_HD V4 comb4(float a, const V4& x, float b, const V4& y, float c, const V4& z, float d, const V4& w) {
+  V4 o;
+  for (int i = 0; i < 4; ++i) o.v[i] = a * x.v[i] + b * y.v[i] + c * z.v[i] + d * w.v[i];
+  return o;
+}
+// x.v[j] for a uniform runtime j without indexing the register array
+PDES_HD float pick(const V4& x, int j) { return j == 0 ? x.v[0] : (j == 1 ? x.v[1] : (j == 2 ? x.v[2] : x.v[3])); }
+// the columns behind the image's last one: replicate it (forward operators, smoothing) / zero (adjoint of the difference)
+PDES_HD void tail_replicate(V4& x, bool last, int jl) {
+  const float e = pick(x, jl);
+  if (last) for (int j = 1; j < 4; ++j) if (j > jl) x.v[j] = e;
+}
+PDES_HD void tail_zero(V4& x, bool last, int jl) {
+  if (last) for (int j = 1; j < 4; ++j) if (j > jl) x.v[j] = 0.f;
+}
+
+// what a strip takes from its neighbour lanes
+struct Halo {
+  float l, l2;     // the left neighbour's v[3], v[2]
+  float r, rjl;    // the right neighbour's v[0], v[jl]
+};
+
+// scale * [1,2,1]/4 along the row, replicate edges.  x: tail-replicated.
+PDES_HD V4 hsmooth(const V4& x, const Halo& h, const LaneConst& c, float scale) {
+  const float l = c.first ? x.v[0] : h.l, r = c.last ? x.v[3] : h.r;
+  V4 o;
+  o.v[0] = scale * (0.25f * l + 0.5f * x.v[0] + 0.25f * x.v[1]);
+  o.v[1] = scale * (0.25f * x.v[0] + 0.5f * x.v[1] + 0.25f * x.v[2]);
+  o.v[2] = scale * (0.25f * x.v[1] + 0.5f * x.v[2] + 0.25f * x.v[3]);
+  o.v[3] = scale * (0.25f * x.v[2] + 0.5f * x.v[3] + 0.25f * r);
+  return o;
+}
+// scale * (x A) along the row: clamped central difference; `correct`: one-sided second-order differences in the first /
+// last column (image_gradient.py:43-46).  x: tail-replicated.
+PDES_HD V4 hdiff(const V4& x, const Halo& h, const LaneConst& c, int jl, bool correct, float scale) {
+  const float l = c.first ? x.v[0] : h.l, r = c.last ? x.v[3] : h.r;
+  V4 o;
+  o.v[0] = 0.5f * (x.v[1] - l);
+  o.v[1] = 0.5f * (x.v[2] - x.v[0]);
+  o.v[2] = 0.5f * (x.v[3] - x.v[1]);
+  o.v[3] = 0.5f * (r - x.v[2]);
+  if (correct) {
+    if (c.first) o.v[0] = 0.5f * (-3.f * x.v[0] + 4.f * x.v[1] - x.v[2]);
+    if (c.last) {
+      const float m0 = pick(x, jl);
+      const float m1 = jl >= 1 ? pick(x, jl - 1) : h.l;
+      const float m2 = jl >= 2 ? pick(x, jl - 2) : (jl == 1 ? h.l : h.l2);
+      const float e = 0.5f * (3.f * m0 - 4.f * m1 + m2);
+      for (int j = 0; j < 4; ++j) if (j == jl) o.v[j] = e;
+    }
+  }
+  for (int i = 0; i < 4; ++i) o.v[i] *= scale;
+  return o;
+}
+// scale * (g A^T) along the row.  g: tail-zeroed.
+PDES_HD V4 hdiff_adj(const V4& g, const Halo& h, const LaneConst& c, int jl, float scale) {
+  const float l = c.first ? 0.f : h.l, r = c.last ? 0.f : h.r;
+  const float g0 = g.v[0], gl = c.last ? pick(g, jl) : h.rjl;
+  V4 o;
+  o.v[0] = 0.5f * (l - g.v[1]) + c.cl[0] * g0 + c.cr[0] * gl;
+  o.v[1] = 0.5f * (g.v[0] - g.v[2]) + c.cl[1] * g0 + c.cr[1] * gl;
+  o.v[2] = 0.5f * (g.v[1] - g.v[3]) + c.cl[2] * g0 + c.cr[2] * gl;
+  o.v[3] = 0.5f * (g.v[2] - r) + c.cl[3] * g0 + c.cr[3] * gl;
+  for (int i = 0; i < 4; ++i) o.v[i] *= scale;
+  return o;
+}
+
+// ---- phase B of one strip, in two halves around the neighbour exchange ---------------------------------------------------
+struct FwdVert {          // vertical combinations (tail-replicated) + the strip's own values
+  V4 us, ud, as, bd;      // S_rows u, A_rows u, S_rows sigma1, A_rows sigma2
+  V4 u, s1, s2;
+};
+PDES_HD FwdVert fwd_vert(const BPlane& U, const BPlane& X1, const BPlane& X2, int r, const RowGeom& g, const LaneConst& c, int jl) {
+  FwdVert o;
+  o.u = ldrow(U, r, c.cs); o.s1 = ldrow(X1, r, c.cs); o.s2 = ldrow(X2, r, c.cs);
+  const V4 u_up = ldrow(U, g.up, c.cs), u_dn = ldrow(U, g.dn, c.cs), u_far = ldrow(U, g.farF, c.cs);
+  const V4 a_up = ldrow(X1, g.up, c.cs), a_dn = ldrow(X1, g.dn, c.cs);
+  const V4 b_up = ldrow(X2, g.up, c.cs), b_dn = ldrow(X2, g.dn, c.cs), b_far = ldrow(X2, g.farF, c.cs);
+  o.us = vsmooth3(u_up, o.u, u_dn);
+  o.ud = comb4(g.f_own, o.u, g.f_up, u_up, g.f_dn, u_dn, g.f_far, u_far);
+  o.as = vsmooth3(a_up, o.s1, a_dn);
+  o.bd = comb4(g.f_own, o.s2, g.f_up, b_up, g.f_dn, b_dn, g.f_far, b_far);
+  tail_replicate(o.us, c.last, jl); tail_replicate(o.ud, c.last, jl);
+  tail_replicate(o.as, c.last, jl); tail_replicate(o.bd, c.last, jl);
+  return o;
+}
+
+struct StripOut {
+  V4 d1, d2;              // direct part of dL/dsigma1, dL/dsigma2 (kept by the lane until phase C)
+  float du;               // direct part of dL/du: the Dirichlet term of the strip's border column (first / last strip)
+  V4 p1, p2, cc;          // adjoint sources a_const K r1, a_const K r2, a_cont c (zero outside the image)
+};
+// `own`: the strip's row belongs to the band (its pixels enter the sums)
+PDES_HD StripOut fwd_finish(const FwdVert& f, const Halo& hus, const Halo& hud, const Halo& has, const Halo& hbd, const V4& K,
+                            int r, int n, const LaneConst& c, int jl, const LossParams& p, int flags, float fn, bool own,
+                            float* sums) {
+  const bool correct = !(flags & kUncorrected);
+  const V4 ghu = hdiff(f.us, hus, c, jl, correct, fn);
+  const V4 gvu = hsmooth(f.ud, hud, c, fn);
+  const V4 gh1 = hdiff(f.as, has, c, jl, correct, fn);
+  const V4 gv2 = hsmooth(f.bd, hbd, c, fn);
+  const bool tb = (r == 0) || (r == n - 1);
+  StripOut o;
+  o.du = 0.f;
+  for (int j = 0; j < 4; ++j) {
+    const float k = K.v[j], x1 = f.s1.v[j], x2 = f.s2.v[j];
+    float r1 = x1 + k * ghu.v[j], r2 = x2 + k * gvu.v[j], q1 = 1.f, q2 = 1.f;
+    if (flags & kNonlinear) {                 // darcy.py:179-191
+      const float sq = sqrt_f(k);
+      r1 += p.beta1 * sq * x1 * x1 + p.beta2 * k * x1 * x1 * x1;
+      r2 += p.beta1 * sq * x2 * x2 + p.beta2 * k * x2 * x2 * x2;
+      q1 += 2.f * p.beta1 * sq * x1 + 3.f * p.beta2 * k * x1 * x1;
+      q2 += 2.f * p.beta1 * sq * x2 + 3.f * p.beta2 * k * x2 * x2;
+    }
+    const float cc = ((flags & kNoTB) && tb) ? 0.f : gh1.v[j] + gv2.v[j];     // darcy.py:224
+    const bool in = c.valid[j];
+    o.p1.v[j] = in ? p.a_const * k * r1 : 0.f;
+    o.p2.v[j] = in ? p.a_const * k * r2 : 0.f;
+    o.cc.v[j] = in ? p.a_cont * cc : 0.f;
+    o.d1.v[j] = p.a_const * r1 * q1;
+    o.d2.v[j] = p.a_const * r2 * q2 + (tb ? p.b_neu * x2 : 0.f);
+    if (own && in) {
+      sums[0] += r1 * r1 + r2 * r2;
+      sums[1] += cc * cc;
+      if (tb) sums[3] += x2 * x2;
+    }
+  }
+  // Dirichlet columns (darcy.py:226-233): u = 1 on the left, u = 0 on the right
+  if (c.first) { const float e = f.u.v[0] - 1.f; o.du = p.b_dir * e; if (own) sums[2] += e * e; }
+  if (c.last) {                               // (never the first strip too: n >= 8)
+    const float e = pick(f.u, jl);
+    o.du = p.b_dir * e;
+    if (own) sums[2] += e * e;
+  }
+  return o;
+}
+
+// ---- phase C of one strip -----------------------------------------------------------------------------------------------
+struct AdjVert {
+  V4 p1s, p2d, ccs, ccd;  // S_rows p1, A^T_rows p2, S_rows cc, A^T_rows cc
+};
+PDES_HD AdjVert adj_vert(const BPlane& G1, const BPlane& G2, const BPlane& GC, int r, const RowGeom& g, const LaneConst& c, int jl) {
+  AdjVert o;
+  const V4 p1 = ldrow(G1, r, c.cs), p1_up = ldrow(G1, g.up, c.cs), p1_dn = ldrow(G1, g.dn, c.cs);
+  const V4 p2 = ldrow(G2, r, c.cs), p2_up = ldrow(G2, g.up, c.cs), p2_dn = ldrow(G2, g.dn, c.cs), p2_far = ldrow(G2, g.farA, c.cs);
+  const V4 cc = ldrow(GC, r, c.cs), cc_up = ldrow(GC, g.up, c.cs), cc_dn = ldrow(GC, g.dn, c.cs), cc_far = ldrow(GC, g.farA, c.cs);
+  o.p1s = vsmooth3(p1_up, p1, p1_dn);
+  o.p2d = comb4(g.a_own, p2, g.a_up, p2_up, g.a_dn, p2_dn, g.a_far, p2_far);
+  o.ccs = vsmooth3(cc_up, cc, cc_dn);
+  o.ccd = comb4(g.a_own, cc, g.a_up, cc_up, g.a_dn, cc_dn, g.a_far, cc_far);
+  tail_zero(o.p1s, c.last, jl); tail_zero(o.ccs, c.last, jl);               // -> the column difference's adjoint
+  tail_replicate(o.p2d, c.last, jl); tail_replicate(o.ccd, c.last, jl);     // -> the (symmetric) column smoothing
+  return o;
+}
+// dL/du, dL/dsigma1, dL/dsigma2 of the strip
+PDES_HD void adj_finish(const AdjVert& a, const Halo& hp1, const Halo& hp2, const Halo& hcs, const Halo& hcd, const StripOut& s,
+                        const LaneConst& c, int jl, float fn, V4& du, V4& d1, V4& d2) {
+  const V4 ghT_p1 = hdiff_adj(a.p1s, hp1, c, jl, fn);
+  const V4 gvT_p2 = hsmooth(a.p2d, hp2, c, fn);
+  const V4 ghT_c = hdiff_adj(a.ccs, hcs, c, jl, fn);
+  const V4 gvT_c = hsmooth(a.ccd, hcd, c, fn);
+  for (int j = 0; j < 4; ++j) {
+    du.v[j] = ghT_p1.v[j] + gvT_p2.v[j];
+    d1.v[j] = s.d1.v[j] + ghT_c.v[j];
+    d2.v[j] = s.d2.v[j] + gvT_c.v[j];
+  }
+  if (c.first) du.v[0] += s.du;
+  if (c.last) for (int j = 0; j < 4; ++j) if (j == jl) du.v[j] += s.du;
+}
+
+// slot of (pass, wave, lane) -> source row of the band (may be >= sr1: an idle slot)
+PDES_HD int slot_row(const Plan& p, const BandGeo& g, int pass, int wave, int lane) {
+  return g.sr0 + (pass * p.waves + wave) * p.rpp + lane / p.spr;
+}
+
+}  // namespace band
+}  // namespace pdes

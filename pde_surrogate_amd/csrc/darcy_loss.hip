@@ -35,7 +35,7 @@ namespace pdes {
 // darcy_loss_generic.hip: any square n >= 2, SobelFilter(correct=False), filter_size = 5
 int launch_loss_generic(const float* K, const float* y, float* gy, float* partials, int B, int n, LossParams p,
                         int flags, hipStream_t st);
-int loss_generic_tiles(int n);
+int loss_generic_tiles(int n, int flags);
 int launch_sobel_generic(const float* img, float* gh, float* gv, int nimg, int n, int correct, int five, hipStream_t st);
 int launch_sobel_adjoint_generic(const float* ghb, const float* gvb, float* out, int nimg, int n, int correct, int five,
                                  hipStream_t st);
@@ -463,13 +463,13 @@ using namespace pdes;
 
 static bool fast_size(int H) { return H == 16 || H == 32 || H == 64; }
 static bool loss_fast(int H, int flags) {
-  return fast_size(H) && !(flags & PDES_LOSS_UNCORRECTED) && !((flags & PDES_LOSS_NONLINEAR) && (flags & PDES_LOSS_NO_TB));
+  return fast_size(H) && !(flags & (PDES_LOSS_UNCORRECTED | PDES_LOSS_TILED | PDES_LOSS_GENERIC)) && !((flags & PDES_LOSS_NONLINEAR) && (flags & PDES_LOSS_NO_TB));
 }
 
 extern "C" int pdes_darcy_loss_partial_rows(int B, int H, int W, int flags) {
   if (B <= 0 || H != W || H < 2) return PDES_ENOSUP;
   if (loss_fast(H, flags)) return B;
-  const int t = loss_generic_tiles(H);
+  const int t = loss_generic_tiles(H, flags);
   return t > 0 ? B * t : PDES_ENOSUP;
 }
 

@@ -19,6 +19,8 @@
 // not cover, not a hot path.
 #include "pdes_common.h"
 #include "darcy_generic.h"
+#include "darcy_band.h"
+#include "../../include/pdes_hip.h"
 
 namespace pdes {
 
@@ -93,6 +95,174 @@ __global__ __launch_bounds__(GEN_NT) void darcy_loss_strips_kernel(const float* 
   }
 }
 
+
+// ---- the row-band kernel (8 <= n <= 256): darcy_band.h --------------------------------------------------------------------
+// grid = (bands of an image, images), block = 64 * plan.waves, dynamic LDS = 3 planes of plan.rows_f rows.  Neighbour
+// strips are neighbour lanes: DPP wave shifts (lane 0 / 63 receive 0 and never use it: a row starts at a first strip).
+constexpr long long BAND_LDSF = 16384 - 64;          // floats of dynamic LDS a band workgroup may use (64 KiB - reductions)
+
+__device__ __forceinline__ float wave_shr1(float v) {      // lane i <- lane i - 1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ band::Halo halo_of(const band::V4& x, int jl) {
+  band::Halo h;
+  h.l = wave_shr1(x.v[3]);
+  h.l2 = wave_shr1(x.v[2]);
+  h.r = wave_shl1(x.v[0]);
+  h.rjl = wave_shl1(band::pick(x, jl));
+  return h;
+}
+
+template <bool BWD, int NPASS>
+__global__ __launch_bounds__(512) void darcy_loss_band_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
+                                                              float* __restrict__ gyp, float* __restrict__ partials,
+                                                              LossParams p, band::Plan pl, int flags, int vec) {
+  using namespace band;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[8 * 4];
+  const int bi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int n = pl.n, jl = pl.jl, w = pl.w, spr = pl.spr;
+  const size_t nn = (size_t)n * n;
+  const float fn = (float)n;
+  const bool correct = !(flags & kUncorrected);
+  const BandGeo g = band_geo(pl, bi);
+  const LaneConst c = lane_const(pl, lane, correct);
+  const float* Kb = Kp + (size_t)b * nn;
+  const float* yb = yp + (size_t)b * 3 * nn;
+  float* gb = BWD ? gyp + (size_t)b * 3 * nn : nullptr;
+  const int plane = pl.rows_f * w, rows_f = g.fr1 - g.fr0;
+
+  // the conductivities of this lane's strips: requested first, used after the staging
+  V4 kk[NPASS];
+  int row[NPASS];
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k) {
+    row[k] = slot_row(pl, g, k, wave, lane);
+    const bool ok = c.active && row[k] < g.sr1;
+    const float* kp = Kb + (size_t)row[k] * n + 4 * c.cs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kk[k].v[j] = 0.f;
+    if (ok) {
+      if (vec) kk[k] = *reinterpret_cast<const V4*>(&(const float4&)(p.nt ? nt_load4(reinterpret_cast<const float4*>(kp))
+                                                                         : *reinterpret_cast<const float4*>(kp)));
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c.valid[j]) kk[k].v[j] = kp[j];
+      }
+    }
+  }
+  // ---- the three fields on rows fr0 .. fr1 -> LDS.  Batches of four loads in flight per thread.
+  if (vec) {
+    const int per = rows_f * spr;
+    const float inv = 1.0f / (float)spr;
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+      const float4* src = reinterpret_cast<const float4*>(yb + q * nn + (size_t)g.fr0 * n);      // rows are contiguous: strip i
+      float* dst = lds + q * plane;
+#pragma unroll 1
+      for (int base = tid; base < per; base += 4 * nthreads) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = base + u * nthreads;
+          if (i < per) v[u] = p.nt ? nt_load4(src + i) : src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = base + u * nthreads;
+          if (i < per) *reinterpret_cast<float4*>(dst + 4 * i) = v[u];           // w == 4 spr == n: the plane is the row range itself
+        }
+      }
+    }
+    (void)inv;
+  } else {
+    const int per = rows_f * n;
+    const float inv = 1.0f / (float)n;
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+      const float* src = yb + q * nn + (size_t)g.fr0 * n;
+      float* dst = lds + q * plane;
+#pragma unroll 1
+      for (int base = tid; base < per; base += 8 * nthreads) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * nthreads;
+          if (i < per) v[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * nthreads;
+          if (i < per) {
+            const int rr = (int)(((float)i + 0.5f) * inv);          // i / n (exact: i < 2^16, n <= 256)
+            dst[rr * w + (i - rr * n)] = v[u];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const BPlane U{lds, g.fr0, g.fr1, w}, X1{lds + plane, g.fr0, g.fr1, w}, X2{lds + 2 * plane, g.fr0, g.fr1, w};
+  float sums[4] = {0.f, 0.f, 0.f, 0.f};
+  StripOut so[NPASS];
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k) {
+    const int r = row[k], rc = r < g.sr1 ? r : g.sr1 - 1;
+    const bool ok = c.active && r < g.sr1, own = ok && r >= g.r0 && r < g.r1;
+    const FwdVert f = fwd_vert(U, X1, X2, rc, row_geom(rc, n, correct), c, jl);
+    so[k] = fwd_finish(f, halo_of(f.us, jl), halo_of(f.ud, jl), halo_of(f.as, jl), halo_of(f.bd, jl), kk[k], rc, n, c, jl, p,
+                       flags, fn, own, sums);
+  }
+  {
+    const float t0 = wave_sum(sums[0]), t1 = wave_sum(sums[1]), t2 = wave_sum(sums[2]), t3 = wave_sum(sums[3]);
+    if (lane == 0) { red[wave * 4 + 0] = t0; red[wave * 4 + 1] = t1; red[wave * 4 + 2] = t2; red[wave * 4 + 3] = t3; }
+  }
+  __syncthreads();                     // also: every read of the field planes is done
+  if (tid < 4) {
+    float t = 0.f;
+    for (int wv = 0; wv < pl.waves; ++wv) t += red[wv * 4 + tid];           // fixed order: deterministic
+    partials[((size_t)b * pl.nbands + bi) * 4 + tid] = t;
+  }
+  if (!BWD) return;
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k) {
+    if (c.active && row[k] < g.sr1) {
+      float* q = lds + (row[k] - g.fr0) * w + 4 * c.cs;
+      st4(q, so[k].p1.v); st4(q + plane, so[k].p2.v); st4(q + 2 * plane, so[k].cc.v);
+    }
+  }
+  __syncthreads();
+  const BPlane G1{lds, g.fr0, g.fr1, w}, G2{lds + plane, g.fr0, g.fr1, w}, GC{lds + 2 * plane, g.fr0, g.fr1, w};
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k) {
+    const int r = row[k], rc = r < g.r0 ? g.r0 : (r < g.r1 ? r : g.r1 - 1);
+    const bool own = c.active && r >= g.r0 && r < g.r1;
+    const AdjVert a = adj_vert(G1, G2, GC, rc, row_geom(rc, n, correct), c, jl);
+    V4 du, d1, d2;
+    adj_finish(a, halo_of(a.p1s, jl), halo_of(a.p2d, jl), halo_of(a.ccs, jl), halo_of(a.ccd, jl), so[k], c, jl, fn, du, d1, d2);
+    if (own) {
+      float* o = gb + (size_t)r * n + 4 * c.cs;
+      if (vec) {
+        if (p.nt) {
+          nt_store4(reinterpret_cast<float4*>(o), make_float4(du.v[0], du.v[1], du.v[2], du.v[3]));
+          nt_store4(reinterpret_cast<float4*>(o + nn), make_float4(d1.v[0], d1.v[1], d1.v[2], d1.v[3]));
+          nt_store4(reinterpret_cast<float4*>(o + 2 * nn), make_float4(d2.v[0], d2.v[1], d2.v[2], d2.v[3]));
+        } else {
+          st4(o, du.v); st4(o + nn, d1.v); st4(o + 2 * nn, d2.v);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c.valid[j]) { o[j] = du.v[j]; o[nn + j] = d1.v[j]; o[2 * nn + j] = d2.v[j]; }
+      }
+    }
+  }
+}
+
 // ---- stand-alone gradients and adjoints, one thread per pixel -------------------------------------------------------
 template <bool FIVE>
 __global__ __launch_bounds__(256) void sobel_generic_kernel(const float* __restrict__ img, float* __restrict__ gh,
@@ -129,9 +299,16 @@ __global__ __launch_bounds__(256) void sobel_adjoint_generic_kernel(const float*
 // ---- launchers (darcy_loss.hip's entry points validate the arguments) -----------------------------------------------
 constexpr int STRIP_MIN_N = 8;        // below: the per-pixel kernel (the adjoint tables of the strip form need n >= 6)
 
-int loss_generic_tiles(int n) {       // tiles per image (<= 0: size not supported)
+// the row-band kernel serves 8 <= n <= 256 unless the caller asks for the tile kernel (PDES_LOSS_TILED: cross-checks)
+static bool band_plan(int n, int flags, band::Plan& pl) {
+  return !(flags & PDES_LOSS_TILED) && band::choose_plan(n, BAND_LDSF, pl);
+}
+
+int loss_generic_tiles(int n, int flags) {       // tiles (bands) per image (<= 0: size not supported)
   int tr = 0, tc = 0;
   if (n < 2) return 0;
+  band::Plan pl;
+  if (band_plan(n, flags, pl)) return pl.nbands;
   if (n >= STRIP_MIN_N) {
     if (!choose_strip_tile(n, GEN_LDSF, tr, tc)) return 0;
   } else if (!choose_tile(n, GEN_LDSF, tr, tc)) return 0;
@@ -142,6 +319,20 @@ int launch_loss_generic(const float* K, const float* y, float* gy, float* partia
                         int flags, hipStream_t st) {
   int tr = 0, tc = 0;
   if (n < 2) return PDES_ENOSUP;
+  band::Plan pl;
+  if (band_plan(n, flags, pl)) {
+    const int vec = ((n & 3) == 0 && aligned16(K) && aligned16(y) && (!gy || aligned16(gy))) ? 1 : 0;
+    const dim3 grid(pl.nbands, B), block(64 * pl.waves);
+    const size_t shmem = (size_t)pl.lds_floats * sizeof(float);
+    if (pl.npass == 1) {
+      if (gy) hipLaunchKernelGGL((darcy_loss_band_kernel<true, 1>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
+      else hipLaunchKernelGGL((darcy_loss_band_kernel<false, 1>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
+    } else {
+      if (gy) hipLaunchKernelGGL((darcy_loss_band_kernel<true, 2>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
+      else hipLaunchKernelGGL((darcy_loss_band_kernel<false, 2>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
+    }
+    return PDES_OK;
+  }
   const bool strips = n >= STRIP_MIN_N;
   if (strips ? !choose_strip_tile(n, GEN_LDSF, tr, tc) : !choose_tile(n, GEN_LDSF, tr, tc)) return PDES_ENOSUP;
   const int ntc = cdiv(n, tc);

@@ -41,6 +41,11 @@ def _check_sobel(sobel_filter, H):
     return bool(getattr(sobel_filter, 'correct', True))
 
 
+# cross-checks (tests, tools/bench_loss_generic.py): bits OR-ed into every launch's flags -- 16 = PDES_LOSS_GENERIC (the
+# any-size kernels at 16 / 32 / 64 too), 8 = PDES_LOSS_TILED (the tile kernel instead of the row-band kernel)
+EXTRA_FLAGS = 0
+
+
 def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta2=0.0, use_tb=True, correct=True):
     """Raw launch: returns (terms[5] = {total, const, cont, dir, neu} device tensor, grad_y or None).
     use_tb=False: the continuity term leaves out rows 0 and H-1 (darcy.py:224); correct=False: the gradients of
@@ -50,7 +55,7 @@ def darcy_loss_launch(K, y, weights, want_grad, nonlinear=False, beta1=0.0, beta
         K = torch.zeros((B, 1, H, W), device=y.device, dtype=torch.float32)
     K = K.detach().contiguous()
     y = y.detach().contiguous()
-    flags = (1 if nonlinear else 0) | (0 if use_tb else 2) | (0 if correct else 4)
+    flags = (1 if nonlinear else 0) | (0 if use_tb else 2) | (0 if correct else 4) | EXTRA_FLAGS
     partials = torch.empty((_lib.loss_partial_rows(B, H, W, flags), 4), device=y.device, dtype=torch.float32)
     terms = torch.empty(5, device=y.device, dtype=torch.float32)
     grad = torch.empty_like(y) if want_grad else None

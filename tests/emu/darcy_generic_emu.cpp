@@ -7,6 +7,7 @@
 #include <vector>
 #include <cstddef>
 #include "../../pde_surrogate_amd/csrc/darcy_generic.h"
+#include "../../pde_surrogate_amd/csrc/darcy_band.h"
 
 using namespace pdes;
 using namespace pdes::gen;
@@ -84,6 +85,147 @@ void emu_sobel_adjoint(const float* ghb, const float* gvb, float* out, int nimg,
         out[base + (size_t)r * n + c] = a;
       }
   }
+}
+
+// ---- the row-band kernel (csrc/darcy_band.h), lane by lane ------------------------------------------------------------------
+// One workgroup = `waves` arrays of 64 lanes; a DPP wave shift is a read of the adjacent lane's array entry (lane 0 /
+// lane 63 receive 0, as with bound_ctrl).  Every lane -- idle ones included -- runs the arithmetic, as on the GPU.
+// waves/npass <= 0: the kernel's own plan for `lds_floats_max` floats of LDS.  partials: (B * bands, 4).  Returns the bands
+// per image (0: no plan).
+static band::Halo halo_from(const band::V4* x, int lane, int jl) {
+  band::Halo h;
+  h.l = lane > 0 ? x[lane - 1].v[3] : 0.f;
+  h.l2 = lane > 0 ? x[lane - 1].v[2] : 0.f;
+  h.r = lane < 63 ? x[lane + 1].v[0] : 0.f;
+  h.rjl = lane < 63 ? band::pick(x[lane + 1], jl) : 0.f;
+  return h;
+}
+
+int emu_darcy_loss_band(const float* Kp, const float* yp, float* gyp, float* partials, int B, int n, float a_const,
+                        float a_cont, float b_dir, float b_neu, float beta1, float beta2, int flags, int waves, int npass,
+                        int nbands, long long lds_floats_max, int* plan_out) {
+  using namespace band;
+  Plan pl;
+  if (!choose_plan(n, lds_floats_max, pl)) return 0;
+  if (waves > 0) {                       // a forced plan (tests walk band heights the chooser would not pick)
+    pl.waves = waves; pl.npass = npass; pl.cap = waves * pl.rpp * npass; pl.nbands = nbands;
+    const int own_max = (n + nbands - 1) / nbands;
+    if (own_max + 2 > pl.cap && nbands > 1) return 0;
+    if (nbands == 1 && pl.cap < n) return 0;
+    if (n / nbands < 3) return 0;
+    pl.rows_f = imin(own_max + 4, n);
+    pl.lds_floats = 3ll * pl.rows_f * pl.w;
+  }
+  if (plan_out) { plan_out[0] = pl.waves; plan_out[1] = pl.npass; plan_out[2] = pl.nbands; plan_out[3] = pl.rpp; plan_out[4] = (int)pl.lds_floats; }
+  LossParams p{a_const, a_cont, b_dir, b_neu, beta1, beta2, 0};
+  const bool correct = !(flags & kUncorrected);
+  const size_t nn = (size_t)n * n;
+  const float fn = (float)n;
+  const int jl = pl.jl, plane = pl.rows_f * pl.w;
+  for (int b = 0; b < B; ++b)
+    for (int bi = 0; bi < pl.nbands; ++bi) {
+      const BandGeo g = band_geo(pl, bi);
+      std::vector<float> lds((size_t)pl.lds_floats, -12345.f);       // poison
+      const float* Kb = Kp + b * nn;
+      const float* yb = yp + b * 3 * nn;
+      float* gb = gyp ? gyp + b * 3 * nn : nullptr;
+      // stage the fields (rows fr0 .. fr1; columns >= n stay poisoned: the tails are rebuilt in registers)
+      for (int q = 0; q < 3; ++q)
+        for (int r = g.fr0; r < g.fr1; ++r)
+          for (int c = 0; c < n; ++c) lds[(size_t)q * plane + (r - g.fr0) * pl.w + c] = yb[q * nn + (size_t)r * n + c];
+      const BPlane U{lds.data(), g.fr0, g.fr1, pl.w}, X1{lds.data() + plane, g.fr0, g.fr1, pl.w},
+          X2{lds.data() + 2 * plane, g.fr0, g.fr1, pl.w};
+      const int nslots = pl.npass * pl.waves;
+      std::vector<StripOut> keep((size_t)nslots * 64);
+      double sums[4] = {0, 0, 0, 0};
+      std::vector<float> lane_sums((size_t)pl.waves * 64 * 4, 0.f);
+      // ---- phase B
+      for (int pass = 0; pass < pl.npass; ++pass)
+        for (int wave = 0; wave < pl.waves; ++wave) {
+          FwdVert f[64];
+          V4 us[64], ud[64], as[64], bd[64];
+          int rc[64];
+          for (int lane = 0; lane < 64; ++lane) {
+            const LaneConst c = lane_const(pl, lane, correct);
+            const int r = slot_row(pl, g, pass, wave, lane);
+            rc[lane] = r < g.sr1 ? r : g.sr1 - 1;
+            f[lane] = fwd_vert(U, X1, X2, rc[lane], row_geom(rc[lane], n, correct), c, jl);
+            us[lane] = f[lane].us; ud[lane] = f[lane].ud; as[lane] = f[lane].as; bd[lane] = f[lane].bd;
+          }
+          for (int lane = 0; lane < 64; ++lane) {
+            const LaneConst c = lane_const(pl, lane, correct);
+            const int r = slot_row(pl, g, pass, wave, lane);
+            const bool ok = c.active && r < g.sr1, own = ok && r >= g.r0 && r < g.r1;
+            V4 K;
+            for (int j = 0; j < 4; ++j) K.v[j] = (ok && c.valid[j]) ? Kb[(size_t)r * n + 4 * c.cs + j] : 0.f;
+            keep[(size_t)(pass * pl.waves + wave) * 64 + lane] =
+                fwd_finish(f[lane], halo_from(us, lane, jl), halo_from(ud, lane, jl), halo_from(as, lane, jl),
+                           halo_from(bd, lane, jl), K, rc[lane], n, c, jl, p, flags, fn, own,
+                           &lane_sums[((size_t)wave * 64 + lane) * 4]);
+          }
+        }
+      for (int k = 0; k < 4; ++k) {
+        float t = 0.f;
+        for (int wave = 0; wave < pl.waves; ++wave) {
+          float wsum = 0.f;
+          for (int lane = 0; lane < 64; ++lane) wsum += lane_sums[((size_t)wave * 64 + lane) * 4 + k];
+          t += wsum;
+        }
+        sums[k] = t;
+        partials[((size_t)b * pl.nbands + bi) * 4 + k] = t;
+      }
+      if (!gb) continue;
+      // ---- the planes become the sources (after the barrier), rows sr0 .. sr1
+      std::fill(lds.begin(), lds.end(), -54321.f);
+      for (int pass = 0; pass < pl.npass; ++pass)
+        for (int wave = 0; wave < pl.waves; ++wave)
+          for (int lane = 0; lane < 64; ++lane) {
+            const LaneConst c = lane_const(pl, lane, correct);
+            const int r = slot_row(pl, g, pass, wave, lane);
+            if (!(c.active && r < g.sr1)) continue;
+            const StripOut& s = keep[(size_t)(pass * pl.waves + wave) * 64 + lane];
+            float* q = lds.data() + (r - g.fr0) * pl.w + 4 * c.cs;
+            st4(q, s.p1.v); st4(q + plane, s.p2.v); st4(q + 2 * plane, s.cc.v);
+          }
+      const BPlane G1{lds.data(), g.fr0, g.fr1, pl.w}, G2{lds.data() + plane, g.fr0, g.fr1, pl.w},
+          GC{lds.data() + 2 * plane, g.fr0, g.fr1, pl.w};
+      // ---- phase C
+      for (int pass = 0; pass < pl.npass; ++pass)
+        for (int wave = 0; wave < pl.waves; ++wave) {
+          AdjVert a[64];
+          V4 p1s[64], p2d[64], ccs[64], ccd[64];
+          int rc[64];
+          for (int lane = 0; lane < 64; ++lane) {
+            const LaneConst c = lane_const(pl, lane, correct);
+            const int r = slot_row(pl, g, pass, wave, lane);
+            rc[lane] = r < g.r0 ? g.r0 : (r < g.r1 ? r : g.r1 - 1);          // idle / halo slots: any own row
+            a[lane] = adj_vert(G1, G2, GC, rc[lane], row_geom(rc[lane], n, correct), c, jl);
+            p1s[lane] = a[lane].p1s; p2d[lane] = a[lane].p2d; ccs[lane] = a[lane].ccs; ccd[lane] = a[lane].ccd;
+          }
+          for (int lane = 0; lane < 64; ++lane) {
+            const LaneConst c = lane_const(pl, lane, correct);
+            const int r = slot_row(pl, g, pass, wave, lane);
+            const bool own = c.active && r >= g.r0 && r < g.r1;
+            V4 du, d1, d2;
+            adj_finish(a[lane], halo_from(p1s, lane, jl), halo_from(p2d, lane, jl), halo_from(ccs, lane, jl),
+                       halo_from(ccd, lane, jl), keep[(size_t)(pass * pl.waves + wave) * 64 + lane], c, jl, fn, du, d1, d2);
+            if (!own) continue;
+            for (int j = 0; j < 4; ++j)
+              if (c.valid[j]) {
+                const size_t o = (size_t)r * n + 4 * c.cs + j;
+                gb[o] = du.v[j]; gb[nn + o] = d1.v[j]; gb[2 * nn + o] = d2.v[j];
+              }
+          }
+        }
+    }
+  return pl.nbands;
+}
+
+int emu_band_plan(int n, long long lds_floats_max, int* out) {
+  band::Plan pl;
+  if (!band::choose_plan(n, lds_floats_max, pl)) return 0;
+  out[0] = pl.waves; out[1] = pl.npass; out[2] = pl.nbands; out[3] = pl.rpp; out[4] = (int)pl.lds_floats; out[5] = pl.cap;
+  return 1;
 }
 
 int emu_choose_tile(int n, long long budget, int* tr, int* tc) {

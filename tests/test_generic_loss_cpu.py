@@ -194,3 +194,76 @@ def test_g21_reference_variants_at_65(emu):
         for five in (0, 1):
             emu.emu_sobel_adjoint(_p(wh), _p(wv), _p(out), 2, 65, correct, five)
             assert rel_l2(out, g[f'adj65_f{3 + 2 * five}{sfx}']) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------- the row-band kernel
+BAND_LDS = 16384 - 64          # floats of LDS the band kernel may use (BAND_LDSF of darcy_loss_generic.hip)
+
+
+def _band(emu, K, y, weights, flags=0, b1=0.0, b2=0.0, plan=(0, 0, 0), grad=True):
+    B, _, n, _ = y.shape
+    ncont = B * (n - 2) * n if flags & 2 else B * n * n
+    gy = np.full_like(y, np.nan) if grad else None
+    part = np.zeros((B * n, 4), np.float32)
+    out = (ctypes.c_int * 6)()
+    nb = emu.emu_darcy_loss_band(_p(K), _p(y), _p(gy), _p(part), B, n, 2.0 * weights[0] / (B * n * n), 2.0 * weights[1] / ncont,
+                                 2.0 * weights[2] / (B * n), 2.0 * weights[3] / (2 * B * n), b1, b2, flags, plan[0], plan[1],
+                                 plan[2], BAND_LDS if not plan[0] else 1 << 22, out)
+    if nb <= 0:
+        return None, None, 0, None
+    s = part[:B * nb].astype(np.float64).sum(0)
+    terms = np.array([s[0] / (B * n * n), s[1] / ncont, s[2] / (B * n), s[3] / (2 * B * n)])
+    return terms, gy, nb, list(out)
+
+
+@pytest.fixture(scope='module')
+def bemu(emu):
+    emu.emu_darcy_loss_band.argtypes = [P, P, P, P, I, I, F, F, F, F, F, F, I, I, I, I, LL, P]
+    emu.emu_band_plan.argtypes = [I, LL, P]
+    return emu
+
+
+@pytest.mark.parametrize('n', [8, 9, 10, 11, 12, 20, 33, 48, 63, 64, 65, 66, 67, 100, 128, 129, 131, 200, 253, 256])
+@pytest.mark.parametrize('flags', [0, 4])
+def test_band_kernel_own_plan_vs_oracle(bemu, n, flags):
+    """the row-band form (csrc/darcy_band.h) with the plan the kernel itself chooses: every width class (n mod 4, one to
+    three partial columns in the last strip), rows per wave from 32 down to 1, one band and many, correct=True/False"""
+    K, y = _fields(2, n, 300 + n)
+    w = (1.0, 1.0, 10.0, 10.0)
+    terms, gy, nb, plan = _band(bemu, K, y, w, flags)
+    assert nb > 0, 'no plan'
+    ref_t, ref_g = _oracle(K, y, w, flags)
+    np.testing.assert_allclose(terms, ref_t, rtol=1e-5)
+    assert np.isfinite(gy).all()
+    assert rel_l2(gy, ref_g) < 1e-5
+    assert plan[4] <= BAND_LDS
+
+
+@pytest.mark.parametrize('n,plan', [(8, (1, 1, 1)), (9, (1, 1, 3)), (12, (1, 1, 4)), (17, (1, 1, 2)), (17, (2, 2, 1)), (20, (1, 1, 6)),
+                                    (33, (2, 1, 3)), (33, (4, 2, 1)), (65, (4, 2, 3)), (65, (8, 1, 3)), (65, (2, 2, 7)),
+                                    (66, (4, 1, 7)), (67, (8, 2, 2)), (128, (8, 2, 5)), (128, (4, 2, 10)), (130, (8, 2, 10))])
+@pytest.mark.parametrize('flags', [0, 1, 2, 4, 6])
+def test_band_kernel_forced_plans_and_flags(bemu, n, plan, flags):
+    """forced workgroup shapes / band counts (bands of 3 rows up to the whole image; halo rows at both ends), with the
+    nonlinear law, use_tb=False, correct=False and the two together"""
+    K, y = _fields(1, n, 500 + n + 7 * flags)
+    w = (1.0, 1.0, 10.0, 10.0)
+    b1, b2 = (0.1, 0.1) if flags & 1 else (0.0, 0.0)
+    terms, gy, nb, _ = _band(bemu, K, y, w, flags, b1, b2, plan)
+    assert nb == plan[2], 'the forced plan does not fit'
+    ref_t, ref_g = _oracle(K, y, w, flags, b1, b2)
+    np.testing.assert_allclose(terms, ref_t, rtol=1e-5)
+    assert np.isfinite(gy).all()
+    assert rel_l2(gy, ref_g) < 1e-5
+    # forward only: the same sums
+    t2, _, _, _ = _band(bemu, K, y, w, flags, b1, b2, plan, grad=False)
+    np.testing.assert_array_equal(t2, terms)
+
+
+def test_band_plans_cover_8_to_256(bemu):
+    out = (ctypes.c_int * 6)()
+    for n in range(8, 257):
+        assert bemu.emu_band_plan(n, BAND_LDS, out), n
+        waves, npass, nbands, rpp, lds, cap = list(out)
+        assert lds <= BAND_LDS and n // nbands >= 3 and (nbands == 1 and cap >= n or -(-n // nbands) + 2 <= cap), (n, list(out))
+    assert not bemu.emu_band_plan(7, BAND_LDS, out) and not bemu.emu_band_plan(257, BAND_LDS, out)

@@ -229,6 +229,75 @@ def test_generic_kernel_vs_oracle(dev, n, B, flags):
     np.testing.assert_allclose(terms2.cpu().numpy(), terms.cpu().numpy(), rtol=1e-6)
 
 
+BAND_CASES = [(n, B, f) for n, B in [(8, 5), (9, 3), (10, 3), (11, 3), (17, 4), (20, 7), (48, 3), (63, 2), (65, 5), (66, 2), (67, 2),
+                                     (100, 2), (128, 3), (129, 2), (131, 1), (200, 2), (253, 1), (256, 2)]
+              for f in (0, 4, 3)]
+
+
+@pytest.mark.parametrize('n,B,flags', BAND_CASES)
+def test_band_kernel_vs_oracle_and_tile_kernel(dev, n, B, flags, monkeypatch):
+    """the row-band kernel (csrc/darcy_band.h: 8 <= n <= 256) against the fp64 oracle and against the tile kernel
+    (PDES_LOSS_TILED) on the same inputs: every width class (n mod 4), 32 rows per wave down to one, one band and many,
+    16-byte and scalar accesses; correct=False (4), nonlinear + use_tb=False (3)"""
+    from oracle import darcy as od
+    from pde_surrogate_amd.models import darcy
+    K, y, Kd, yd = _fields(B, n, 4000 + n + flags, dev)
+    w = (0.7, 1.3, 9.0, 11.0)
+    nl, tb, correct = bool(flags & 1), not (flags & 2), not (flags & 4)
+    monkeypatch.setattr(darcy, 'EXTRA_FLAGS', 16)                   # (64 would otherwise be the specialised kernel)
+    terms, grad = darcy.darcy_loss_launch(Kd, yd, w, True, nl, 0.1, 0.2, tb, correct)
+    rt, rg = od.loss_and_grad_autograd(torch.from_numpy(K).double(), torch.from_numpy(y).double(), 10.0, 0.1, 0.2, nl,
+                                       weights=w, correct=correct, use_tb=tb)
+    ref = [float(w[0] * rt[1] + w[1] * rt[2] + w[2] * rt[3] + w[3] * rt[4])] + [float(v) for v in rt[1:]]
+    np.testing.assert_allclose(terms.cpu().numpy(), ref, rtol=LOSS_RTOL)
+    assert torch.isfinite(grad).all()
+    assert rel_l2(grad.cpu().numpy(), rg.numpy()) < GRAD_RL2
+    terms2, g2 = darcy.darcy_loss_launch(Kd, yd, w, False, nl, 0.1, 0.2, tb, correct)      # forward only: the same sums
+    assert g2 is None and torch.equal(terms2, terms)
+    monkeypatch.setattr(darcy, 'EXTRA_FLAGS', 16 | 8)
+    terms_t, grad_t = darcy.darcy_loss_launch(Kd, yd, w, True, nl, 0.1, 0.2, tb, correct)
+    np.testing.assert_allclose(terms.cpu().numpy(), terms_t.cpu().numpy(), rtol=2e-6)
+    assert rel_l2(grad.cpu().numpy(), grad_t.cpu().numpy()) < 2e-6
+    # an unaligned base pointer takes the scalar-access path of the same kernel
+    if n % 4 == 0:
+        monkeypatch.setattr(darcy, 'EXTRA_FLAGS', 16)
+        pad = torch.empty(Kd.numel() + 1, device=dev)
+        Ku = pad[1:].view_as(Kd).copy_(Kd)
+        assert Ku.data_ptr() % 16 == 4
+        terms_u, grad_u = darcy.darcy_loss_launch(Ku, yd, w, True, nl, 0.1, 0.2, tb, correct)
+        assert torch.equal(terms_u, terms) and torch.equal(grad_u, grad)
+
+
+@pytest.mark.parametrize('n', [16, 32, 64])
+def test_band_kernel_equals_the_specialised_kernels(dev, n, monkeypatch):
+    """at 16 / 32 / 64 the row-band kernel is the specialised kernel without the compile-time size: same loss terms and
+    gradient to rounding (1e-6), linear and nonlinear, B = 32 and one odd batch"""
+    from pde_surrogate_amd.models import darcy
+    for B in (32, 5):
+        for nl in (False, True):
+            _, _, Kd, yd = _fields(B, n, 77 + n + B, dev)
+            monkeypatch.setattr(darcy, 'EXTRA_FLAGS', 0)
+            t0, g0 = darcy.darcy_loss_launch(Kd, yd, (1, 1, 10, 10), True, nl, 0.1, 0.1)
+            monkeypatch.setattr(darcy, 'EXTRA_FLAGS', 16)
+            t1, g1 = darcy.darcy_loss_launch(Kd, yd, (1, 1, 10, 10), True, nl, 0.1, 0.1)
+            np.testing.assert_allclose(t1.cpu().numpy(), t0.cpu().numpy(), rtol=1e-6)
+            assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6
+
+
+def test_band_kernel_is_deterministic_and_its_partial_rows_are_its_bands(dev):
+    from pde_surrogate_amd import _lib
+    from pde_surrogate_amd.models import darcy
+    torch.manual_seed(5)
+    K = torch.exp(0.5 * torch.randn(6, 1, 65, 65, device=dev))
+    y = torch.randn(6, 3, 65, 65, device=dev)
+    t0, g0 = darcy.darcy_loss_launch(K, y, (1, 1, 10, 10), True)
+    t1, g1 = darcy.darcy_loss_launch(K, y, (1, 1, 10, 10), True)
+    assert torch.equal(t0, t1) and torch.equal(g0, g1)
+    assert _lib.loss_partial_rows(6, 65, 65, 0) == 6 * 3                  # three bands of 22 / 21 rows per image
+    assert _lib.loss_partial_rows(6, 65, 65, 8) != _lib.loss_partial_rows(6, 65, 65, 0)      # PDES_LOSS_TILED: the tile kernel's rows
+    assert _lib.loss_partial_rows(6, 64, 64, 0) == 6 and _lib.loss_partial_rows(6, 64, 64, 16) >= 6
+
+
 def test_generic_kernel_is_deterministic(dev):
     """the tiled kernel keeps the per-image sums inside one workgroup (fixed-order reductions): same inputs twice are
     bit-identical, loss terms and gradient"""

@@ -34,9 +34,19 @@ def rate(n, B, flags, iters=30, warm=30):
     return us, by / us / 1e3
 
 
-for n, B, flags, name in ((64, 16384, 0, 'specialised 64x64'), (64, 16384, 4, 'generic 64x64 (correct=False)'),
-                          (65, 16384, 0, 'generic 65x65'), (128, 4096, 0, 'generic 128x128'), (48, 28672, 0, 'generic 48x48'),
-                          (256, 1024, 0, 'generic 256x256'), (32, 65536, 0, 'specialised 32x32'), (32, 65536, 4, 'generic 32x32'),
-                          (64, 32, 4, 'generic 64x64 at the training batch'), (128, 32, 0, 'generic 128x128 at batch 32')):
+# flags: 4 = correct=False, 16 = PDES_LOSS_GENERIC (never the specialisation), 8 = PDES_LOSS_TILED (the tile kernel of rounds 1-3)
+CASES = [(64, 16384, 0, 'specialised 64x64'), (64, 16384, 16, 'row bands 64x64'), (64, 16384, 4, 'row bands 64x64 (correct=False)'),
+         (64, 16384, 24, 'tiles 64x64'),
+         (65, 16384, 0, 'row bands 65x65'), (65, 16384, 8, 'tiles 65x65'),
+         (128, 4096, 0, 'row bands 128x128'), (128, 4096, 8, 'tiles 128x128'),
+         (48, 28672, 0, 'row bands 48x48'), (48, 28672, 8, 'tiles 48x48'),
+         (100, 6554, 0, 'row bands 100x100'), (130, 3878, 0, 'row bands 130x130'), (200, 1638, 0, 'row bands 200x200'),
+         (256, 1024, 0, 'row bands 256x256'), (256, 1024, 8, 'tiles 256x256'),
+         (32, 65536, 0, 'specialised 32x32'), (32, 65536, 16, 'row bands 32x32'),
+         (64, 32, 16, 'row bands 64x64 at the training batch'), (64, 32, 0, 'specialised 64x64 at the training batch'),
+         (65, 32, 0, 'row bands 65x65 at batch 32'), (128, 32, 0, 'row bands 128x128 at batch 32'), (128, 32, 8, 'tiles 128x128 at batch 32')]
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if any(a in c[3] for a in sys.argv[1:])]
+for n, B, flags, name in CASES:
     us, gbs = rate(n, B, flags)
     print(f'{name:40s} B={B:6d}  {us:9.1f} us  {gbs:8.1f} GB/s  {gbs / 8000:.3f} of 8 TB/s', flush=True)
