@@ -37,6 +37,7 @@ using gen::sqrt_f;
 using gen::st4;
 
 constexpr int kMinN = 8, kMaxN = 256;
+constexpr int kRowTab = 12;      // dwords of the row table per field row (RowTab below)
 
 struct V4 { float v[4]; };
 
@@ -45,10 +46,13 @@ struct Plan {
   int n, spr, jl, rpp, w;      // strips per row, last real column of the last strip, rows per wave and pass, LDS row stride
   int waves, npass, cap;       // workgroup: waves, passes, source rows it can hold = waves * rpp * npass
   int nbands, rows_f;          // bands per image; field rows of the tallest band
-  long long lds_floats;        // 3 * rows_f * w
+  int own_base, own_rem;       // band b owns own_base (+1 for b < own_rem) rows: first row b * own_base + min(b, own_rem)
+  int inv_spr;                 // lane / spr == (lane * inv_spr) >> 16 for lane < 64
+  int planes;                  // LDS planes: 3, or 4 when n is not a multiple of 4 (K is staged too; outputs leave through them)
+  long long lds_floats;        // planes * rows_f * w + the row table (kRowTab floats per field row)
 };
 
-PDES_HD int band_lo(int band, int nbands, int n) { return (int)(((long long)band * n) / nbands); }
+PDES_HD int band_lo(const Plan& p, int band) { return band * p.own_base + imin(band, p.own_rem); }
 
 // waves in {1,2,4,8}, passes in {1,2}: the most strip slots doing own work; ties -> the larger workgroup (fewer bands,
 // less halo).  False: size not served by the band kernel.
@@ -69,8 +73,11 @@ inline bool choose_plan(int n, long long lds_floats_max, Plan& best) {
         if (n / p.nbands < 3) continue;
       }
       const int own_max = (n + p.nbands - 1) / p.nbands;
+      p.own_base = n / p.nbands; p.own_rem = n % p.nbands;
+      p.inv_spr = 65536 / spr + 1;
       p.rows_f = imin(own_max + 4, n);
-      p.lds_floats = 3ll * p.rows_f * p.w;
+      p.planes = (n & 3) ? 4 : 3;
+      p.lds_floats = (long long)p.planes * p.rows_f * p.w + (long long)kRowTab * p.rows_f;
       if (p.lds_floats > lds_floats_max) continue;
       const double eff = (double)n / ((double)p.nbands * p.cap);
       if (!found || eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && waves * npass >= best.waves * best.npass)) {
@@ -87,7 +94,7 @@ struct BandGeo {
 };
 PDES_HD BandGeo band_geo(const Plan& p, int band) {
   BandGeo g;
-  g.r0 = band_lo(band, p.nbands, p.n); g.r1 = band_lo(band + 1, p.nbands, p.n);
+  g.r0 = band_lo(p, band); g.r1 = band_lo(p, band + 1);
   g.sr0 = imax(g.r0 - 1, 0); g.sr1 = imin(g.r1 + 1, p.n);
   g.fr0 = imax(g.sr0 - 1, 0); g.fr1 = imin(g.sr1 + 1, p.n);
   return g;
@@ -125,7 +132,7 @@ PDES_HD RowGeom row_geom(int r, int n, bool correct) {
 
 // ---- what a lane knows about its strip column (constant over the passes) ---------------------------------------------
 struct LaneConst {
-  int cs;                  // strip of the row
+  int cs, lrow;            // strip of the row; row of the wave's pass (lane / spr)
   bool active;             // lane < rpp * spr
   bool first, last;
   bool valid[4];           // column < n
@@ -134,7 +141,8 @@ struct LaneConst {
 PDES_HD LaneConst lane_const(const Plan& p, int lane, bool correct) {
   LaneConst c;
   c.active = lane < p.rpp * p.spr;
-  c.cs = lane % p.spr;
+  c.lrow = (lane * p.inv_spr) >> 16;
+  c.cs = lane - c.lrow * p.spr;
   c.first = c.cs == 0;
   c.last = c.cs == p.spr - 1;
   for (int j = 0; j < 4; ++j) {
@@ -162,10 +170,46 @@ struct BPlane {
   const float* p;
   int fr0, fr1, w;
 };
-PDES_HD V4 ldrow(const BPlane& P, int r, int cs) {       // r clamped into the plane (the caller masks what it must)
-  const int rr = r < P.fr0 ? P.fr0 : (r >= P.fr1 ? P.fr1 - 1 : r);
+PDES_HD V4 ldoff(const BPlane& P, int off) {
   V4 o;
-  ld4(P.p + (rr - P.fr0) * P.w + 4 * cs, o.v);
+  ld4(P.p + off, o.v);
+  return o;
+}
+// The row table of a band, built once per workgroup (one thread per field row) behind the planes: what row_geom says about
+// a row, with the neighbour rows as plane offsets -- a strip reads 2 x 16 bytes per phase instead of re-deriving ~50
+// selects.  Entry of field row r (fr0 <= r < fr1) at dword kRowTab * (r - fr0):
+//   ints   [0..3]  (up - fr0) w, (dn - fr0) w, (farF - fr0) w, (farA - fr0) w        (rows clamped into the plane)
+//   floats [4..7]  f_own, f_up, f_dn, f_far        [8..11]  a_own, a_up, a_dn, a_far
+union Dword { float f; int i; };
+PDES_HD void rowtab_build(float* tab, int r, int n, bool correct, int fr0, int fr1, int w) {
+  const RowGeom g = row_geom(r, n, correct);
+  float* t = tab + kRowTab * (r - fr0);
+  const int rows[4] = {g.up, g.dn, g.farF, g.farA};
+  for (int k = 0; k < 4; ++k) {
+    const int rr = rows[k] < fr0 ? fr0 : (rows[k] >= fr1 ? fr1 - 1 : rows[k]);
+    Dword d;
+    d.i = (rr - fr0) * w;
+    t[k] = d.f;
+  }
+  t[4] = g.f_own; t[5] = g.f_up; t[6] = g.f_dn; t[7] = g.f_far;
+  t[8] = g.a_own; t[9] = g.a_up; t[10] = g.a_dn; t[11] = g.a_far;
+}
+struct RowTab {
+  int o_own, o_up, o_dn, o_far;     // float offsets of the strip (row, cs) and of its neighbour rows in a plane
+  float k_own, k_up, k_dn, k_far;   // the vertical difference (forward or adjoint)
+};
+template <bool ADJ>
+PDES_HD RowTab rowtab_read(const float* tab, int r, int cs, int fr0, int w) {
+  const float* t = tab + kRowTab * (r - fr0);
+  float a[4], b[4];
+  ld4(t, a);
+  ld4(t + (ADJ ? 8 : 4), b);
+  Dword d0, d1, d2;
+  d0.f = a[0]; d1.f = a[1]; d2.f = ADJ ? a[3] : a[2];
+  RowTab o;
+  o.o_own = (r - fr0) * w + 4 * cs;
+  o.o_up = d0.i + 4 * cs; o.o_dn = d1.i + 4 * cs; o.o_far = d2.i + 4 * cs;
+  o.k_own = b[0]; o.k_up = b[1]; o.k_dn = b[2]; o.k_far = b[3];
   return o;
 }
 PDES_HD V4 vsmooth3(const V4& up, const V4& own, const V4& dn) {
@@ -181,12 +225,20 @@ PDES_HD V4 comb4(float a, const V4& x, float b, const V4& y, float c, const V4& 
 // x.v[j] for a uniform runtime j without indexing the register array
 PDES_HD float pick(const V4& x, int j) { return j == 0 ? x.v[0] : (j == 1 ? x.v[1] : (j == 2 ? x.v[2] : x.v[3])); }
 // the columns behind the image's last one: replicate it (forward operators, smoothing) / zero (adjoint of the difference)
-PDES_HD void tail_replicate(V4& x, bool last, int jl) {
-  const float e = pick(x, jl);
-  if (last) for (int j = 1; j < 4; ++j) if (j > jl) x.v[j] = e;
+// The functions below are instantiated per WIDTH CLASS J: J = 0 .. 3 is jl, the last real column of the last strip (J = 3: a
+// multiple of 4 behind pointers that are not 16-byte aligned); J = 4 is the aligned multiple of 4 (jl = 3, every access 16
+// bytes).  With jl a compile-time constant the tail handling is a handful of selects on the lane's `last` flag.
+template <int J> struct WidthClass { static constexpr int jl = J == 4 ? 3 : J; static constexpr bool aligned = J == 4; };
+
+template <int J>
+PDES_HD void tail_replicate(V4& x, const LaneConst& c) {
+  constexpr int jl = WidthClass<J>::jl;
+  for (int j = 1; j < 4; ++j) if (j > jl) x.v[j] = c.last ? x.v[jl] : x.v[j];
 }
-PDES_HD void tail_zero(V4& x, bool last, int jl) {
-  if (last) for (int j = 1; j < 4; ++j) if (j > jl) x.v[j] = 0.f;
+template <int J>
+PDES_HD void tail_zero(V4& x, const LaneConst& c) {
+  constexpr int jl = WidthClass<J>::jl;
+  for (int j = 1; j < 4; ++j) if (j > jl) x.v[j] = c.last ? 0.f : x.v[j];
 }
 
 // what a strip takes from its neighbour lanes
@@ -207,7 +259,9 @@ PDES_HD V4 hsmooth(const V4& x, const Halo& h, const LaneConst& c, float scale) 
 }
 // scale * (x A) along the row: clamped central difference; `correct`: one-sided second-order differences in the first /
 // last column (image_gradient.py:43-46).  x: tail-replicated.
-PDES_HD V4 hdiff(const V4& x, const Halo& h, const LaneConst& c, int jl, bool correct, float scale) {
+template <int J>
+PDES_HD V4 hdiff(const V4& x, const Halo& h, const LaneConst& c, bool correct, float scale) {
+  constexpr int jl = WidthClass<J>::jl;
   const float l = c.first ? x.v[0] : h.l, r = c.last ? x.v[3] : h.r;
   V4 o;
   o.v[0] = 0.5f * (x.v[1] - l);
@@ -215,22 +269,22 @@ PDES_HD V4 hdiff(const V4& x, const Halo& h, const LaneConst& c, int jl, bool co
   o.v[2] = 0.5f * (x.v[3] - x.v[1]);
   o.v[3] = 0.5f * (r - x.v[2]);
   if (correct) {
-    if (c.first) o.v[0] = 0.5f * (-3.f * x.v[0] + 4.f * x.v[1] - x.v[2]);
-    if (c.last) {
-      const float m0 = pick(x, jl);
-      const float m1 = jl >= 1 ? pick(x, jl - 1) : h.l;
-      const float m2 = jl >= 2 ? pick(x, jl - 2) : (jl == 1 ? h.l : h.l2);
-      const float e = 0.5f * (3.f * m0 - 4.f * m1 + m2);
-      for (int j = 0; j < 4; ++j) if (j == jl) o.v[j] = e;
-    }
+    const float e0 = 0.5f * (-3.f * x.v[0] + 4.f * x.v[1] - x.v[2]);
+    o.v[0] = c.first ? e0 : o.v[0];
+    const float m1 = jl >= 1 ? x.v[jl >= 1 ? jl - 1 : 0] : h.l;
+    const float m2 = jl >= 2 ? x.v[jl >= 2 ? jl - 2 : 0] : (jl == 1 ? h.l : h.l2);
+    const float e = 0.5f * (3.f * x.v[jl] - 4.f * m1 + m2);
+    o.v[jl] = c.last ? e : o.v[jl];
   }
   for (int i = 0; i < 4; ++i) o.v[i] *= scale;
   return o;
 }
 // scale * (g A^T) along the row.  g: tail-zeroed.
-PDES_HD V4 hdiff_adj(const V4& g, const Halo& h, const LaneConst& c, int jl, float scale) {
+template <int J>
+PDES_HD V4 hdiff_adj(const V4& g, const Halo& h, const LaneConst& c, float scale) {
+  constexpr int jl = WidthClass<J>::jl;
   const float l = c.first ? 0.f : h.l, r = c.last ? 0.f : h.r;
-  const float g0 = g.v[0], gl = c.last ? pick(g, jl) : h.rjl;
+  const float g0 = g.v[0], gl = jl >= 2 ? g.v[jl] : (c.last ? g.v[jl] : h.rjl);      // (jl >= 2: n-1, n-2, n-3 are all in the last strip)
   V4 o;
   o.v[0] = 0.5f * (l - g.v[1]) + c.cl[0] * g0 + c.cr[0] * gl;
   o.v[1] = 0.5f * (g.v[0] - g.v[2]) + c.cl[1] * g0 + c.cr[1] * gl;
@@ -245,18 +299,19 @@ struct FwdVert {          // vertical combinations (tail-replicated) + the strip
   V4 us, ud, as, bd;      // S_rows u, A_rows u, S_rows sigma1, A_rows sigma2
   V4 u, s1, s2;
 };
-PDES_HD FwdVert fwd_vert(const BPlane& U, const BPlane& X1, const BPlane& X2, int r, const RowGeom& g, const LaneConst& c, int jl) {
+template <int J>
+PDES_HD FwdVert fwd_vert(const BPlane& U, const BPlane& X1, const BPlane& X2, const RowTab& t, const LaneConst& c) {
   FwdVert o;
-  o.u = ldrow(U, r, c.cs); o.s1 = ldrow(X1, r, c.cs); o.s2 = ldrow(X2, r, c.cs);
-  const V4 u_up = ldrow(U, g.up, c.cs), u_dn = ldrow(U, g.dn, c.cs), u_far = ldrow(U, g.farF, c.cs);
-  const V4 a_up = ldrow(X1, g.up, c.cs), a_dn = ldrow(X1, g.dn, c.cs);
-  const V4 b_up = ldrow(X2, g.up, c.cs), b_dn = ldrow(X2, g.dn, c.cs), b_far = ldrow(X2, g.farF, c.cs);
+  o.u = ldoff(U, t.o_own); o.s1 = ldoff(X1, t.o_own); o.s2 = ldoff(X2, t.o_own);      // (the three planes share their geometry)
+  const V4 u_up = ldoff(U, t.o_up), u_dn = ldoff(U, t.o_dn), u_far = ldoff(U, t.o_far);
+  const V4 a_up = ldoff(X1, t.o_up), a_dn = ldoff(X1, t.o_dn);
+  const V4 b_up = ldoff(X2, t.o_up), b_dn = ldoff(X2, t.o_dn), b_far = ldoff(X2, t.o_far);
   o.us = vsmooth3(u_up, o.u, u_dn);
-  o.ud = comb4(g.f_own, o.u, g.f_up, u_up, g.f_dn, u_dn, g.f_far, u_far);
+  o.ud = comb4(t.k_own, o.u, t.k_up, u_up, t.k_dn, u_dn, t.k_far, u_far);
   o.as = vsmooth3(a_up, o.s1, a_dn);
-  o.bd = comb4(g.f_own, o.s2, g.f_up, b_up, g.f_dn, b_dn, g.f_far, b_far);
-  tail_replicate(o.us, c.last, jl); tail_replicate(o.ud, c.last, jl);
-  tail_replicate(o.as, c.last, jl); tail_replicate(o.bd, c.last, jl);
+  o.bd = comb4(t.k_own, o.s2, t.k_up, b_up, t.k_dn, b_dn, t.k_far, b_far);
+  tail_replicate<J>(o.us, c); tail_replicate<J>(o.ud, c);
+  tail_replicate<J>(o.as, c); tail_replicate<J>(o.bd, c);
   return o;
 }
 
@@ -266,13 +321,15 @@ struct StripOut {
   V4 p1, p2, cc;          // adjoint sources a_const K r1, a_const K r2, a_cont c (zero outside the image)
 };
 // `own`: the strip's row belongs to the band (its pixels enter the sums)
+template <int J>
 PDES_HD StripOut fwd_finish(const FwdVert& f, const Halo& hus, const Halo& hud, const Halo& has, const Halo& hbd, const V4& K,
-                            int r, int n, const LaneConst& c, int jl, const LossParams& p, int flags, float fn, bool own,
+                            int r, int n, const LaneConst& c, const LossParams& p, int flags, float fn, bool own,
                             float* sums) {
+  constexpr int jl = WidthClass<J>::jl;
   const bool correct = !(flags & kUncorrected);
-  const V4 ghu = hdiff(f.us, hus, c, jl, correct, fn);
+  const V4 ghu = hdiff<J>(f.us, hus, c, correct, fn);
   const V4 gvu = hsmooth(f.ud, hud, c, fn);
-  const V4 gh1 = hdiff(f.as, has, c, jl, correct, fn);
+  const V4 gh1 = hdiff<J>(f.as, has, c, correct, fn);
   const V4 gv2 = hsmooth(f.bd, hbd, c, fn);
   const bool tb = (r == 0) || (r == n - 1);
   StripOut o;
@@ -288,7 +345,7 @@ PDES_HD StripOut fwd_finish(const FwdVert& f, const Halo& hus, const Halo& hud, 
       q2 += 2.f * p.beta1 * sq * x2 + 3.f * p.beta2 * k * x2 * x2;
     }
     const float cc = ((flags & kNoTB) && tb) ? 0.f : gh1.v[j] + gv2.v[j];     // darcy.py:224
-    const bool in = c.valid[j];
+    const bool in = j <= jl || c.valid[j];         // (columns up to jl exist in every strip)
     o.p1.v[j] = in ? p.a_const * k * r1 : 0.f;
     o.p2.v[j] = in ? p.a_const * k * r2 : 0.f;
     o.cc.v[j] = in ? p.a_cont * cc : 0.f;
@@ -301,11 +358,11 @@ PDES_HD StripOut fwd_finish(const FwdVert& f, const Halo& hus, const Halo& hud, 
     }
   }
   // Dirichlet columns (darcy.py:226-233): u = 1 on the left, u = 0 on the right
-  if (c.first) { const float e = f.u.v[0] - 1.f; o.du = p.b_dir * e; if (own) sums[2] += e * e; }
-  if (c.last) {                               // (never the first strip too: n >= 8)
-    const float e = pick(f.u, jl);
-    o.du = p.b_dir * e;
-    if (own) sums[2] += e * e;
+  {                                           // (a strip is never first and last: n >= 8)
+    const float e = c.first ? f.u.v[0] - 1.f : f.u.v[jl];
+    const bool edge = c.first || c.last;
+    o.du = edge ? p.b_dir * e : 0.f;
+    sums[2] += (own && edge) ? e * e : 0.f;
   }
   return o;
 }
@@ -314,38 +371,41 @@ PDES_HD StripOut fwd_finish(const FwdVert& f, const Halo& hus, const Halo& hud, 
 struct AdjVert {
   V4 p1s, p2d, ccs, ccd;  // S_rows p1, A^T_rows p2, S_rows cc, A^T_rows cc
 };
-PDES_HD AdjVert adj_vert(const BPlane& G1, const BPlane& G2, const BPlane& GC, int r, const RowGeom& g, const LaneConst& c, int jl) {
+template <int J>
+PDES_HD AdjVert adj_vert(const BPlane& G1, const BPlane& G2, const BPlane& GC, const RowTab& t, const LaneConst& c) {
   AdjVert o;
-  const V4 p1 = ldrow(G1, r, c.cs), p1_up = ldrow(G1, g.up, c.cs), p1_dn = ldrow(G1, g.dn, c.cs);
-  const V4 p2 = ldrow(G2, r, c.cs), p2_up = ldrow(G2, g.up, c.cs), p2_dn = ldrow(G2, g.dn, c.cs), p2_far = ldrow(G2, g.farA, c.cs);
-  const V4 cc = ldrow(GC, r, c.cs), cc_up = ldrow(GC, g.up, c.cs), cc_dn = ldrow(GC, g.dn, c.cs), cc_far = ldrow(GC, g.farA, c.cs);
+  const V4 p1 = ldoff(G1, t.o_own), p1_up = ldoff(G1, t.o_up), p1_dn = ldoff(G1, t.o_dn);
+  const V4 p2 = ldoff(G2, t.o_own), p2_up = ldoff(G2, t.o_up), p2_dn = ldoff(G2, t.o_dn), p2_far = ldoff(G2, t.o_far);
+  const V4 cc = ldoff(GC, t.o_own), cc_up = ldoff(GC, t.o_up), cc_dn = ldoff(GC, t.o_dn), cc_far = ldoff(GC, t.o_far);
   o.p1s = vsmooth3(p1_up, p1, p1_dn);
-  o.p2d = comb4(g.a_own, p2, g.a_up, p2_up, g.a_dn, p2_dn, g.a_far, p2_far);
+  o.p2d = comb4(t.k_own, p2, t.k_up, p2_up, t.k_dn, p2_dn, t.k_far, p2_far);
   o.ccs = vsmooth3(cc_up, cc, cc_dn);
-  o.ccd = comb4(g.a_own, cc, g.a_up, cc_up, g.a_dn, cc_dn, g.a_far, cc_far);
-  tail_zero(o.p1s, c.last, jl); tail_zero(o.ccs, c.last, jl);               // -> the column difference's adjoint
-  tail_replicate(o.p2d, c.last, jl); tail_replicate(o.ccd, c.last, jl);     // -> the (symmetric) column smoothing
+  o.ccd = comb4(t.k_own, cc, t.k_up, cc_up, t.k_dn, cc_dn, t.k_far, cc_far);
+  tail_zero<J>(o.p1s, c); tail_zero<J>(o.ccs, c);                           // -> the column difference's adjoint
+  tail_replicate<J>(o.p2d, c); tail_replicate<J>(o.ccd, c);                 // -> the (symmetric) column smoothing
   return o;
 }
 // dL/du, dL/dsigma1, dL/dsigma2 of the strip
+template <int J>
 PDES_HD void adj_finish(const AdjVert& a, const Halo& hp1, const Halo& hp2, const Halo& hcs, const Halo& hcd, const StripOut& s,
-                        const LaneConst& c, int jl, float fn, V4& du, V4& d1, V4& d2) {
-  const V4 ghT_p1 = hdiff_adj(a.p1s, hp1, c, jl, fn);
+                        const LaneConst& c, float fn, V4& du, V4& d1, V4& d2) {
+  constexpr int jl = WidthClass<J>::jl;
+  const V4 ghT_p1 = hdiff_adj<J>(a.p1s, hp1, c, fn);
   const V4 gvT_p2 = hsmooth(a.p2d, hp2, c, fn);
-  const V4 ghT_c = hdiff_adj(a.ccs, hcs, c, jl, fn);
+  const V4 ghT_c = hdiff_adj<J>(a.ccs, hcs, c, fn);
   const V4 gvT_c = hsmooth(a.ccd, hcd, c, fn);
   for (int j = 0; j < 4; ++j) {
     du.v[j] = ghT_p1.v[j] + gvT_p2.v[j];
     d1.v[j] = s.d1.v[j] + ghT_c.v[j];
     d2.v[j] = s.d2.v[j] + gvT_c.v[j];
   }
-  if (c.first) du.v[0] += s.du;
-  if (c.last) for (int j = 0; j < 4; ++j) if (j == jl) du.v[j] += s.du;
+  du.v[0] += c.first ? s.du : 0.f;
+  du.v[jl] += c.last ? s.du : 0.f;
 }
 
 // slot of (pass, wave, lane) -> source row of the band (may be >= sr1: an idle slot)
-PDES_HD int slot_row(const Plan& p, const BandGeo& g, int pass, int wave, int lane) {
-  return g.sr0 + (pass * p.waves + wave) * p.rpp + lane / p.spr;
+PDES_HD int slot_row(const Plan& p, const BandGeo& g, int pass, int wave, const LaneConst& c) {
+  return g.sr0 + (pass * p.waves + wave) * p.rpp + c.lrow;
 }
 
 }  // namespace band

@@ -25,6 +25,7 @@
 namespace pdes {
 
 using namespace gen;
+using gen::imin;
 
 // 256 threads and 40 KiB of tile planes per workgroup: four workgroups per CU, whose load / stencil / store phases
 // overlap (one 1024-thread workgroup with 128 KiB per CU ran its phases back to back: 0.10 of 8 TB/s)
@@ -107,24 +108,29 @@ __device__ __forceinline__ float wave_shr1(float v) {      // lane i <- lane i -
 __device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ band::Halo halo_of(const band::V4& x, int jl) {
+template <int J>
+__device__ __forceinline__ band::Halo halo_of(const band::V4& x) {       // (what a caller does not use is never computed)
   band::Halo h;
   h.l = wave_shr1(x.v[3]);
   h.l2 = wave_shr1(x.v[2]);
   h.r = wave_shl1(x.v[0]);
-  h.rjl = wave_shl1(band::pick(x, jl));
+  h.rjl = wave_shl1(x.v[band::WidthClass<J>::jl]);
   return h;
 }
 
-template <bool BWD, int NPASS>
-__global__ __launch_bounds__(512) void darcy_loss_band_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
+// J = 4: n is a multiple of 4 and every pointer 16-byte aligned -> 16-byte global accesses, no tail code.  J = 0 .. 3
+// (= the last real column of the last strip): scalar global accesses over CONTIGUOUS ranges (a band's rows are one range of
+// the plane): the fields and the conductivities enter through the LDS planes, the gradient leaves through them.
+template <bool BWD, int NPASS, int J>
+__global__ __launch_bounds__(512, 4) void darcy_loss_band_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
                                                               float* __restrict__ gyp, float* __restrict__ partials,
-                                                              LossParams p, band::Plan pl, int flags, int vec) {
+                                                              LossParams p, band::Plan pl, int flags) {
   using namespace band;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[8 * 4];
   const int bi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
-  const int n = pl.n, jl = pl.jl, w = pl.w, spr = pl.spr;
+  constexpr bool A = J == 4;
+  const int n = pl.n, w = pl.w;
   const size_t nn = (size_t)n * n;
   const float fn = (float)n;
   const bool correct = !(flags & kUncorrected);
@@ -134,88 +140,113 @@ __global__ __launch_bounds__(512) void darcy_loss_band_kernel(const float* __res
   const float* yb = yp + (size_t)b * 3 * nn;
   float* gb = BWD ? gyp + (size_t)b * 3 * nn : nullptr;
   const int plane = pl.rows_f * w, rows_f = g.fr1 - g.fr0;
+  float* tab = lds + pl.planes * plane;                      // the row table (darcy_band.h), read after the first barrier
+  if (tid < rows_f) rowtab_build(tab, g.fr0 + tid, n, correct, g.fr0, g.fr1, w);
 
-  // the conductivities of this lane's strips: requested first, used after the staging
-  V4 kk[NPASS];
   int row[NPASS];
 #pragma unroll
-  for (int k = 0; k < NPASS; ++k) {
-    row[k] = slot_row(pl, g, k, wave, lane);
-    const bool ok = c.active && row[k] < g.sr1;
-    const float* kp = Kb + (size_t)row[k] * n + 4 * c.cs;
+  for (int k = 0; k < NPASS; ++k) row[k] = slot_row(pl, g, k, wave, c);
+  V4 kk[NPASS];
+  if (A) {
+    // the conductivities of this lane's strips: requested first, used after the staging
 #pragma unroll
-    for (int j = 0; j < 4; ++j) kk[k].v[j] = 0.f;
-    if (ok) {
-      if (vec) kk[k] = *reinterpret_cast<const V4*>(&(const float4&)(p.nt ? nt_load4(reinterpret_cast<const float4*>(kp))
-                                                                         : *reinterpret_cast<const float4*>(kp)));
-      else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (c.valid[j]) kk[k].v[j] = kp[j];
-      }
+    for (int k = 0; k < NPASS; ++k) {
+      const bool ok = c.active && row[k] < g.sr1;
+      const float4* kp = reinterpret_cast<const float4*>(Kb + (size_t)row[k] * n + 4 * c.cs);
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) t = p.nt ? nt_load4(kp) : *kp;
+      kk[k].v[0] = t.x; kk[k].v[1] = t.y; kk[k].v[2] = t.z; kk[k].v[3] = t.w;
     }
-  }
-  // ---- the three fields on rows fr0 .. fr1 -> LDS.  Batches of four loads in flight per thread.
-  if (vec) {
-    const int per = rows_f * spr;
-    const float inv = 1.0f / (float)spr;
+    // the three fields on rows fr0 .. fr1 (w == n: a plane is the row range itself).  The loads of ALL planes are issued
+    // before the first LDS store: bytes in flight are what the staging phase runs on
+    const int per = rows_f * pl.spr;
 #pragma unroll 1
-    for (int q = 0; q < 3; ++q) {
-      const float4* src = reinterpret_cast<const float4*>(yb + q * nn + (size_t)g.fr0 * n);      // rows are contiguous: strip i
-      float* dst = lds + q * plane;
-#pragma unroll 1
-      for (int base = tid; base < per; base += 4 * nthreads) {
-        float4 v[4];
+    for (int base = tid; base < per; base += 2 * nthreads) {
+      float4 v[3][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = base + u * nthreads;
-          if (i < per) v[u] = p.nt ? nt_load4(src + i) : src[i];
-        }
+      for (int q = 0; q < 3; ++q) {
+        const float4* src = reinterpret_cast<const float4*>(yb + q * nn + (size_t)g.fr0 * n);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
           const int i = base + u * nthreads;
-          if (i < per) *reinterpret_cast<float4*>(dst + 4 * i) = v[u];           // w == 4 spr == n: the plane is the row range itself
+          if (i < per) v[q][u] = p.nt ? nt_load4(src + i) : src[i];
         }
       }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        float4* dst = reinterpret_cast<float4*>(lds + q * plane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = base + u * nthreads;
+          if (i < per) dst[i] = v[q][u];
+        }
+      }
     }
-    (void)inv;
   } else {
     const int per = rows_f * n;
     const float inv = 1.0f / (float)n;
+    const bool kplane = pl.planes == 4;
 #pragma unroll 1
-    for (int q = 0; q < 3; ++q) {
-      const float* src = yb + q * nn + (size_t)g.fr0 * n;
-      float* dst = lds + q * plane;
-#pragma unroll 1
-      for (int base = tid; base < per; base += 8 * nthreads) {
-        float v[8];
+    for (int base = tid; base < per; base += 4 * nthreads) {
+      float v[4][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+      for (int q = 0; q < 4; ++q) {
+        const float* src = (q < 3 ? yb + q * nn : Kb) + (size_t)g.fr0 * n;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
           const int i = base + u * nthreads;
-          if (i < per) v[u] = src[i];
+          if (i < per && (q < 3 || kplane)) v[q][u] = p.nt ? __builtin_nontemporal_load(src + i) : src[i];
         }
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = base + u * nthreads;
-          if (i < per) {
-            const int rr = (int)(((float)i + 0.5f) * inv);          // i / n (exact: i < 2^16, n <= 256)
-            dst[rr * w + (i - rr * n)] = v[u];
-          }
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * nthreads;
+        if (i < per) {
+          const int rr = (int)(((float)i + 0.5f) * inv);          // i / n (exact: i < 2^16, n <= 256)
+          const int o = rr * w + (i - rr * n);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < 3 || kplane) lds[q * plane + o] = v[q][u];
         }
       }
     }
   }
   __syncthreads();
+  if (!A) {
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+      const int rc = row[k] < g.sr1 ? row[k] : g.sr1 - 1;
+      if (pl.planes == 4) ld4(lds + 3 * plane + (rc - g.fr0) * w + 4 * c.cs, kk[k].v);
+      else {                              // (a multiple of 4 behind an unaligned pointer, no room for a fourth plane)
+        const float* kp = Kb + (size_t)rc * n + 4 * c.cs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kk[k].v[j] = kp[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kk[k].v[j] = c.valid[j] ? kk[k].v[j] : 0.f;        // (tail columns of the plane were never written)
+    }
+  }
 
   const BPlane U{lds, g.fr0, g.fr1, w}, X1{lds + plane, g.fr0, g.fr1, w}, X2{lds + 2 * plane, g.fr0, g.fr1, w};
   float sums[4] = {0.f, 0.f, 0.f, 0.f};
   StripOut so[NPASS];
+#ifdef PDES_TUNE
+  if (flags & 4096) {                  // timing experiment: no arithmetic (the staged values pass through)
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+      const int rc = row[k] < g.sr1 ? row[k] : g.sr1 - 1;
+      const int o = (rc - g.fr0) * w + 4 * c.cs;
+      so[k].p1 = ldoff(U, o); so[k].p2 = ldoff(X1, o); so[k].cc = ldoff(X2, o); so[k].d1 = kk[k]; so[k].d2 = kk[k]; so[k].du = 0.f;
+    }
+  } else
+#endif
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int r = row[k], rc = r < g.sr1 ? r : g.sr1 - 1;
     const bool ok = c.active && r < g.sr1, own = ok && r >= g.r0 && r < g.r1;
-    const FwdVert f = fwd_vert(U, X1, X2, rc, row_geom(rc, n, correct), c, jl);
-    so[k] = fwd_finish(f, halo_of(f.us, jl), halo_of(f.ud, jl), halo_of(f.as, jl), halo_of(f.bd, jl), kk[k], rc, n, c, jl, p,
-                       flags, fn, own, sums);
+    const FwdVert f = fwd_vert<J>(U, X1, X2, rowtab_read<false>(tab, rc, c.cs, g.fr0, w), c);
+    so[k] = fwd_finish<J>(f, halo_of<J>(f.us), halo_of<J>(f.ud), halo_of<J>(f.as), halo_of<J>(f.bd), kk[k], rc, n, c, p, flags, fn,
+                          own, sums);
   }
   {
     const float t0 = wave_sum(sums[0]), t1 = wave_sum(sums[1]), t2 = wave_sum(sums[2]), t3 = wave_sum(sums[3]);
@@ -237,31 +268,67 @@ __global__ __launch_bounds__(512) void darcy_loss_band_kernel(const float* __res
   }
   __syncthreads();
   const BPlane G1{lds, g.fr0, g.fr1, w}, G2{lds + plane, g.fr0, g.fr1, w}, GC{lds + 2 * plane, g.fr0, g.fr1, w};
+  constexpr int NKEEP = A ? 1 : NPASS;          // (A stores each pass at once)
+  V4 du[NKEEP], d1[NKEEP], d2[NKEEP];
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int r = row[k], rc = r < g.r0 ? g.r0 : (r < g.r1 ? r : g.r1 - 1);
     const bool own = c.active && r >= g.r0 && r < g.r1;
-    const AdjVert a = adj_vert(G1, G2, GC, rc, row_geom(rc, n, correct), c, jl);
-    V4 du, d1, d2;
-    adj_finish(a, halo_of(a.p1s, jl), halo_of(a.p2d, jl), halo_of(a.ccs, jl), halo_of(a.ccd, jl), so[k], c, jl, fn, du, d1, d2);
-    if (own) {
+    constexpr int kk_ = 0;
+    const int ko = A ? kk_ : k;
+#ifdef PDES_TUNE
+    if (flags & 4096) {
+      const int o = (rc - g.fr0) * w + 4 * c.cs;
+      du[ko] = ldoff(G1, o); d1[ko] = ldoff(G2, o); d2[ko] = ldoff(GC, o);
+    } else
+#endif
+    {
+      const AdjVert a = adj_vert<J>(G1, G2, GC, rowtab_read<true>(tab, rc, c.cs, g.fr0, w), c);
+      adj_finish<J>(a, halo_of<J>(a.p1s), halo_of<J>(a.p2d), halo_of<J>(a.ccs), halo_of<J>(a.ccd), so[k], c, fn, du[ko], d1[ko], d2[ko]);
+    }
+    if (A && own) {
       float* o = gb + (size_t)r * n + 4 * c.cs;
-      if (vec) {
-        if (p.nt) {
-          nt_store4(reinterpret_cast<float4*>(o), make_float4(du.v[0], du.v[1], du.v[2], du.v[3]));
-          nt_store4(reinterpret_cast<float4*>(o + nn), make_float4(d1.v[0], d1.v[1], d1.v[2], d1.v[3]));
-          nt_store4(reinterpret_cast<float4*>(o + 2 * nn), make_float4(d2.v[0], d2.v[1], d2.v[2], d2.v[3]));
-        } else {
-          st4(o, du.v); st4(o + nn, d1.v); st4(o + 2 * nn, d2.v);
-        }
+      if (p.nt) {
+        nt_store4(reinterpret_cast<float4*>(o), make_float4(du[0].v[0], du[0].v[1], du[0].v[2], du[0].v[3]));
+        nt_store4(reinterpret_cast<float4*>(o + nn), make_float4(d1[0].v[0], d1[0].v[1], d1[0].v[2], d1[0].v[3]));
+        nt_store4(reinterpret_cast<float4*>(o + 2 * nn), make_float4(d2[0].v[0], d2[0].v[1], d2[0].v[2], d2[0].v[3]));
       } else {
+        st4(o, du[0].v); st4(o + nn, d1[0].v); st4(o + 2 * nn, d2[0].v);
+      }
+    }
+  }
+  if (A) return;
+#ifdef PDES_TUNE
+  if (flags & 8192) return;
+#endif
+  // the general path: own strips -> the planes (every source has been read) -> one contiguous range per plane
+  __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c.valid[j]) { o[j] = du.v[j]; o[nn + j] = d1.v[j]; o[2 * nn + j] = d2.v[j]; }
+  for (int k = 0; k < NPASS; ++k) {
+    if (c.active && row[k] >= g.r0 && row[k] < g.r1) {
+      float* q = lds + (row[k] - g.fr0) * w + 4 * c.cs;
+      const int ko = A ? 0 : k;
+      st4(q, du[ko].v); st4(q + plane, d1[ko].v); st4(q + 2 * plane, d2[ko].v);
+    }
+  }
+  __syncthreads();
+  {
+    const int per = (g.r1 - g.r0) * n;
+    const float inv = 1.0f / (float)n;
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+      float* dst = gb + q * nn + (size_t)g.r0 * n;
+      const float* src = lds + q * plane + (g.r0 - g.fr0) * w;
+#pragma unroll 2
+      for (int i = tid; i < per; i += nthreads) {
+        const int rr = (int)(((float)i + 0.5f) * inv);
+        const float v = src[rr * w + (i - rr * n)];
+        if (p.nt) __builtin_nontemporal_store(v, dst + i); else dst[i] = v;
       }
     }
   }
 }
+
 
 // ---- stand-alone gradients and adjoints, one thread per pixel -------------------------------------------------------
 template <bool FIVE>
@@ -321,16 +388,25 @@ int launch_loss_generic(const float* K, const float* y, float* gy, float* partia
   if (n < 2) return PDES_ENOSUP;
   band::Plan pl;
   if (band_plan(n, flags, pl)) {
-    const int vec = ((n & 3) == 0 && aligned16(K) && aligned16(y) && (!gy || aligned16(gy))) ? 1 : 0;
+    const bool a16 = (n & 3) == 0 && aligned16(K) && aligned16(y) && (!gy || aligned16(gy));
     const dim3 grid(pl.nbands, B), block(64 * pl.waves);
     const size_t shmem = (size_t)pl.lds_floats * sizeof(float);
-    if (pl.npass == 1) {
-      if (gy) hipLaunchKernelGGL((darcy_loss_band_kernel<true, 1>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
-      else hipLaunchKernelGGL((darcy_loss_band_kernel<false, 1>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
-    } else {
-      if (gy) hipLaunchKernelGGL((darcy_loss_band_kernel<true, 2>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
-      else hipLaunchKernelGGL((darcy_loss_band_kernel<false, 2>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags, vec);
+#define PDES_BAND_LAUNCH(BWD_, NP_, J_) \
+    hipLaunchKernelGGL((darcy_loss_band_kernel<BWD_, NP_, J_>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags)
+#define PDES_BAND_LAUNCH_J(J_)                                                                             \
+    do {                                                                                                   \
+      if (pl.npass == 1) { if (gy) PDES_BAND_LAUNCH(true, 1, J_); else PDES_BAND_LAUNCH(false, 1, J_); }     \
+      else { if (gy) PDES_BAND_LAUNCH(true, 2, J_); else PDES_BAND_LAUNCH(false, 2, J_); }                   \
+    } while (0)
+    switch (a16 ? 4 : pl.jl) {
+      case 4: PDES_BAND_LAUNCH_J(4); break;
+      case 3: PDES_BAND_LAUNCH_J(3); break;
+      case 2: PDES_BAND_LAUNCH_J(2); break;
+      case 1: PDES_BAND_LAUNCH_J(1); break;
+      default: PDES_BAND_LAUNCH_J(0); break;
     }
+#undef PDES_BAND_LAUNCH_J
+#undef PDES_BAND_LAUNCH
     return PDES_OK;
   }
   const bool strips = n >= STRIP_MIN_N;

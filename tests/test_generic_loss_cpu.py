@@ -237,6 +237,11 @@ def test_band_kernel_own_plan_vs_oracle(bemu, n, flags):
     assert np.isfinite(gy).all()
     assert rel_l2(gy, ref_g) < 1e-5
     assert plan[4] <= BAND_LDS
+    if n % 4 == 0:              # the general instantiation (what an unaligned pointer selects) at a multiple of 4: same numbers
+        for extra in (256, 256 | 512):          # with / without a fourth (K) plane
+            t2, g2, _, _ = _band(bemu, K, y, w, flags | extra)
+            np.testing.assert_allclose(t2, terms, rtol=1e-6)
+            assert rel_l2(g2, gy) < 1e-6
 
 
 @pytest.mark.parametrize('n,plan', [(8, (1, 1, 1)), (9, (1, 1, 3)), (12, (1, 1, 4)), (17, (1, 1, 2)), (17, (2, 2, 1)), (20, (1, 1, 6)),

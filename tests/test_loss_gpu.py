@@ -253,7 +253,8 @@ def test_band_kernel_vs_oracle_and_tile_kernel(dev, n, B, flags, monkeypatch):
     assert torch.isfinite(grad).all()
     assert rel_l2(grad.cpu().numpy(), rg.numpy()) < GRAD_RL2
     terms2, g2 = darcy.darcy_loss_launch(Kd, yd, w, False, nl, 0.1, 0.2, tb, correct)      # forward only: the same sums
-    assert g2 is None and torch.equal(terms2, terms)
+    assert g2 is None
+    np.testing.assert_allclose(terms2.cpu().numpy(), terms.cpu().numpy(), rtol=1e-6)      # (another instantiation: other contractions)
     monkeypatch.setattr(darcy, 'EXTRA_FLAGS', 16 | 8)
     terms_t, grad_t = darcy.darcy_loss_launch(Kd, yd, w, True, nl, 0.1, 0.2, tb, correct)
     np.testing.assert_allclose(terms.cpu().numpy(), terms_t.cpu().numpy(), rtol=2e-6)
@@ -265,7 +266,8 @@ def test_band_kernel_vs_oracle_and_tile_kernel(dev, n, B, flags, monkeypatch):
         Ku = pad[1:].view_as(Kd).copy_(Kd)
         assert Ku.data_ptr() % 16 == 4
         terms_u, grad_u = darcy.darcy_loss_launch(Ku, yd, w, True, nl, 0.1, 0.2, tb, correct)
-        assert torch.equal(terms_u, terms) and torch.equal(grad_u, grad)
+        np.testing.assert_allclose(terms_u.cpu().numpy(), terms.cpu().numpy(), rtol=1e-6)      # (the general instantiation)
+        assert rel_l2(grad_u.cpu().numpy(), grad.cpu().numpy()) < 1e-6
 
 
 @pytest.mark.parametrize('n', [16, 32, 64])
