@@ -291,6 +291,19 @@ def cglow_timing(dev, steps=60, warm=15, cpu_steps=3):
            'n_params': net.model_size[0], 'descriptors_per_generate': len(net._specs),
            'samples_per_s': round(B / dt, 1), 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
            'mean_loss_over_the_run': round(means[0], 3), 'finite': bool(np.isfinite(means[0]))}
+    # algorithmic flops of the convolutions (the flow operators -- ActNorm, invertible 1x1, affine coupling, squeeze -- are
+    # O(pixels x channels): not counted): forward = sum 2 cin cout k^2 Hout Wout B over the descriptors; a training step
+    # runs forward + data gradient + weight gradient of (almost) every layer = 3 x that
+    fwd = 0
+    for sp in net._specs:
+        if sp.kind in ('conv', 'raw'):
+            h = 32 * sp.scale[0] // sp.scale[1] // sp.stride
+            fwd += 2 * sp.cin * sp.cout * sp.k * sp.k * h * h * B
+    out['algorithmic_gflop_per_step'] = {'forward_convolutions': round(fwd / 1e9, 3), 'step_approx_3x': round(3 * fwd / 1e9, 3)}
+    out['roofline'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'achieved': round(3 * fwd / dt / 1e12, 2),
+                       'frac': round(3 * fwd / dt / 157.3e12, 4),
+                       'note': 'whole step against the f32 matrix peak: 437 launches on 8x8 .. 32x32 maps, launch-count bound '
+                               '(~12 us per dependent kernel), see profiles/r04_*_cglow_*'}
     if cpu_steps:
         from oracle import glow as oglow
         sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
@@ -300,18 +313,32 @@ def cglow_timing(dev, steps=60, warm=15, cpu_steps=3):
         opt = torch.optim.Adam([sd[k] for k in keys], lr=1e-3)
         shapes = oglow.latent_shapes(sd, 3, 32)
         xc = data[:B].cpu()
-        times = []
-        for i in range(cpu_steps + 1):
+
+        def cpu_step():
             t0 = time.perf_counter()
             opt.zero_grad(set_to_none=True)
             eps = [torch.randn((B,) + s) for s in shapes]
             loss = oglow.reverse_kl_loss(sd, xc, eps, 150.0, 50.0, True)[0]
             loss.backward()
             opt.step()
-            times.append(time.perf_counter() - t0)
-        cdt = float(np.mean(times[1:]))
-        out['cpu_baseline'] = {'value': round(B / cdt, 2), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                               'sample': f'{cpu_steps} steps after 1 warm-up, bs {B}, oracle/glow.py on PyTorch-CPU fp32'}
+            return time.perf_counter() - t0
+        # the same thread sweep as cpu_baseline(): a 128-core box runs this workload fastest on a fraction of its cores
+        phys, logical = physical_cores(), os.cpu_count() or 1
+        cands = sorted({t for t in (8, 16, 32, 64, phys) if 1 <= t <= logical})
+        sweep = {}
+        for t in cands:
+            torch.set_num_threads(t)
+            cpu_step()
+            sweep[t] = cpu_step()
+        best = min(cands, key=lambda t: sweep[t])
+        torch.set_num_threads(best)
+        times = [cpu_step() for _ in range(cpu_steps)]
+        cdt = float(np.mean(times))
+        out['cpu_baseline'] = {'value': round(B / cdt, 2), 'unit': 'samples/s', 'cores': best, 'kind': 'port',
+                               'physical_cores': phys, 'cpu_model': cpu_model(),
+                               'thread_sweep_s_per_step': {str(t): round(v, 3) for t, v in sweep.items()},
+                               'sample': f'{cpu_steps} steps at bs {B} on {best} threads (best of a sweep over {cands}, 1 warm-up '
+                                         f'+ 1 timed step each), oracle/glow.py on PyTorch-CPU fp32'}
     return out
 
 

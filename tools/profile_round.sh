@@ -57,5 +57,14 @@ python $ROOT/tools/pmc_summary.py $(db $OUT/pmc_mfma) > $OUT/pmc_mfma.txt
 
 # (E) per-layer stand-alone timings (HIP events)
 python $ROOT/tools/bench_conv.py > $OUT/per_layer_conv_microbench.log 2>&1
-rm -rf $OUT/bench $OUT/pmc_loss_* $OUT/pmc_conv_* $OUT/pmc_mfma       # the databases stay on the box
+# (F) the conditional-Glow reverse-KL leg: kernel trace + stats and the timeline of its last step
+rocprofv3 --kernel-trace --stats --output-format rocpd -d $OUT/cglow -o cglow -- \
+    python $ROOT/bench.py --leg cglow --no-cpu-baseline > $OUT/cglow_bench.json 2> $OUT/cglow_bench.err
+D=$(db $OUT/cglow)
+python $ROOT/tools/rocprof_summary.py $D > $OUT/cglow_kernel_stats.csv
+python $ROOT/tools/timeline.py $D > $OUT/cglow_step_timeline.txt
+
+# (G) the any-size loss kernels by field size (HIP events)
+python $ROOT/tools/bench_loss_generic.py 2>&1 | grep -v amdgpu.ids > $OUT/loss_kernel_generic_sizes.log
+rm -rf $OUT/bench $OUT/pmc_loss_* $OUT/pmc_conv_* $OUT/pmc_mfma $OUT/cglow       # the databases stay on the box
 ls -la $OUT
