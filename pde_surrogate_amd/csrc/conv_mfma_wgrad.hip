@@ -264,9 +264,16 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void 
     __syncthreads();
     auto step = [&](int tt, Stage& sfree, const Stage& snext) __attribute__((always_inline)) {
       const int buf = tt & 1;
+      // (-DPDES_WG_NOSTAGE / -DPDES_WG_NOMFMA: component timing builds, EXPERIMENTS.md round 4 -- never shipped)
+#ifndef PDES_WG_NOSTAGE
       issue(tile0 + min(tt + 2, tpw - 1), sfree);
+#endif
+#ifndef PDES_WG_NOMFMA
       mfma_tile(buf);
+#endif
+#ifndef PDES_WG_NOSTAGE
       if (tt + 1 < tpw) commit(tile0 + tt + 1, buf ^ 1, snext);
+#endif
       __syncthreads();
     };
     int tt = 0;
