@@ -973,7 +973,10 @@ class _HipNet(nn.Module):
                 return False
         return True
 
-    MAX_OUTSTANDING = 8      # engines per (batch, size): forwards whose backward has not run yet
+    # engines per (batch, size): forwards whose backward has not run yet.  A guard against leaked graphs (each engine holds
+    # the activations of a forward: 0.1 GB at B = 32), not a limit of the kernels: raise it per class or per instance
+    # (`net.MAX_OUTSTANDING = 64`) or with PDES_MAX_OUTSTANDING in the environment when a loop really holds more forwards.
+    MAX_OUTSTANDING = int(os.environ.get('PDES_MAX_OUTSTANDING', '8'))
 
     def _pool(self, x):
         if not self._is_flat(x.device):
@@ -1000,7 +1003,8 @@ class _HipNet(nn.Module):
                 return eng
         if len(pool) >= self.MAX_OUTSTANDING:
             raise RuntimeError(f'{len(pool)} forward passes of shape {key} are waiting for their backward: call '
-                               'backward() (or drop the outputs / use torch.no_grad()) before running more')
+                               'backward() (or drop the outputs / use torch.no_grad()) before running more, or raise '
+                               'net.MAX_OUTSTANDING (PDES_MAX_OUTSTANDING) if the loop really holds that many')
         with _lib.device_guard(x.device):
             eng = self._new_engine(key)
         pool.append(eng)

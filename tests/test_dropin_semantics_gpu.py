@@ -92,6 +92,10 @@ def test_too_many_outstanding_forwards_is_an_error_not_an_oom(dev):
     held = [net(x) for _ in range(net.MAX_OUTSTANDING)]
     with pytest.raises(RuntimeError, match='waiting for their backward'):
         net(x)
+    net.MAX_OUTSTANDING = net.MAX_OUTSTANDING + 2        # the cap is a guard, not a limit of the kernels: raise it per instance
+    held += [net(x), net(x)]
+    with pytest.raises(RuntimeError, match='MAX_OUTSTANDING'):
+        net(x)
     del held
     net(x)
 
