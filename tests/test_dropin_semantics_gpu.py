@@ -135,7 +135,7 @@ def test_data_parallel_branch_on_one_rank(dev):
         pg = dist.new_group([0])
         x = torch.exp(0.5 * torch.randn(32, 1, 64, 64, device=dev))
         finals, hooks = [], []
-        for group, mode in ((None, False), (pg, False), (pg, 'segments')):
+        for group, mode in ((None, False), (pg, False), (pg, 'segments'), (pg, 'forward')):
             torch.manual_seed(1)
             with contextlib.redirect_stdout(io.StringIO()):
                 net = DenseED(1, 3, 64, [6, 8, 6]).to(dev).train()
@@ -152,13 +152,42 @@ def test_data_parallel_branch_on_one_rank(dev):
                 from pde_surrogate_amd import _lib
                 tr._hook_fn = _lib.BUCKET_FN(spy)
                 tr._hook = _lib.BucketHook(tr._hook_fn, None)
-            for _ in range(3):
+            if mode == 'forward':                             # as bench.py does on a host-bound node: switched between steps
+                tr2mode, mode_now = mode, tr.launch_mode
+                assert mode_now == 'forward'
+                tr.set_launch_mode(False)
                 tr.step(x, 1e-3)
+                tr.set_launch_mode(tr2mode)
+                for _ in range(2):
+                    tr.step(x, 1e-3)
+            else:
+                for _ in range(3):
+                    tr.step(x, 1e-3)
             torch.cuda.synchronize()
             hooks.append(seen)
             finals.append((torch.cat([p.detach().reshape(-1) for p in net.parameters()]), tr.epoch_means()))
+            if group is not None:                             #  the communicator is released, twice is fine
+                tr.close()
+                assert tr._rccl is None
+                tr.close()
         assert hooks[0] == [] and len(hooks[1]) == 3          # one early bucket per step
         assert hooks[2] == hooks[1]                           # ... also when the step is replayed as segment graphs
+        assert hooks[3] == hooks[1]                           # ... and with only the forward pass as a graph
+        np.testing.assert_allclose(finals[3][1], finals[0][1], rtol=1e-5)
+        assert rel_l2(finals[3][0].cpu().numpy(), finals[0][0].cpu().numpy()) < 1e-4
+        # the NUMA pinning of a rank under an initialised group (one rank, one GPU): a plan inside the allowed CPUs, or a
+        # stated reason -- and the process keeps running on what it was given
+        from pde_surrogate_amd import parallel
+        before = os.sched_getaffinity(0)
+        info = parallel.pin_rank_to_gpu_numa(dev, 0, 1)
+        assert isinstance(info, dict) and 'pinned' in info
+        if info['pinned']:
+            now = os.sched_getaffinity(0)
+            assert now <= before and len(now) == info['n_cpus'] > 0
+            for tid in os.listdir('/proc/self/task'):
+                os.sched_setaffinity(int(tid), before)        # (leave the test process as it was)
+        else:
+            assert info['why']
         np.testing.assert_allclose(finals[2][1], finals[0][1], rtol=1e-5)
         assert rel_l2(finals[2][0].cpu().numpy(), finals[0][0].cpu().numpy()) < 1e-4
         first = hooks[1][0]
