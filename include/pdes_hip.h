@@ -281,6 +281,21 @@ int pdes_conv_backward_weight(const pdes_context* ctx, const pdes_conv_desc* des
 /* T_in (+)= gamma * (conv^T(g)) * 1[bn(x) > 0]; also dgamma/dbeta and the finished channels'
  * {sum T, sum T xhat} (autograd of conv2d wrt input, ReLU, BatchNorm wrt gamma/beta). */
 int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_desc* descs, int n, void* stream);
+/* Which packed weight images the forward / data-gradient kernels selected for `desc` under ctx's options READ (a
+ * capability query of the two dispatch chains above: nothing is enqueued).  The weight-gradient kernels read no weights.
+ * A caller that rebuilds its images every step (pdes_pack_all2) can leave out the ones no pass of any of its
+ * descriptors reads -- and must re-query when it changes an option of the context. */
+#define PDES_IMG_DIRECT_FWD 1      /* pdes_pack_item.w_fwd   */
+#define PDES_IMG_DIRECT_BWD 2      /* pdes_pack_item.w_bwd   */
+#define PDES_IMG_MFMA_FWD 4        /* pdes_mfma_pack_item.wm_fwd */
+#define PDES_IMG_MFMA_BWD 8        /* ... wm_bwd */
+#define PDES_IMG_UP_FWD 16         /* pdes_up_pack_item.wu_fwd */
+#define PDES_IMG_UP_BWD 32
+#define PDES_IMG_B3_FWD 64         /* pdes_b3_pack_item.wb_fwd */
+#define PDES_IMG_B3_BWD 128
+#define PDES_IMG_B3UP_FWD 256      /* pdes_b3up_pack_item.wbu_fwd */
+#define PDES_IMG_B3UP_BWD 512
+int pdes_conv_image_use(const pdes_context* ctx, const pdes_conv_desc* desc, int* mask);
 /* In place T -> dL/dx for channels [c0, c1) of a (B, ctot, H, W) buffer (BatchNorm backward wrt
  * its input, summed over every consumer BN). */
 int pdes_bn_backward_finalize(const pdes_context* ctx, float* t, const float* x, const double* x_stats, const double* t_stats,

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -30,6 +30,7 @@ SIGNATURES = {
     'pdes_conv_forward': [_c_p, _c_p, _c_i, _c_p],
     'pdes_conv_backward_weight': [_c_p, _c_p, _c_i, _c_p],
     'pdes_conv_backward_data': [_c_p, _c_p, _c_i, _c_p],
+    'pdes_conv_image_use': [_c_p, _c_p, _c_p],
     'pdes_backward': [_c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p],
     'pdes_backward2': [_c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p],
     'pdes_backward_chain': [_c_p, _c_p, _c_i, _c_i, _c_p],
@@ -137,10 +138,15 @@ def context(device=None):
     return ctx
 
 
+OPTIONS_EPOCH = 0
+
+
 def set_option(key, value):
     """override a kernel-selection knob (include/pdes_hip.h lists the keys) on every context of this process;
     value None restores the compiled-in default"""
+    global OPTIONS_EPOCH
     _overrides[key] = value
+    OPTIONS_EPOCH += 1                  # (models re-query which weight images their kernels read: codec.py _pack_weights)
     for h in _contexts.values():
         check(lib().pdes_context_set_option(h, key.encode(), None if value is None else str(value).encode()),
               f'option {key}')

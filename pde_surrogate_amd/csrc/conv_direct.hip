@@ -518,11 +518,16 @@ static int validate(const pdes_conv_desc& d, int mode) {
   return PDES_OK;
 }
 
+// the 7x7 first convolution reads the live weight tensor; every other VALU forward the packed image w_fwd
+bool conv_forward_direct_first7(const pdes_conv_desc& d) {
+  return !d.has_bn && !d.upsample && d.Cin == 1 && d.ksize == 7 && d.stride == 2 && d.pad == 3 && d.w && d.Wout == 32 &&
+         d.Win == 64 && d.Hout % 4 == 0 && d.Hin == 2 * d.Hout && d.Cout % 8 == 0 && d.Cout <= 64;
+}
+
 int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st) {
   const int rc = validate(d, 0);
   if (rc) return rc;
-  if (!d.has_bn && !d.upsample && d.Cin == 1 && d.ksize == 7 && d.stride == 2 && d.pad == 3 && d.w && d.Wout == 32 &&
-      d.Win == 64 && d.Hout % 4 == 0 && d.Hin == 2 * d.Hout && d.Cout % 8 == 0 && d.Cout <= 64) {
+  if (conv_forward_direct_first7(d)) {
     const int LW = ((d.Win + 2 * 3 + 2 + 3) / 4) * 4;
     const size_t lds = ((size_t)13 * LW + (size_t)49 * d.Cout) * sizeof(float);
     hipLaunchKernelGGL(conv_fwd_first7, dim3(d.Hout / 4, d.B), dim3(256), lds, st, d);

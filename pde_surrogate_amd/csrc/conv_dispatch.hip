@@ -10,20 +10,21 @@ int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st);
 bool first_layer_partials(const pdes_conv_desc& d);     // conv_direct.hip: the 7x7 first layer writes per-image partials
-int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st);        // PDES_ENOSUP: shape not covered
+bool conv_forward_direct_first7(const pdes_conv_desc& d);               // conv_direct.hip: reads the live weights, no image
+int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);        // PDES_ENOSUP: shape not covered
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);   // dry: capability query only
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
-int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st);        // nearest-x2 + 3x3, sub-pixel form
-int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st);         // 5x5 with <= 3 output channels
-int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st);             // wide 3x3 layers: bf16 x3 split (conv_mfma_b3.hip)
-int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st);          // nearest-x2 + 3x3, sub-pixel form, bf16 x3 split
+int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);        // nearest-x2 + 3x3, sub-pixel form
+int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st, bool dry = false);         // 5x5 with <= 3 output channels
+int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = false);             // wide 3x3 layers: bf16 x3 split (conv_mfma_b3.hip)
+int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st, bool dry = false);          // nearest-x2 + 3x3, sub-pixel form, bf16 x3 split
 int conv_backward_data_b3(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_backward_data_b3_up(const pdes_conv_desc& d, hipStream_t st, bool dry = false);     // sub-pixel data gradient, bf16 x3 split
 int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
-int conv_forward_small(const pdes_conv_desc& d, hipStream_t st);          // 3x3 on 8x8 maps (conv_small.hip)
+int conv_forward_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false);          // 3x3 on 8x8 maps (conv_small.hip)
 int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st);
-int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
+int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
 int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int upsample_bilinear_forward(const pdes_conv_desc& d, hipStream_t st);   // PDES_UPSAMPLE_BILINEAR_OP descriptors
 int upsample_bilinear_backward(const pdes_conv_desc& d, hipStream_t st);
@@ -145,6 +146,51 @@ extern "C" int pdes_conv_backward_data(const pdes_context* ctx, const pdes_conv_
     if (rc == PDES_ENOSUP) rc = conv_backward_data_direct(descs[i], st);
     if (rc) return rc;
   }
+  return PDES_OK;
+}
+
+
+// Which packed weight images would the forward and the data-gradient pass of this descriptor READ under the context's
+// options?  The same dispatch chains as pdes_conv_forward / pdes_conv_backward_data, as capability queries (nothing is
+// enqueued).  The caller's per-step packing launch can leave out every image no pass reads (the VALU images of a net
+// that runs on the matrix cores, the f32 images of the layers on the bf16-split kernels): models/codec.py _pack_weights.
+extern "C" int pdes_conv_image_use(const pdes_context* ctx, const pdes_conv_desc* desc, int* mask) {
+  if (!desc || !mask) return PDES_EINVAL;
+  *mask = 0;
+  if (is_resample_op(*desc)) return PDES_OK;
+  OptScope scope(ctx);
+  pdes_conv_desc d = *desc;
+  d.eval_mode = 0;                                  // (the data gradient exists in training mode only; the forward chain
+  d.g_fused = 0;                                    //  does not look at the mode)
+  int m = 0;
+  {
+    int rc = PDES_ENOSUP;
+    auto tryf = [&](int r, int bit) { if (rc == PDES_ENOSUP && r != PDES_ENOSUP) { rc = r; m |= bit; } };
+    if (!force_direct()) {
+      tryf(conv_forward_small(d, nullptr, true), PDES_IMG_MFMA_FWD);
+      if (rc == PDES_ENOSUP) tryf(conv_forward_b3_up(d, nullptr, true), PDES_IMG_B3UP_FWD);
+      if (rc == PDES_ENOSUP) tryf(conv_forward_up_mfma(d, nullptr, true), PDES_IMG_UP_FWD);
+      if (rc == PDES_ENOSUP) tryf(conv_forward_fewout(d, nullptr, true), 0);                  // (reads the live weights)
+      if (rc == PDES_ENOSUP) tryf(conv_forward_b3(d, nullptr, true), PDES_IMG_B3_FWD);
+      if (rc == PDES_ENOSUP) tryf(conv_forward_1x1(d, nullptr, true), PDES_IMG_MFMA_FWD);
+      if (rc == PDES_ENOSUP) tryf(conv_forward_mfma(d, nullptr, true), PDES_IMG_MFMA_FWD);
+    }
+    if (rc == PDES_ENOSUP && !conv_forward_direct_first7(d)) m |= PDES_IMG_DIRECT_FWD;
+  }
+  {
+    int rc = PDES_ENOSUP;
+    auto tryb = [&](int r, int bit) { if (rc == PDES_ENOSUP && r != PDES_ENOSUP) { rc = r; m |= bit; } };
+    if (!force_direct()) {
+      tryb(conv_backward_data_small(d, nullptr, true), PDES_IMG_MFMA_BWD);
+      if (rc == PDES_ENOSUP) tryb(conv_backward_data_b3_up(d, nullptr, true), PDES_IMG_B3UP_BWD);
+      if (rc == PDES_ENOSUP) tryb(conv_backward_data_up_mfma(d, nullptr, true), PDES_IMG_UP_BWD);
+      if (rc == PDES_ENOSUP) tryb(conv_backward_data_b3(d, nullptr, true), PDES_IMG_B3_BWD);
+      if (rc == PDES_ENOSUP) tryb(conv_backward_data_1x1(d, nullptr, true), PDES_IMG_MFMA_BWD);
+      if (rc == PDES_ENOSUP) tryb(conv_backward_data_mfma(d, nullptr, true), PDES_IMG_MFMA_BWD);
+    }
+    if (rc == PDES_ENOSUP) m |= PDES_IMG_DIRECT_BWD;
+  }
+  *mask = m;
   return PDES_OK;
 }
 

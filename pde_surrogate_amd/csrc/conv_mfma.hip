@@ -648,17 +648,17 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
 }
 
 // returns PDES_ENOSUP when the shape is not covered (caller falls back to the direct kernels)
-int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st) {
+int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
   int W, H;
   if (!d.wm_fwd || !mfma_shape_ok(d, false, &W, &H) || d.Cin < 16) return PDES_ENOSUP;
   if (d.stride == 2) {
     if ((d.Cout + 15) / 16 == 1) return PDES_ENOSUP;
-    return launch_mfma<3, 2, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st);
+    return launch_mfma<3, 2, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st, dry);
   }
-  if (d.ksize == 5) return launch_mfma<5, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st);
-  return d.ksize == 3 ? launch_mfma<3, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st)
-                      : launch_mfma<1, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st);
+  if (d.ksize == 5) return launch_mfma<5, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st, dry);
+  return d.ksize == 3 ? launch_mfma<3, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st, dry)
+                      : launch_mfma<1, 1, MODE_FWD, KV_PLAIN>(d, d.wm_fwd, W, H, st, dry);
 }
 
 // dry = true: only report whether this implementation would take the descriptor (nothing is enqueued)

@@ -399,8 +399,9 @@ static int launch_p1(const pdes_conv_desc& d, const float* wm, hipStream_t st) {
   return PDES_OK;
 }
 
-int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st) {
+int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   if (!p1_enabled(false) || !d.wm_fwd || !p1_shape_ok(d, false)) return PDES_ENOSUP;
+  if (dry) return PDES_OK;
   return launch_p1<P1_FWD>(d, d.wm_fwd, st);
 }
 

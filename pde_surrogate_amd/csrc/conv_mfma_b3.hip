@@ -502,8 +502,9 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
   return PDES_OK;
 }
 
-int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st) {
+int conv_forward_b3(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   if (!b3_enabled() || !d.wb_fwd || !b3_shape_ok(d, false)) return PDES_ENOSUP;
+  if (dry) return PDES_OK;
   return launch_b3<B3_FWD>(d, d.wb_fwd, st);
 }
 

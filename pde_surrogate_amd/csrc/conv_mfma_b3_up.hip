@@ -320,8 +320,9 @@ static bool b3up_shape_ok(const pdes_conv_desc& d) {
   return H % 2 == 0;
 }
 
-int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st) {
+int conv_forward_b3_up(const pdes_conv_desc& d, hipStream_t st, bool dry) {        // dry: capability query only
   if (!(opt().mfma_b3 & 4) || !d.wbu_fwd || !b3up_shape_ok(d)) return PDES_ENOSUP;
+  if (dry) return PDES_OK;
   const int nchunk = (d.Cin + 31) / 32, kpad = nchunk * 32, nt_total = (d.Cout + 15) / 16;
   const int twg = d.Win >= 32 ? 2 : 1;
   const int tail_on = (opt().b3_tail && d.w) ? 1 : 0;

@@ -189,11 +189,12 @@ __global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d)
 }
 
 // PDES_ENOSUP when the layer is not of this shape (the caller tries the generic kernels next)
-int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st) {
+int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st, bool dry) {       // dry: capability query only
   if (d.ksize != 5 || d.stride != 1 || d.pad != 2 || d.upsample || !d.has_bn || d.Cout * 5 > 16 || d.Cin < 16)
     return PDES_ENOSUP;
   if (d.out_stats || d.Hin != d.Hout || d.Win != d.Wout || d.nrep != PDES_NREP || !d.w) return PDES_ENOSUP;
   if (!(d.Win == 64 || d.Win == 32 || d.Win == 16) || d.Hin % 2) return PDES_ENOSUP;
+  if (dry) return PDES_OK;
   const int kpad = (d.Cin + 15) & ~15;
   const int R = 2;            // rows per workgroup (4 measured +0.4 % on the step)
   dim3 grid(d.Hin / R, d.B), block(256);

@@ -400,9 +400,9 @@ static int launch_up(const pdes_conv_desc& d, const float* wm, hipStream_t st, b
   return PDES_OK;
 }
 
-int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st) {
+int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry) {
   if (!d.wu_fwd || !up_shape_ok(d) || d.Cin < 16 || d.nrep != PDES_NREP) return PDES_ENOSUP;
-  return launch_up<UP_FWD>(d, d.wu_fwd, st);
+  return launch_up<UP_FWD>(d, d.wu_fwd, st, dry);
 }
 
 // dry = true: only report whether this implementation would take the descriptor (nothing is enqueued)

@@ -366,9 +366,10 @@ __global__ __launch_bounds__(64) void small_reduce_kernel(const float* __restric
 
 int wgrad_small_splits(const pdes_conv_desc& d) { return (d.B + 3) / 4; }       // four images (one per wave) per workgroup
 
-int conv_forward_small(const pdes_conv_desc& d, hipStream_t st) {
+int conv_forward_small(const pdes_conv_desc& d, hipStream_t st, bool dry) {       // dry: capability query only
   const bool s2 = small_fwd_s2_applies(d);
   if ((!conv_small_applies(d) && !s2) || !d.wm_fwd) return PDES_ENOSUP;
+  if (dry) return PDES_OK;
   if (!d.x || !d.out) return PDES_EINVAL;
   if (d.has_bn && (!d.gamma || !d.beta || (d.eval_mode ? (!d.run_mean || !d.run_var) : !d.x_stats))) return PDES_EINVAL;
   if (!aligned16(d.x) || !aligned16(d.out)) return PDES_EALIGN;

@@ -574,4 +574,4 @@ extern "C" int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar
   return PDES_OK;
 }
 
-extern "C" int pdes_abi_version(void) { return 21; }
+extern "C" int pdes_abi_version(void) { return 22; }

@@ -857,6 +857,7 @@ class _HipNet(nn.Module):
             it.Cout, it.Cin, it.kk, it.cout_pad, it.cin_pad = s.cout, s.cin, kk, _pad16(s.cout), _pad16(s.cin)
             items.append(it)
             mx = max(mx, s.cout * s.cin * kk)
+        self._pack_items = {'direct': [(s.conv, it) for s, it in zip([q for q in self._specs if q.conv is not None], items)]}
         arr = (PackItem * len(items))(*items)
         self._pack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._pack_n, self._pack_max = len(items), mx
@@ -878,6 +879,7 @@ class _HipNet(nn.Module):
             it.wm_fwd, it.wm_bwd = wf.data_ptr(), wb.data_ptr()
             it.Cout, it.Cin, it.kk = s.cout, s.cin, kk
             mitems.append(it)
+            self._pack_items.setdefault('mfma', []).append((s.conv, it))
             mmx = max(mmx, nf, nb)
         self._mpack_n, self._mpack_max = len(mitems), mmx
         # effective 2x2 weight images of the nearest-x2 + 3x3 convolutions (sub-pixel decomposition)
@@ -893,6 +895,7 @@ class _HipNet(nn.Module):
             it.w = _get(self._root, s.conv).weight.data_ptr()
             it.wu_fwd, it.wu_bwd, it.Cout, it.Cin = uf.data_ptr(), ub.data_ptr(), s.cout, s.cin
             uitems.append(it)
+            self._pack_items.setdefault('up', []).append((s.conv, it))
             umx = max(umx, nf, nb)
         self._upack_n, self._upack_max = len(uitems), umx
         if uitems:
@@ -912,6 +915,7 @@ class _HipNet(nn.Module):
             it.w = _get(self._root, s.conv).weight.data_ptr()
             it.wb_fwd, it.wb_bwd, it.Cout, it.Cin = bf.data_ptr(), bb.data_ptr(), s.cout, s.cin
             bitems.append(it)
+            self._pack_items.setdefault('b3', []).append((s.conv, it))
             bmx = max(bmx, nf.value // 24, nb.value // 24)
         self._bpack_n, self._bpack_max = len(bitems), bmx
         if bitems:
@@ -931,6 +935,7 @@ class _HipNet(nn.Module):
             it.w = _get(self._root, s.conv).weight.data_ptr()
             it.wbu_fwd, it.wbu_bwd, it.Cout, it.Cin = img.data_ptr(), imgb.data_ptr(), s.cout, s.cin
             buitems.append(it)
+            self._pack_items.setdefault('b3up', []).append((s.conv, it))
             bumx = max(bumx, nf.value // 24, nb.value // 24)
         self._bupack_n, self._bupack_max = len(buitems), bumx
         if buitems:
@@ -941,6 +946,7 @@ class _HipNet(nn.Module):
             arr = (MfmaPackItem * len(mitems))(*mitems)
             self._mpack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self._engines = {}
+        self._lean, self._lean_key, self._lean_keep = None, None, []
 
     def _identity_bn(self, device, c):
         """(ones, zeros, 1 - eps) vectors: gamma / beta = running_mean / running_var of the identity BatchNorm through
@@ -952,8 +958,61 @@ class _HipNet(nn.Module):
                                           torch.full((n,), 1.0 - 1e-5, device=device))
         return t
 
+    # image kinds of the five packing tables: (table, forward bit, backward bit of pdes_conv_image_use)
+    _IMG_BITS = {'direct': 1 | 2, 'mfma': 4 | 8, 'up': 16 | 32, 'b3': 64 | 128, 'b3up': 256 | 512}
+
+    def _lean_tables(self):
+        """the packing tables WITHOUT the images no kernel of any live engine reads under the options in force
+        (pdes_conv_image_use over every descriptor of every engine): for the default net on the matrix cores that drops the
+        28 VALU images, the f32 images of the three bf16-split layers and the f32 sub-pixel images -- 29.5 -> see
+        EXPERIMENTS.md round 4.  Rebuilt when an engine is added or an option changes; older tables stay alive (captured
+        hipGraphs hold their addresses, and they remain sufficient for the engines that existed at capture time)."""
+        engines = [e for pool in self._engines.values() for e in pool]
+        engines += list(getattr(self, '_fwd_engines', {}).values())       # (conditional Glow: the y -> z direction's own chains)
+        key = (_lib.OPTIONS_EPOCH, tuple(id(e) for e in engines))
+        if self._lean_key == key:
+            return self._lean
+        use, L, mask = {}, _lib.lib(), ctypes.c_int(0)
+        for e in engines:
+            for sp, d in zip(e._chain_specs(), e.descs):
+                if sp.conv is None:
+                    continue
+                _lib.check(L.pdes_conv_image_use(e.ctx, ctypes.byref(d), ctypes.byref(mask)), 'pdes_conv_image_use')
+                use[sp.conv] = use.get(sp.conv, 0) | mask.value
+        lean = {}
+        dev = self._flat.device
+        full_max = {'direct': self._pack_max, 'mfma': self._mpack_max, 'up': self._upack_max, 'b3': self._bpack_max,
+                    'b3up': self._bupack_max}
+        for kind, bits in self._IMG_BITS.items():
+            items = [it for name, it in self._pack_items.get(kind, []) if use.get(name, bits) & bits]
+            if items:
+                arr = (type(items[0]) * len(items))(*items)
+                t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+                self._lean_keep.append(t)
+                lean[kind] = (t, len(items), full_max[kind])
+            else:
+                lean[kind] = (None, 0, 0)
+        self._lean, self._lean_key = lean, key
+        return lean
+
     def _pack_weights(self):
-        """rebuild every packed weight image from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables)"""
+        """rebuild the packed weight images from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables),
+        only the images some kernel reads (`_lean_tables`; PDES_PACK_ALL=1 in the environment: every image)"""
+        lean_ok = (self._engines or getattr(self, '_fwd_engines', None)) and os.environ.get('PDES_PACK_ALL', '0') != '1'
+        if lean_ok and self._lean is None and torch.cuda.is_current_stream_capturing():
+            lean_ok = False                 # (building a table copies host memory: never inside a capture -- the full tables do)
+        if lean_ok:
+            lean = self._lean if torch.cuda.is_current_stream_capturing() else self._lean_tables()
+            args, mx = [], 1
+            for kind in ('direct', 'mfma', 'up', 'b3', 'b3up'):
+                t, n, m = lean[kind]
+                args += [t.data_ptr() if n else None, n]
+                mx = max(mx, m)
+            if sum(lean[k][1] for k in lean) == 0:
+                return
+            rc = _lib.lib().pdes_pack_all2(*args, mx, _lib.stream_ptr())
+            _lib.check(rc, 'pdes_pack_all2')
+            return
         mx = max(self._pack_max, self._mpack_max if self._mpack_n else 0, self._upack_max if self._upack_n else 0,
                  self._bpack_max if self._bpack_n else 0, self._bupack_max if self._bupack_n else 0)
         rc = _lib.lib().pdes_pack_all2(self._pack_table.data_ptr(), self._pack_n,
