@@ -978,7 +978,10 @@ class _HipNet(nn.Module):
                 if sp.conv is None:
                     continue
                 _lib.check(L.pdes_conv_image_use(e.ctx, ctypes.byref(d), ctypes.byref(mask)), 'pdes_conv_image_use')
-                use[sp.conv] = use.get(sp.conv, 0) | mask.value
+                m = mask.value
+                if sp.norm is None and getattr(sp, 'kind', None) is None:
+                    m &= ~(2 | 8 | 32 | 128 | 512)         # a DenseED layer that reads the network input has no data gradient
+                use[sp.conv] = use.get(sp.conv, 0) | m
         lean = {}
         dev = self._flat.device
         full_max = {'direct': self._pack_max, 'mfma': self._mpack_max, 'up': self._upack_max, 'b3': self._bpack_max,

@@ -407,3 +407,42 @@ def test_set_launch_mode_switches_between_steps_bit_identically_and_late_trainer
     t_late = best(late)
     print('first trainer %.4f ms per step, a trainer built after a graph closure and six more streams %.4f' % (t_first * 1e3, t_late * 1e3))
     assert t_late < 1.05 * t_first
+
+
+def test_the_packing_launch_leaves_out_images_no_kernel_reads_and_follows_the_options(dev, option):
+    """pdes_conv_image_use -> lean packing tables (models/codec.py _lean_tables): the default net on the matrix cores packs
+    no VALU image at all, no f32 matrix-core image of the three wide layers, one f32 sub-pixel image (the 100 -> 100 layer's forward; its data gradient and both passes of 98 -> 49 run on the bf16-split images); with
+    PDES_CONV_IMPL=direct every VALU image is back (and nothing else is needed), with the bf16 kernels off the f32 images
+    return.  Eight steps with the lean tables end on the parameters of eight steps with every image packed, bit for bit."""
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    data = torch.from_numpy(grf_kle_fields(64, n_kle=64, cache_dir='/tmp')).to(dev)
+
+    def run(env_all):
+        if env_all:
+            os.environ['PDES_PACK_ALL'] = '1'
+        try:
+            net = _net(dev).train()
+            tr = MixedResidualTrainer(net, 32, 64, lr=1e-3, device=dev)
+            for i in range(8):
+                tr.step(data[(i % 2) * 32:(i % 2 + 1) * 32], 1e-3)
+            torch.cuda.synchronize()
+            return net, tr.flat.clone(), tr.epoch_means()
+        finally:
+            os.environ.pop('PDES_PACK_ALL', None)
+    net, flat, means = run(False)
+    _, flat_all, means_all = run(True)
+    assert torch.equal(flat, flat_all) and means == means_all
+    counts = lambda: {k: v[1] for k, v in net._lean_tables().items()}
+    full = {k: len(v) for k, v in net._pack_items.items()}
+    assert full == {'direct': 28, 'mfma': 27, 'up': 2, 'b3': 1, 'b3up': 2}
+    c = counts()
+    assert c['direct'] == 0 and c['up'] == 1 and c['b3'] == 1 and c['b3up'] == 2, c
+    assert c['mfma'] == 27 - 3                      # LastTransUp.conv1 (bf16 split) and the two nearest-x2 layers (sub-pixel split)
+    option('PDES_CONV_IMPL', 'direct')
+    c = counts()
+    assert c == {'direct': 27, 'mfma': 0, 'up': 0, 'b3': 0, 'b3up': 0}         # (the 7x7 first layer reads the live weights)
+    option('PDES_CONV_IMPL', 'auto')
+    option('PDES_MFMA_B3', '0')
+    c = counts()
+    assert c['b3'] == 0 and c['b3up'] == 0 and c['up'] == 2 and c['direct'] == 0 and c['mfma'] == 27 - 2
