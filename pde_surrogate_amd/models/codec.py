@@ -967,11 +967,11 @@ class _HipNet(nn.Module):
         28 VALU images, the f32 images of the three bf16-split layers and the f32 sub-pixel images -- 29.5 -> see
         EXPERIMENTS.md round 4.  Rebuilt when an engine is added or an option changes; older tables stay alive (captured
         hipGraphs hold their addresses, and they remain sufficient for the engines that existed at capture time)."""
-        engines = [e for pool in self._engines.values() for e in pool]
-        engines += list(getattr(self, '_fwd_engines', {}).values())       # (conditional Glow: the y -> z direction's own chains)
-        key = (_lib.OPTIONS_EPOCH, tuple(id(e) for e in engines))
+        key = self._lean_state()
         if self._lean_key == key:
             return self._lean
+        engines = [e for pool in self._engines.values() for e in pool]
+        engines += list(getattr(self, '_fwd_engines', {}).values())       # (conditional Glow: the y -> z direction's own chains)
         use, L, mask = {}, _lib.lib(), ctypes.c_int(0)
         for e in engines:
             for sp, d in zip(e._chain_specs(), e.descs):
@@ -995,8 +995,18 @@ class _HipNet(nn.Module):
                 lean[kind] = (t, len(items), full_max[kind])
             else:
                 lean[kind] = (None, 0, 0)
+        args, mx = [], 1
+        for kind in ('direct', 'mfma', 'up', 'b3', 'b3up'):
+            t, n, m = lean[kind]
+            args += [t.data_ptr() if n else None, n]
+            mx = max(mx, m)
+        self._lean_args = (args, mx, sum(lean[k][1] for k in lean))
         self._lean, self._lean_key = lean, key
         return lean
+
+    def _lean_state(self):
+        """(options epoch, engines alive): engines are only ever added to a flattened net"""
+        return (_lib.OPTIONS_EPOCH, sum(len(p) for p in self._engines.values()), len(getattr(self, '_fwd_engines', ())))
 
     def _pack_weights(self):
         """rebuild the packed weight images from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables),
@@ -1005,16 +1015,11 @@ class _HipNet(nn.Module):
         if lean_ok and self._lean is None and torch.cuda.is_current_stream_capturing():
             lean_ok = False                 # (building a table copies host memory: never inside a capture -- the full tables do)
         if lean_ok:
-            lean = self._lean if torch.cuda.is_current_stream_capturing() else self._lean_tables()
-            args, mx = [], 1
-            for kind in ('direct', 'mfma', 'up', 'b3', 'b3up'):
-                t, n, m = lean[kind]
-                args += [t.data_ptr() if n else None, n]
-                mx = max(mx, m)
-            if sum(lean[k][1] for k in lean) == 0:
-                return
-            rc = _lib.lib().pdes_pack_all2(*args, mx, _lib.stream_ptr())
-            _lib.check(rc, 'pdes_pack_all2')
+            if self._lean_key != self._lean_state() and not torch.cuda.is_current_stream_capturing():
+                self._lean_tables()
+            args, mx, n_items = self._lean_args
+            if n_items:
+                _lib.check(_lib.lib().pdes_pack_all2(*args, mx, _lib.stream_ptr()), 'pdes_pack_all2')
             return
         mx = max(self._pack_max, self._mpack_max if self._mpack_n else 0, self._upack_max if self._upack_n else 0,
                  self._bpack_max if self._bpack_n else 0, self._bupack_max if self._bupack_n else 0)
