@@ -160,8 +160,8 @@ extern "C" int pdes_conv_image_use(const pdes_context* ctx, const pdes_conv_desc
   if (is_resample_op(*desc)) return PDES_OK;
   OptScope scope(ctx);
   pdes_conv_desc d = *desc;
-  d.eval_mode = 0;                                  // (the data gradient exists in training mode only; the forward chain
-  d.g_fused = 0;                                    //  does not look at the mode)
+  d.eval_mode = 0;                                  // (the data gradient exists in training mode only; the forward chain does
+                                                    //  not look at the mode.  g_fused stays the caller's: it moves layers between kernels)
   int m = 0;
   {
     int rc = PDES_ENOSUP;

@@ -964,7 +964,8 @@ class _HipNet(nn.Module):
     def _lean_tables(self):
         """the packing tables WITHOUT the images no kernel of any live engine reads under the options in force
         (pdes_conv_image_use over every descriptor of every engine): for the default net on the matrix cores that drops the
-        28 VALU images, the f32 images of the three bf16-split layers and the f32 sub-pixel images -- 29.5 -> see
+        27 of its 28 VALU images (the query cannot know that the first layer's data gradient is never asked for), the f32
+        images of the three wide layers and one f32 sub-pixel image -- 29.5 -> 20 us,
         EXPERIMENTS.md round 4.  Rebuilt when an engine is added or an option changes; older tables stay alive (captured
         hipGraphs hold their addresses, and they remain sufficient for the engines that existed at capture time)."""
         key = self._lean_state()
@@ -978,10 +979,7 @@ class _HipNet(nn.Module):
                 if sp.conv is None:
                     continue
                 _lib.check(L.pdes_conv_image_use(e.ctx, ctypes.byref(d), ctypes.byref(mask)), 'pdes_conv_image_use')
-                m = mask.value
-                if sp.norm is None and getattr(sp, 'kind', None) is None:
-                    m &= ~(2 | 8 | 32 | 128 | 512)         # a DenseED layer that reads the network input has no data gradient
-                use[sp.conv] = use.get(sp.conv, 0) | m
+                use[sp.conv] = use.get(sp.conv, 0) | mask.value
         lean = {}
         dev = self._flat.device
         full_max = {'direct': self._pack_max, 'mfma': self._mpack_max, 'up': self._upack_max, 'b3': self._bpack_max,
