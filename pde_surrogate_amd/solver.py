@@ -1,11 +1,14 @@
 """The L-BFGS closure of the single-instance solver (reference solve_conv_mixed_residual.py:131-149) as one launch
-sequence -- and, by default, ONE hipGraph replay.
+sequence -- eager on three streams (default) or, with `use_graph=True`, ONE serial hipGraph replay.
 
 At B = 1 the closure is ~100 kernels of a few microseconds each (Decoder forward, fused Sobel + nonlinear Darcy
 residual, backward): pure launch latency when issued one by one through autograd.  `ResidualClosure` runs the same
 arithmetic through the C ABI on the model's primary engine (no autograd graph, gradients land in the flat buffer the
-parameters' `.grad` views alias) and captures it in a hipGraph; `torch.optim.LBFGS` drives it unchanged
-(`optimizer.step(closure)`: it only needs the returned loss and `p.grad`).
+parameters' `.grad` views alias); `torch.optim.LBFGS` drives it unchanged (`optimizer.step(closure)`: it only needs the
+returned loss and `p.grad`).  Round 4 (`tools/bench_solver.py`, fresh processes): eager 1,316 closure evaluations per
+second / 45.4 FlatLBFGS epochs, one hipGraph 1,218 / 43.6 -- the graph serialises the weight gradients the eager form
+runs on the two side streams; it was the faster form (1,208 vs 1,102) while late-built engines drew pool streams that
+shared hardware queues.  The graph remains for host-constrained callers (0.02 instead of 0.45 ms of host time).
 """
 import torch
 
@@ -13,7 +16,7 @@ from . import _lib
 
 
 class ResidualClosure:
-    def __init__(self, model, latent, perm, weight_bound=10.0, nonlinear=False, beta1=0.0, beta2=0.0, use_graph=True):
+    def __init__(self, model, latent, perm, weight_bound=10.0, nonlinear=False, beta1=0.0, beta2=0.0, use_graph=False):
         _lib.require_cuda(latent, perm)
         self.model, self.dev = model, latent.device
         self.wb, self.nl, self.b1, self.b2 = float(weight_bound), bool(nonlinear), float(beta1), float(beta2)

@@ -10,8 +10,10 @@ kernel, the network forward/backward from the HIP convolution kernels; torch.opt
 closure on the host exactly as in the reference (lr 0.5, max_iter 20, history 50).
 
   --mode fused  (default)  the closure is pde_surrogate_amd.solver.ResidualClosure: forward + loss + backward through
-                           the C ABI, captured in ONE hipGraph (B = 1 is pure launch latency); --no-graph replays the
-                           same launches eagerly; L-BFGS is pde_surrogate_amd.lbfgs.FlatLBFGS (torch.optim.LBFGS's
+                           the C ABI as eager launches on three streams (round 4: 1,316 closure evaluations / 45.4
+                           L-BFGS epochs per second; --graph replays them as ONE serial hipGraph: 1,218 / 43.6 --
+                           the graph was the faster form until the weight-gradient streams became per device and
+                           the packing launch lean, tools/bench_solver.py); L-BFGS is pde_surrogate_amd.lbfgs.FlatLBFGS (torch.optim.LBFGS's
                            algorithm on the flat parameter buffer: two bandwidth-bound passes over the curvature
                            history per iteration instead of ~200 tiny kernels and host reads);
   --mode dropin            the reference's closure verbatim on the drop-in modules (autograd).
@@ -60,7 +62,8 @@ def build_parser():
     p.add_argument('-v', '--verbose', action='store_true')
     p.add_argument('--synthetic', action='store_true', help='generate the permeability field instead of reading HDF5')
     p.add_argument('--mode', type=str, default='fused', choices=['fused', 'dropin'], help='closure (module docstring)')
-    p.add_argument('--no-graph', action='store_true', help='fused mode: eager launches instead of one hipGraph replay')
+    p.add_argument('--graph', action='store_true', help='fused mode: the closure as one serial hipGraph replay instead of eager launches')
+    p.add_argument('--no-graph', action='store_true', help='(default since round 4; kept for older command lines)')
     return p
 
 
@@ -115,7 +118,7 @@ def main(argv=None):
     if args.mode == 'fused':
         model.train()
         fused = ResidualClosure(model, fixed_latent, perm_tensor, args.weight_bound, args.nonlinear, b1, b2,
-                                use_graph=not args.no_graph)
+                                use_graph=args.graph and not args.no_graph)
         # the same algorithm and stopping rules as torch.optim.LBFGS, in place on the flat parameter / gradient buffers
         optimizer = FlatLBFGS(model._flat, model._gscratch, lr=args.lr, max_iter=20, history_size=50)
 
