@@ -365,15 +365,18 @@ def rendezvous(gpus):
         raise SystemExit(f'--gpus {gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run '
                          f'--nproc-per-node {gpus} bench.py --gpus {gpus}')
     have_gpu = torch.cuda.is_available()
-    dev = torch.device('cuda', local) if have_gpu else torch.device('cpu')
+    # PDES_BENCH_SHARE_GPU=1 (tests only): the ranks share GPU 0 and rendezvous over gloo (RCCL refuses two ranks on one
+    # device) -- the whole N > 1 code path of this file on a one-GPU box; the numbers of such a run mean nothing
+    share = have_gpu and os.environ.get('PDES_BENCH_SHARE_GPU', '0') == '1'
+    dev = torch.device('cuda', 0 if share else local) if have_gpu else torch.device('cpu')
     if have_gpu:
-        if local >= torch.cuda.device_count():
+        if not share and local >= torch.cuda.device_count():
             raise SystemExit(f'LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible')
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if have_gpu:
+        if have_gpu and not share:
             torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
@@ -759,7 +762,7 @@ def main():
                        'wgrad_stream': not args.graph,
                        'ranks': torch.distributed.get_world_size() if world > 1 else 1,
                        'collective': None if world == 1 else {
-                           'backend': 'nccl (RCCL over xGMI)', 'bytes_per_step': int(trainer.gflat.numel()) * 4,
+                           'backend': 'nccl (RCCL over xGMI)' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend(), 'bytes_per_step': int(trainer.gflat.numel()) * 4,
                            'exchange': 'ncclAllReduce by pointer on the weight-gradient / main stream (parallel.DirectRccl)'
                                        if trainer._rccl is not None else 'torch.distributed.all_reduce',
                            'buckets': 2 if trainer.overlap_allreduce and not args.graph else 1,

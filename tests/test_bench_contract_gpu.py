@@ -33,3 +33,41 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf['traffic'] is None or rf['traffic'] >= 0.99 * rf['algorithmic_bytes_per_launch']
     assert math.isclose(rf['achieved'], rf['algorithmic_bytes_per_launch'] / rf['us_per_launch'] / 1e3, rel_tol=2e-2)
     assert math.isfinite(d['loss_mean_over_run'])
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_two_ranks_sharing_the_gpu():
+    """the WHOLE N > 1 path of bench.py, end to end, on a one-GPU box: `python -m torch.distributed.run --nproc-per-node 2
+    bench.py --gpus 2` with PDES_BENCH_SHARE_GPU=1 (both ranks on GPU 0, rendezvous over gloo -- RCCL refuses two ranks
+    on one device; the trainer then exchanges through torch.distributed): NUMA pinning of both ranks (disjoint CPU sets),
+    the host-bound probe's all-reduce, per-rank step times, the stand-alone exchange timing, ONE JSON line from rank 0
+    with the keys the driver reads -- with --global-batch 64 (strong scaling, 32 per rank: one more branch than the weak
+    default; one invocation, ~2 minutes: gloo moves every gradient through the host)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = ROOT
+    for extra in (['--global-batch', '64'],):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, PDES_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '30', '--warmup', '40'] + extra
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith('{')]
+        assert len(lines) == 1, p.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['ranks'] == 2 and d['steps'] == 30 and d['warmup'] == 40
+        assert d['scaling'] == ('strong' if extra else 'weak') and d['config']['global_batch'] == 64
+        assert d['value'] > 0 and abs(d['value'] - 64 * 30 / (d['ms_per_step'] * 30 / 1e3)) < 1e-3 * d['value']
+        assert len(d['per_rank_ms_per_step']['all']) == 2 and d['per_rank_ms_per_step']['max'] == pytest.approx(d['ms_per_step'], rel=1e-3)
+        assert d['exchange_path'] == 'torch.distributed.all_reduce' and d['config']['collective']['backend'] == 'gloo'
+        assert d['allreduce_us_standalone'] > 0 and d['config']['collective']['buckets'] == 2
+        assert len(d['host_affinity']) == 2
+        if all(h.get('pinned') for h in d['host_affinity']):
+            assert d['host_affinity'][0]['cpus'] != d['host_affinity'][1]['cpus']          # disjoint shares of the node
+        assert d['config']['launch_mode_probe'] is not None and 'cpu_baseline' not in d
+        assert 'roofline' in d and d['roofline']['frac'] > 0.3
