@@ -120,6 +120,17 @@ def make_direct_rccl(group, device):
     return None
 
 
+def share_gpu():
+    """PDES_DP_SHARE_GPU=1 (tests on a one-GPU box): every rank uses GPU 0 and the group is gloo -- RCCL refuses two ranks on
+    one device; the gradient exchange then goes through torch.distributed.all_reduce"""
+    return os.environ.get('PDES_DP_SHARE_GPU', '0') == '1'
+
+
+def local_device(local_rank):
+    """the GPU of this rank: its local rank's, or GPU 0 for every rank under PDES_DP_SHARE_GPU=1"""
+    return torch.device('cuda', 0 if share_gpu() else local_rank)
+
+
 def init_from_env(backend=None):
     """torchrun-style rendezvous: returns (rank, local_rank, world_size); world 1 = no process group"""
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -128,7 +139,7 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = 'nccl' if torch.cuda.is_available() and not share_gpu() else 'gloo'
         kw = {}
         if backend == 'nccl':
             torch.cuda.set_device(local)

@@ -447,3 +447,34 @@ def test_the_packing_launch_leaves_out_images_no_kernel_reads_and_follows_the_op
     option('PDES_MFMA_B3', '0')
     c = counts()
     assert c['b3'] == 0 and c['b3up'] == 0 and c['up'] == 2 and c['direct'] == 1 and c['mfma'] == 27 - 2
+
+
+def test_training_script_under_torchrun_with_two_ranks_sharing_the_gpu(dev, tmp_path):
+    """train_codec_mixed_residual.py launched as the data-parallel job it is on a node -- `python -m torch.distributed.run
+    --nproc-per-node 2 ...` -- on a one-GPU box (PDES_DP_SHARE_GPU=1: both ranks on GPU 0, gloo): both ranks parse, rank 0
+    alone creates the run directory and writes every file once, the per-rank batch is --batch-size (global 16 of
+    ntrain 64: 4 steps per epoch and rank), the logged loss is the mean over the ranks and decreases, the checkpoint's
+    BatchNorm counters say 4 steps per epoch."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PDES_DP_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'train_codec_mixed_residual.py'), '--exp-dir', str(tmp_path),
+           '--ntrain', '64', '--ntest', '16', '--batch-size', '8', '--test-batch-size', '8', '--epochs', '2', '--ckpt-freq', '2',
+           '--synthetic', '--blocks', '111', '--growth-rate', '8', '--init-features', '16', '--plot-freq', '100']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    run = tmp_path / 'codec/mixed_residual/grf_kle512_ntrain64_run1_bs8_lr0.001_epochs2'
+    for f in ('args.txt', 'checkpoints/model_epoch2.pth', 'training/loss_train.txt', 'training/loss_test.txt'):
+        assert os.path.exists(run / f), (f, p.stdout[-1500:])
+    assert len(list((tmp_path / 'codec/mixed_residual').iterdir())) == 1          # one run directory: rank 1 made none
+    lt = np.loadtxt(run / 'training/loss_train.txt')
+    assert lt.shape == (2,) and np.isfinite(lt).all() and lt[1] < lt[0]
+    sd = torch.load(run / 'checkpoints/model_epoch2.pth', map_location='cpu')
+    assert int(sd['features.LastTransUp.norm3.num_batches_tracked']) == 8          # 2 epochs x 64 / (2 ranks x 8)
+    assert p.stdout.count('host affinity (rank 0)') == 1                         # printed by rank 0 only

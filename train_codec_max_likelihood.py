@@ -51,7 +51,7 @@ def main(argv=None):
     args = Parser().parse(argv, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('this build runs on an MI355X (ROCm) only -- there is no CPU fallback for the HIP kernels')
-    device = torch.device('cuda', local_rank if world > 1 else args.cuda % torch.cuda.device_count())
+    device = (parallel.local_device(local_rank) if world > 1 else torch.device('cuda', args.cuda % torch.cuda.device_count()))
     torch.cuda.set_device(device)
     is_main = rank == 0
     say = print if is_main else (lambda *a, **k: None)
