@@ -516,8 +516,10 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
       if (lane < 16 && ci < d.Cin) {
         const long long ro = (long long)rep_of_block(d.nrep) * d.rep_stride;
+#ifndef PDES_DG_NOATOM          // (component-timing build: EXPERIMENTS.md round 4)
         atomicAdd(&d.bn_grad[ro + 2 * ci], (double)dg);
         atomicAdd(&d.bn_grad[ro + 2 * ci + 1], (double)db);
+#endif
         if (ci >= d.final_c0 && ci < d.final_c1) {
           atomicAdd(&d.t_stats[ro + 2 * ci], (double)st);
           atomicAdd(&d.t_stats[ro + 2 * ci + 1], (double)sx);
