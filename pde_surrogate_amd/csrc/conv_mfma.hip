@@ -457,7 +457,9 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
 #pragma unroll
             for (int ow = 0; ow < NOWN; ++ow) t += sred[(ow * 16 + c) * 2 + w];
             const int cc = nt_base * 16 + c;
+#ifndef PDES_FW_NOATOM          // (component-timing build: EXPERIMENTS.md round 4)
             if (cc < d.Cout) atomicAdd(&os[2 * (d.out_coff + cc) + w], (double)t);
+#endif
           }
         } else if (lane < 16 && co < d.Cout) {
           atomicAdd(&os[2 * (d.out_coff + co)], (double)s);
