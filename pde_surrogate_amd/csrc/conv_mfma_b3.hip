@@ -389,8 +389,10 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
         q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
         if (lane < 16 && co < d.Cout) {
           double* os = d.out_stats + (long long)rep_of_block(d.nrep) * d.rep_stride;
+#ifndef PDES_FW_NOATOM          // (component-timing build: EXPERIMENTS.md round 4)
           atomicAdd(&os[2 * (d.out_coff + co)], (double)s);
           atomicAdd(&os[2 * (d.out_coff + co) + 1], (double)q);
+#endif
         }
       }
     }

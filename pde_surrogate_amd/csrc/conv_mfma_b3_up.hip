@@ -298,8 +298,10 @@ __global__ __launch_bounds__(256, 2) void conv_b3_up_fwd_kernel(pdes_conv_desc d
     q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
     if (lane < 16 && nt_w < nt_total && cn < d.Cout) {
       double* os = d.out_stats + (long long)rep_of_block(d.nrep) * d.rep_stride;
+#ifndef PDES_FW_NOATOM          // (component-timing build: EXPERIMENTS.md round 4)
       atomicAdd(&os[2 * (d.out_coff + cn)], (double)s);
       atomicAdd(&os[2 * (d.out_coff + cn) + 1], (double)q);
+#endif
     }
   }
 }
