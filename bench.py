@@ -101,6 +101,17 @@ def physical_cores():
     return len(cores) or (os.cpu_count() or 1)
 
 
+AFFINITY_AT_START = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
+
+
+def unpin_host():
+    """the CPU baselines time the box's host cores, not the one NUMA node `pin_host` bound the GPU ranks to: give every thread
+    of the process the affinity it started with (the pinned process understated the CPU numbers)"""
+    if AFFINITY_AT_START is not None:
+        from pde_surrogate_amd import parallel
+        parallel.set_affinity_all_threads(AFFINITY_AT_START)
+
+
 def cpu_baseline(bs, steps=10, warm=2):
     """the CPU oracle (port of the reference's PyTorch-CPU path) on this box's host cores (2 warm-up +
     >= 10 timed full steps at bs = 32, plus the loss-only forward + backward rate, and bs = 8 for config 1).  The rates
@@ -393,7 +404,7 @@ def pin_host(dev, local, world):
     """each rank onto its share of the cores of its GPU's NUMA node (parallel.pin_rank_to_gpu_numa); all ranks' plans are
     gathered for the line"""
     from pde_surrogate_amd import parallel
-    info = parallel.pin_rank_to_gpu_numa(dev, local, world)
+    info = parallel.pin_rank_to_gpu_numa(dev, local, parallel.local_world_size(world))
     if world > 1:
         got = [None] * world
         torch.distributed.all_gather_object(got, info)
@@ -474,10 +485,12 @@ def dp1_rccl_timing(dev, data, perm, B, steps, warmup):
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
         h = host_enqueue_timing(tr, load, 50)
+        res_exchange = ('ncclAllReduce by pointer on the weight-gradient / main stream (parallel.DirectRccl)' if tr._rccl is not None
+                        else 'torch.distributed.all_reduce')
+        tr.close()                                            # the communicator goes before its process group
         return {'dp1_rccl_ms_per_step': round(1e3 * (t2 - t0) / steps, 4),
                 'dp1_rccl_host_enqueue_ms_per_step': h['host_enqueue_ms_per_step'], 'steps': steps,
-                'exchange': 'ncclAllReduce by pointer on the weight-gradient / main stream (parallel.DirectRccl)' if tr._rccl is not None
-                            else 'torch.distributed.all_reduce',
+                'exchange': res_exchange,
                 'buckets': 2 if tr.overlap_allreduce else 1, 'bucket_a_bytes': int(tr.gflat.numel() - tr._bucket_off) * 4,
                 'bytes_per_step': int(tr.gflat.numel()) * 4}
     finally:
@@ -516,6 +529,118 @@ def segments_timing(dev, data, perm, B, steps=100):
     return {'ms_per_step': round(dt * 1e3, 4), 'host_enqueue_ms_per_step': h['host_enqueue_ms_per_step'],
             'graphs': len(pr.graphs), 'kernel_nodes': int(sum(pr.nodes)), 'operations_per_step': pr.n_ops,
             'segments': [list(s_) for s_ in pr.segments]}
+
+
+def config4_timing(dev, B, ntrain=4096, steps=128, warm=32):
+    """configs[3] of BASELINE.json: channelized (two-valued, sharp-interface) 64 x 64 fields, ntrain 4096, bs 32, the default
+    DenseED from scratch on the fused step -- the same kernels as the headline (they are data independent), on the input
+    family that stresses the Sobel / residual stencils and the BatchNorm statistics (reference pointer:
+    train_codec_mixed_residual.py:134-143; parity pinned by G23)"""
+    import contextlib
+    import io
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MixedResidualTrainer
+    from pde_surrogate_amd.utils.data import channelized_fields
+    from pde_surrogate_amd.utils.practices import OneCycleScheduler
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
+    tr = MixedResidualTrainer(model, B, 64, lr=1e-3, weight_bound=10.0, device=dev)
+    data = torch.from_numpy(channelized_fields(ntrain)).to(dev)
+    perm = torch.randperm(ntrain, generator=torch.Generator(device='cpu').manual_seed(1)).to(dev)
+    sched = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)
+    total = warm + steps
+
+    def step(i):
+        lo = (i * B) % (ntrain - B + 1)
+        tr.load_batch(data, perm[lo:lo + B])
+        tr.step(None, sched.step((i + 1) / total))
+    for i in range(warm):
+        step(i)
+    tr.epoch_means()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(warm, total):
+        step(i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    means = tr.epoch_means()
+    return {'workload': 'configs[3]: channelized 64x64 (two-valued fields, sharp interfaces; synthetic, '
+                        'utils/data.channelized_fields), ntrain=%d, bs=%d, default DenseED, fused step' % (ntrain, B),
+            'samples_per_s': round(B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 4), 'steps': steps, 'warmup': warm,
+            'loss_mean_over_timed_steps': round(means[0], 4)}
+
+
+def dropin_timing(dev, data, perm, B, steps=100, warm=20):
+    """the reference's loop body VERBATIM (train_codec_mixed_residual.py:224-240) on the drop-in modules: `model(input)` through
+    autograd, the three loss functions of models/darcy.py, `loss.backward()`, `torch.optim.Adam`, the per-step
+    `loss.item()` -- what a maintainer of the reference gets by changing only the imports, beside the
+    fused trainer of the headline"""
+    import contextlib
+    import io
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.models.darcy import (conv_constitutive_constraint as constitutive_constraint,
+                                                conv_continuity_constraint as continuity_constraint,
+                                                conv_boundary_condition as boundary_condition)
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    from pde_surrogate_amd.utils.practices import OneCycleScheduler, adjust_learning_rate
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48).to(dev)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    scheduler = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)
+    sobel_filter = SobelFilter(64, correct=True, device=dev)
+    weight_bound, n, total = 10.0, data.shape[0], warm + steps
+    model.train()
+    loss_train = 0.
+
+    def body(i):
+        nonlocal loss_train
+        lo = (i * B) % (n - B + 1)
+        input = data[perm[lo:lo + B]]                      # (the DataLoader's batch: a gather of the shuffled indices)
+        model.zero_grad()
+        output = model(input)
+        loss_pde = constitutive_constraint(input, output, sobel_filter) + continuity_constraint(output, sobel_filter)
+        loss_dirichlet, loss_neumann = boundary_condition(output)
+        loss_boundary = loss_dirichlet + loss_neumann
+        loss = loss_pde + loss_boundary * weight_bound
+        loss.backward()
+        lr = scheduler.step((i + 1) / total)
+        adjust_learning_rate(optimizer, lr)
+        optimizer.step()
+        loss_train += loss.item()
+    for i in range(warm):
+        body(i)
+    torch.cuda.synchronize(dev)
+    loss_train = 0.
+    t0 = time.perf_counter()
+    for i in range(warm, total):
+        body(i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    # the same loop without the reference's per-step host read of the loss (what that synchronisation costs)
+    t1 = time.perf_counter()
+    item, k = loss_train, min(steps, 50)
+    for i in range(k):
+        lo = (i * B) % (n - B + 1)
+        input = data[perm[lo:lo + B]]
+        model.zero_grad()
+        output = model(input)
+        loss_pde = constitutive_constraint(input, output, sobel_filter) + continuity_constraint(output, sobel_filter)
+        loss_dirichlet, loss_neumann = boundary_condition(output)
+        loss = loss_pde + (loss_dirichlet + loss_neumann) * weight_bound
+        loss.backward()
+        optimizer.step()
+    torch.cuda.synchronize(dev)
+    dt_nosync = (time.perf_counter() - t1) / k
+    return {'loop': 'reference loop body verbatim: model(input) -> constitutive + continuity + boundary loss functions -> '
+                    'loss.backward() -> torch.optim.Adam.step() -> loss.item()', 'samples_per_s': round(B * steps / dt, 1),
+            'ms_per_step': round(dt / steps * 1e3, 4), 'ms_per_step_without_loss_item': round(dt_nosync * 1e3, 4),
+            'steps': steps, 'warmup': warm, 'loss_mean_over_timed_steps': round(item / steps, 4),
+            'loss_kernel_launches_per_step': 2,
+            'note': 'one forward-only + one backward launch of the fused loss kernel per step (the three functions share one '
+                    'autograd node; upstream gradients reach the kernel through device memory: no host sync in backward); '
+                    'torch.optim.Adam is torch\'s (multi-tensor) optimiser over 82 parameter views of the flat buffer'}
 
 
 def allreduce_timing(trainer, iters=50):
@@ -664,7 +789,7 @@ def main():
     # host needs to enqueue a step against how long the GPU needs to finish it.  Eight ranks share one host: where the host
     # side comes within 0.8 of the step, the remaining steps replay the forward pass as a hipGraph (bit-identical kernels,
     # ~0.1 ms less host work per step, +0.6 % GPU time on an unconstrained host).  The ranks decide together (MAX).
-    probe, i = None, 0
+    probe, i, place_probe = None, 0, None
     can_probe = args.launch_mode == 'auto' and not args.graph and not args.segments and args.warmup >= 16
     while i < args.warmup:
         if can_probe and probe is None and i >= min(args.warmup // 2, 24) and args.warmup - i >= 14:
@@ -686,6 +811,32 @@ def main():
             if ratio > 0.8:
                 trainer.set_launch_mode('forward')
                 probe['switched_to'] = 'forward'
+            continue
+        if (world > 1 and place_probe is None and not args.graph and os.environ.get('PDES_DP_BUCKET_STREAM') is None
+                and trainer.overlap_allreduce and (probe is not None or not can_probe) and args.warmup - i >= 62):
+            # where bucket A's all-reduce goes (MixedResidualTrainer.set_bucket_placement): 20 steps in each placement, the
+            # ranks agree on the slowest rank's time (MAX) and keep the fastest placement.  The 8-GPU node is the first
+            # place this exchange runs for real: the choice is measured there instead of assumed here.
+            place_probe = {}
+            for where in trainer.BUCKET_PLACEMENTS:
+                try:
+                    trainer.set_bucket_placement(where)
+                except ValueError:
+                    continue
+                for _ in range(2):
+                    trainer.step(batch(i), sched.step((i + 1) / total))
+                    i += 1
+                sync()
+                q0 = time.perf_counter()
+                for _ in range(18):
+                    trainer.step(batch(i), sched.step((i + 1) / total))
+                    i += 1
+                torch.cuda.synchronize(dev)
+                t = torch.tensor([time.perf_counter() - q0], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                place_probe[where] = round(float(t.item()) / 18 * 1e3, 4)
+            best = min(place_probe, key=place_probe.get)
+            trainer.set_bucket_placement(best)
             continue
         trainer.step(batch(i), sched.step((i + 1) / total))
         i += 1
@@ -727,7 +878,17 @@ def main():
             seg = segments_timing(dev, data, perm, B)
         except Exception as e:
             seg = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
-    mark('host / dp1 / segment legs')
+    c4, dropin = None, None
+    if world == 1 and not args.no_extras and not args.graph:
+        try:
+            c4 = config4_timing(dev, B, steps=min(args.steps, 128))
+        except Exception as e:
+            c4 = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
+        try:
+            dropin = dropin_timing(dev, data, perm, B, steps=min(args.steps, 100))
+        except Exception as e:
+            dropin = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
+    mark('host / dp1 / segment / config-4 / drop-in legs')
     if rank == 0:
         traffic, traffic_src = None, None
         import glob
@@ -765,9 +926,11 @@ def main():
                            'backend': 'nccl (RCCL over xGMI)' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend(), 'bytes_per_step': int(trainer.gflat.numel()) * 4,
                            'exchange': 'ncclAllReduce by pointer on the weight-gradient / main stream (parallel.DirectRccl)'
                                        if trainer._rccl is not None else 'torch.distributed.all_reduce',
-                           'buckets': 2 if trainer.overlap_allreduce and not args.graph else 1,
-                           'overlapped_with_backward': bool(trainer.overlap_allreduce and not args.graph),
+                           'buckets': 2 if trainer.overlap_allreduce and trainer.bucket_stream != 'main' and not args.graph else 1,
+                           'overlapped_with_backward': bool(trainer.overlap_allreduce and trainer.bucket_stream != 'main' and not args.graph),
                            'allreduce_us_standalone': round(ar_us, 1),
+                           'bucket_placement': trainer.bucket_stream,
+                           'bucket_placement_probe_ms_per_step': place_probe,
                            'note': 'bucket A (conv weights of the last layers, ~3/4 of the bytes) is all-reduced from the '
                                    'weight-gradient stream inside pdes_backward; allreduce_us_standalone is the exchange '
                                    'timed alone after the run (what the step would pay without the overlap)'},
@@ -806,6 +969,10 @@ def main():
             out['dp1_rccl'] = dp1
         if seg is not None:
             out['segment_graphs'] = seg
+        if c4 is not None:
+            out['config4_channelized'] = c4
+        if dropin is not None:
+            out['dropin'] = dropin
         if world == 1 and not args.no_extras:
             out['roofline_1x1'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s',
                                    'kernel': 'conv1x1_mfma_kernel (forward, data gradient), conv1x1_wgrad_kernel',
@@ -820,7 +987,10 @@ def main():
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--leg', 'cglow'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else [])
             try:
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=600, check=True)
+                # (the child starts with the affinity this process started with, pins itself for its GPU part and unpins
+                #  for its CPU baseline)
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=600, check=True,
+                                   preexec_fn=(lambda: os.sched_setaffinity(0, AFFINITY_AT_START)) if AFFINITY_AT_START else None)
                 out['cglow_reverse_kl'] = json.loads(r.stdout.decode().strip().splitlines()[-1])
             except Exception as e:                      # noqa: BLE001  (the headline line must not depend on an extra leg)
                 out['cglow_reverse_kl'] = {'error': f'{type(e).__name__}: {e}'}
@@ -829,10 +999,12 @@ def main():
             out['config5_solver'] = config5_timing(dev)
             mark('config-5 solver leg')
         if world == 1 and not args.no_cpu_baseline:
+            unpin_host()
             out['cpu_baseline'] = cpu_baseline(B)
             mark('cpu_baseline')
         emit(out)
     if world > 1:
+        trainer.close()                                       # the RCCL communicator goes before its process group
         torch.distributed.destroy_process_group()
 
 

@@ -39,7 +39,7 @@ extern "C" {
  * arguments; these select among equivalent kernels and exist for A/B measurements and cross-checks).
  *   pdes_context_create   n_events order-only events are created on the CURRENT device (pdes_backward with a
  *                         second stream needs n_layers + 1); returns hipError_t > 0 on failure.
- *   pdes_context_set_option  value = decimal string (NULL = default); PDES_ENOSUP: unknown key.  The eight keys
+ *   pdes_context_set_option  value = decimal string (NULL = default); PDES_ENOSUP: unknown key.  The nine keys
  *                         (csrc/pdes_options.h; each selects between EQUIVALENT kernels, for cross-checks and re-tuning):
  *                           "PDES_CONV_IMPL"   "direct": the generic VALU kernels for every convolution | "auto"
  *                           "PDES_MFMA_B3"     bit mask of the bf16 x3 split kernels, default 31 (0: the exact-f32 pipe everywhere):
@@ -53,6 +53,9 @@ extern "C" {
  *                           "PDES_LOSS_NT"     streaming accesses in the loss kernel: -1 by working-set size (default), 0, 1
  *                           "PDES_FORK_SIGNAL" 1: pdes_backward's fork events ride on the finalize kernel's completion signal |
  *                                              0: hipEventRecord
+ *                           "PDES_WGRAD_HOLD"  pdes_backward with a second stream: the weight gradient of a layer of at least this
+ *                                              many MFLOP (2 B Hout Wout Cout Cin k^2 / 1e6) is released behind the layer's data
+ *                                              gradient instead of beside it; 0: never
  *   pdes_context_load_env every key above that is set in the process environment, read ONCE, now.
  *   pdes_context_device   the device the context's events belong to.
  */
@@ -108,7 +111,13 @@ int pdes_stat_replicas(void);
 int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
                     int B, int H, int W, float w_const, float w_cont, float w_dir, float w_neu,
                     int flags, float beta1, float beta2, void* stream);
-/* rows of `partials` the call above writes for these arguments (> 0), or PDES_ENOSUP */
+/* The same launch with the four term weights {w_const, w_cont, w_dir, w_neu} read from DEVICE memory (4 floats) by the
+ * kernels: what the autograd backward of the reference's three loss functions needs -- the upstream gradients of the
+ * terms are device scalars there (models/darcy.py:162-233 under `loss.backward()`, train_codec_mixed_residual.py:233), and
+ * reading them on the host would stall the backward pass once per loss function. */
+int pdes_darcy_loss_dw(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials, float* loss_out,
+                       int B, int H, int W, const float* w_dev, int flags, float beta1, float beta2, void* stream);
+/* rows of `partials` the calls above write for these arguments (> 0), or PDES_ENOSUP */
 int pdes_darcy_loss_partial_rows(int B, int H, int W, int flags);
 
 /* Stand-alone Sobel gradients of `nimg` single-channel images (either output may be NULL); correct = the

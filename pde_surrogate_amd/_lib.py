@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int
@@ -22,6 +22,7 @@ SIGNATURES = {
     'pdes_context_load_env': [_c_p],
     'pdes_context_device': [_c_p],
     'pdes_darcy_loss': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_p],
+    'pdes_darcy_loss_dw': [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_p],
     'pdes_darcy_loss_partial_rows': [_c_i, _c_i, _c_i, _c_i],
     'pdes_sobel_grad': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
     'pdes_sobel_grad_adjoint': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],

@@ -163,7 +163,11 @@ extern "C" int pdes_conv_image_use(const pdes_context* ctx, const pdes_conv_desc
   d.eval_mode = 0;                                  // (the data gradient exists in training mode only; the forward chain does
                                                     //  not look at the mode.  g_fused stays the caller's: it moves layers between kernels)
   int m = 0;
-  {
+  // a caller switches out_stats between its training (accumulate) and evaluation (NULL) forwards and a kernel may be
+  // selected by it (the few-output forward takes no statistics): a descriptor that carries statistics is queried BOTH
+  // ways, the masks OR-ed
+  for (int pass = 0; pass < (desc->out_stats ? 2 : 1); ++pass) {
+    d.out_stats = pass ? nullptr : desc->out_stats;
     int rc = PDES_ENOSUP;
     auto tryf = [&](int r, int bit) { if (rc == PDES_ENOSUP && r != PDES_ENOSUP) { rc = r; m |= bit; } };
     if (!force_direct()) {
@@ -177,6 +181,7 @@ extern "C" int pdes_conv_image_use(const pdes_context* ctx, const pdes_conv_desc
     }
     if (rc == PDES_ENOSUP && !conv_forward_direct_first7(d)) m |= PDES_IMG_DIRECT_FWD;
   }
+  d.out_stats = desc->out_stats;
   {
     int rc = PDES_ENOSUP;
     auto tryb = [&](int r, int bit) { if (rc == PDES_ENOSUP && r != PDES_ENOSUP) { rc = r; m |= bit; } };
@@ -315,13 +320,26 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
   };
 
   const bool use_signal = opt().fork_signal != 0;
+  // PDES_WGRAD_HOLD: a layer whose weight gradient is at least that many MFLOP is released behind its DATA gradient
+  // (one hipEventRecord on the main stream) instead of behind its finalize.  Both kernels of such a layer fill the chip
+  // by themselves: side by side the data gradient -- the one the chain waits for -- takes twice as long (196 -> 98 at
+  // 32 x 32, B = 32: 172 us beside its weight gradient, 78 us alone), behind it the weight gradient overlaps the
+  // narrow layers that follow, which leave most of the chip idle.
+  const long long hold_mflop = opt().wgrad_hold;
+  auto held = [&](int i) {
+    const pdes_conv_desc& d = descs[i];
+    if (!fork || hold_mflop <= 0 || i == 0 || is_resample_op(d) || !(d.has_bn || d.t_in)) return false;
+    const long long mflop = 2LL * d.B * d.Hout * d.Wout * d.Cout * d.Cin * d.ksize * d.ksize / 1000000LL;
+    return mflop >= hold_mflop;
+  };
   for (int i = n - 1; i >= 0; --i) {
     const pdes_conv_desc& d = descs[i];
     hipEvent_t signalled = nullptr;
+    const bool hold = held(i);
     if (d.fin_tstats && !d.g_fused) {
       // this layer's weight gradient is released by the completion of ITS finalize kernel: the fork event rides on
       // that kernel's completion signal, no barrier packet sits between the finalize and the data gradient
-      if (fork && use_signal && i != 0 && !is_resample_op(d)) signalled = cx->events[nev++];
+      if (fork && use_signal && i != 0 && !is_resample_op(d) && !hold) signalled = cx->events[nev++];
       int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
                                            d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
                                            d.rep_stride, st, signalled, d.g_add, d.fin_coef);
@@ -329,13 +347,17 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
     // (saves the event hop; its scratch / dw are disjoint from what the second stream still works on)
-    if (!is_resample_op(d)) {
+    if (!is_resample_op(d) && !hold) {
       const int rc = release(i, fork && i == 0, signalled);
       if (rc) return rc;
     }
     // (a convolution without a BatchNorm in front has a data gradient only when the caller gave it somewhere to go)
     if (d.has_bn || is_resample_op(d) || d.t_in) {
       const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
+      if (rc) return rc;
+    }
+    if (hold) {                                           // released by an event recorded behind the data gradient
+      const int rc = release(i, false, nullptr);
       if (rc) return rc;
     }
   }

@@ -32,7 +32,22 @@ struct LossParams {
   float b_neu;     // w_neu   * 2 / (2 B n)
   float beta1, beta2;
   int nt;          // 1: streaming (non-temporal) global loads / stores
+  const float* wdev;   // pdes_darcy_loss_dw: the four term weights live in DEVICE memory -- the fields above were computed
+                       // for weights of 1 and the backward kernels multiply them by wdev[0..3] (NULL: weights by value)
 };
+
+#ifdef __HIPCC__
+// the per-term weights of pdes_darcy_loss_dw: four uniform (scalar) loads at the head of a backward kernel
+__device__ __forceinline__ LossParams loss_params_weighted(LossParams p) {
+  if (p.wdev) {
+    p.a_const *= p.wdev[0];
+    p.a_cont *= p.wdev[1];
+    p.b_dir *= p.wdev[2];
+    p.b_neu *= p.wdev[3];
+  }
+  return p;
+}
+#endif
 
 namespace gen {
 

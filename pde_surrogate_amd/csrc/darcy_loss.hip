@@ -184,9 +184,10 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS)
                                                                 const float* __restrict__ yp,
                                                                 float* __restrict__ gyp,
                                                                 float* __restrict__ partials,
-                                                                LossParams p) {
+                                                                LossParams p_in) {
   using G = Geo<N>;
   constexpr int SPR = G::SPR, NSTRIP = G::NSTRIP, NT = G::NT, SPT = G::SPT, NW = G::NW;
+  const LossParams p = BWD ? loss_params_weighted(p_in) : p_in;
   __shared__ float4 lds[3 * NSTRIP + NW];   // 3 planes + NW x 4 floats of reduction scratch
   const int b = blockIdx.x, tid = threadIdx.x;
   const float fn = (float)N;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? (NONLIN ? 3 : PDES_LOSS_WPS)
 __global__ __launch_bounds__(256) void darcy_loss_finalize(const float* __restrict__ partials, int B,
                                                            float* __restrict__ out, double inv_n, double inv_cont,
                                                            double inv_dir, double inv_neu, float w0,
-                                                           float w1, float w2, float w3) {
+                                                           float w1, float w2, float w3, const float* __restrict__ wdev) {
   __shared__ double sh[4][4];
   double acc[4] = {0, 0, 0, 0};
   for (int b = threadIdx.x; b < B; b += 256) {
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(256) void darcy_loss_finalize(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
     const double lc = t[0] * inv_n, lt = t[1] * inv_cont, ld = t[2] * inv_dir, ln = t[3] * inv_neu;
+    if (wdev) { w0 = wdev[0]; w1 = wdev[1]; w2 = wdev[2]; w3 = wdev[3]; }
     out[0] = (float)(w0 * lc + w1 * lt + w2 * ld + w3 * ln);
     out[1] = (float)lc; out[2] = (float)lt; out[3] = (float)ld; out[4] = (float)ln;
   }
@@ -473,10 +475,10 @@ extern "C" int pdes_darcy_loss_partial_rows(int B, int H, int W, int flags) {
   return t > 0 ? B * t : PDES_ENOSUP;
 }
 
-extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
-                               float* loss_out, int B, int H, int W, float w_const, float w_cont,
-                               float w_dir, float w_neu, int flags, float beta1, float beta2,
-                               void* stream) {
+static int darcy_loss_impl(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
+                           float* loss_out, int B, int H, int W, float w_const, float w_cont,
+                           float w_dir, float w_neu, const float* w_dev, int flags, float beta1, float beta2,
+                           void* stream) {
   if (!K || !y || !partials || B <= 0) return PDES_EINVAL;
   const int nonlinear = flags & PDES_LOSS_NONLINEAR, no_tb = (flags & PDES_LOSS_NO_TB) ? 1 : 0;
   if (H != W || H < 2) return PDES_ENOSUP;       // SobelFilter has ONE imsize x imsize modifier: square fields (image_gradient.py:43-46)
@@ -496,6 +498,7 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
   p.b_neu = (float)(2.0 * w_neu / (2.0 * B * W));
   p.beta1 = beta1;
   p.beta2 = beta2;
+  p.wdev = w_dev;
   // streaming accesses once the 7 planes/sample no longer fit the 256 MiB Infinity Cache; at training
   // batch sizes y was just produced and grad_y is consumed next, so those stay cacheable
   OptScope scope(ctx);
@@ -510,10 +513,25 @@ extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const fl
   PDES_LAUNCH_CHECK();
   if (loss_out) {
     hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partials, rows, loss_out, 1.0 / ntot, 1.0 / ncont,
-                       1.0 / ((double)B * H), 1.0 / (2.0 * B * W), w_const, w_cont, w_dir, w_neu);
+                       1.0 / ((double)B * H), 1.0 / (2.0 * B * W), w_const, w_cont, w_dir, w_neu, w_dev);
     PDES_LAUNCH_CHECK();
   }
   return PDES_OK;
+}
+
+extern "C" int pdes_darcy_loss(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
+                               float* loss_out, int B, int H, int W, float w_const, float w_cont,
+                               float w_dir, float w_neu, int flags, float beta1, float beta2,
+                               void* stream) {
+  return darcy_loss_impl(ctx, K, y, grad_y, partials, loss_out, B, H, W, w_const, w_cont, w_dir, w_neu, nullptr, flags, beta1,
+                         beta2, stream);
+}
+
+extern "C" int pdes_darcy_loss_dw(const pdes_context* ctx, const float* K, const float* y, float* grad_y, float* partials,
+                                  float* loss_out, int B, int H, int W, const float* w_dev, int flags, float beta1,
+                                  float beta2, void* stream) {
+  if (!w_dev) return PDES_EINVAL;
+  return darcy_loss_impl(ctx, K, y, grad_y, partials, loss_out, B, H, W, 1.f, 1.f, 1.f, 1.f, w_dev, flags, beta1, beta2, stream);
 }
 
 extern "C" int pdes_sobel_grad(const float* img, float* gh, float* gv, int nimg, int H, int W,
@@ -574,4 +592,4 @@ extern "C" int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar
   return PDES_OK;
 }
 
-extern "C" int pdes_abi_version(void) { return 22; }
+extern "C" int pdes_abi_version(void) { return 23; }

@@ -43,8 +43,9 @@ template <bool BWD>
 __global__ __launch_bounds__(GEN_NT) void darcy_loss_generic_kernel(const float* __restrict__ Kp,
                                                                     const float* __restrict__ yp,
                                                                     float* __restrict__ gyp,
-                                                                    float* __restrict__ partials, LossParams p, int n,
+                                                                    float* __restrict__ partials, LossParams p_in, int n,
                                                                     int tr, int tc, int ntc, int flags) {
+  const LossParams p = BWD ? loss_params_weighted(p_in) : p_in;
   __shared__ __attribute__((aligned(16))) float lds[GEN_LDSF];
   __shared__ float red[(GEN_NT / 64) * 4];
   const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(GEN_NT) void darcy_loss_generic_kernel(const float*
 template <bool BWD>
 __global__ __launch_bounds__(GEN_NT) void darcy_loss_strips_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
                                                                    float* __restrict__ gyp, float* __restrict__ partials,
-                                                                   LossParams p, int n, int tr, int tc, int ntc, int flags) {
+                                                                   LossParams p_in, int n, int tr, int tc, int ntc, int flags) {
+  const LossParams p = BWD ? loss_params_weighted(p_in) : p_in;
   __shared__ __attribute__((aligned(16))) float lds[GEN_LDSF];
   __shared__ float red[(GEN_NT / 64) * 4];
   const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -124,8 +126,9 @@ __device__ __forceinline__ band::Halo halo_of(const band::V4& x) {       // (wha
 template <bool BWD, int NPASS, int J>
 __global__ __launch_bounds__(512, 4) void darcy_loss_band_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
                                                               float* __restrict__ gyp, float* __restrict__ partials,
-                                                              LossParams p, band::Plan pl, int flags) {
+                                                              LossParams p_in, band::Plan pl, int flags) {
   using namespace band;
+  const LossParams p = BWD ? loss_params_weighted(p_in) : p_in;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[8 * 4];
   const int bi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;

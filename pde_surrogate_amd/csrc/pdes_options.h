@@ -2,7 +2,7 @@
 // Nothing in the library reads the environment on its own: pdes_context_load_env() does, once, when the caller
 // asks for it; every other read goes through opt(), which resolves to the options of the context the running
 // entry point was called with (or to the compiled-in defaults for a NULL context).
-// Eight options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
+// Ten options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
 // parts; the A/B measurements that settled the defaults, and the knobs that went with them, are in EXPERIMENTS.md.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -21,6 +21,10 @@ struct Options {
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS : workgroup target of the split-K weight-gradient plan
   int loss_nt = -1;             // PDES_LOSS_NT   : streaming loads / stores in the loss kernel: -1 = by working-set size, 0, 1
   int fork_signal = 1;          // PDES_FORK_SIGNAL: fork events ride on the finalize kernel's completion signal (0: hipEventRecord)
+  int wgrad_mtw = 1;            // PDES_WGRAD_MTW  : M-tiles per workgroup of the dense blocks' 3x3 weight gradients (1 | 2)
+  int wgrad_hold = 0;           // PDES_WGRAD_HOLD : pdes_backward releases the weight gradient of a layer with >= this many MFLOP
+                                //                  (2 B Hout Wout Cout Cin k^2 / 1e6) behind the layer's DATA gradient instead of beside
+                                //                  it (0: never): two kernels that each fill the chip gain nothing from running together
 };
 
 struct Context {

@@ -1010,11 +1010,15 @@ class _HipNet(nn.Module):
         """rebuild the packed weight images from the live weights: one launch (direct, MFMA, sub-pixel, bf16-split tables),
         only the images some kernel reads (`_lean_tables`; PDES_PACK_ALL=1 in the environment: every image)"""
         lean_ok = (self._engines or getattr(self, '_fwd_engines', None)) and os.environ.get('PDES_PACK_ALL', '0') != '1'
-        if lean_ok and self._lean is None and torch.cuda.is_current_stream_capturing():
-            lean_ok = False                 # (building a table copies host memory: never inside a capture -- the full tables do)
-        if lean_ok:
-            if self._lean_key != self._lean_state() and not torch.cuda.is_current_stream_capturing():
+        if lean_ok and self._lean_key != self._lean_state():
+            if torch.cuda.is_current_stream_capturing():
+                # building a table copies host memory: never inside a capture.  No table yet, or one made for other
+                # options / fewer engines (an option changed or an engine was added since the last eager pack): the graph
+                # being captured gets the FULL tables -- a stale lean table could leave out an image its kernels read
+                lean_ok = False
+            else:
                 self._lean_tables()
+        if lean_ok:
             args, mx, n_items = self._lean_args
             if n_items:
                 _lib.check(_lib.lib().pdes_pack_all2(*args, mx, _lib.stream_ptr()), 'pdes_pack_all2')

@@ -16,6 +16,8 @@ microseconds, and the step of an 8-rank job must not become host-bound.
 """
 import ctypes
 import os
+import socket
+import sys
 
 import torch
 import torch.distributed as dist
@@ -84,9 +86,14 @@ class DirectRccl:
             self._comm = None
 
     def __del__(self):
+        # garbage collection only.  At interpreter shutdown the communicator is left to the process exit: ncclCommDestroy
+        # may block on a peer that has already gone, and a hang inside the C call cannot be caught -- callers that want a
+        # clean teardown call close() (before destroy_process_group)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
-        except Exception:                                    # noqa: BLE001  (interpreter shutdown)
+        except Exception:                                    # noqa: BLE001
             pass
 
 
@@ -172,8 +179,11 @@ def _cpulist_str(cpus):
 def gpu_numa_cpus(device, sysfs='/sys/bus/pci/devices'):
     """(numa_node, cpus local to it) of a GPU from sysfs: `<sysfs>/<pci address>/{numa_node,local_cpulist}` with the PCI
     address torch reports for the device; (None, []) when the files are not there (containers without sysfs)"""
-    pr = torch.cuda.get_device_properties(device)
-    addr = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+    try:                                   # (pinning is an optimisation: a torch without these attributes must not abort a run)
+        pr = torch.cuda.get_device_properties(device)
+        addr = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+    except (AttributeError, RuntimeError):
+        return None, []
     try:
         with open(os.path.join(sysfs, addr, 'numa_node')) as f:
             node = int(f.read().strip())
@@ -184,26 +194,58 @@ def gpu_numa_cpus(device, sysfs='/sys/bus/pci/devices'):
     return node, cpus
 
 
-def plan_affinity(local_rank, nodes, cpulists, allowed):
+def cpu_core_groups(cpus, sysfs='/sys/devices/system/cpu'):
+    """the hardware threads of `cpus` grouped by physical core (`topology/thread_siblings_list`), cores in the order of
+    their first thread; without sysfs every CPU is its own core"""
+    groups, seen = [], set()
+    for c in cpus:
+        if c in seen:
+            continue
+        sib = [c]
+        try:
+            with open(os.path.join(sysfs, f'cpu{c}', 'topology', 'thread_siblings_list')) as f:
+                sib = [t for t in _parse_cpulist(f.read()) if t in set(cpus)] or [c]
+        except (OSError, ValueError):
+            pass
+        sib = [t for t in sib if t not in seen]
+        seen.update(sib)
+        groups.append(sib)
+    return groups
+
+
+def plan_affinity(local_rank, nodes, cpulists, allowed, core_groups=None):
     """pure part of `pin_rank_to_gpu_numa`: `nodes[r]` / `cpulists[r]` = NUMA node and local CPUs of local rank r's GPU,
-    `allowed` = the CPUs this process may run on.  The ranks whose GPUs hang off the same node share that node's CPUs in
-    contiguous, disjoint slices (rank order), so that eight enqueueing host threads (+ their runtime helper threads) do
-    not migrate across sockets or sit on each other's cores.  Returns the CPU list for `local_rank` ([] = leave as is)."""
+    `allowed` = the CPUs this process may run on.  The ranks whose GPUs hang off the same node share that node's PHYSICAL
+    cores in contiguous, disjoint slices (rank order) -- a rank gets every hardware thread of its cores (`core_groups`: the
+    node's CPUs grouped by core, `cpu_core_groups`; None: every CPU its own core), so that eight enqueueing host threads (+
+    their runtime helper threads) neither migrate across sockets nor sit on each other's cores or SMT siblings.
+    Returns the CPU list for `local_rank` ([] = leave as is)."""
     mine = [c for c in cpulists[local_rank] if c in allowed]
     if not mine:
         return []
     peers = [r for r in range(len(nodes)) if nodes[r] == nodes[local_rank] and cpulists[r] == cpulists[local_rank]]
     k, n = peers.index(local_rank), len(peers)
-    per = len(mine) // n
+    cores = [[c] for c in mine] if core_groups is None else \
+        [g for g in ([t for t in grp if t in set(mine)] for grp in core_groups) if g]
+    per = len(cores) // n
     if per == 0:
         return mine
-    return mine[k * per:(k + 1) * per]
+    return sorted(t for grp in cores[k * per:(k + 1) * per] for t in grp)
+
+
+def local_world_size(world=1):
+    """ranks on THIS host: LOCAL_WORLD_SIZE of torchrun, else `world` (a single-node launch)"""
+    try:
+        return max(1, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    except ValueError:
+        return max(1, world)
 
 
 def pin_rank_to_gpu_numa(device, local_rank=0, local_world=1, group=None):
     """bind this process (every existing thread; new ones inherit) to its share of the cores of its GPU's NUMA node.
     A step is ~0.5 ms of host enqueue work per 1.7 ms of GPU time on EACH rank: a rank whose thread wanders to the other
-    socket pays remote-memory latency on every launch packet.  PDES_PIN=0 disables.  Returns a dict for the logs:
+    socket pays remote-memory latency on every launch packet.  `local_world`: the ranks on this host (`local_world_size`);
+    only ranks that report this host's name count as peers.  PDES_PIN=0 disables.  Returns a dict for the logs:
     {'numa_node', 'cpus', 'n_cpus'} or {'pinned': False, 'why': ...}."""
     if os.environ.get('PDES_PIN', '1') == '0':
         return {'pinned': False, 'why': 'PDES_PIN=0'}
@@ -211,32 +253,41 @@ def pin_rank_to_gpu_numa(device, local_rank=0, local_world=1, group=None):
         return {'pinned': False, 'why': 'no sched_setaffinity on this platform'}
     if torch.device(device).type != 'cuda':
         return {'pinned': False, 'why': 'no GPU'}
-    node, cpus = gpu_numa_cpus(device)
+    node, cpus = gpu_numa_cpus(device)               # (never raises: every rank reaches the collective below)
     nodes, lists = [node] * max(local_world, 1), [cpus] * max(local_world, 1)
     if local_world > 1 and dist.is_available() and dist.is_initialized():
+        host = socket.gethostname()
         got = [None] * dist.get_world_size(group)
-        dist.all_gather_object(got, (local_rank, node, cpus), group=group)
-        for lr, nd, cl in got:                       # one node: local rank == rank; keyed by local rank all the same
-            if lr < local_world:
+        dist.all_gather_object(got, (host, local_rank, node, cpus), group=group)
+        for h, lr, nd, cl in got:                    # peers = the ranks of THIS host, keyed by their local rank
+            if h == host and 0 <= lr < local_world:
                 nodes[lr], lists[lr] = nd, cl
     if node is None or node < 0 or not cpus:
         return {'pinned': False, 'why': 'no numa_node / local_cpulist in sysfs for the GPU'}
+    if local_rank >= len(nodes):
+        return {'pinned': False, 'why': f'local rank {local_rank} outside the {len(nodes)} ranks of this host'}
     allowed = os.sched_getaffinity(0)
-    take = plan_affinity(local_rank, nodes, lists, allowed)
+    take = plan_affinity(local_rank, nodes, lists, allowed, cpu_core_groups(cpus))
     if not take:
         return {'pinned': False, 'why': 'the node\'s CPUs are outside this process\'s allowed set', 'numa_node': node}
+    n_threads = set_affinity_all_threads(take)
+    return {'pinned': True, 'numa_node': node, 'cpus': _cpulist_str(take), 'n_cpus': len(take), 'threads_moved': n_threads}
+
+
+def set_affinity_all_threads(cpus):
+    """sched_setaffinity for every thread of this process (new threads inherit); returns the number of threads moved"""
     n_threads = 0
     try:
         for tid in os.listdir('/proc/self/task'):
             try:
-                os.sched_setaffinity(int(tid), take)
+                os.sched_setaffinity(int(tid), cpus)
                 n_threads += 1
             except OSError:
                 pass
     except OSError:
-        os.sched_setaffinity(0, take)
+        os.sched_setaffinity(0, cpus)
         n_threads = 1
-    return {'pinned': True, 'numa_node': node, 'cpus': _cpulist_str(take), 'n_cpus': len(take), 'threads_moved': n_threads}
+    return n_threads
 
 
 def shard_indices(perm, step, batch_size, rank, world_size):

@@ -157,6 +157,17 @@ class MixedResidualTrainer:
         self._hook = None
         self.host_prof = None             # a dict: host seconds per phase of _step are accumulated into it (bench.py)
         self.overlap_allreduce = os.environ.get('PDES_DP_OVERLAP', '1') != '0'
+        # where bucket A's all-reduce is enqueued (set_bucket_placement; PDES_DP_BUCKET_STREAM in the environment):
+        #   'wgrad'   on the weight-gradient stream that just reduced its split-K partials (default; the weight gradients
+        #             released to that stream afterwards queue behind the communication kernel),
+        #   'wgrad_b' on the OTHER weight-gradient stream behind one event (the first stream keeps computing),
+        #   'main'    not at the hook at all: the whole buffer in one all-reduce on the main stream after the backward pass
+        #             (= PDES_DP_OVERLAP=0: no overlap, nothing shares a stream with the exchange).
+        # In every placement the main stream waits for bucket A before bucket B is enqueued: the two collectives of the one
+        # communicator are ordered by the streams themselves, not by an assumption about RCCL.
+        self.bucket_stream = 'wgrad'
+        self._bucket_event = None
+        self.set_bucket_placement(os.environ.get('PDES_DP_BUCKET_STREAM', 'wgrad'))
         self._rccl = None
         if self.world > 1 or process_group is not None:
             self._hook_fn = _lib.BUCKET_FN(self._on_bucket)          # keep the callback object alive
@@ -183,6 +194,17 @@ class MixedResidualTrainer:
         except Exception:                                    # noqa: BLE001
             pass
 
+    BUCKET_PLACEMENTS = ('wgrad', 'wgrad_b', 'main')
+
+    def set_bucket_placement(self, where):
+        """choose BETWEEN steps the stream bucket A's all-reduce is enqueued on (see __init__); bench.py times the three
+        during its warm-up under torchrun and keeps the fastest"""
+        if where not in self.BUCKET_PLACEMENTS:
+            raise ValueError(f'bucket placement {where!r}: one of {self.BUCKET_PLACEMENTS}')
+        if where == 'wgrad_b' and getattr(self.model, 'wgrad_streams', 2) != 2:
+            raise ValueError("bucket placement 'wgrad_b' needs the second weight-gradient stream (PDES_WGRAD_STREAMS=2)")
+        self.bucket_stream = where
+
     def set_launch_mode(self, use_graph):
         """switch BETWEEN steps among eager launches (False), 'forward' (the forward pass + loss as one hipGraph, eager
         backward) and 'segments' (linear graphs per stage): the three replay the same kernels and are bit-identical; the
@@ -206,17 +228,28 @@ class MixedResidualTrainer:
         """pdes_bucket_hook: the weight gradients of layers [first_layer, n) are final on the weight-gradient stream"""
         try:
             off = self.model._conv_off[first_layer]
-            side = self.eng._side_stream()
+            side, other = self.eng._side_stream(), None
             if stream is not None and stream != side.cuda_stream and stream == self.eng._side_stream('b').cuda_stream:
-                side = self.eng._side_stream('b')            # (the segment program alternates the two weight-gradient streams)
+                side, other = self.eng._side_stream('b'), side   # (the segment program alternates the two weight-gradient streams)
+            if self.bucket_stream == 'wgrad_b':
+                # the other weight-gradient stream, behind an event recorded where the reduced gradients are final
+                tgt = other if other is not None else self.eng._side_stream('b')
+                ev = torch.cuda.Event()
+                ev.record(side)
+                tgt.wait_event(ev)
+                side = tgt
             if self._rccl is not None:
-                # bucket A on the weight-gradient stream itself, behind the early split-K reduce just enqueued there
-                self._rccl.all_reduce_sum_(self.gflat.data_ptr() + 4 * off, self.gflat.numel() - off, stream)
+                # bucket A behind the early split-K reduce just enqueued on the weight-gradient stream
+                self._rccl.all_reduce_sum_(self.gflat.data_ptr() + 4 * off, self.gflat.numel() - off, side.cuda_stream)
                 self._bucket_work = True
             else:
                 with torch.cuda.stream(side):
                     self._bucket_work = torch.distributed.all_reduce(self.gflat[off:], op=torch.distributed.ReduceOp.SUM,
                                                                      group=self.pg, async_op=True)
+            # the main stream waits for bucket A before bucket B is enqueued (_exchange_rest): for the stream handed to the
+            # hook pdes_backward2's final join already does, the event makes it hold for every placement
+            self._bucket_event = torch.cuda.Event()
+            self._bucket_event.record(side)
             self._bucket_off = off
             return 0
         except Exception as e:                                  # never let an exception cross the C ABI
@@ -238,7 +271,7 @@ class MixedResidualTrainer:
             self.gflat.zero_()
             m._grad_dirty = False
         t2 = time.perf_counter() if prof is not None else 0.0
-        hook = self._hook if (self.overlap_allreduce and not self.use_graph) else None
+        hook = self._hook if (self.overlap_allreduce and self.bucket_stream != 'main' and not self.use_graph) else None
         self._hook_error = None
         try:
             self.eng.backward(self.grad_y, tail=tail, bucket_hook=hook)
@@ -339,7 +372,7 @@ class MixedResidualTrainer:
         if not self.eng.arena_clean:
             self.eng.arena.zero_()
         self.eng.arena_clean = False
-        hook = self._hook if self.overlap_allreduce else None
+        hook = self._hook if (self.overlap_allreduce and self.bucket_stream != 'main') else None
         self._hook_error = None
         try:
             self._program.run(hook)
@@ -358,6 +391,9 @@ class MixedResidualTrainer:
         main stream waits for all of it"""
         work, off = self._bucket_work, self._bucket_off
         self._bucket_work = None
+        ev, self._bucket_event = self._bucket_event, None
+        if work is not None and ev is not None:               # bucket A is complete before anything else of the exchange starts
+            torch.cuda.current_stream(self.dev).wait_event(ev)
         if self._rccl is not None:
             n = self.gflat.numel() if work is None else off   # no early bucket: everything; else the head of the buffer
             if n:                                             # on the main stream: behind the end-of-step launch, in front of Adam

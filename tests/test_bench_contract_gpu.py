@@ -54,18 +54,23 @@ def test_bench_under_torchrun_with_two_ranks_sharing_the_gpu():
             port = s.getsockname()[1]
         env = dict(os.environ, PDES_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-               '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '30', '--warmup', '40'] + extra
+               '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '30', '--warmup', '100'] + extra
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-3000:]
         lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith('{')]
         assert len(lines) == 1, p.stdout[-2000:]
         d = json.loads(lines[0])
-        assert d['n_gpus'] == 2 and d['ranks'] == 2 and d['steps'] == 30 and d['warmup'] == 40
+        assert d['n_gpus'] == 2 and d['ranks'] == 2 and d['steps'] == 30 and d['warmup'] == 100
         assert d['scaling'] == ('strong' if extra else 'weak') and d['config']['global_batch'] == 64
         assert d['value'] > 0 and abs(d['value'] - 64 * 30 / (d['ms_per_step'] * 30 / 1e3)) < 1e-3 * d['value']
         assert len(d['per_rank_ms_per_step']['all']) == 2 and d['per_rank_ms_per_step']['max'] == pytest.approx(d['ms_per_step'], rel=1e-3)
         assert d['exchange_path'] == 'torch.distributed.all_reduce' and d['config']['collective']['backend'] == 'gloo'
-        assert d['allreduce_us_standalone'] > 0 and d['config']['collective']['buckets'] == 2
+        coll = d['config']['collective']
+        # the placement of bucket A's all-reduce is probed during the warm-up (20 steps each, MAX over
+        # the ranks) and the fastest kept; both are in the line
+        assert set(coll['bucket_placement_probe_ms_per_step']) == {'wgrad', 'wgrad_b', 'main'}
+        assert coll['bucket_placement'] == min(coll['bucket_placement_probe_ms_per_step'], key=coll['bucket_placement_probe_ms_per_step'].get)
+        assert d['allreduce_us_standalone'] > 0 and coll['buckets'] == (1 if coll['bucket_placement'] == 'main' else 2)
         assert len(d['host_affinity']) == 2
         if all(h.get('pinned') for h in d['host_affinity']):
             assert d['host_affinity'][0]['cpus'] != d['host_affinity'][1]['cpus']          # disjoint shares of the node

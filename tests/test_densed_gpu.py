@@ -549,6 +549,8 @@ VARIANTS = {   # name -> (option or environment variable, value A, value B): pai
     '1x1_all': ('PDES_MFMA_1X1', '0', '7'),
     '1x1_wgrad': ('PDES_MFMA_1X1', '3', '7'),
     'fork_signal': ('PDES_FORK_SIGNAL', '0', '1'),
+    'wgrad_hold': ('PDES_WGRAD_HOLD', '0', '5000'),          # the three widest weight gradients released behind their data gradients
+    'wgrad_mtw': ('PDES_WGRAD_MTW', '1', '2'),               # dense-block weight gradients: two M-tiles per workgroup
 }
 
 
@@ -567,7 +569,7 @@ def test_backward_variants_agree(dev, monkeypatch, option, variant):
     y0, l0, g0 = _run_default(dev, B=32)
     setk(vb)
     y1, l1, g1 = _run_default(dev, B=32)
-    same_schedule = variant in ('wgrad_streams', 'fork_signal')          # same kernels, other launch order: bit-level agreement
+    same_schedule = variant in ('wgrad_streams', 'fork_signal', 'wgrad_hold')          # same kernels, other launch order: bit-level agreement
     ytol = 1e-6 if same_schedule else 2e-6
     assert torch.equal(y0, y1) or rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < ytol
     assert abs(l1 - l0) <= 1e-5 * abs(l0)

@@ -240,13 +240,18 @@ def _dp2_body(rank, out, cfg):
     kw, B = DP_CFGS[cfg]
     data = torch.from_numpy(grf_kle_fields(6 * B, n_kle=64, cache_dir="/tmp")).to(dev)
     res = {}
-    for overlap in ('1', '0'):
-        os.environ['PDES_DP_OVERLAP'] = overlap
+    for overlap in ('1', '0', 'wgrad_b', 'main'):
+        # '1' / '0': bucket A from the hook on the weight-gradient stream / one all-reduce after the backward pass;
+        # 'wgrad_b' / 'main': the other placements of bucket A (MixedResidualTrainer.set_bucket_placement)
+        os.environ['PDES_DP_OVERLAP'] = '0' if overlap == '0' else '1'
         torch.manual_seed(1)
         with contextlib.redirect_stdout(io.StringIO()):
             net = DenseED(1, 3, 64, **kw).to(dev).train()
         tr = MixedResidualTrainer(net, B, 64, lr=1e-3, device=dev)
-        assert tr.world == 2 and tr._hook is not None and tr.overlap_allreduce == (overlap == '1')
+        assert tr.world == 2 and tr._hook is not None and tr.overlap_allreduce == (overlap != '0')
+        assert tr.bucket_stream == 'wgrad'
+        if overlap in ('wgrad_b', 'main'):
+            tr.set_bucket_placement(overlap)
         buckets = []
         orig = tr._on_bucket
 
@@ -264,12 +269,15 @@ def _dp2_body(rank, out, cfg):
                         int(tr._bucket_off), int(tr.gflat.numel()))
         del tr, net
     assert res['0'][2] == [] and len(res['1'][2]) in (0, 3)    # the hook runs once per step, only in overlap mode
+    assert res['main'][2] == [] and res['wgrad_b'][2] == res['1'][2]
     if cfg == 'default_b32':
         assert len(res['1'][2]) == 3
         assert 0 < res['1'][3] < res['1'][4]                   # bucket A is a proper tail slice of the gradient buffer
     if cfg == 'default_b32':    # (the small net's 8- and 16-channel layers run on the VALU kernels, whose weight gradients are
         #                         fp32 atomics: not bit-reproducible from run to run, with or without buckets)
         assert torch.equal(res['1'][0], res['0'][0]), 'two-bucket overlapped exchange != one all-reduce after the backward pass'
+        assert torch.equal(res['wgrad_b'][0], res['0'][0]), 'bucket A on the other weight-gradient stream != one all-reduce'
+        assert torch.equal(res['main'][0], res['0'][0]), "bucket placement 'main' != one all-reduce"
     # (Adam's first steps are ~lr * sign(g): where the gradient is rounding noise the sign may differ between two runs)
     assert float(((res['1'][0] - res['0'][0]).abs() > 1e-6).float().mean()) < 0.02
     out[rank] = (res['1'][0], res['1'][1], res['1'][3] / res['1'][4])

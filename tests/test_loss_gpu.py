@@ -110,6 +110,63 @@ def test_g2_g3_dropin_functions_fixture(dev, tag, nl):
         assert rel_l2(y.grad.cpu().numpy(), g[f'{tag}_grad_{nm}']) < GRAD_RL2, nm
 
 
+def test_dropin_loss_functions_share_one_launch_and_never_sync(dev, monkeypatch):
+    """the reference's loop body (train_codec_mixed_residual.py:228-233) on the drop-in functions is ONE
+    forward-only launch of the fused kernel and ONE backward launch (the three functions return entries of the same
+    autograd result), the upstream gradients reach the kernel through device memory -- `loss.backward()` contains no
+    device -> host synchronisation (torch's sync-debug mode raises on any) -- and nothing stale is ever served: another
+    conductivity, an in-place change of the output, another `use_tb`, or grad mode switched off start a new launch."""
+    from pde_surrogate_amd.models import darcy
+    from pde_surrogate_amd.utils.image_gradient import SobelFilter
+    calls = []
+    real = darcy.darcy_loss_launch
+
+    def counting(K, y, weights, want_grad, *a, **k):
+        calls.append(('bwd' if want_grad else 'fwd', torch.is_tensor(weights)))
+        return real(K, y, weights, want_grad, *a, **k)
+    monkeypatch.setattr(darcy, 'darcy_loss_launch', counting)
+    Kn, yn, K, y0 = _fields(4, 64, 11, dev)
+    sob = SobelFilter(64, correct=True, device=dev)
+    y = y0.clone().requires_grad_(True)
+    loss_pde = darcy.conv_constitutive_constraint(K, y, sob) + darcy.conv_continuity_constraint(y, sob)
+    ld, ln = darcy.conv_boundary_condition(y)
+    loss = loss_pde + (ld + ln) * 10.0
+    assert calls == [('fwd', False)]
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        loss.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert calls == [('fwd', False), ('bwd', True)]
+    fused, *_ = darcy.darcy_mixed_residual_loss(K, y0.clone().requires_grad_(True), 10.0)
+    ref_terms, ref_grad = real(K, y0, (1.0, 1.0, 10.0, 10.0), True)
+    np.testing.assert_allclose(float(loss), float(ref_terms[0]), rtol=1e-6)
+    np.testing.assert_allclose(float(fused), float(ref_terms[0]), rtol=1e-6)
+    assert rel_l2(y.grad.cpu().numpy(), ref_grad.cpu().numpy()) < 1e-6
+    # the remembered pair was dropped by its backward; whatever is remembered next must never be served stale
+    del calls[:]
+    y = y0.clone().requires_grad_(True)
+    a = darcy.conv_constitutive_constraint(K, y, sob)
+    b = darcy.conv_constitutive_constraint(K * 2.0, y, sob)                  # another conductivity
+    assert len(calls) == 2 and float(b) != float(a)
+    c = darcy.conv_continuity_constraint(y, sob, use_tb=False)              # another row range
+    d = darcy.conv_continuity_constraint(y, sob)
+    assert len(calls) == 4 and float(c) != float(d)
+    with torch.no_grad():
+        e = darcy.conv_continuity_constraint(y, sob)                        # grad mode off: its own (graph-free) result
+    assert len(calls) == 5 and not e.requires_grad and float(e) == float(d)
+    yv = y0.clone()
+    f = darcy.conv_boundary_condition(yv)[0]
+    yv.mul_(2.0)                                                            # in-place change of the output
+    g = darcy.conv_boundary_condition(yv)[0]
+    assert len(calls) == 7 and float(f) != float(g)
+    lc_nl = darcy.conv_constitutive_constraint_nonlinear(K, yv, sob, 0.1, 0.1)
+    lc_lin = darcy.conv_constitutive_constraint(K, yv, sob)
+    assert len(calls) == 9 and float(lc_nl) != float(lc_lin)
+    assert float(darcy.conv_continuity_constraint(yv, sob)) == float(real(K, yv, (1, 1, 1, 1), False)[0][2]) and len(calls) == 9
+
+
 def test_g4_closed_form(dev):
     from pde_surrogate_amd.models import darcy
     g = golden('G4_closed_form.npz')

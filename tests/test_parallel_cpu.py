@@ -166,6 +166,32 @@ def test_affinity_plan_shares_a_numa_node_between_its_ranks():
     few = set(range(8))
     assert [len(plan_affinity(r, nodes, lists, few)) for r in range(8)] == [2, 2, 2, 2, 0, 0, 0, 0]
     assert plan_affinity(0, [0], [n0], allowed) == n0
+    # slices by PHYSICAL core -- with the SMT siblings (c, c + 128) grouped, a rank gets both hardware threads of
+    # each of its 16 cores and no two ranks share a core
+    groups0 = [[c, c + 128] for c in range(64)]
+    by_core = [plan_affinity(r, nodes, lists, allowed, groups0 if r < 4 else [[c, c + 128] for c in range(64, 128)]) for r in range(8)]
+    assert _cpulist_str(by_core[0]) == '0-15,128-143' and _cpulist_str(by_core[3]) == '48-63,176-191'
+    assert _cpulist_str(by_core[4]) == '64-79,192-207'
+    cores_of = lambda plan: {c % 128 for c in plan}
+    assert all(len(p_) == 32 and len(cores_of(p_)) == 16 for p_ in by_core)
+    assert all(not (cores_of(by_core[a]) & cores_of(by_core[b])) for a in range(4) for b in range(a + 1, 4))
+
+
+def test_core_groups_and_local_world_size(tmp_path, monkeypatch):
+    """parallel.cpu_core_groups reads `topology/thread_siblings_list` (hardware threads of one core stay together; no sysfs:
+    every CPU its own core); parallel.local_world_size = torchrun's LOCAL_WORLD_SIZE, not the global world size"""
+    from pde_surrogate_amd.parallel import cpu_core_groups, local_world_size
+    for c in range(4):
+        d = tmp_path / f'cpu{c}' / 'topology'
+        d.mkdir(parents=True)
+        (d / 'thread_siblings_list').write_text(f'{c % 2},{c % 2 + 2}\n')
+    assert cpu_core_groups([0, 1, 2, 3], sysfs=str(tmp_path)) == [[0, 2], [1, 3]]
+    assert cpu_core_groups([0, 1], sysfs=str(tmp_path)) == [[0], [1]]            # siblings outside the list are left out
+    assert cpu_core_groups([5, 6], sysfs=str(tmp_path / 'absent')) == [[5], [6]]
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert local_world_size(16) == 8
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
+    assert local_world_size(4) == 4
 
 
 def test_mean_over_ranks_and_buffer_broadcast_world2_gloo():

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Same-process A/B of run-time knobs (options of the library's context, pdes_context_set_option):
-    python tools/archive/ab_env.py PDES_MFMA_1X1 0 1 2 3        -> ms per training step for each value, interleaved rounds
-    python tools/archive/ab_env.py PDES_MFMA_NG 1 2 -- PDES_FEW_R 2 4    several knobs, one after the other ('-' = unset)
+    python tools/ab_env.py PDES_MFMA_1X1 0 1 2 3        -> ms per training step for each value, interleaved rounds
+    python tools/ab_env.py PDES_MFMA_NG 1 2 -- PDES_FEW_R 2 4    several knobs, one after the other ('-' = unset)
 Different gpurun boxes differ by ~2 %, one process repeats to ~0.1 %, so knob decisions are made here."""
 import contextlib
 import io
 import os
 import sys
 import time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pde_surrogate_amd import _lib
 from pde_surrogate_amd.models.codec import DenseED

@@ -184,6 +184,7 @@ def main(argv=None):
         torch.manual_seed(args.seed + 1000 * rank)      # the latents' noise differs between the ranks (the parameters do not)
     scheduler = OneCycleScheduler(lr_max=args.lr, div_factor=args.lr_div, pct_start=args.lr_pct)
     sobel_filter = SobelFilter(args.imsize, correct=True, device=device)
+    trainer = None
     if args.mode == 'fused':
         trainer = ReverseKLTrainer(model, args.batch_size, args.imsize, lr=args.lr, weight_decay=args.weight_decay,
                                    weight_bound=args.weight_bound, beta=args.beta, device=device)
@@ -326,6 +327,8 @@ def main(argv=None):
         with open(args.run_dir + '/args.txt', 'w') as f:
             json.dump(vars(args), f, indent=4)
     if world > 1:
+        if trainer is not None:
+            trainer.close()                  # the direct RCCL communicator goes before its process group
         torch.distributed.destroy_process_group()
     return logger
 

@@ -83,6 +83,7 @@ def main(argv=None):
     say(f'# out pixels: {y_test[0].size}')
 
     scheduler = OneCycleScheduler(lr_max=args.lr, div_factor=args.lr_div, pct_start=args.lr_pct)
+    trainer = None
     if args.mode == 'fused':
         trainer = MaxLikelihoodTrainer(model, args.batch_size, args.imsize, lr=args.lr, weight_decay=args.weight_decay,
                                        device=device, use_graph=args.graph)
@@ -170,6 +171,8 @@ def main(argv=None):
         with open(args.run_dir + "/args.txt", 'w') as args_file:
             json.dump(vars(args), args_file, indent=4)
     if world > 1:
+        if trainer is not None:
+            trainer.close()                  # the direct RCCL communicator goes before its process group
         torch.distributed.destroy_process_group()
     return logger
 

@@ -178,7 +178,7 @@ def main(argv=None):
     is_main = rank == 0
     say = print if is_main else (lambda *a, **k: None)
     if world > 1:                 # each rank onto its share of the cores of its GPU's NUMA node (PDES_PIN=0 disables)
-        pin = parallel.pin_rank_to_gpu_numa(device, local_rank, world)
+        pin = parallel.pin_rank_to_gpu_numa(device, local_rank, parallel.local_world_size(world))
         say('host affinity (rank 0):', pin)
 
     args.train_dir = args.run_dir + '/training'
@@ -211,6 +211,7 @@ def main(argv=None):
 
     scheduler = OneCycleScheduler(lr_max=args.lr, div_factor=args.lr_div, pct_start=args.lr_pct)
     sobel_filter = SobelFilter(args.imsize, correct=True, device=device)
+    trainer = None
     if args.mode == 'fused':
         trainer = MixedResidualTrainer(model, args.batch_size, args.imsize, lr=args.lr, weight_decay=args.weight_decay,
                                        weight_bound=args.weight_bound, device=device, use_graph=args.graph)
@@ -320,6 +321,8 @@ def main(argv=None):
         with open(args.run_dir + "/args.txt", 'w') as args_file:
             json.dump(vars(args), args_file, indent=4)
     if world > 1:
+        if trainer is not None:
+            trainer.close()                  # the direct RCCL communicator goes before its process group
         torch.distributed.destroy_process_group()
 
 
