@@ -22,7 +22,7 @@ static const Knob kKnobs[] = {
     {"PDES_MFMA_B3", &Options::mfma_b3},       {"PDES_B3_TAIL", &Options::b3_tail},     {"PDES_MFMA_1X1", &Options::mfma_1x1},
     {"PDES_MFMA_SMALL", &Options::mfma_small}, {"PDES_WGRAD_WGS", &Options::wgrad_wgs}, {"PDES_LOSS_NT", &Options::loss_nt},
     {"PDES_FORK_SIGNAL", &Options::fork_signal}, {"PDES_WGRAD_HOLD", &Options::wgrad_hold},
-    {"PDES_WGRAD_MTW", &Options::wgrad_mtw},
+    {"PDES_FIN_ONLOAD", &Options::fin_onload},
 };
 
 static int set_knob(Options& o, const char* key, const char* value) {

@@ -1,6 +1,7 @@
 // C-ABI entry points for the convolution family: walk a host array of descriptors and enqueue
 // one kernel per descriptor on the caller's stream.  Kernel selection lives here so the Python
 // side never needs to know which implementation (MFMA or VALU) serves a shape.
+#include <stdlib.h>
 #include "pdes_common.h"
 #include "pdes_options.h"
 #include "../../include/pdes_hip.h"
@@ -13,6 +14,8 @@ bool first_layer_partials(const pdes_conv_desc& d);     // conv_direct.hip: the 
 bool conv_forward_direct_first7(const pdes_conv_desc& d);               // conv_direct.hip: reads the live weights, no image
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);        // PDES_ENOSUP: shape not covered
 int conv_backward_data_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);   // dry: capability query only
+void set_dgrad_stop_event(hipEvent_t e);        // conv_mfma.hip: completion signal for the next finalize-on-load data gradient
+bool dgrad_stop_event_pending();
 int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_forward_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);        // nearest-x2 + 3x3, sub-pixel form
 int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st, bool dry = false);         // 5x5 with <= 3 output channels
@@ -76,6 +79,19 @@ static int op_backward(const pdes_conv_desc& d, hipStream_t st) {
 // option PDES_CONV_IMPL=direct forces the VALU reference kernels (used by the GPU tests to cross-check
 // the matrix-core kernels against them); anything else = automatic selection.
 static bool force_direct() { return opt().conv_direct != 0; }
+
+// PDES_FIN_ONLOAD: does this layer's backward apply the BatchNorm-backward finalize of its output gradient on operand
+// load (no finalize launch)?  The dense blocks' layers: 3x3, stride 1, <= 16 output channels (ONE chunk of the data
+// gradient's K dimension, one N-tile of the weight gradient), both passes on the matrix-core kernels that implement it
+// (capability queries: nothing is enqueued).  `t` receives the descriptor with g_fused = 1.
+static bool fin_onload(const pdes_conv_desc& d, pdes_conv_desc* t) {
+  if (!opt().fin_onload || force_direct() || is_resample_op(d) || !d.fin_tstats || d.g_fused) return false;
+  if (d.ksize != 3 || d.stride != 1 || d.upsample || d.Cout > 16 || !d.has_bn || !d.t_in || d.g_add) return false;
+  *t = d;
+  t->g_fused = 1;
+  return conv_backward_data_small(*t, nullptr, true) == PDES_ENOSUP && conv_backward_data_mfma(*t, nullptr, true) == PDES_OK &&
+         conv_backward_weight_mfma(*t, nullptr, true) == PDES_OK;
+}
 }  // namespace pdes
 
 using namespace pdes;
@@ -205,7 +221,10 @@ extern "C" int pdes_backward_chain(const pdes_context* ctx, const pdes_conv_desc
   if (!descs || lo < 0 || hi <= lo) return PDES_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int i = hi - 1; i >= lo; --i) {
-    const pdes_conv_desc& d = descs[i];
+    pdes_conv_desc df;
+    OptScope scope(ctx);
+    const bool onl = fin_onload(descs[i], &df);
+    const pdes_conv_desc& d = onl ? df : descs[i];
     if (d.fin_tstats && !d.g_fused) {
       const int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
                                                  d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
@@ -224,7 +243,10 @@ extern "C" int pdes_backward_weights(const pdes_context* ctx, const pdes_conv_de
   if (!descs || lo < 0 || hi <= lo) return PDES_EINVAL;
   for (int i = hi - 1; i >= lo; --i) {
     if (is_resample_op(descs[i])) continue;
-    const int rc = pdes_conv_backward_weight(ctx, &descs[i], 1, stream);
+    pdes_conv_desc df;
+    OptScope scope(ctx);
+    const bool onl = fin_onload(descs[i], &df);
+    const int rc = pdes_conv_backward_weight(ctx, onl ? &df : &descs[i], 1, stream);
     if (rc) return rc;
   }
   return PDES_OK;
@@ -252,6 +274,15 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
   if (fork && (!cx || (int)cx->events.size() < n + 4)) return PDES_EINVAL;
   OptScope scope(ctx);
   const bool have_red = reduce_items && reduce_index;
+#ifdef PDES_TIMING_KNOBS
+  // Component-timing build only (tools/ab_timing.py; wrong numbers, right launch structure -- never shipped): bits of the
+  // environment variable PDES_TIMING, read per call: 1 no weight-gradient kernels (fork events kept), 2 no fork events
+  // either, 4 every finalize as ONE workgroup (launch + completion signal kept, no work), 8 no finalize launch at all
+  // (forks by hipEventRecord), 16 no data-gradient kernels
+  const int timing = getenv("PDES_TIMING") ? atoi(getenv("PDES_TIMING")) : 0;
+#else
+  const int timing = 0;
+#endif
   auto per_of = [&](int i) { return (long long)descs[i].Cout * descs[i].Cin * descs[i].ksize * descs[i].ksize; };
 
   // ---- second-stream schedule.  A layer's weight gradient is released (one event) as soon as its output gradient
@@ -277,7 +308,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
   };
   auto release = [&](int i, bool on_main, hipEvent_t signalled) -> int {
     hipStream_t wsi = (two && (i & 1)) ? wsb : ws;
-    if (fork && !on_main) {
+    if (fork && !on_main && !(timing & 2)) {
       hipEvent_t e = signalled;
       hipError_t he = hipSuccess;
       if (!e) {
@@ -288,8 +319,12 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       if (he != hipSuccess) return (int)he;
       if (wsi != ws) b_dirty = true;
     }
-    const int rc = pdes_conv_backward_weight(ctx, &descs[i], 1, on_main ? st : wsi);
-    if (rc) return rc;
+    if (!(timing & 1)) {
+      pdes_conv_desc df;
+      const bool onl = fin_onload(descs[i], &df);
+      const int rc = pdes_conv_backward_weight(ctx, onl ? &df : &descs[i], 1, on_main ? st : wsi);
+      if (rc) return rc;
+    }
     if (have_red && reduce_index[i] >= 0) per_done += per_of(i);
     // The split-K partials of the last layers (the widest ones: LastTransUp holds ~3/4 of the weights) are reduced
     // on the second stream as soon as >= 60 % of the weights' partials exist; the rest waits for the end.
@@ -332,17 +367,28 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     const long long mflop = 2LL * d.B * d.Hout * d.Wout * d.Cout * d.Cin * d.ksize * d.ksize / 1000000LL;
     return mflop >= hold_mflop;
   };
+  hipEvent_t carried = nullptr;      // completion signal of the data gradient just launched, for the next layer's fork
   for (int i = n - 1; i >= 0; --i) {
-    const pdes_conv_desc& d = descs[i];
-    hipEvent_t signalled = nullptr;
+    // finalize on load (PDES_FIN_ONLOAD): no finalize launch for this layer; its weight gradient is released by an event
+    // recorded behind the kernel that completed its output gradient's accumulator (the previous data gradient)
+    pdes_conv_desc df;
+    const bool onl = fin_onload(descs[i], &df);
+    const pdes_conv_desc& d = onl ? df : descs[i];
+    hipEvent_t signalled = onl ? carried : nullptr;     // (set by the previous iteration's data-gradient launch)
     const bool hold = held(i);
     if (d.fin_tstats && !d.g_fused) {
       // this layer's weight gradient is released by the completion of ITS finalize kernel: the fork event rides on
       // that kernel's completion signal, no barrier packet sits between the finalize and the data gradient
-      if (fork && use_signal && i != 0 && !is_resample_op(d) && !hold) signalled = cx->events[nev++];
-      int rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
-                                           d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
-                                           d.rep_stride, st, signalled, d.g_add, d.fin_coef);
+      if (fork && use_signal && i != 0 && !is_resample_op(d) && !hold && !(timing & (2 | 8))) signalled = cx->events[nev++];
+      int rc = PDES_OK;
+      if (timing & 4)              // (one channel of one image: a single workgroup)
+        rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, 1,
+                                         d.g_ctot, d.g_coff, d.g_coff + 1, 256, d.eps, d.nrep,
+                                         d.rep_stride, st, signalled, d.g_add, d.fin_coef);
+      else if (!(timing & 8))
+        rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, d.B,
+                                         d.g_ctot, d.g_coff, d.g_coff + d.Cout, d.Hout * d.Wout, d.eps, d.nrep,
+                                         d.rep_stride, st, signalled, d.g_add, d.fin_coef);
       if (rc) return rc;
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
@@ -352,9 +398,26 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       if (rc) return rc;
     }
     // (a convolution without a BatchNorm in front has a data gradient only when the caller gave it somewhere to go)
-    if (d.has_bn || is_resample_op(d) || d.t_in) {
+    if ((d.has_bn || is_resample_op(d) || d.t_in) && !(timing & 16)) {
+      // the NEXT layer (i - 1) finalizes on load: its weight gradient is released by THIS data gradient's completion.
+      // Where this launch can carry a completion signal (a finalize-on-load data gradient itself: inside a dense block),
+      // the fork event rides on it, as it rides on the finalize kernel elsewhere -- no barrier packet on the chain
+      pdes_conv_desc dn;
+      hipEvent_t se = nullptr;
+      if (fork && use_signal && opt().fin_onload >= 2 && onl && i >= 2 && !(timing & (2 | 8)) && fin_onload(descs[i - 1], &dn) &&
+          !held(i - 1)) {
+        se = cx->events[nev++];
+        set_dgrad_stop_event(se);
+      }
       const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
+      if (se && dgrad_stop_event_pending()) {       // (the kernel family that took the launch does not carry signals)
+        set_dgrad_stop_event(nullptr);
+        se = nullptr;
+      }
+      carried = se;
       if (rc) return rc;
+    } else {
+      carried = nullptr;
     }
     if (hold) {                                           // released by an event recorded behind the data gradient
       const int rc = release(i, false, nullptr);

@@ -25,6 +25,7 @@
 // and the epilogue applies the ReLU mask and gamma, accumulates into T, and reduces dgamma / dbeta /
 // {sum T, sum T xhat}.
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "pdes_common.h"
 #include "pdes_options.h"
 #include "../../include/pdes_hip.h"
@@ -81,16 +82,29 @@ __device__ unsigned long long pdes_trace_buf[16];
 #define TRACC(i, t0)
 #endif
 
+// pdes_backward2 may ask the NEXT data-gradient launch of this file to carry a completion signal (an event that completes
+// with the kernel, hipExtLaunchKernelGGL's stop event): the fork of the following layer's weight gradient then costs no
+// barrier packet behind the kernel.  Consumed by the launch; a kernel family that does not look at it leaves it pending.
+static thread_local hipEvent_t tl_stop_event = nullptr;
+void set_dgrad_stop_event(hipEvent_t e) { tl_stop_event = e; }
+bool dgrad_stop_event_pending() { return tl_stop_event != nullptr; }
+
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-inserted x2 (stride-2 data gradient)
 
 // NG = 2 (forward of the 16-output-channel layers only): TWO K-split wave groups of 4 waves each; group g stages and
 // multiplies the chunks g, g+2, ... out of its own double-buffered LDS tile, halving the serial chunk chain of a
 // workgroup (a dense layer at batch 32 has one workgroup per CU, i.e. otherwise one wave per SIMD).
-template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, int NG>
+// GF (data gradient of a layer with ONE chunk of output channels, the dense blocks' 16-channel layers): `g` still holds
+// the accumulator T of the layer's output channels and the BatchNorm-backward finalize
+//     g = invstd (T - mean(T) - xhat mean(T xhat))        (bn_bwd_finalize_kernel, the same expression)
+// is applied while the tile is staged (x = the raw activation `out`, read beside T): no finalize launch in front of
+// this kernel (pdes_backward2, option PDES_FIN_ONLOAD).
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, int NG, bool GF = false>
 __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : ((NT_W == 1 && KS != 5 && S == 1) ? 3 : 1))
 void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
   static_assert(NG == 1 || (NG == 2 && WAVES_K == 4 && MODE == MODE_FWD && PIPE), "wave groups: K-split forward only");
+  static_assert(!GF || (MODE == MODE_BWD && !PIPE && KM == KV_PLAIN && NG == 1), "finalize on load: one-chunk data gradient");
   using G = TileGeo<KS, TWG, MT, S>;
   const int ntp = (nt_total + 7) & ~7;       // N-tiles of the packed weight image (zero padded)
   constexpr int KK = KS * KS;
@@ -135,6 +149,20 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   const int tiles_x = Wout / G::TW;
   const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
 
+  // GF: {mean, invstd, mean(T), mean(T xhat)} of the 16 staged channels (the batch statistics of the OUTPUT buffer)
+  __shared__ float4 gfc[GF ? 16 : 1];
+  const float* xo_base = nullptr;           // GF: the raw activation beside g (same layout: out_ctot == g_ctot, out_coff == g_coff)
+  // one statistic load per thread, issued FIRST (thread = (channel, {sum T, sum T xhat}, replica)): their round trip runs
+  // under the geometry arithmetic and the tile loads; reduced with shuffles in front of the first barrier
+  double gf_sv = 0.0;
+  float2 gf_ce = make_float2(0.f, 0.f);
+  if constexpr (GF) {
+    static_assert(PDES_NREP == 8, "finalize on load: 16 channels x 2 sums x 8 replicas = one load per thread");
+    xo_base = d.out + ((size_t)b * d.out_ctot + d.out_coff) * d.Hout * d.Wout;
+    const int c = d.g_coff + min((int)threadIdx.x >> 4, d.Cout - 1);
+    gf_sv = d.fin_tstats[(long long)(threadIdx.x & 7) * d.rep_stride + 2 * c + ((threadIdx.x >> 3) & 1)];
+    if (d.fin_coef) gf_ce = reinterpret_cast<const float2*>(d.fin_coef)[c];
+  }
   // FWD: per-channel {mean, gamma*invstd, beta, -} as one float4 (a single ds_read_b128 per staged float4)
   float4* cf4 = reinterpret_cast<float4*>(smem);
   if (MODE == MODE_FWD) {
@@ -188,6 +216,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
   struct Stage {
     float4 pv[G::NPV]; float ph[NPHS];
+    float4 xv[GF ? G::NPV : 1]; float xh[GF ? NPHS : 1];      // GF: the raw activation at the same places
   };
   Stage sA, sB;
   // loads are unconditional (row offsets are clamped into the image above, the channel is clamped
@@ -203,6 +232,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       const float* p = src + ch * HWs + vg[i];
       if constexpr (kmode == KV_PLAIN) {
         pv[i] = *reinterpret_cast<const float4*>(p);
+        if constexpr (GF) st.xv[i] = *reinterpret_cast<const float4*>(xo_base + ch * HWs + vg[i]);
       } else {                                       // raw pair; expanded to (x, 0, y, 0) at commit time
         const float2 t = *reinterpret_cast<const float2*>(p);
         pv[i].x = t.x; pv[i].y = t.y;
@@ -213,6 +243,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       for (int i = 0; i < G::NPH; ++i) {
         const int ch = min((tid + 256 * i) / (G::ROWS * G::NHC), cmax);
         ph[i] = src[ch * HWs + hg[i]];
+        if constexpr (GF) st.xh[i] = xo_base[ch * HWs + hg[i]];
       }
     }
   };
@@ -235,6 +266,12 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
           z.w = ok ? fmaxf(0.f, (z.w - k.x) * k.y + k.z) : 0.f;
         } else if (!ok) {
           z = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if constexpr (GF) {
+          const float4 k = gfc[ch], x = st.xv[i];
+          z.x = k.y * (z.x - k.z - (x.x - k.x) * k.y * k.w);
+          z.y = k.y * (z.y - k.z - (x.y - k.x) * k.y * k.w);
+          z.z = k.y * (z.z - k.z - (x.z - k.x) * k.y * k.w);
+          z.w = k.y * (z.w - k.z - (x.w - k.x) * k.y * k.w);
         }
         *reinterpret_cast<float4*>(t + vl[i]) = z;
       }
@@ -251,6 +288,9 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
             z = ok ? fmaxf(0.f, (z - k.x) * k.y + k.z) : 0.f;
           } else if (!ok) {
             z = 0.f;
+          } else if constexpr (GF) {
+            const float4 k = gfc[ch];
+            z = k.y * (z - k.z - (st.xh[i] - k.x) * k.y * k.w);
           }
           t[hl[i]] = z;
         }
@@ -338,6 +378,20 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
       const size_t idx = cb + (size_t)(oy0 + mt / TWG) * d.Win + ox0 + (mt % TWG) * 16;
       xpre[mt] = *reinterpret_cast<const float4*>(d.x + idx);
       tpre[mt] = d.t_accumulate ? *reinterpret_cast<const float4*>(d.t_in + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if constexpr (GF) {
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) gf_sv += __shfl_xor(gf_sv, o, 64);          // the 8 replicas (fixed order)
+    const double sx = __shfl_down(gf_sv, 8, 64);                                // lane & 15 == 0: {sum T} here, {sum T xhat} 8 lanes up
+    if ((threadIdx.x & 15) == 0) {
+      const int k16 = threadIdx.x >> 4;
+      const double n = (double)d.B * d.Hout * d.Wout, inv_n = 1.0 / n;
+      MeanInv mi;
+      mi.mean = gf_ce.x; mi.invstd = gf_ce.y;
+      if (!(gf_ce.y > 0.f))                    // (not published: never on the training path, every channel has a forward consumer)
+        mi = batch_mean_invstd(nullptr, d.fin_xstats, d.rep_stride, n, d.eps, d.g_coff + min(k16, d.Cout - 1), false);
+      gfc[k16] = make_float4(mi.mean, mi.invstd, (float)(gf_sv * inv_n), (float)(sx * inv_n));
     }
   }
   __syncthreads();                 // cf visible
@@ -563,8 +617,12 @@ static bool mfma_shape_ok(const pdes_conv_desc& d, bool bwd, int* W, int* H) {
 template <int KS, int S, int MODE, int KM>
 static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, hipStream_t st, bool dry = false) {
   const bool bwd = MODE == MODE_BWD;
-  if (d.g_fused) return PDES_ENOSUP;       // finalize-on-load exists for PDES_OP_COPY only (flow_ops.hip)
   const int kC = bwd ? d.Cout : d.Cin, nC = bwd ? d.Cin : d.Cout;
+  // finalize on load: the one-chunk 3x3 data gradient only (GF instantiations below); PDES_OP_COPY has its own (flow_ops.hip)
+  constexpr bool gf_able = MODE == MODE_BWD && KS == 3 && S == 1 && KM == KV_PLAIN;
+  if (d.g_fused && !(gf_able && kC <= 16 && nC > 16 && d.fin_tstats && d.fin_xstats && d.out && d.g_ctot == d.out_ctot &&
+                     d.g_coff == d.out_coff))
+    return PDES_ENOSUP;
   const int kpad = (kC + 15) & ~15, nchunk = kpad / 16;
   const int nt_total = (nC + 15) / 16;
   const int twg = W >= 32 ? 2 : 1;
@@ -627,7 +685,19 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
       if (nchunk > 1)                                                                                         \
         hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, true, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
-      else                                                                                                    \
+      else if (d.g_fused) {                                                                                   \
+        if constexpr (gf_able && WK_ == 1 && NTW_ == 1) {                                                     \
+          hipEvent_t se = tl_stop_event;                                                                      \
+          tl_stop_event = nullptr;                                                                            \
+          if (se)                                                                                             \
+            hipExtLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1, true>), grid, block, lds, st, \
+                                  nullptr, se, 0, d, wm, nt_total);                                           \
+          else                                                                                                \
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1, true>), grid, block, lds, st, \
+                               d, wm, nt_total);                                                              \
+        } else                                                                                                \
+          return PDES_ENOSUP;                                                                                 \
+      } else                                                                                                  \
         hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1>), grid, block, lds, st, \
                            d, wm, nt_total);                                                                  \
     }                                                                                                         \

@@ -44,29 +44,28 @@ struct WGeo {
 };
 
 // PIPE: > 2 pixel tiles per workgroup, prefetch two ahead.
-// MTW: M-tiles (16 input channels each) per workgroup.  Every workgroup of an M-tile stages the SAME gradient tile (the
-// B operand): with two M-tiles per workgroup and half as many pixel tiles each (the same number of workgroups and of
-// MFMAs per workgroup) the gradient is staged half as often and the pipeline has half as many barrier rounds, each with
-// twice the matrix work.  `mt_off`: first M-tile of this launch (an odd tile count = a pair launch + a single launch).
 // FEW (5x5, Cout*5 <= 16): the N dimension is (output channel, kernel column kx) instead of 16 output channels
 // (conv_mfma_fewout.hip): 5 accumulators (kernel rows) and 5 MFMAs per pixel k-step instead of 25, the B
 // operand is the gradient tile read with a per-lane column shift of -kx.
-template <int KS, int TWG, int NTW, int S, bool PIPE, bool FEW, int MTW = 1>
-__global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 3 : 1) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
-                                                             int n_ngroups, int co_off, int mt_off) {
+// GF (one N-tile, the dense blocks' 16-output-channel layers): `g` still holds the accumulator T of the layer's output
+// channels; the BatchNorm-backward finalize g = invstd (T - mean(T) - xhat mean(T xhat)) is applied while the gradient
+// tile is staged (x = the raw activation `out`, read beside T) -- the expression of bn_bwd_finalize_kernel, which then
+// is not launched for this layer (pdes_backward2, option PDES_FIN_ONLOAD).
+template <int KS, int TWG, int NTW, int S, bool PIPE, bool FEW, bool GF = false>
+__global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1) ? 3 : 1) void conv_mfma_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int tpw,
+                                                             int n_ngroups, int co_off) {
+  static_assert(!GF || (NTW == 1 && !FEW), "finalize on load: one N-tile, generic form");
   using G = WGeo<KS, TWG, S>;
   constexpr int KK = KS * KS;
   constexpr int NPG4 = 16 * NTW * G::TH * G::TW / 4 / 256;      // g float4 per thread per tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(!FEW || (KS == 5 && NTW == 1 && S == 1), "few-output form: 5x5, stride 1");
-  static_assert(MTW == 1 || (!FEW && NTW == 1), "several M-tiles per workgroup: one N-tile, generic form");
-  constexpr int MC = 16 * MTW;                                   // input channels per workgroup
   constexpr int GROW = G::TW + 8;                                // FEW: gradient row with 4 zero columns either side
   constexpr int GPL = ((G::TH * GROW - 8 + 31) / 32) * 32 + 8;  // FEW: plane stride == 8 (mod 32); plane 3 stays zero
   constexpr int GAREA = FEW ? 4 * GPL : 16 * NTW * G::GS;
-  constexpr int LDSB = MC * G::CS + GAREA;                       // one buffer: z image then g image
-  float* zt = smem;                                            // [2][ [16*MTW][CS] | [16*NTW][GS] ]
-  float* gt = smem + MC * G::CS;
+  constexpr int LDSB = 16 * G::CS + GAREA;                       // one buffer: z image then g image
+  float* zt = smem;                                            // [2][ [16][CS] | [16*NTW][GS] ]
+  float* gt = smem + 16 * G::CS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hc = d.Hin, Wc = d.Win;                             // conv-input size (nearest-x2: the _up kernel)
@@ -74,13 +73,13 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
   const int groups = tps / tpw;
   const int b = blockIdx.x / groups, tg = blockIdx.x % groups;
   const int mtile = blockIdx.y / n_ngroups, ng = blockIdx.y % n_ngroups;
-  const int ci0 = (mt_off + mtile * MTW) * 16, co0 = co_off + ng * 16 * NTW;   // co_off: first channel of this launch's N range
+  const int ci0 = mtile * 16, co0 = co_off + ng * 16 * NTW;   // co_off: first channel of this launch's N range
   const int HWi = d.Hin * d.Win, HWo = d.Hout * d.Wout;
 
   // BN coefficients of this thread's staging channels are per element; keep the 16 channels' in LDS-free regs:
   // every thread needs (mean, scale, beta) of channel ch(e) for its NPZ elements -> recompute from a tiny table
-  __shared__ float cf[MC][3];
-  if (tid < MC) {
+  __shared__ float cf[16][3];
+  if (tid < 16) {
     const int c = ci0 + tid;
     float m = 0.f, s = 0.f, bt = 0.f;
     if (c < d.Cin) {
@@ -94,42 +93,69 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
     }
     cf[tid][0] = m; cf[tid][1] = s; cf[tid][2] = bt;
   }
+  __shared__ float4 gfc[GF ? 16 : 1];        // GF: {mean, invstd, mean(T), mean(T xhat)} of the 16 gradient channels
+  // one statistic load per thread, issued here (thread = (channel, {sum T, sum T xhat}, replica)); reduced with shuffles
+  // behind the first tiles' loads (gf_table)
+  double gf_sv = 0.0;
+  float2 gf_ce = make_float2(0.f, 0.f);
+  if constexpr (GF) {
+    static_assert(PDES_NREP == 8, "finalize on load: 16 channels x 2 sums x 8 replicas = one load per thread");
+    const int c = d.g_coff + min(co_off + (int)(blockIdx.y % n_ngroups) * 16 * NTW + (tid >> 4), d.Cout - 1);
+    gf_sv = d.fin_tstats[(long long)(tid & 7) * d.rep_stride + 2 * c + ((tid >> 3) & 1)];
+    if (d.fin_coef) gf_ce = reinterpret_cast<const float2*>(d.fin_coef)[c];
+  }
+  auto gf_table = [&]() __attribute__((always_inline)) {
+    if constexpr (GF) {
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) gf_sv += __shfl_xor(gf_sv, o, 64);
+      const double sx = __shfl_down(gf_sv, 8, 64);
+      if ((tid & 15) == 0) {
+        const double n = (double)d.B * d.Hout * d.Wout, inv_n = 1.0 / n;
+        MeanInv mi;
+        mi.mean = gf_ce.x; mi.invstd = gf_ce.y;
+        if (!(gf_ce.y > 0.f))
+          mi = batch_mean_invstd(nullptr, d.fin_xstats, d.rep_stride, n, d.eps,
+                                 d.g_coff + min(co_off + (int)(blockIdx.y % n_ngroups) * 16 * NTW + (tid >> 4), d.Cout - 1), false);
+        gfc[tid >> 4] = make_float4(mi.mean, mi.invstd, (float)(gf_sv * inv_n), (float)(sx * inv_n));
+      }
+    }
+  };
 
   if (FEW) {                     // pad columns and the zero plane are never written by the staging
     for (int i = tid; i < GAREA; i += 256) { gt[i] = 0.f; if (PIPE) gt[LDSB + i] = 0.f; }
   }
   const float* xb = d.x + ((size_t)b * d.x_ctot + ci0) * HWi;
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff + co0) * HWo;
+  const float* xob = GF ? d.out + ((size_t)b * d.out_ctot + d.out_coff + co0) * HWo : nullptr;    // GF: raw activation beside g
   const int crem = d.Cin - ci0, corem = d.Cout - co0;
 
   const bool halo_live = (G::NL + G::NR) > 0 && tiles_x > 1;
   // Register stages hold RAW loads (addresses clamped into the image, no select on the loaded value):
   // anything that consumes a load right after issuing it would drain vmcnt and serialise the prefetch
   // with the matrix work.  Validity is applied when a stage is committed to LDS.
-  constexpr int NPVM = (G::NV4 * MTW + 255) / 256, NPHM = (G::NH * MTW + 255) / 256;     // per thread, all M-tiles
-  constexpr int NPHS = NPHM > 0 ? NPHM : 1;
-  struct Stage { float4 pv[NPVM]; float4 pg[NPG4]; float ph[NPHS]; };
+  constexpr int NPHS = G::NPH > 0 ? G::NPH : 1;
+  struct Stage { float4 pv[G::NPV]; float4 pg[NPG4]; float ph[NPHS]; float4 px[GF ? NPG4 : 1]; };
   Stage sA, sB;
   auto issue = [&](int tile, Stage& st) __attribute__((always_inline)) {
     const int oy0 = (tile / tiles_x) * G::TH, ox0 = (tile % tiles_x) * G::TW;
 #pragma unroll
-    for (int i = 0; i < NPVM; ++i) {
+    for (int i = 0; i < G::NPV; ++i) {
       const int e = tid + 256 * i;
       const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
       const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
       const int cy = oy0 * S - G::PADL + r, cx = ox0 * S + 4 * j;
-      const int chc = max(min(ch, crem - 1), 0), cyc = min(max(cy, 0), Hc - 1);
+      const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hc - 1);
       st.pv[i] = *reinterpret_cast<const float4*>(xb + (size_t)chc * HWi + cyc * d.Win + cx);
     }
     if (halo_live) {
 #pragma unroll
-      for (int i = 0; i < NPHM; ++i) {
+      for (int i = 0; i < G::NPH; ++i) {
         const int e = tid + 256 * i;
         const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
         const int r = rem / G::NHC, h = rem % G::NHC;
         const int cy = oy0 * S - G::PADL + r;
         const int cx = h < G::NL ? ox0 * S - G::NL + h : ox0 * S + G::TWI + (h - G::NL);
-        const int chc = max(min(ch, crem - 1), 0), cyc = min(max(cy, 0), Hc - 1), cxc = min(max(cx, 0), Wc - 1);
+        const int chc = min(ch, crem - 1), cyc = min(max(cy, 0), Hc - 1), cxc = min(max(cx, 0), Wc - 1);
         st.ph[i] = xb[(size_t)chc * HWi + cyc * d.Win + cxc];
       }
     }
@@ -140,6 +166,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
       const int oy = oy0 + (4 * p4) / G::TW, ox = ox0 + (4 * p4) % G::TW;
       const size_t off = (size_t)min(ch, corem - 1) * HWo + oy * d.Wout + ox;
       st.pg[i] = *reinterpret_cast<const float4*>(gb + off);
+      if constexpr (GF) st.px[i] = *reinterpret_cast<const float4*>(xob + off);
     }
   };
   auto bnrelu = [&](float x, int ch, bool ok) __attribute__((always_inline)) {
@@ -150,9 +177,9 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
     float* ztb = zt + buf * LDSB;
     float* gtb = gt + buf * LDSB;
 #pragma unroll
-    for (int i = 0; i < NPVM; ++i) {
+    for (int i = 0; i < G::NPV; ++i) {
       const int e = tid + 256 * i;
-      if (e < G::NV4 * MTW) {
+      if (e < G::NV4) {
         const int ch = e / (G::ROWS * (G::TWI / 4)), rem = e % (G::ROWS * (G::TWI / 4));
         const int r = rem / (G::TWI / 4), j = rem % (G::TWI / 4);
         const int cy = oy0 * S - G::PADL + r;
@@ -164,9 +191,9 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
       }
     }
 #pragma unroll
-    for (int i = 0; i < NPHM; ++i) {
+    for (int i = 0; i < G::NPH; ++i) {
       const int e = tid + 256 * i;
-      if (e < G::NH * MTW) {
+      if (e < G::NH) {
         const int ch = e / (G::ROWS * G::NHC), rem = e % (G::ROWS * G::NHC);
         const int r = rem / G::NHC, h = rem % G::NHC;
         const int cy = oy0 * S - G::PADL + r;
@@ -189,19 +216,25 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
         continue;
       }
       float* dst = gtb + ch * G::GS + 4 * p4;                               // 8-byte aligned (GS even)
-      const float4 gv = st.pg[i];
+      float4 gv = st.pg[i];
+      if constexpr (GF) {
+        const float4 k = gfc[min(ch, 15)], x = st.px[i];
+        gv.x = k.y * (gv.x - k.z - (x.x - k.x) * k.y * k.w);
+        gv.y = k.y * (gv.y - k.z - (x.y - k.x) * k.y * k.w);
+        gv.z = k.y * (gv.z - k.z - (x.z - k.x) * k.y * k.w);
+        gv.w = k.y * (gv.w - k.z - (x.w - k.x) * k.y * k.w);
+      }
       *reinterpret_cast<float2*>(dst) = ok ? make_float2(gv.x, gv.y) : make_float2(0.f, 0.f);
       *reinterpret_cast<float2*>(dst + 2) = ok ? make_float2(gv.z, gv.w) : make_float2(0.f, 0.f);
     }
   };
 
   constexpr int NACC = FEW ? KS : KK;
-  constexpr int NTM = NTW * MTW;                 // accumulator tiles per tap: N-tiles (MTW == 1) or M-tiles (NTW == 1)
-  v4f acc[NACC][NTM];
+  v4f acc[NACC][NTW];
 #pragma unroll
   for (int t = 0; t < NACC; ++t)
 #pragma unroll
-    for (int nt = 0; nt < NTM; ++nt) acc[t][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   // wave w owns rows [w*TH/4, (w+1)*TH/4) of each pixel tile
   constexpr int RPW = (G::TH >= 4) ? G::TH / 4 : 1;
@@ -242,18 +275,10 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
-            if constexpr (MTW == 1) {
-              const float a = ztb[a_lane + (row * S + ky) * G::LDW + (G::COL0 - G::PADL) + 4 * ks * S + kx];
+            const float a = ztb[a_lane + (row * S + ky) * G::LDW + (G::COL0 - G::PADL) + 4 * ks * S + kx];
 #pragma unroll
-              for (int nt = 0; nt < NTW; ++nt)
-                acc[ky * KS + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[ky * KS + kx][nt], 0, 0, 0);
-            } else {
-#pragma unroll
-              for (int mt = 0; mt < MTW; ++mt) {
-                const float a = ztb[a_lane + mt * 16 * G::CS + (row * S + ky) * G::LDW + (G::COL0 - G::PADL) + 4 * ks * S + kx];
-                acc[ky * KS + kx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[0], acc[ky * KS + kx][mt], 0, 0, 0);
-              }
-            }
+            for (int nt = 0; nt < NTW; ++nt)
+              acc[ky * KS + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[ky * KS + kx][nt], 0, 0, 0);
           }
       }
     }
@@ -261,6 +286,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
   if constexpr (!PIPE) {
     // <= 2 tiles per workgroup: one register stage, one LDS buffer (smaller footprint -> more resident workgroups)
     issue(tile0, sA);
+    gf_table();
     __syncthreads();               // cf visible
     for (int tt = 0; tt < tpw; ++tt) {
       commit(tile0 + tt, 0, sA);
@@ -275,6 +301,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
     // over-wait, and peeled copies of the loop body cost registers (occupancy) -- both measured slower.
     issue(tile0, sA);
     issue(tile0 + 1, sB);
+    gf_table();
     __syncthreads();               // cf visible
     commit(tile0, 0, sA);
     __syncthreads();
@@ -298,22 +325,21 @@ __global__ __launch_bounds__(256, (NTW == 1 && KS <= 3 && S == 1 && MTW == 1) ? 
   }
 
   // ---- sum the 4 waves through LDS, then write this pixel split's partial dW
-  float* red = smem;               // [4][NACC*NTM*4][64]
-  constexpr int NR = NACC * NTM * 4;
+  float* red = smem;               // [4][NACC*NTW*4][64]
+  constexpr int NR = NACC * NTW * 4;
 #pragma unroll
   for (int t = 0; t < NACC; ++t)
 #pragma unroll
-    for (int nt = 0; nt < NTM; ++nt)
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * NR + (t * NTM + nt) * 4 + r) * 64 + lane] = acc[t][nt][r];
+      for (int r = 0; r < 4; ++r) red[(wave * NR + (t * NTW + nt) * 4 + r) * 64 + lane] = acc[t][nt][r];
   __syncthreads();
   float* pout = part + (size_t)blockIdx.x * d.Cout * d.Cin * KK;
   for (int q = wave; q < NR; q += 4) {
     const float s = red[(0 * NR + q) * 64 + lane] + red[(1 * NR + q) * 64 + lane] +
                     red[(2 * NR + q) * 64 + lane] + red[(3 * NR + q) * 64 + lane];
-    const int r = q & 3, ntm = (q >> 2) % NTM, t = (q >> 2) / NTM;
-    const int nt = MTW == 1 ? ntm : 0, mt = MTW == 1 ? 0 : ntm;
-    const int ci = ci0 + mt * 16 + (lane >> 4) * 4 + r;
+    const int r = q & 3, nt = (q >> 2) % NTW, t = (q >> 2) / NTW;
+    const int ci = ci0 + (lane >> 4) * 4 + r;
     if constexpr (FEW) {             // t = kernel row ky, column n = (co, kx)
       const int n = lane & 15, co = n / 5, kx = n % 5;
       if (n < 15 && co < d.Cout && ci < d.Cin) pout[(((size_t)co * d.Cin + ci) * KS + t) * KS + kx] = s;
@@ -574,7 +600,7 @@ __global__ __launch_bounds__(64) void wgrad_reduce_all_kernel(const pdes_reduce_
 bool wgrad_small_applies(const pdes_conv_desc& d);     // conv_small.hip
 int wgrad_small_splits(const pdes_conv_desc& d);
 // tile / split plan shared by the launcher and pdes_conv_wgrad_plan
-struct WgradPlan { int twg, tps, tpw, nsplit, ntw, ngroups, gy, mtw; long long per; };
+struct WgradPlan { int twg, tps, tpw, nsplit, ntw, ngroups, gy; long long per; };
 static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   const int KK = d.ksize * d.ksize;
   const bool up = d.upsample && d.ksize == 3;            // sub-pixel form: tiles of the LOW-res map
@@ -586,13 +612,6 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   p->ngroups = (ntiles + p->ntw - 1) / p->ntw;
   p->gy = mtiles * p->ngroups;
   p->per = (long long)d.Cout * d.Cin * KK;
-  // PDES_WGRAD_MTW=2: the 16-output-channel 3x3 layers of the dense blocks take two M-tiles per workgroup (the pixel
-  // split below then halves the tiles per workgroup: the same grid, the gradient tile staged half as often)
-  p->mtw = 1;
-  if (opt().wgrad_mtw == 2 && d.ksize == 3 && d.stride == 1 && !up && ntiles == 1 && mtiles >= 2 && !wgrad_b3_applies(d)) {
-    p->mtw = 2;
-    p->gy = mtiles / 2 + (mtiles & 1);
-  }
   if (wgrad_b3_applies(d)) {                             // bf16 x3 kernel for the wide layers: its own split count
     p->nsplit = wgrad_b3_splits(d);
     p->tpw = p->tps;
@@ -616,15 +635,10 @@ static bool wgrad_plan(const pdes_conv_desc& d, WgradPlan* p) {
   return (long long)p->nsplit * p->per * 4 <= d.ws_bytes;
 }
 
-static int launch_wgrad_pairs(const pdes_conv_desc& d, const WgradPlan& pl, hipStream_t st);
-
 template <int KS, int S>
 static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   WgradPlan pl;
   if (!wgrad_plan(d, &pl)) return PDES_ENOSUP;
-  if constexpr (KS == 3 && S == 1) {
-    if (pl.mtw == 2) return launch_wgrad_pairs(d, pl, st);
-  }
   const int twg = pl.twg, ntw = pl.ntw, ngroups = pl.ngroups, gy = pl.gy, tpw = pl.tpw, nsplit = pl.nsplit;
   const long long per = pl.per;
   (void)gy;
@@ -642,16 +656,26 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
     if constexpr (KS == 5 && NTW_ == 1 && S == 1) {                                                           \
       if (d.Cout * 5 <= 16) {                    /* few-output form; its LDS need is below the generic one */ \
         if (tpw > 2)                                                                                          \
-          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_), 0); \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
         else                                                                                                  \
-          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_), 0); \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
         break;                                                                                                \
       }                                                                                                       \
     }                                                                                                         \
+    if (d.g_fused) {                               /* finalize on load: the one-N-tile 3x3 layers (GF) */   \
+      if constexpr (KS == 3 && S == 1 && NTW_ == 1) {                                                         \
+        if (tpw > 2)                                                                                          \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
+        else                                                                                                  \
+          hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false, true>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
+        break;                                                                                                \
+      }                                                                                                       \
+      return PDES_ENOSUP;                                                                                     \
+    }                                                                                                         \
     if (tpw > 2)                                                                                              \
-      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_), 0); \
+      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, true, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
     else                                                                                                      \
-      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_), 0); \
+      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS, TWG_, NTW_, S, false, false>), grid, block, lds, st, d, d.ws, tpw, ngroups_l, (COFF_)); \
   } while (0)
   // an odd number of N-tiles >= 3: pairs with the two-tile kernel, the last tile with the one-tile kernel
   // (instead of a padding tile: 98 output channels are 7 tiles, not 8)
@@ -666,34 +690,6 @@ static int launch_wgrad(const pdes_conv_desc& d, hipStream_t st) {
   PDES_LAUNCH_CHECK();
   if (!d.ws_defer) {      // otherwise the caller reduces every layer at once with pdes_wgrad_reduce_all
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)per, nsplit);
-    PDES_LAUNCH_CHECK();
-  }
-  return PDES_OK;
-}
-
-// the dense blocks' 16-output-channel 3x3 layers with TWO M-tiles per workgroup (WgradPlan.mtw == 2): pairs of M-tiles
-// in one launch, an odd last tile in a second one (same pixel split, disjoint rows of the same partial buffer)
-static int launch_wgrad_pairs(const pdes_conv_desc& d, const WgradPlan& pl, hipStream_t st) {
-  const int mtiles = (d.Cin + 15) / 16, pairs = mtiles / 2;
-  dim3 block(256);
-#define PDES_WGP_LAUNCH(TWG_, MTW_, GY_, MOFF_)                                                              \
-  do {                                                                                                        \
-    using G = WGeo<3, TWG_, 1>;                                                                               \
-    dim3 grid(pl.nsplit, (GY_));                                                                              \
-    size_t lds = (size_t)(pl.tpw > 2 ? 2 : 1) * (16 * MTW_ * G::CS + 16 * G::GS) * sizeof(float);             \
-    const size_t red = (size_t)4 * 9 * MTW_ * 4 * 64 * sizeof(float);                                         \
-    if (red > lds) lds = red;                                                                                 \
-    if (pl.tpw > 2)                                                                                           \
-      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<3, TWG_, 1, 1, true, false, MTW_>), grid, block, lds, st, d, d.ws, pl.tpw, 1, 0, (MOFF_)); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((conv_mfma_wgrad_kernel<3, TWG_, 1, 1, false, false, MTW_>), grid, block, lds, st, d, d.ws, pl.tpw, 1, 0, (MOFF_)); \
-  } while (0)
-  if (pl.twg == 2) { PDES_WGP_LAUNCH(2, 2, pairs, 0); if (mtiles & 1) PDES_WGP_LAUNCH(2, 1, 1, mtiles - 1); }
-  else { PDES_WGP_LAUNCH(1, 2, pairs, 0); if (mtiles & 1) PDES_WGP_LAUNCH(1, 1, 1, mtiles - 1); }
-#undef PDES_WGP_LAUNCH
-  PDES_LAUNCH_CHECK();
-  if (!d.ws_defer) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)pl.per, 64)), dim3(64), 0, st, d.ws, d.dw, (int)pl.per, pl.nsplit);
     PDES_LAUNCH_CHECK();
   }
   return PDES_OK;
@@ -745,7 +741,11 @@ int conv_backward_weight_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry)
     return PDES_ENOSUP;
   if (d.stride != 1 && !(d.stride == 2 && d.ksize == 3 && !d.upsample)) return PDES_ENOSUP;
   if (d.nrep != PDES_NREP) return PDES_EINVAL;
-  if (d.g_fused || !wgrad_shape_ok(d)) return PDES_ENOSUP;    // finalize-on-load exists for PDES_OP_COPY only (flow_ops.hip)
+  if (!wgrad_shape_ok(d)) return PDES_ENOSUP;
+  // finalize on load: the one-N-tile stride-1 3x3 layers (the GF instantiations); PDES_OP_COPY has its own (flow_ops.hip)
+  if (d.g_fused && !(d.ksize == 3 && d.stride == 1 && !d.upsample && d.Cout <= 16 && !wgrad_b3_applies(d) && d.fin_tstats &&
+                     d.fin_xstats && d.out && d.g_ctot == d.out_ctot && d.g_coff == d.out_coff))
+    return PDES_ENOSUP;
   if (dry) { WgradPlan pl; return wgrad_plan(d, &pl) ? PDES_OK : PDES_ENOSUP; }
   if (d.ksize == 1 && d.stride == 1 && !d.upsample) {      // conv_mfma_1x1.hip: one split per image
     WgradPlan pl;

@@ -21,7 +21,10 @@ struct Options {
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS : workgroup target of the split-K weight-gradient plan
   int loss_nt = -1;             // PDES_LOSS_NT   : streaming loads / stores in the loss kernel: -1 = by working-set size, 0, 1
   int fork_signal = 1;          // PDES_FORK_SIGNAL: fork events ride on the finalize kernel's completion signal (0: hipEventRecord)
-  int wgrad_mtw = 1;            // PDES_WGRAD_MTW  : M-tiles per workgroup of the dense blocks' 3x3 weight gradients (1 | 2)
+  int fin_onload = 2;           // PDES_FIN_ONLOAD : 1: the backward of the dense blocks' 16-output-channel 3x3 layers applies the BatchNorm-
+                                //                  backward finalize of the layer's output gradient on operand load (no finalize launch
+                                //                  for them); 2 (default): and the forks inside a dense block ride on the data
+                                //                  gradients' completion signals; 0: one finalize launch per layer
   int wgrad_hold = 0;           // PDES_WGRAD_HOLD : pdes_backward releases the weight gradient of a layer with >= this many MFLOP
                                 //                  (2 B Hout Wout Cout Cin k^2 / 1e6) behind the layer's DATA gradient instead of beside
                                 //                  it (0: never): two kernels that each fill the chip gain nothing from running together

@@ -199,6 +199,24 @@ def test_g11_headline_batch_all_gradient_tensors():
     assert errs[0][0] < 1e-3, errs[:5]
 
 
+def test_g23_channelized_batch_all_gradient_tensors():
+    """BASELINE configs[3]: the default DenseED on channelized (two-valued) fields, B = 32 -- the oracle against the
+    reference's output, loss terms, running statistics and every gradient tensor"""
+    g = golden('G23_densed_channelized_b32.npz')
+    sd = _default_sd()
+    tr = train.CpuTrainer(sd, [6, 8, 6])
+    assert tr.keys == [str(s) for s in g['param_names']]
+    y, loss, parts = tr.forward_loss(torch.from_numpy(g['x']), True)
+    assert rel_l2(y.detach().numpy()[0], g['y0']) < 1e-5 and rel_l2(y.detach().numpy()[31], g['y_last']) < 1e-5
+    np.testing.assert_allclose([float(loss.detach())] + [float(p.detach()) for p in parts], g['terms'], rtol=1e-5)
+    loss.backward()
+    errs = sorted(((rel_l2(sd[k].grad.numpy(), g['grad/' + k]), k) for k in tr.keys), reverse=True)
+    assert errs[0][0] < 1e-3, errs[:5]
+    for k in g.files:
+        if k.startswith('sd/'):
+            np.testing.assert_allclose(sd[k[3:]].detach().numpy(), g[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
 def _load_flat(sd, keys, flat):
     off = 0
     with torch.no_grad():

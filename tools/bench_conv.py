@@ -43,7 +43,8 @@ def main(B=32, only=None):
         if only is not None and i not in only:
             continue
         d = eng.descs[i]
-        if os.environ.get('BENCH_FUSED') == '1' and d.fin_tstats and s.norm is not None:
+        if os.environ.get('BENCH_FUSED') == '1' and d.fin_tstats and s.norm is not None and s.k == 3 and s.stride == 1 \
+                and not s.up and s.cout <= 16:
             d.g_fused = 1          # time the finalize-on-load variants (values are meaningless here, timing is not)
         ref = ctypes.byref(d)
         fl = 2.0 * s.cout * s.cin * s.k * s.k * d.Hout * d.Wout * B

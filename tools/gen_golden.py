@@ -12,6 +12,7 @@ whether the local torch reproduces it).
     python tools/gen_golden.py glow       # only G18-G20 (conditional Glow)
     python tools/gen_golden.py round3     # only G21 (any field size; correct=False through the loss functions)
     python tools/gen_golden.py round4     # only W_seeded (seeded initial parameters) and G22 (DenseED at B = 64 / 128 / 256)
+    python tools/gen_golden.py round5     # only G23 (BASELINE configs[3]: the default DenseED on channelized fields, B = 32)
 """
 import hashlib
 import io
@@ -374,6 +375,54 @@ def gen_round4():
     np.savez_compressed(os.path.join(OUT, 'G22_densed_batches.npz'), **g)
     for f in ('W_seeded.npz', 'G22_densed_batches.npz'):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def gen_round5():
+    """round 5.  G23: BASELINE configs[3] -- the default DenseED (seeded initial parameters, W_seeded) on CHANNELIZED
+    fields (two-valued, sharp interfaces: the build's synthetic generator, the fields are stored), B = 32, train mode:
+    the reference's forward + loss + backward (train_codec_mixed_residual.py:134-143, :224-233).  Output, the five loss
+    terms, ALL 82 gradient tensors, the running statistics after the forward, and the reference's own fp32 rounding floor
+    against the fp64 oracle per tensor (as G11).  This is the input family SURVEY section 7 flags for E[x^2] - E[x]^2
+    cancellation in the first BatchNorms and for ReLU flips."""
+    from pde_surrogate_amd.utils.data import channelized_fields
+    from oracle import train as otrain
+    sob = SobelFilter(64, correct=True)
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    g6 = np.load(os.path.join(OUT, 'G6_densed_default.npz'))
+    assert sd_sha(net.state_dict()) == str(g6['sha256'])
+    w0 = {k: v.numpy().copy() for k, v in net.state_dict().items()}
+    xb = channelized_fields(32, seed=23)
+    assert sorted(np.unique(xb).tolist()) == [1.0, 10.0]
+    net.train()
+    xt = torch.from_numpy(xb)
+    yo = net(xt)
+    terms = ref_loss(xt, yo, sob, 10.0)
+    terms[0].backward()
+    names = [k for k, _ in net.named_parameters()]
+    g = {'x': xb, 'y0': yo.detach().numpy()[0], 'y_last': yo.detach().numpy()[31], 'y_slice': yo.detach().numpy()[:, :, ::8, ::8],
+         'terms': np.array([float(t) for t in terms], np.float64), 'param_names': np.array(names)}
+    grads = {k: p.grad.numpy().copy() for k, p in net.named_parameters()}
+    for k in names:
+        g['grad/' + k] = grads[k]
+    for k, v in net.state_dict().items():
+        if 'running' in k:
+            g['sd/' + k] = v.numpy().copy()
+    sd64 = {k: (torch.from_numpy(w0[k]).double() if w0[k].dtype == np.float32 else torch.from_numpy(w0[k]).clone()) for k in w0}
+    tr64 = otrain.CpuTrainer(sd64, [6, 8, 6])
+    _, l64, _ = tr64.forward_loss(xt.double(), True)
+    l64.backward()
+    assert list(tr64.keys) == names
+    floor = np.array([float(np.linalg.norm(grads[k].astype(np.float64) - sd64[k].grad.numpy()) / np.linalg.norm(sd64[k].grad.numpy()))
+                      for k in names])
+    g['ref_fp32_vs_fp64_floor'] = floor
+    for k, f in zip(names, floor):
+        if f > 3e-4:
+            g['grad64/' + k] = sd64[k].grad.numpy()
+    print('G23 loss %.6f terms %s floor max %.2e (%s)' % (float(terms[0]), [round(float(t), 5) for t in terms[1:]], floor.max(),
+                                                          names[int(floor.argmax())]))
+    np.savez_compressed(os.path.join(OUT, 'G23_densed_channelized_b32.npz'), **g)
+    print('G23_densed_channelized_b32.npz', os.path.getsize(os.path.join(OUT, 'G23_densed_channelized_b32.npz')))
 
 
 def gen_dropout():
@@ -787,6 +836,7 @@ def main():
     gen_glow()
     gen_round3()
     gen_round4()
+    gen_round5()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
@@ -804,5 +854,8 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'round4':  # only W_seeded (initial parameters) and G22 (B = 64 / 128 / 256)
         torch.set_num_threads(8)
         gen_round4()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round5':  # only G23 (default DenseED on channelized fields, B = 32)
+        torch.set_num_threads(8)
+        gen_round5()
     else:
         main()
