@@ -100,7 +100,7 @@ enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-in
 //     g = invstd (T - mean(T) - xhat mean(T xhat))        (bn_bwd_finalize_kernel, the same expression)
 // is applied while the tile is staged (x = the raw activation `out`, read beside T): no finalize launch in front of
 // this kernel (pdes_backward2, option PDES_FIN_ONLOAD).
-template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, int NG, bool GF = false>
+template <int KS, int TWG, int MT, int S, int WAVES_K, int NT_W, int MODE, int KM, bool PIPE, int NG, bool GF = false, bool TPI = false>
 __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : ((NT_W == 1 && KS != 5 && S == 1) ? 3 : 1))
 void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
   static_assert(NG == 1 || (NG == 2 && WAVES_K == 4 && MODE == MODE_FWD && PIPE), "wave groups: K-split forward only");
@@ -322,6 +322,20 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   const int wks = WAVES_K == 4 ? __builtin_amdgcn_readfirstlane(wk) : 0;    // wave-uniform -> SGPR
   const int ksteps = kpad / 4;
   float bA[KK][NT_W], bB[KK][NT_W];
+  // TP ("tile pipelined" data gradient: ONE chunk of <= 16 output channels, one N-tile per wave -- the dense blocks' layers):
+  // the weights of all four k-steps stay in registers (36 values) and the loop runs M-tile by M-tile, each tile's epilogue
+  // (mask, gamma, T +=, store) straight behind its 36 MFMAs.  With the k-step loop outside (all 8 tiles accumulating, one
+  // epilogue at the end) every workgroup of the launch -- one round on the chip -- loaded, multiplied and stored in
+  // lock-step: three phases in sequence (27 us for 180 <- 16 channels at 32 x 32: 9 of loads, 11.5 of MFMAs, 5 of stores);
+  // tile by tile the stores of one tile and the returning loads of the next run under the MFMAs of the tiles between.
+  // Stand-alone (B = 32) it gains where several workgroups share a CU (180 <- 16 channels at 32 x 32: 28.0 -> 25.7 us,
+  // 128 <- 16: 21.6 -> 20.7) and loses where one workgroup per CU is latency bound (48 <- 16: 13.6 -> 15.1, 16 x 16 maps
+  // +0.3 ... 0.6 us); inside the step -- beside the weight-gradient streams -- it wins everywhere: same process, threshold
+  // on the input channels 0 (never) / 48 / 96 / 128: 1.6580 / 1.6442 / 1.6429 / 1.6548 ms per step, the 16-wide maps on top
+  // 1.6440 -> 1.6372.  Selected by the launcher (TPI; options PDES_DG_TILEPIPE, PDES_DG_TILEPIPE16).
+  static_assert(!TPI || (MODE == MODE_BWD && !PIPE && NT_W == 1 && WAVES_K == 1 && KS == 3 && KM == KV_PLAIN && NG == 1), "tile pipeline");
+  constexpr bool TP = TPI;
+  float bC[TP ? KK : 1][NT_W], bD[TP ? KK : 1][NT_W];
   auto load_b = [&](int kstep, float (&dst)[KK][NT_W]) {
     const float* wp = wm + ((size_t)min(kstep, ksteps - 1) * KK * ntp + nt_base) * 64 + lane;
 #pragma unroll
@@ -353,6 +367,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   // virtual step v of this wave group <-> chunk grp + NG * v (clamped for the loads, tested for the work)
   auto cidx = [&](int v) __attribute__((always_inline)) { return min(grp + NG * v, nchunk - 1); };
   load_b(cidx(0) * 4 + wks, bA);
+  if constexpr (TP) { load_b(1, bB); load_b(2, bC); load_b(3, bD); }
   issue(cidx(0), sA);
   // data gradient: the BatchNorm coefficients of this wave's input channels are only needed in the epilogue;
   // their 32 replica loads + fp64 arithmetic are issued here so that they overlap the matrix work
@@ -369,15 +384,26 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   // to L2 / HBM runs under the matrix loop instead of at the head of the epilogue (where it was half of the kernel:
   // 8.9 of 18.3 us for 16 -> 180 channels at 32 x 32)
   constexpr bool EPI_PRE = MODE == MODE_BWD && NT_W == 1 && WAVES_K == 1;
+  constexpr int TPD = 3;                      // TP: tiles of x / T in flight ahead of the tile being multiplied
   float4 xpre[EPI_PRE ? MT : 1], tpre[EPI_PRE ? MT : 1];
+  size_t epi_cb = 0;
+  auto epi_load = [&](int mt) __attribute__((always_inline)) {
+    const size_t idx = epi_cb + (size_t)(oy0 + mt / TWG) * d.Win + ox0 + (mt % TWG) * 16;
+    xpre[mt] = *reinterpret_cast<const float4*>(d.x + idx);
+#ifdef PDES_DG_NOTLOAD           // (component-timing build: the data gradient without its T loads)
+    tpre[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+    tpre[mt] = d.t_accumulate ? *reinterpret_cast<const float4*>(d.t_in + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+  };
   if constexpr (EPI_PRE) {
     const int cic = min(nt_base * 16 + (lane & 15), d.Cin - 1);
-    const size_t cb = ((size_t)b * d.x_ctot + cic) * (size_t)(d.Hin * d.Win) + (size_t)((lane >> 4) * 4);
+    epi_cb = ((size_t)b * d.x_ctot + cic) * (size_t)(d.Hin * d.Win) + (size_t)((lane >> 4) * 4);
+    // (GF without the tile pipeline: requested behind the commit below instead -- the staged T / x tiles and all eight
+    //  x / T quads do not fit the register budget of three workgroups per CU together)
+    if constexpr (!GF || TP) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const size_t idx = cb + (size_t)(oy0 + mt / TWG) * d.Win + ox0 + (mt % TWG) * 16;
-      xpre[mt] = *reinterpret_cast<const float4*>(d.x + idx);
-      tpre[mt] = d.t_accumulate ? *reinterpret_cast<const float4*>(d.t_in + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int mt = 0; mt < (TP ? (TPD < MT ? TPD : MT) : MT); ++mt) epi_load(mt);
     }
   }
   if constexpr (GF) {
@@ -397,6 +423,10 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   __syncthreads();                 // cf visible
   TR(2);
   if (grp < nchunk) commit(cidx(0), 0, sA);
+  if constexpr (EPI_PRE && GF && !TP) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) epi_load(mt);
+  }
   __syncthreads();
   TR(3);
 
@@ -435,7 +465,72 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
     __syncthreads();
     TRACC(10, tt);     // barrier wait
   };
-  if constexpr (!PIPE) {
+  if constexpr (TP) {
+    // M-tile by M-tile: 36 MFMAs, then the tile's epilogue
+    const float* tb = tile + a_lane;
+    const int HWi = d.Hin * d.Win;
+    const int ci = nt_base * 16 + (lane & 15);
+    const BnC k = kepi[0];
+    const float scale = k.gamma * k.invstd;
+    const bool live = ci < d.Cin, fin = ci >= d.final_c0 && ci < d.final_c1;
+    float* tb2 = d.t_in + (size_t)b * d.x_ctot * HWi + (size_t)min(ci, d.Cin - 1) * HWi + (size_t)((lane >> 4) * 4);
+    float dg = 0.f, db = 0.f, st = 0.f, sx = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      v4f a4 = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 * 4 < kC) {                      // (scalar: k-steps that lie entirely in the zero padding are skipped)
+          const float (&bw)[KK][NT_W] = s4 == 0 ? bA : (s4 == 1 ? bB : (s4 == 2 ? bC : bD));
+#pragma unroll
+          for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+              const float a = tb[s4 * 4 * G::CS + ((mt / TWG) * S + ky) * G::LDW + (G::COL0 - G::PADL) + (mt % TWG) * 16 * S + kx];
+#ifdef PDES_DG_NOMFMA            // (component-timing build: what the dense data gradients' MFMAs cost the step)
+              a4[0] += a * bw[ky * KS + kx][0];
+#else
+              a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ky * KS + kx][0], a4, 0, 0, 0);
+#endif
+            }
+        }
+      }
+      if (mt + TPD < MT) epi_load(mt + TPD);     // (requested behind this tile's MFMAs, consumed TPD tiles later)
+      if (live) {
+        const float xs[4] = {xpre[mt].x, xpre[mt].y, xpre[mt].z, xpre[mt].w};
+        float ts[4] = {tpre[mt].x, tpre[mt].y, tpre[mt].z, tpre[mt].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = (xs[r] - k.mean) * scale + k.beta;
+          const float xh = (xs[r] - k.mean) * k.invstd;
+          const float dyv = (y > 0.f) ? a4[r] : 0.f;
+          db += dyv; dg += dyv * xh;
+          ts[r] += k.gamma * dyv;
+          if (fin) { st += ts[r]; sx += ts[r] * xh; }
+        }
+#ifdef PDES_DG_NOTSTORE          // (component-timing build: the data gradient without its T stores)
+        if (ts[0] == 123.456f)
+#endif
+        *reinterpret_cast<float4*>(tb2 + (size_t)(oy0 + mt / TWG) * d.Win + ox0 + (mt % TWG) * 16) = make_float4(ts[0], ts[1], ts[2], ts[3]);
+      }
+    }
+    dg += __shfl_xor(dg, 16, 64); dg += __shfl_xor(dg, 32, 64);
+    db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+    st += __shfl_xor(st, 16, 64); st += __shfl_xor(st, 32, 64);
+    sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
+    if (lane < 16 && live) {
+      const long long ro = (long long)rep_of_block(d.nrep) * d.rep_stride;
+#ifndef PDES_DG_NOATOM
+      atomicAdd(&d.bn_grad[ro + 2 * ci], (double)dg);
+      atomicAdd(&d.bn_grad[ro + 2 * ci + 1], (double)db);
+#endif
+      if (fin) {
+        atomicAdd(&d.t_stats[ro + 2 * ci], (double)st);
+        atomicAdd(&d.t_stats[ro + 2 * ci + 1], (double)sx);
+      }
+    }
+    return;
+  } else if constexpr (!PIPE) {
     step(0, sA, sA, bA, bB);
   } else {
     const int nv = (nchunk + NG - 1) / NG;     // the same number of steps (barriers) for every wave group
@@ -689,7 +784,16 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
         if constexpr (gf_able && WK_ == 1 && NTW_ == 1) {                                                     \
           hipEvent_t se = tl_stop_event;                                                                      \
           tl_stop_event = nullptr;                                                                            \
-          if (se)                                                                                             \
+          constexpr bool tp_able = true;                                                                      \
+          const int tp_min = (TWG_ == 2 && MT_ == 8) ? opt().dg_tilepipe : opt().dg_tilepipe16;              \
+          if (tp_min > 0 && nC >= tp_min) {                                                                         \
+            if (se)                                                                                           \
+              hipExtLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1, true, tp_able>), grid, block, lds, st, \
+                                    nullptr, se, 0, d, wm, nt_total);                                         \
+            else                                                                                              \
+              hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1, true, tp_able>), grid, block, lds, st, \
+                                 d, wm, nt_total);                                                            \
+          } else if (se)                                                                                      \
             hipExtLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1, true>), grid, block, lds, st, \
                                   nullptr, se, 0, d, wm, nt_total);                                           \
           else                                                                                                \
@@ -697,9 +801,16 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
                                d, wm, nt_total);                                                              \
         } else                                                                                                \
           return PDES_ENOSUP;                                                                                 \
-      } else                                                                                                  \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1>), grid, block, lds, st, \
-                           d, wm, nt_total);                                                                  \
+      } else {                                                                                                \
+        constexpr bool tp_able2 = gf_able && WK_ == 1 && NTW_ == 1;                                           \
+        const int tp_min2 = (TWG_ == 2 && MT_ == 8) ? opt().dg_tilepipe : opt().dg_tilepipe16;               \
+        if (tp_able2 && tp_min2 > 0 && nC >= tp_min2)                                                                            \
+          hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1, false, tp_able2>), grid, block, lds, st, \
+                             d, wm, nt_total);                                                                \
+        else                                                                                                  \
+          hipLaunchKernelGGL((conv_mfma_kernel<KS, TWG_, MT_, S, WK_, NTW_, MODE, KM, false, 1>), grid, block, lds, st, \
+                             d, wm, nt_total);                                                                \
+      }                                                                                                       \
     }                                                                                                         \
     rc = PDES_OK;                                                                                             \
   }

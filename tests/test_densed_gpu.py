@@ -598,6 +598,7 @@ VARIANTS = {   # name -> (option or environment variable, value A, value B): pai
     'fork_signal': ('PDES_FORK_SIGNAL', '0', '1'),
     'fin_onload': ('PDES_FIN_ONLOAD', '0', '2'),             # dense layers: BatchNorm-backward finalize on operand load vs a launch
     'fin_onload_signal': ('PDES_FIN_ONLOAD', '1', '2'),      # ... its forks by hipEventRecord vs on the data gradients' completion signals
+    'dg_tilepipe': ('PDES_DG_TILEPIPE', '0', '48'),           # dense data gradients: one epilogue at the end vs tile by tile (same sums, same order)
     'wgrad_hold': ('PDES_WGRAD_HOLD', '0', '5000'),          # the three widest weight gradients released behind their data gradients
 }
 
@@ -617,7 +618,7 @@ def test_backward_variants_agree(dev, monkeypatch, option, variant):
     y0, l0, g0 = _run_default(dev, B=32)
     setk(vb)
     y1, l1, g1 = _run_default(dev, B=32)
-    same_schedule = variant in ('wgrad_streams', 'fork_signal', 'wgrad_hold', 'fin_onload_signal')          # same kernels, other launch order: bit-level agreement
+    same_schedule = variant in ('wgrad_streams', 'fork_signal', 'wgrad_hold', 'fin_onload_signal', 'dg_tilepipe')          # same kernels, other launch order: bit-level agreement
     ytol = 1e-6 if same_schedule else 2e-6
     assert torch.equal(y0, y1) or rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < ytol
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
