@@ -318,7 +318,9 @@ def test_segment_graph_program_equals_eager_step(dev, mode, monkeypatch):
         assert prog is not None and sum(prog.nodes) >= 30
         if mode == 'segments':
             assert prog.early is not None and prog.early[0] == 17           # the early bucket = the layers from TransUp1 on
-            assert sum(prog.nodes) >= 110                                    # every kernel of the step sits in a graph
+            # every kernel of the step sits in a graph: 115 with one finalize launch per layer, 95 since the 20 dense layers
+            # finalize on operand load (PDES_FIN_ONLOAD, round 5)
+            assert sum(prog.nodes) >= 90
 
 
 def test_segment_graph_program_rejects_dropout_and_serves_the_data_driven_trainer(dev):
