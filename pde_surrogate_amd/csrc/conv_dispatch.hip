@@ -278,7 +278,8 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
   // Component-timing build only (tools/ab_timing.py; wrong numbers, right launch structure -- never shipped): bits of the
   // environment variable PDES_TIMING, read per call: 1 no weight-gradient kernels (fork events kept), 2 no fork events
   // either, 4 every finalize as ONE workgroup (launch + completion signal kept, no work), 8 no finalize launch at all
-  // (forks by hipEventRecord), 16 no data-gradient kernels
+  // (forks by hipEventRecord), 16 no data-gradient kernels, 32 neither weight-gradient kernel nor fork for the layers that
+  // finalize on load (the dense layers)
   const int timing = getenv("PDES_TIMING") ? atoi(getenv("PDES_TIMING")) : 0;
 #else
   const int timing = 0;
@@ -393,7 +394,10 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
     // (saves the event hop; its scratch / dw are disjoint from what the second stream still works on)
-    if (!is_resample_op(d) && !hold) {
+    if ((timing & 32) && onl) {
+      // (component timing: neither the weight-gradient kernel nor the fork of a finalize-on-load layer -- the upper bound of
+      //  what folding those weight gradients into the data-gradient launches could win)
+    } else if (!is_resample_op(d) && !hold) {
       const int rc = release(i, fork && i == 0, signalled);
       if (rc) return rc;
     }
@@ -404,7 +408,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       // the fork event rides on it, as it rides on the finalize kernel elsewhere -- no barrier packet on the chain
       pdes_conv_desc dn;
       hipEvent_t se = nullptr;
-      if (fork && use_signal && opt().fin_onload >= 2 && onl && i >= 2 && !(timing & (2 | 8)) && fin_onload(descs[i - 1], &dn) &&
+      if (fork && use_signal && opt().fin_onload >= 2 && onl && i >= 2 && !(timing & (2 | 8 | 32)) && fin_onload(descs[i - 1], &dn) &&
           !held(i - 1)) {
         se = cx->events[nev++];
         set_dgrad_stop_event(se);

@@ -4,7 +4,7 @@ pdes_backward2 reads the environment variable PDES_TIMING per call; wrong number
     PDES_EXTRA_FLAGS=-DPDES_TIMING_KNOBS python -m pde_surrogate_amd.build --force      (never ship that build)
     python tools/ab_timing.py 0 1 3 4 8 12 ...        -> ms per step for each value of PDES_TIMING, interleaved rounds
 bits: 1 no weight-gradient kernels (fork events kept), 2 no fork events, 4 finalize as one workgroup, 8 no finalize launch,
-16 no data-gradient kernels"""
+16 no data-gradient kernels, 32 neither weight-gradient kernel nor fork for the dense (finalize-on-load) layers"""
 import contextlib
 import io
 import os
