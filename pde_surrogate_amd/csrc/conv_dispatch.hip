@@ -394,7 +394,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     }
     // the very last weight gradient (first layer) has nothing left to overlap with: it stays on the main stream
     // (saves the event hop; its scratch / dw are disjoint from what the second stream still works on)
-    if ((timing & 32) && onl) {
+    if (((timing & 32) && onl) || ((timing & 64) && onl && d.Hout * d.Wout <= 256)) {      // (64: the small maps only)
       // (component timing: neither the weight-gradient kernel nor the fork of a finalize-on-load layer -- the upper bound of
       //  what folding those weight gradients into the data-gradient launches could win)
     } else if (!is_resample_op(d) && !hold) {
@@ -408,7 +408,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       // the fork event rides on it, as it rides on the finalize kernel elsewhere -- no barrier packet on the chain
       pdes_conv_desc dn;
       hipEvent_t se = nullptr;
-      if (fork && use_signal && opt().fin_onload >= 2 && onl && i >= 2 && !(timing & (2 | 8 | 32)) && fin_onload(descs[i - 1], &dn) &&
+      if (fork && use_signal && opt().fin_onload >= 2 && onl && i >= 2 && !(timing & (2 | 8 | 32)) && !((timing & 64) && descs[i - 1].Hout * descs[i - 1].Wout <= 256) && fin_onload(descs[i - 1], &dn) &&
           !held(i - 1)) {
         se = cx->events[nev++];
         set_dgrad_stop_event(se);
