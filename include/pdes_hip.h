@@ -46,7 +46,7 @@ extern "C" {
  *                                              1 wide 3x3 forward + data gradient, 2 wide 3x3 weight gradient, 4 nearest-x2 forward,
  *                                              8 nearest-x2 data gradient, 16 nearest-x2 weight gradient
  *                           "PDES_B3_TAIL"     1: <= 4 channels of a last 32-channel chunk on one f32 MFMA per tap | 0: a whole bf16 chunk
- *                           "PDES_MFMA_1X1"    bit mask of the register-operand 1x1 kernels, default 7: 1 forward, 2 data gradient,
+ *                           "PDES_MFMA_1X1"    bit mask of the register-operand 1x1 kernels, default 5: 1 forward, 2 data gradient,
  *                                              4 weight gradient (0: the LDS-tiled generic kernels)
  *                           "PDES_MFMA_SMALL"  1: matrix-core kernels for 3x3 convolutions on 8x8 maps | 0: VALU kernels
  *                           "PDES_WGRAD_WGS"   workgroup target of the split-K weight-gradient plan (default 256)

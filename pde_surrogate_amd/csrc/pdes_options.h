@@ -16,7 +16,10 @@ struct Options {
                                 //                  1 wide 3x3 forward + data gradient, 2 wide 3x3 weight gradient, 4 nearest-x2 forward,
                                 //                  8 nearest-x2 data gradient, 16 nearest-x2 weight gradient
   int b3_tail = 1;              // PDES_B3_TAIL   : <= 4 channels of the last 32-channel chunk on one f32 MFMA per tap instead of six bf16 ones
-  int mfma_1x1 = 7;             // PDES_MFMA_1X1  : bit mask of the register-operand 1x1 kernels: 1 forward, 2 data gradient, 4 weight gradient
+  int mfma_1x1 = 5;             // PDES_MFMA_1X1  : bit mask of the register-operand 1x1 kernels: 1 forward, 2 data gradient, 4 weight gradient
+                                //                  (round 5: the data gradient back on the LDS-tiled kernel -- 22.2 vs 25.1 us stand-alone for
+                                //                  144 <- 72 at 32 x 32, 1.634 vs 1.640 ms per step same process; round 2 had found the opposite
+                                //                  inside the step of the time)
   int mfma_small = 1;           // PDES_MFMA_SMALL: matrix-core kernels for 3x3 convolutions on 8x8 maps (conv_small.hip)
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS : workgroup target of the split-K weight-gradient plan
   int loss_nt = -1;             // PDES_LOSS_NT   : streaming loads / stores in the loss kernel: -1 = by working-set size, 0, 1
