@@ -975,7 +975,8 @@ def main():
             out['dropin'] = dropin
         if world == 1 and not args.no_extras:
             out['roofline_1x1'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s',
-                                   'kernel': 'conv1x1_mfma_kernel (forward, data gradient), conv1x1_wgrad_kernel',
+                                   'kernel': 'conv1x1_mfma_kernel (forward), conv_mfma_kernel<1, ...> (data gradient: the LDS-tiled '
+                                             'implicit GEMM, PDES_MFMA_1X1 = 5 since round 5), conv1x1_wgrad_kernel',
                                    'layers': conv1x1_timing(dev, B),
                                    'note': 'the 1x1 channel-halving layers, HIP-event timed stand-alone at the training '
                                            'batch; 0.33-0.68 GFLOP GEMMs: launch / prologue / statistics epilogue bound'}
