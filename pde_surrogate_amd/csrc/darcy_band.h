@@ -8,13 +8,22 @@
 // Reference (file:line relative to the reference repository): utils/image_gradient.py:26-92 (SobelFilter for any imsize,
 // correct=True/False), models/darcy.py:162-233 (the loss functions; their docstrings use 65 x 65 fields).
 //
-// Geometry.  An image row is SPR = ceil(n / 4) strips; the last strip holds jl + 1 = ((n - 1) & 3) + 1 real columns.  A wave
-// takes RPP = 64 / SPR whole rows per pass (lanes beyond RPP * SPR idle), so a strip's left / right neighbour is the
-// adjacent lane and never another wave.  A workgroup of `waves` waves owns a BAND of rows [r0, r1) of one image: it computes
+// Geometry.  An image row is SPR = ceil(n / 4) strips; the last strip holds jl + 1 = ((n - 1) & 3) + 1 real columns.  The
+// strips of a workgroup pass are packed DENSELY into its 64 * waves lanes: slot s = 64 wave + lane holds strip s % SPR of
+// the pass's row s / SPR, RPW = 64 waves / SPR whole rows per pass (the slots behind RPW * SPR idle: 65 x 65 fills 255 of 256
+// lanes, 130 x 130 495 of 512; a wave-by-wave packing of whole rows would leave 13 resp. 31 of every 64 idle).  A strip's
+// left / right neighbour is the adjacent lane; where a row runs across a wave boundary (64 not a multiple of SPR: `seam`)
+// lane 63 and the next wave's lane 0 hand each other their edge columns through a few LDS words.  A workgroup owns a BAND
+// of rows [r0, r1) of one image: it computes
 // the residuals ("sources") on [r0 - 1, r1 + 1) in `npass` passes from the fields on [r0 - 2, r1 + 2) (three LDS planes of
 // row stride 4 * SPR floats), keeps the direct terms of its own rows in registers, overwrites the planes with the
 // sources and applies the adjoint stencils on its own rows.  Rows 0 .. 2 and n-3 .. n-1 couple through the reference's
 // boundary `modifier` (one-sided differences): bands are at least 3 rows, so those sit in the first / last band together.
+//
+// Global memory.  A strip is four consecutive floats of an image row: 16-byte accesses when n is a multiple of 4 behind
+// aligned pointers (width class J = 4), otherwise the same four-dword accesses at DWORD alignment (global_load_dwordx4 needs
+// no more on this part), the row's last strip read as the row's last four floats and shifted (never a byte outside the
+// row), its jl + 1 real columns stored one by one.
 //
 // Arithmetic: S = replicate-edge [1,2,1]/4 smoother, A = clamped central difference (x modifier when `correct`):
 // grad_h = n S_rows(.) A_cols, grad_v = n A_rows(.) S_cols, adjoints with A^T.  The column operators are written as the
@@ -43,44 +52,60 @@ struct V4 { float v[4]; };
 
 // ---- the plan of a field size ---------------------------------------------------------------------------------------
 struct Plan {
-  int n, spr, jl, rpp, w;      // strips per row, last real column of the last strip, rows per wave and pass, LDS row stride
-  int waves, npass, cap;       // workgroup: waves, passes, source rows it can hold = waves * rpp * npass
+  int n, spr, jl, rpw, w;      // strips per row, last real column of the last strip, rows per workgroup pass, LDS row stride
+  int waves, npass, cap;       // workgroup: waves, passes, source rows it can hold = rpw * npass
   int nbands, rows_f;          // bands per image; field rows of the tallest band
   int own_base, own_rem;       // band b owns own_base (+1 for b < own_rem) rows: first row b * own_base + min(b, own_rem)
-  int inv_spr;                 // lane / spr == (lane * inv_spr) >> 16 for lane < 64
-  int planes;                  // LDS planes: 3, or 4 when n is not a multiple of 4 (K is staged too; outputs leave through them)
-  long long lds_floats;        // planes * rows_f * w + the row table (kRowTab floats per field row)
+  int inv_spr;                 // slot / spr == (slot * inv_spr) >> 16 for slot < 512
+  int seam;                    // rows run across wave boundaries (64 % spr != 0 and more than one wave)
+  long long lds_floats;        // 3 * rows_f * w + the row table (kRowTab floats per field row)
 };
 
 PDES_HD int band_lo(const Plan& p, int band) { return band * p.own_base + imin(band, p.own_rem); }
 
-// waves in {1,2,4,8}, passes in {1,2}: the most strip slots doing own work; ties -> the larger workgroup (fewer bands,
-// less halo).  False: size not served by the band kernel.
+// fills the fields that follow from (n, waves, npass, nbands); false: the shape cannot hold the bands
+inline bool make_plan(int n, int waves, int npass, int nbands, Plan& p) {
+  const int spr = (n + 3) >> 2;
+  p.n = n; p.spr = spr; p.jl = (n - 1) & 3; p.w = 4 * spr;
+  p.waves = waves; p.npass = npass; p.rpw = 64 * waves / spr; p.cap = p.rpw * npass;
+  p.nbands = nbands;
+  if (nbands < 1 || p.rpw < 1) return false;
+  const int own_max = (n + nbands - 1) / nbands;
+  if (nbands == 1 ? p.cap < n : (own_max + 2 > p.cap || n / nbands < 3)) return false;
+  p.own_base = n / nbands; p.own_rem = n % nbands;
+  p.inv_spr = 65536 / spr + 1;
+  p.seam = (waves > 1 && 64 % spr != 0) ? 1 : 0;
+  p.rows_f = imin(own_max + 4, n);
+  p.lds_floats = 3ll * p.rows_f * p.w + (long long)kRowTab * p.rows_f;
+  return true;
+}
+
+// waves in {1, 2, 4, 8} (workgroups of 3, 5, 6, 7 waves load the four SIMDs of a CU unevenly: measured 10-45 % slower at the
+// same slot use), passes in {1, 2}: the most strip slots doing own work.  Ties (measured, EXPERIMENTS.md round 5): two
+// passes before one (half the bands, half the halo rows: 5-12 %), then 4 waves, 2, 8, 1 (2-4 %).  False: size not served.
+PDES_HD int plan_rank(int waves, int npass) {
+  const int wr = waves == 4 ? 0 : (waves == 2 ? 1 : (waves == 8 ? 2 : 3));
+  return (2 - npass) * 4 + wr;       // smaller is better
+}
 inline bool choose_plan(int n, long long lds_floats_max, Plan& best) {
   if (n < kMinN || n > kMaxN) return false;
-  const int spr = (n + 3) >> 2, rpp = 64 / spr;
+  const int spr = (n + 3) >> 2;
   bool found = false;
   double best_eff = -1.0;
   for (int waves = 1; waves <= 8; waves *= 2)
     for (int npass = 1; npass <= 2; ++npass) {
-      Plan p;
-      p.n = n; p.spr = spr; p.jl = (n - 1) & 3; p.rpp = rpp; p.w = 4 * spr;
-      p.waves = waves; p.npass = npass; p.cap = waves * rpp * npass;
-      if (p.cap >= n) p.nbands = 1;
-      else {
-        if (p.cap < 5) continue;
-        p.nbands = (n + (p.cap - 2) - 1) / (p.cap - 2);
-        if (n / p.nbands < 3) continue;
+      const int cap = (64 * waves / spr) * npass;
+      int nbands = 1;
+      if (cap < n) {
+        if (cap < 5) continue;
+        nbands = (n + (cap - 2) - 1) / (cap - 2);
       }
-      const int own_max = (n + p.nbands - 1) / p.nbands;
-      p.own_base = n / p.nbands; p.own_rem = n % p.nbands;
-      p.inv_spr = 65536 / spr + 1;
-      p.rows_f = imin(own_max + 4, n);
-      p.planes = (n & 3) ? 4 : 3;
-      p.lds_floats = (long long)p.planes * p.rows_f * p.w + (long long)kRowTab * p.rows_f;
-      if (p.lds_floats > lds_floats_max) continue;
-      const double eff = (double)n / ((double)p.nbands * p.cap);
-      if (!found || eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && waves * npass >= best.waves * best.npass)) {
+      Plan p;
+      if (!make_plan(n, waves, npass, nbands, p) || p.lds_floats > lds_floats_max) continue;
+      const double eff = (double)n * spr / ((double)nbands * npass * 64 * waves);
+      const bool tie = found && eff > best_eff - 1e-9 && eff < best_eff + 1e-9;
+      const bool tie_wins = tie && plan_rank(waves, npass) < plan_rank(best.waves, best.npass);
+      if (!found || eff >= best_eff + 1e-9 || tie_wins) {
         best = p; best_eff = eff; found = true;
       }
     }
@@ -132,22 +157,16 @@ PDES_HD RowGeom row_geom(int r, int n, bool correct) {
 
 // ---- what a lane knows about its strip column (constant over the passes) ---------------------------------------------
 struct LaneConst {
-  int cs, lrow;            // strip of the row; row of the wave's pass (lane / spr)
-  bool active;             // lane < rpp * spr
+  int cs, lrow;            // strip of the row; row of the workgroup's pass (slot / spr)
+  bool active;             // slot < rpw * spr
   bool first, last;
   bool valid[4];           // column < n
   float cl[4], cr[4];      // adjoint of the column difference: border terms cl[j] g[0] + cr[j] g[n-1]
 };
-PDES_HD LaneConst lane_const(const Plan& p, int lane, bool correct) {
-  LaneConst c;
-  c.active = lane < p.rpp * p.spr;
-  c.lrow = (lane * p.inv_spr) >> 16;
-  c.cs = lane - c.lrow * p.spr;
-  c.first = c.cs == 0;
-  c.last = c.cs == p.spr - 1;
+// the border terms of the column difference's adjoint (needed by phase C only: the kernel fills them in behind phase B)
+PDES_HD void lane_const_adj(const Plan& p, LaneConst& c, bool correct) {
   for (int j = 0; j < 4; ++j) {
     const int col = 4 * c.cs + j;
-    c.valid[j] = col < p.n;
     c.cl[j] = 0.f; c.cr[j] = 0.f;
     if (correct) {
       if (col == 0) c.cl[j] = -1.5f;
@@ -161,6 +180,19 @@ PDES_HD LaneConst lane_const(const Plan& p, int lane, bool correct) {
       if (col == p.n - 1) c.cr[j] = 0.5f;
     }
   }
+}
+PDES_HD LaneConst lane_const(const Plan& p, int slot, bool correct, bool with_adj = true) {       // slot = 64 wave + lane
+  LaneConst c;
+  c.active = slot < p.rpw * p.spr;
+  c.lrow = (slot * p.inv_spr) >> 16;
+  c.cs = slot - c.lrow * p.spr;
+  c.first = c.cs == 0;
+  c.last = c.cs == p.spr - 1;
+  for (int j = 0; j < 4; ++j) {
+    c.valid[j] = 4 * c.cs + j < p.n;
+    c.cl[j] = 0.f; c.cr[j] = 0.f;
+  }
+  if (with_adj) lane_const_adj(p, c, correct);
   return c;
 }
 
@@ -403,9 +435,27 @@ PDES_HD void adj_finish(const AdjVert& a, const Halo& hp1, const Halo& hp2, cons
   du.v[jl] += c.last ? s.du : 0.f;
 }
 
-// slot of (pass, wave, lane) -> source row of the band (may be >= sr1: an idle slot)
-PDES_HD int slot_row(const Plan& p, const BandGeo& g, int pass, int wave, const LaneConst& c) {
-  return g.sr0 + (pass * p.waves + wave) * p.rpp + c.lrow;
+// (pass, slot) -> source row of the band (may be >= sr1: an idle slot)
+PDES_HD int slot_row(const Plan& p, const BandGeo& g, int pass, const LaneConst& c) {
+  return g.sr0 + pass * p.rpw + c.lrow;
+}
+
+// the last strip of a row arrives as the row's LAST FOUR floats (columns n-4 .. n-1): its jl + 1 real columns are the
+// vector's last ones -> shifted to the front, the tail zeroed
+template <int J>
+PDES_HD V4 last_strip_shift(const V4& x, const LaneConst& c) {
+  constexpr int jl = WidthClass<J>::jl;
+  V4 o;
+  for (int j = 0; j < 4; ++j) {
+    const int src = j + 3 - jl < 3 ? j + 3 - jl : 3;
+    o.v[j] = c.last ? (j <= jl ? x.v[src] : 0.f) : x.v[j];
+  }
+  return o;
+}
+// float offset of the strip's four-dword access in its image row
+template <int J>
+PDES_HD int strip_col(const Plan& p, const LaneConst& c) {
+  return (WidthClass<J>::jl < 3 && c.last) ? p.n - 4 : 4 * c.cs;
 }
 
 }  // namespace band

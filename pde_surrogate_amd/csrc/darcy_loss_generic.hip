@@ -17,6 +17,8 @@
 // Stand-alone Sobel / adjoint kernels (3x3 and 5x5): one thread per pixel straight from global memory (the 9..50
 // taps of a pixel hit L1/L2); these are the autograd-facing SobelFilter.grad_h / grad_v of fields the fused loss does
 // not cover, not a hot path.
+#include <cstdio>
+#include <cstdlib>
 #include "pdes_common.h"
 #include "darcy_generic.h"
 #include "darcy_band.h"
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(GEN_NT) void darcy_loss_strips_kernel(const float* 
 
 
 // ---- the row-band kernel (8 <= n <= 256): darcy_band.h --------------------------------------------------------------------
-// grid = (bands of an image, images), block = 64 * plan.waves, dynamic LDS = 3 planes of plan.rows_f rows.  Neighbour
-// strips are neighbour lanes: DPP wave shifts (lane 0 / 63 receive 0 and never use it: a row starts at a first strip).
+// grid = (bands of an image, images), block = 64 * plan.waves, dynamic LDS = 3 planes of plan.rows_f rows + the row table.
+// Neighbour strips are neighbour lanes: DPP wave shifts; lane 0 / 63 receive 0 there, and -- SEAM: rows run across wave
+// boundaries -- take the neighbour wave's edge columns from `seam` instead (written in front of a barrier of their own).
 constexpr long long BAND_LDSF = 16384 - 64;          // floats of dynamic LDS a band workgroup may use (64 KiB - reductions)
 
 __device__ __forceinline__ float wave_shr1(float v) {      // lane i <- lane i - 1
@@ -110,20 +113,77 @@ __device__ __forceinline__ float wave_shr1(float v) {      // lane i <- lane i -
 __device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
-template <int J>
-__device__ __forceinline__ band::Halo halo_of(const band::V4& x) {       // (what a caller does not use is never computed)
+// seam[sq ..]: what the neighbour WAVE published for this lane and quantity (lane 0: its left neighbour's v[3], v[2]; lane 63:
+// its right neighbour's v[0], v[jl]); sq < 0: no neighbour wave on that side (or not an edge lane)
+template <int J, bool SEAM>
+__device__ __forceinline__ band::Halo halo_of(const band::V4& x, int lane, const float* seam, int sq) {       // (what a caller does not use is never computed)
   band::Halo h;
   h.l = wave_shr1(x.v[3]);
   h.l2 = wave_shr1(x.v[2]);
   h.r = wave_shl1(x.v[0]);
   h.rjl = wave_shl1(x.v[band::WidthClass<J>::jl]);
+  if (SEAM) {
+    float2 e = make_float2(0.f, 0.f);
+    if (sq >= 0) e = *reinterpret_cast<const float2*>(seam + sq);
+    h.l = lane == 0 ? e.x : h.l; h.l2 = lane == 0 ? e.y : h.l2;
+    h.r = lane == 63 ? e.x : h.r; h.rjl = lane == 63 ? e.y : h.rjl;
+  }
   return h;
+}
+// lane 0 / lane 63 of a wave publish the edge columns of four quantities: sb = 16 floats of the (pass, wave):
+// [0..7] lane 0's (v[0], v[jl]) x 4, [8..15] lane 63's (v[3], v[2]) x 4
+template <int J>
+__device__ __forceinline__ void seam_publish(float* sb, int lane, const band::V4& a, const band::V4& b, const band::V4& c,
+                                             const band::V4& d) {
+  constexpr int jl = band::WidthClass<J>::jl;
+  if (lane == 0 || lane == 63) {
+    const bool hi = lane == 63;
+    float e[8];
+    e[0] = hi ? a.v[3] : a.v[0]; e[1] = hi ? a.v[2] : a.v[jl];
+    e[2] = hi ? b.v[3] : b.v[0]; e[3] = hi ? b.v[2] : b.v[jl];
+    e[4] = hi ? c.v[3] : c.v[0]; e[5] = hi ? c.v[2] : c.v[jl];
+    e[6] = hi ? d.v[3] : d.v[0]; e[7] = hi ? d.v[2] : d.v[jl];
+    float* q = sb + (hi ? 8 : 0);
+    gen::st4(q, e); gen::st4(q + 4, e + 4);
+  }
+}
+// behind the barrier: lane 0 reads what lane 63 of the wave before published, lane 63 what lane 0 of the wave behind did
+__device__ __forceinline__ int seam_source(int pass, int lane, int wave, int waves) {
+  if ((lane == 0 && wave > 0) || (lane == 63 && wave + 1 < waves))
+    return pass * 8 * 16 + (lane == 0 ? (wave - 1) * 16 + 8 : (wave + 1) * 16);
+  return -64;
+}
+
+// four consecutive floats of global memory: 16-byte aligned (A) or dword aligned (global_load / store_dwordx4 take both)
+typedef float vec4_a16 __attribute__((ext_vector_type(4)));
+typedef float vec4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <bool A>
+__device__ __forceinline__ band::V4 gld4(const float* q, int nt) {
+  band::V4 o;
+  if (A) {
+    const vec4_a16 t = nt ? __builtin_nontemporal_load(reinterpret_cast<const vec4_a16*>(q)) : *reinterpret_cast<const vec4_a16*>(q);
+    o.v[0] = t[0]; o.v[1] = t[1]; o.v[2] = t[2]; o.v[3] = t[3];
+  } else {
+    const vec4_a4 t = nt ? __builtin_nontemporal_load(reinterpret_cast<const vec4_a4*>(q)) : *reinterpret_cast<const vec4_a4*>(q);
+    o.v[0] = t[0]; o.v[1] = t[1]; o.v[2] = t[2]; o.v[3] = t[3];
+  }
+  return o;
+}
+template <bool A>
+__device__ __forceinline__ void gst4(float* q, const band::V4& x, int nt) {
+  if (A) {
+    const vec4_a16 t = {x.v[0], x.v[1], x.v[2], x.v[3]};
+    if (nt) __builtin_nontemporal_store(t, reinterpret_cast<vec4_a16*>(q)); else *reinterpret_cast<vec4_a16*>(q) = t;
+  } else {
+    const vec4_a4 t = {x.v[0], x.v[1], x.v[2], x.v[3]};
+    if (nt) __builtin_nontemporal_store(t, reinterpret_cast<vec4_a4*>(q)); else *reinterpret_cast<vec4_a4*>(q) = t;
+  }
 }
 
 // J = 4: n is a multiple of 4 and every pointer 16-byte aligned -> 16-byte global accesses, no tail code.  J = 0 .. 3
-// (= the last real column of the last strip): scalar global accesses over CONTIGUOUS ranges (a band's rows are one range of
-// the plane): the fields and the conductivities enter through the LDS planes, the gradient leaves through them.
-template <bool BWD, int NPASS, int J>
+// (= the last real column of the last strip): the same accesses at dword alignment; a row's last strip is read as the
+// row's last four floats and shifted, and stored column by column.
+template <bool BWD, int NPASS, int J, bool SEAM>
 __global__ __launch_bounds__(512, 4) void darcy_loss_band_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
                                                               float* __restrict__ gyp, float* __restrict__ partials,
                                                               LossParams p_in, band::Plan pl, int flags) {
@@ -131,202 +191,149 @@ __global__ __launch_bounds__(512, 4) void darcy_loss_band_kernel(const float* __
   const LossParams p = BWD ? loss_params_weighted(p_in) : p_in;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[8 * 4];
+  __shared__ __attribute__((aligned(16))) float seam[SEAM ? NPASS * 8 * 16 : 4];
   const int bi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   constexpr bool A = J == 4;
+  constexpr int jl = WidthClass<J>::jl;
   const int n = pl.n, w = pl.w;
   const size_t nn = (size_t)n * n;
   const float fn = (float)n;
   const bool correct = !(flags & kUncorrected);
   const BandGeo g = band_geo(pl, bi);
-  const LaneConst c = lane_const(pl, lane, correct);
+  LaneConst c = lane_const(pl, tid, correct, false);
   const float* Kb = Kp + (size_t)b * nn;
   const float* yb = yp + (size_t)b * 3 * nn;
   float* gb = BWD ? gyp + (size_t)b * 3 * nn : nullptr;
   const int plane = pl.rows_f * w, rows_f = g.fr1 - g.fr0;
-  float* tab = lds + pl.planes * plane;                      // the row table (darcy_band.h), read after the first barrier
+  float* tab = lds + 3 * plane;                              // the row table (darcy_band.h), read after the first barrier
   if (tid < rows_f) rowtab_build(tab, g.fr0 + tid, n, correct, g.fr0, g.fr1, w);
 
   int row[NPASS];
 #pragma unroll
-  for (int k = 0; k < NPASS; ++k) row[k] = slot_row(pl, g, k, wave, c);
+  for (int k = 0; k < NPASS; ++k) row[k] = slot_row(pl, g, k, c);
+  const int scol = strip_col<J>(pl, c);
+  // the conductivities of this lane's strips: requested first, used after the staging
   V4 kk[NPASS];
-  if (A) {
-    // the conductivities of this lane's strips: requested first, used after the staging
 #pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-      const bool ok = c.active && row[k] < g.sr1;
-      const float4* kp = reinterpret_cast<const float4*>(Kb + (size_t)row[k] * n + 4 * c.cs);
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) t = p.nt ? nt_load4(kp) : *kp;
-      kk[k].v[0] = t.x; kk[k].v[1] = t.y; kk[k].v[2] = t.z; kk[k].v[3] = t.w;
-    }
-    // the three fields on rows fr0 .. fr1 (w == n: a plane is the row range itself).  The loads of ALL planes are issued
-    // before the first LDS store: bytes in flight are what the staging phase runs on
+  for (int k = 0; k < NPASS; ++k) {
+    const bool ok = c.active && row[k] < g.sr1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kk[k].v[j] = 0.f;
+    if (ok) kk[k] = gld4<A>(Kb + (size_t)row[k] * n + scol, p.nt);
+  }
+  {
+    // the three fields on rows fr0 .. fr1, strip by strip (w = 4 spr: strip i of the range is float4 i of a plane).  The
+    // loads of ALL planes are issued before the first LDS store: bytes in flight are what the staging phase runs on
     const int per = rows_f * pl.spr;
+    const float inv_s = 1.0f / (float)pl.spr;
 #pragma unroll 1
     for (int base = tid; base < per; base += 2 * nthreads) {
-      float4 v[3][2];
+      V4 v[3][2];
+      bool lastf[2];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const float4* src = reinterpret_cast<const float4*>(yb + q * nn + (size_t)g.fr0 * n);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = base + u * nthreads;
-          if (i < per) v[q][u] = p.nt ? nt_load4(src + i) : src[i];
+      for (int u = 0; u < 2; ++u) {
+        const int i = base + u * nthreads;
+        int off = 4 * i;
+        lastf[u] = false;
+        if (!A) {
+          const int rr = (int)(((float)i + 0.5f) * inv_s);          // i / spr (exact: i < 2^15, spr <= 64)
+          const int cs = i - rr * pl.spr;
+          lastf[u] = cs == pl.spr - 1;
+          off = rr * n + ((jl < 3 && lastf[u]) ? n - 4 : 4 * cs);
         }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (i < per) v[q][u] = gld4<A>(yb + q * nn + (size_t)g.fr0 * n + off, p.nt);
       }
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        float4* dst = reinterpret_cast<float4*>(lds + q * plane);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = base + u * nthreads;
-          if (i < per) dst[i] = v[q][u];
-        }
-      }
-    }
-  } else {
-    const int per = rows_f * n;
-    const float inv = 1.0f / (float)n;
-    const bool kplane = pl.planes == 4;
-#pragma unroll 1
-    for (int base = tid; base < per; base += 4 * nthreads) {
-      float v[4][4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float* src = (q < 3 ? yb + q * nn : Kb) + (size_t)g.fr0 * n;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = base + u * nthreads;
-          if (i < per && (q < 3 || kplane)) v[q][u] = p.nt ? __builtin_nontemporal_load(src + i) : src[i];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const int i = base + u * nthreads;
         if (i < per) {
-          const int rr = (int)(((float)i + 0.5f) * inv);          // i / n (exact: i < 2^16, n <= 256)
-          const int o = rr * w + (i - rr * n);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < 3 || kplane) lds[q * plane + o] = v[q][u];
+          for (int q = 0; q < 3; ++q) {
+            V4 x = v[q][u];
+            if (!A && jl < 3) {
+              LaneConst cl;
+              cl.last = lastf[u];
+              x = last_strip_shift<J>(x, cl);
+            }
+            st4(lds + q * plane + 4 * i, x.v);
+          }
         }
       }
     }
   }
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k)
+    if (!A && jl < 3) kk[k] = last_strip_shift<J>(kk[k], c);
   __syncthreads();
-  if (!A) {
-#pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-      const int rc = row[k] < g.sr1 ? row[k] : g.sr1 - 1;
-      if (pl.planes == 4) ld4(lds + 3 * plane + (rc - g.fr0) * w + 4 * c.cs, kk[k].v);
-      else {                              // (a multiple of 4 behind an unaligned pointer, no room for a fourth plane)
-        const float* kp = Kb + (size_t)rc * n + 4 * c.cs;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) kk[k].v[j] = kp[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) kk[k].v[j] = c.valid[j] ? kk[k].v[j] : 0.f;        // (tail columns of the plane were never written)
-    }
-  }
 
   const BPlane U{lds, g.fr0, g.fr1, w}, X1{lds + plane, g.fr0, g.fr1, w}, X2{lds + 2 * plane, g.fr0, g.fr1, w};
   float sums[4] = {0.f, 0.f, 0.f, 0.f};
   StripOut so[NPASS];
-#ifdef PDES_TUNE
-  if (flags & 4096) {                  // timing experiment: no arithmetic (the staged values pass through)
-#pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-      const int rc = row[k] < g.sr1 ? row[k] : g.sr1 - 1;
-      const int o = (rc - g.fr0) * w + 4 * c.cs;
-      so[k].p1 = ldoff(U, o); so[k].p2 = ldoff(X1, o); so[k].cc = ldoff(X2, o); so[k].d1 = kk[k]; so[k].d2 = kk[k]; so[k].du = 0.f;
-    }
-  } else
-#endif
+  int sq = -64;
+  // Phase B.  The vertical half of a pass reads the field planes, the horizontal half works on registers: behind a barrier
+  // in the middle of the LAST pass (with seams every pass has one there) no wave reads the fields any more, and the
+  // sources of the passes before go into the planes at once instead of waiting in registers through the last pass
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int r = row[k], rc = r < g.sr1 ? r : g.sr1 - 1;
     const bool ok = c.active && r < g.sr1, own = ok && r >= g.r0 && r < g.r1;
     const FwdVert f = fwd_vert<J>(U, X1, X2, rowtab_read<false>(tab, rc, c.cs, g.fr0, w), c);
-    so[k] = fwd_finish<J>(f, halo_of<J>(f.us), halo_of<J>(f.ud), halo_of<J>(f.as), halo_of<J>(f.bd), kk[k], rc, n, c, p, flags, fn,
-                          own, sums);
+    if (SEAM) seam_publish<J>(seam + (k * 8 + wave) * 16, lane, f.us, f.ud, f.as, f.bd);
+    if (SEAM || k == NPASS - 1) __syncthreads();
+    if (SEAM) sq = seam_source(k, lane, wave, pl.waves);
+    if (BWD && k == NPASS - 1) {
+#pragma unroll
+      for (int kp = 0; kp < NPASS - 1; ++kp)
+        if (c.active && row[kp] < g.sr1) {
+          float* q = lds + (row[kp] - g.fr0) * w + 4 * c.cs;
+          st4(q, so[kp].p1.v); st4(q + plane, so[kp].p2.v); st4(q + 2 * plane, so[kp].cc.v);
+        }
+    }
+    so[k] = fwd_finish<J>(f, halo_of<J, SEAM>(f.us, lane, seam, sq), halo_of<J, SEAM>(f.ud, lane, seam, sq + 2),
+                          halo_of<J, SEAM>(f.as, lane, seam, sq + 4), halo_of<J, SEAM>(f.bd, lane, seam, sq + 6), kk[k], rc, n, c, p,
+                          flags, fn, own, sums);
+    if (BWD && k == NPASS - 1 && ok) {
+      float* q = lds + (r - g.fr0) * w + 4 * c.cs;
+      st4(q, so[k].p1.v); st4(q + plane, so[k].p2.v); st4(q + 2 * plane, so[k].cc.v);
+    }
   }
   {
     const float t0 = wave_sum(sums[0]), t1 = wave_sum(sums[1]), t2 = wave_sum(sums[2]), t3 = wave_sum(sums[3]);
     if (lane == 0) { red[wave * 4 + 0] = t0; red[wave * 4 + 1] = t1; red[wave * 4 + 2] = t2; red[wave * 4 + 3] = t3; }
   }
-  __syncthreads();                     // also: every read of the field planes is done
+  __syncthreads();                     // the sources and the waves' sums are in LDS (and the seam words have been read)
   if (tid < 4) {
     float t = 0.f;
     for (int wv = 0; wv < pl.waves; ++wv) t += red[wv * 4 + tid];           // fixed order: deterministic
     partials[((size_t)b * pl.nbands + bi) * 4 + tid] = t;
   }
   if (!BWD) return;
-#pragma unroll
-  for (int k = 0; k < NPASS; ++k) {
-    if (c.active && row[k] < g.sr1) {
-      float* q = lds + (row[k] - g.fr0) * w + 4 * c.cs;
-      st4(q, so[k].p1.v); st4(q + plane, so[k].p2.v); st4(q + 2 * plane, so[k].cc.v);
-    }
-  }
-  __syncthreads();
+  lane_const_adj(pl, c, correct);
   const BPlane G1{lds, g.fr0, g.fr1, w}, G2{lds + plane, g.fr0, g.fr1, w}, GC{lds + 2 * plane, g.fr0, g.fr1, w};
-  constexpr int NKEEP = A ? 1 : NPASS;          // (A stores each pass at once)
-  V4 du[NKEEP], d1[NKEEP], d2[NKEEP];
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int r = row[k], rc = r < g.r0 ? g.r0 : (r < g.r1 ? r : g.r1 - 1);
     const bool own = c.active && r >= g.r0 && r < g.r1;
-    constexpr int kk_ = 0;
-    const int ko = A ? kk_ : k;
-#ifdef PDES_TUNE
-    if (flags & 4096) {
-      const int o = (rc - g.fr0) * w + 4 * c.cs;
-      du[ko] = ldoff(G1, o); d1[ko] = ldoff(G2, o); d2[ko] = ldoff(GC, o);
-    } else
-#endif
+    V4 du, d1, d2;
     {
       const AdjVert a = adj_vert<J>(G1, G2, GC, rowtab_read<true>(tab, rc, c.cs, g.fr0, w), c);
-      adj_finish<J>(a, halo_of<J>(a.p1s), halo_of<J>(a.p2d), halo_of<J>(a.ccs), halo_of<J>(a.ccd), so[k], c, fn, du[ko], d1[ko], d2[ko]);
-    }
-    if (A && own) {
-      float* o = gb + (size_t)r * n + 4 * c.cs;
-      if (p.nt) {
-        nt_store4(reinterpret_cast<float4*>(o), make_float4(du[0].v[0], du[0].v[1], du[0].v[2], du[0].v[3]));
-        nt_store4(reinterpret_cast<float4*>(o + nn), make_float4(d1[0].v[0], d1[0].v[1], d1[0].v[2], d1[0].v[3]));
-        nt_store4(reinterpret_cast<float4*>(o + 2 * nn), make_float4(d2[0].v[0], d2[0].v[1], d2[0].v[2], d2[0].v[3]));
-      } else {
-        st4(o, du[0].v); st4(o + nn, d1[0].v); st4(o + 2 * nn, d2[0].v);
+      if (SEAM) {
+        seam_publish<J>(seam + (k * 8 + wave) * 16, lane, a.p1s, a.p2d, a.ccs, a.ccd);
+        __syncthreads();
+        sq = seam_source(k, lane, wave, pl.waves);
       }
+      adj_finish<J>(a, halo_of<J, SEAM>(a.p1s, lane, seam, sq), halo_of<J, SEAM>(a.p2d, lane, seam, sq + 2),
+                    halo_of<J, SEAM>(a.ccs, lane, seam, sq + 4), halo_of<J, SEAM>(a.ccd, lane, seam, sq + 6), so[k], c, fn, du, d1, d2);
     }
-  }
-  if (A) return;
-#ifdef PDES_TUNE
-  if (flags & 8192) return;
-#endif
-  // the general path: own strips -> the planes (every source has been read) -> one contiguous range per plane
-  __syncthreads();
+    if (own) {
+      float* o = gb + (size_t)r * n + 4 * c.cs;
+      if (jl == 3 || !c.last) {
+        gst4<A>(o, du, p.nt); gst4<A>(o + nn, d1, p.nt); gst4<A>(o + 2 * nn, d2, p.nt);
+      } else {
 #pragma unroll
-  for (int k = 0; k < NPASS; ++k) {
-    if (c.active && row[k] >= g.r0 && row[k] < g.r1) {
-      float* q = lds + (row[k] - g.fr0) * w + 4 * c.cs;
-      const int ko = A ? 0 : k;
-      st4(q, du[ko].v); st4(q + plane, d1[ko].v); st4(q + 2 * plane, d2[ko].v);
-    }
-  }
-  __syncthreads();
-  {
-    const int per = (g.r1 - g.r0) * n;
-    const float inv = 1.0f / (float)n;
-#pragma unroll 1
-    for (int q = 0; q < 3; ++q) {
-      float* dst = gb + q * nn + (size_t)g.r0 * n;
-      const float* src = lds + q * plane + (g.r0 - g.fr0) * w;
-#pragma unroll 2
-      for (int i = tid; i < per; i += nthreads) {
-        const int rr = (int)(((float)i + 0.5f) * inv);
-        const float v = src[rr * w + (i - rr * n)];
-        if (p.nt) __builtin_nontemporal_store(v, dst + i); else dst[i] = v;
+        for (int j = 0; j <= jl; ++j) { o[j] = du.v[j]; o[nn + j] = d1.v[j]; o[2 * nn + j] = d2.v[j]; }
       }
     }
   }
@@ -371,7 +378,16 @@ constexpr int STRIP_MIN_N = 8;        // below: the per-pixel kernel (the adjoin
 
 // the row-band kernel serves 8 <= n <= 256 unless the caller asks for the tile kernel (PDES_LOSS_TILED: cross-checks)
 static bool band_plan(int n, int flags, band::Plan& pl) {
-  return !(flags & PDES_LOSS_TILED) && band::choose_plan(n, BAND_LDSF, pl);
+  if (flags & PDES_LOSS_TILED) return false;
+#ifdef PDES_BAND_PLAN_ENV
+  if (const char* e = getenv("PDES_BAND_PLAN")) {          // plan-sweep builds (tools/sweep_band_plan.sh): "waves,npass,nbands"
+    int wv = 0, np = 0, nb = 0;
+    if (sscanf(e, "%d,%d,%d", &wv, &np, &nb) == 3 && n >= band::kMinN && n <= band::kMaxN && band::make_plan(n, wv, np, nb, pl) &&
+        pl.lds_floats <= BAND_LDSF)
+      return true;
+  }
+#endif
+  return band::choose_plan(n, BAND_LDSF, pl);
 }
 
 int loss_generic_tiles(int n, int flags) {       // tiles (bands) per image (<= 0: size not supported)
@@ -394,12 +410,14 @@ int launch_loss_generic(const float* K, const float* y, float* gy, float* partia
     const bool a16 = (n & 3) == 0 && aligned16(K) && aligned16(y) && (!gy || aligned16(gy));
     const dim3 grid(pl.nbands, B), block(64 * pl.waves);
     const size_t shmem = (size_t)pl.lds_floats * sizeof(float);
-#define PDES_BAND_LAUNCH(BWD_, NP_, J_) \
-    hipLaunchKernelGGL((darcy_loss_band_kernel<BWD_, NP_, J_>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags)
+#define PDES_BAND_LAUNCH(BWD_, NP_, J_, S_) \
+    hipLaunchKernelGGL((darcy_loss_band_kernel<BWD_, NP_, J_, S_>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags)
+#define PDES_BAND_LAUNCH_S(BWD_, NP_, J_) \
+    do { if (pl.seam) PDES_BAND_LAUNCH(BWD_, NP_, J_, true); else PDES_BAND_LAUNCH(BWD_, NP_, J_, false); } while (0)
 #define PDES_BAND_LAUNCH_J(J_)                                                                             \
     do {                                                                                                   \
-      if (pl.npass == 1) { if (gy) PDES_BAND_LAUNCH(true, 1, J_); else PDES_BAND_LAUNCH(false, 1, J_); }     \
-      else { if (gy) PDES_BAND_LAUNCH(true, 2, J_); else PDES_BAND_LAUNCH(false, 2, J_); }                   \
+      if (pl.npass == 1) { if (gy) PDES_BAND_LAUNCH_S(true, 1, J_); else PDES_BAND_LAUNCH_S(false, 1, J_); }     \
+      else { if (gy) PDES_BAND_LAUNCH_S(true, 2, J_); else PDES_BAND_LAUNCH_S(false, 2, J_); }                   \
     } while (0)
     switch (a16 ? 4 : pl.jl) {
       case 4: PDES_BAND_LAUNCH_J(4); break;
@@ -408,6 +426,7 @@ int launch_loss_generic(const float* K, const float* y, float* gy, float* partia
       case 1: PDES_BAND_LAUNCH_J(1); break;
       default: PDES_BAND_LAUNCH_J(0); break;
     }
+#undef PDES_BAND_LAUNCH_S
 #undef PDES_BAND_LAUNCH_J
 #undef PDES_BAND_LAUNCH
     return PDES_OK;

@@ -88,19 +88,29 @@ void emu_sobel_adjoint(const float* ghb, const float* gvb, float* out, int nimg,
 }
 
 // ---- the row-band kernel (csrc/darcy_band.h), lane by lane ------------------------------------------------------------------
-// One workgroup = `waves` arrays of 64 lanes; a DPP wave shift is a read of the adjacent lane's array entry (lane 0 /
-// lane 63 receive 0, as with bound_ctrl).  Every lane -- idle ones included -- runs the arithmetic, as on the GPU.
+// One workgroup = an array of 64 * waves slots; a strip's neighbour is the adjacent slot (inside a wave a DPP shift, across
+// a wave boundary the seam words of darcy_loss_generic.hip; the first / last slot of the workgroup receive 0).  Every slot
+// -- idle ones included -- runs the arithmetic, as on the GPU.  Global memory is touched as the kernel touches it: four
+// floats per strip, a row's last strip as the row's last four floats, shifted.
 // waves/npass <= 0: the kernel's own plan for `lds_floats_max` floats of LDS.  partials: (B * bands, 4).  Returns the bands
 // per image (0: no plan).
 }  // extern "C"
 
-static band::Halo halo_from(const band::V4* x, int lane, int jl) {       // jl = WidthClass<J>::jl
+static band::Halo halo_from(const std::vector<band::V4>& x, int slot, int jl) {       // jl = WidthClass<J>::jl
   band::Halo h;
-  h.l = lane > 0 ? x[lane - 1].v[3] : 0.f;
-  h.l2 = lane > 0 ? x[lane - 1].v[2] : 0.f;
-  h.r = lane < 63 ? x[lane + 1].v[0] : 0.f;
-  h.rjl = lane < 63 ? band::pick(x[lane + 1], jl) : 0.f;
+  const int last = (int)x.size() - 1;
+  h.l = slot > 0 ? x[slot - 1].v[3] : 0.f;
+  h.l2 = slot > 0 ? x[slot - 1].v[2] : 0.f;
+  h.r = slot < last ? x[slot + 1].v[0] : 0.f;
+  h.rjl = slot < last ? band::pick(x[slot + 1], jl) : 0.f;
   return h;
+}
+
+template <int J>
+static band::V4 strip_load(const float* rowp, const band::Plan& pl, const band::LaneConst& c) {
+  band::V4 x;
+  ld4(rowp + band::strip_col<J>(pl, c), x.v);
+  return band::WidthClass<J>::jl < 3 ? band::last_strip_shift<J>(x, c) : x;
 }
 
 template <int J>
@@ -111,57 +121,53 @@ static int band_emulation(const float* Kp, const float* yp, float* gyp, float* p
   const bool correct = !(flags & kUncorrected);
   const size_t nn = (size_t)n * n;
   const float fn = (float)n;
-  const int jl = WidthClass<J>::jl, plane = pl.rows_f * pl.w;
+  const int jl = WidthClass<J>::jl, plane = pl.rows_f * pl.w, nslot = 64 * pl.waves;
   for (int b = 0; b < B; ++b)
     for (int bi = 0; bi < pl.nbands; ++bi) {
       const BandGeo g = band_geo(pl, bi);
-      std::vector<float> lds((size_t)pl.planes * pl.rows_f * pl.w, -12345.f);       // poison
+      std::vector<float> lds((size_t)3 * pl.rows_f * pl.w, -12345.f);       // poison
       const float* Kb = Kp + b * nn;
       const float* yb = yp + b * 3 * nn;
       float* gb = gyp ? gyp + b * 3 * nn : nullptr;
-      // stage the fields (rows fr0 .. fr1; columns >= n stay poisoned: the tails are rebuilt in registers); the
-      // conductivities too when there is a fourth plane (n not a multiple of 4: no 16-byte global accesses)
-      for (int q = 0; q < pl.planes; ++q)
+      // stage the fields, strip by strip (rows fr0 .. fr1)
+      for (int q = 0; q < 3; ++q)
         for (int r = g.fr0; r < g.fr1; ++r)
-          for (int c = 0; c < n; ++c)
-            lds[(size_t)q * plane + (r - g.fr0) * pl.w + c] = q < 3 ? yb[q * nn + (size_t)r * n + c] : Kb[(size_t)r * n + c];
+          for (int cs = 0; cs < pl.spr; ++cs) {
+            LaneConst c;
+            c.cs = cs; c.last = cs == pl.spr - 1;
+            const V4 x = strip_load<J>(yb + q * nn + (size_t)r * n, pl, c);
+            st4(lds.data() + (size_t)q * plane + (r - g.fr0) * pl.w + 4 * cs, x.v);
+          }
       const BPlane U{lds.data(), g.fr0, g.fr1, pl.w}, X1{lds.data() + plane, g.fr0, g.fr1, pl.w},
           X2{lds.data() + 2 * plane, g.fr0, g.fr1, pl.w};
       std::vector<float> tab((size_t)kRowTab * pl.rows_f, -999.f);           // (behind the planes in the kernel's LDS)
       for (int r = g.fr0; r < g.fr1; ++r) rowtab_build(tab.data(), r, n, correct, g.fr0, g.fr1, pl.w);
-      const int nslots = pl.npass * pl.waves;
-      std::vector<StripOut> keep((size_t)nslots * 64);
-      std::vector<float> lane_sums((size_t)pl.waves * 64 * 4, 0.f);
+      std::vector<StripOut> keep((size_t)pl.npass * nslot);
+      std::vector<float> lane_sums((size_t)nslot * 4, 0.f);
       // ---- phase B
-      for (int pass = 0; pass < pl.npass; ++pass)
-        for (int wave = 0; wave < pl.waves; ++wave) {
-          FwdVert f[64];
-          V4 us[64], ud[64], as[64], bd[64];
-          int rc[64];
-          for (int lane = 0; lane < 64; ++lane) {
-            const LaneConst c = lane_const(pl, lane, correct);
-            const int r = slot_row(pl, g, pass, wave, c);
-            rc[lane] = r < g.sr1 ? r : g.sr1 - 1;
-            f[lane] = fwd_vert<J>(U, X1, X2, rowtab_read<false>(tab.data(), rc[lane], c.cs, g.fr0, pl.w), c);
-            us[lane] = f[lane].us; ud[lane] = f[lane].ud; as[lane] = f[lane].as; bd[lane] = f[lane].bd;
-          }
-          for (int lane = 0; lane < 64; ++lane) {
-            const LaneConst c = lane_const(pl, lane, correct);
-            const int r = slot_row(pl, g, pass, wave, c);
-            const bool ok = c.active && r < g.sr1, own = ok && r >= g.r0 && r < g.r1;
-            V4 K;
-            for (int j = 0; j < 4; ++j) K.v[j] = 0.f;
-            if (ok) {
-              if (pl.planes == 4) ld4(lds.data() + 3 * plane + (r - g.fr0) * pl.w + 4 * c.cs, K.v);
-              else ld4(Kb + (size_t)r * n + 4 * c.cs, K.v);                       // (J = 4, or J = 3 without a K plane)
-              for (int j = 0; j < 4; ++j) if (!c.valid[j]) K.v[j] = 0.f;          // (poisoned tail columns)
-            }
-            keep[(size_t)(pass * pl.waves + wave) * 64 + lane] =
-                fwd_finish<J>(f[lane], halo_from(us, lane, jl), halo_from(ud, lane, jl), halo_from(as, lane, jl),
-                              halo_from(bd, lane, jl), K, rc[lane], n, c, p, flags, fn, own,
-                              &lane_sums[((size_t)wave * 64 + lane) * 4]);
-          }
+      for (int pass = 0; pass < pl.npass; ++pass) {
+        std::vector<FwdVert> f(nslot);
+        std::vector<V4> us(nslot), ud(nslot), as(nslot), bd(nslot);
+        std::vector<int> rc(nslot);
+        for (int slot = 0; slot < nslot; ++slot) {
+          const LaneConst c = lane_const(pl, slot, correct);
+          const int r = slot_row(pl, g, pass, c);
+          rc[slot] = r < g.sr1 ? r : g.sr1 - 1;
+          f[slot] = fwd_vert<J>(U, X1, X2, rowtab_read<false>(tab.data(), rc[slot], c.cs, g.fr0, pl.w), c);
+          us[slot] = f[slot].us; ud[slot] = f[slot].ud; as[slot] = f[slot].as; bd[slot] = f[slot].bd;
         }
+        for (int slot = 0; slot < nslot; ++slot) {
+          const LaneConst c = lane_const(pl, slot, correct);
+          const int r = slot_row(pl, g, pass, c);
+          const bool ok = c.active && r < g.sr1, own = ok && r >= g.r0 && r < g.r1;
+          V4 K;
+          for (int j = 0; j < 4; ++j) K.v[j] = 0.f;
+          if (ok) K = strip_load<J>(Kb + (size_t)r * n, pl, c);
+          keep[(size_t)pass * nslot + slot] =
+              fwd_finish<J>(f[slot], halo_from(us, slot, jl), halo_from(ud, slot, jl), halo_from(as, slot, jl),
+                            halo_from(bd, slot, jl), K, rc[slot], n, c, p, flags, fn, own, &lane_sums[(size_t)slot * 4]);
+        }
+      }
       for (int k = 0; k < 4; ++k) {
         float t = 0.f;
         for (int wave = 0; wave < pl.waves; ++wave) {
@@ -175,60 +181,40 @@ static int band_emulation(const float* Kp, const float* yp, float* gyp, float* p
       // ---- the planes become the sources (after the barrier), rows sr0 .. sr1
       std::fill(lds.begin(), lds.end(), -54321.f);
       for (int pass = 0; pass < pl.npass; ++pass)
-        for (int wave = 0; wave < pl.waves; ++wave)
-          for (int lane = 0; lane < 64; ++lane) {
-            const LaneConst c = lane_const(pl, lane, correct);
-            const int r = slot_row(pl, g, pass, wave, c);
-            if (!(c.active && r < g.sr1)) continue;
-            const StripOut& s = keep[(size_t)(pass * pl.waves + wave) * 64 + lane];
-            float* q = lds.data() + (r - g.fr0) * pl.w + 4 * c.cs;
-            st4(q, s.p1.v); st4(q + plane, s.p2.v); st4(q + 2 * plane, s.cc.v);
-          }
+        for (int slot = 0; slot < nslot; ++slot) {
+          const LaneConst c = lane_const(pl, slot, correct);
+          const int r = slot_row(pl, g, pass, c);
+          if (!(c.active && r < g.sr1)) continue;
+          const StripOut& s = keep[(size_t)pass * nslot + slot];
+          float* q = lds.data() + (r - g.fr0) * pl.w + 4 * c.cs;
+          st4(q, s.p1.v); st4(q + plane, s.p2.v); st4(q + 2 * plane, s.cc.v);
+        }
       const BPlane G1{lds.data(), g.fr0, g.fr1, pl.w}, G2{lds.data() + plane, g.fr0, g.fr1, pl.w},
           GC{lds.data() + 2 * plane, g.fr0, g.fr1, pl.w};
-      // ---- phase C
-      std::vector<V4> out((size_t)nslots * 64 * 3);
-      for (int pass = 0; pass < pl.npass; ++pass)
-        for (int wave = 0; wave < pl.waves; ++wave) {
-          AdjVert a[64];
-          V4 p1s[64], p2d[64], ccs[64], ccd[64];
-          int rc[64];
-          for (int lane = 0; lane < 64; ++lane) {
-            const LaneConst c = lane_const(pl, lane, correct);
-            const int r = slot_row(pl, g, pass, wave, c);
-            rc[lane] = r < g.r0 ? g.r0 : (r < g.r1 ? r : g.r1 - 1);          // idle / halo slots: any own row
-            a[lane] = adj_vert<J>(G1, G2, GC, rowtab_read<true>(tab.data(), rc[lane], c.cs, g.fr0, pl.w), c);
-            p1s[lane] = a[lane].p1s; p2d[lane] = a[lane].p2d; ccs[lane] = a[lane].ccs; ccd[lane] = a[lane].ccd;
-          }
-          for (int lane = 0; lane < 64; ++lane) {
-            const LaneConst c = lane_const(pl, lane, correct);
-            const size_t slot = (size_t)(pass * pl.waves + wave) * 64 + lane;
-            adj_finish<J>(a[lane], halo_from(p1s, lane, jl), halo_from(p2d, lane, jl), halo_from(ccs, lane, jl),
-                          halo_from(ccd, lane, jl), keep[slot], c, fn, out[slot * 3], out[slot * 3 + 1], out[slot * 3 + 2]);
+      // ---- phase C: own strips leave as four floats, a row's last strip column by column
+      for (int pass = 0; pass < pl.npass; ++pass) {
+        std::vector<AdjVert> a(nslot);
+        std::vector<V4> p1s(nslot), p2d(nslot), ccs(nslot), ccd(nslot);
+        for (int slot = 0; slot < nslot; ++slot) {
+          const LaneConst c = lane_const(pl, slot, correct);
+          const int r = slot_row(pl, g, pass, c);
+          const int rc = r < g.r0 ? g.r0 : (r < g.r1 ? r : g.r1 - 1);          // idle / halo slots: any own row
+          a[slot] = adj_vert<J>(G1, G2, GC, rowtab_read<true>(tab.data(), rc, c.cs, g.fr0, pl.w), c);
+          p1s[slot] = a[slot].p1s; p2d[slot] = a[slot].p2d; ccs[slot] = a[slot].ccs; ccd[slot] = a[slot].ccd;
+        }
+        for (int slot = 0; slot < nslot; ++slot) {
+          const LaneConst c = lane_const(pl, slot, correct);
+          const int r = slot_row(pl, g, pass, c);
+          V4 out[3];
+          adj_finish<J>(a[slot], halo_from(p1s, slot, jl), halo_from(p2d, slot, jl), halo_from(ccs, slot, jl),
+                        halo_from(ccd, slot, jl), keep[(size_t)pass * nslot + slot], c, fn, out[0], out[1], out[2]);
+          if (!(c.active && r >= g.r0 && r < g.r1)) continue;
+          for (int q = 0; q < 3; ++q) {
+            float* o = gb + q * nn + (size_t)r * n + 4 * c.cs;
+            if (jl == 3 || !c.last) st4(o, out[q].v);
+            else for (int j = 0; j <= jl; ++j) o[j] = out[q].v[j];
           }
         }
-      // ---- the gradient leaves: 16-byte stores of own strips (A), or through the planes and out as one contiguous range
-      if (J != 4) std::fill(lds.begin(), lds.end(), -777.f);          // (after a barrier: every source has been read)
-      for (int pass = 0; pass < pl.npass; ++pass)
-        for (int wave = 0; wave < pl.waves; ++wave)
-          for (int lane = 0; lane < 64; ++lane) {
-            const LaneConst c = lane_const(pl, lane, correct);
-            const int r = slot_row(pl, g, pass, wave, c);
-            if (!(c.active && r >= g.r0 && r < g.r1)) continue;
-            const size_t slot = (size_t)(pass * pl.waves + wave) * 64 + lane;
-            for (int q = 0; q < 3; ++q) {
-              if (J != 4) st4(lds.data() + q * plane + (r - g.fr0) * pl.w + 4 * c.cs, out[slot * 3 + q].v);
-              else st4(gb + q * nn + (size_t)r * n + 4 * c.cs, out[slot * 3 + q].v);
-            }
-          }
-      if (J != 4) {
-        const int per = (g.r1 - g.r0) * n;
-        const float inv = 1.0f / (float)n;
-        for (int q = 0; q < 3; ++q)
-          for (int i = 0; i < per; ++i) {
-            const int rr = (int)(((float)i + 0.5f) * inv);
-            gb[q * nn + (size_t)g.r0 * n + i] = lds[(size_t)q * plane + (g.r0 + rr - g.fr0) * pl.w + (i - rr * n)];
-          }
       }
     }
   return pl.nbands;
@@ -241,23 +227,14 @@ int emu_darcy_loss_band(const float* Kp, const float* yp, float* gyp, float* par
                         int nbands, long long lds_floats_max, int* plan_out) {
   using namespace band;
   Plan pl;
-  if (!choose_plan(n, lds_floats_max, pl)) return 0;
   if (waves > 0) {                       // a forced plan (tests walk band heights the chooser would not pick)
-    pl.waves = waves; pl.npass = npass; pl.cap = waves * pl.rpp * npass; pl.nbands = nbands;
-    const int own_max = (n + nbands - 1) / nbands;
-    if (own_max + 2 > pl.cap && nbands > 1) return 0;
-    if (nbands == 1 && pl.cap < n) return 0;
-    if (n / nbands < 3) return 0;
-    pl.own_base = n / nbands; pl.own_rem = n % nbands;
-    pl.rows_f = imin(own_max + 4, n);
-    pl.lds_floats = (long long)pl.planes * pl.rows_f * pl.w + (long long)kRowTab * pl.rows_f;
-  }
-  if (plan_out) { plan_out[0] = pl.waves; plan_out[1] = pl.npass; plan_out[2] = pl.nbands; plan_out[3] = pl.rpp; plan_out[4] = (int)pl.lds_floats; }
+    if (n < kMinN || n > kMaxN || !make_plan(n, waves, npass, nbands, pl)) return 0;
+  } else if (!choose_plan(n, lds_floats_max, pl)) return 0;
+  if (plan_out) { plan_out[0] = pl.waves; plan_out[1] = pl.npass; plan_out[2] = pl.nbands; plan_out[3] = pl.rpw; plan_out[4] = (int)pl.lds_floats; }
   LossParams p{a_const, a_cont, b_dir, b_neu, beta1, beta2, 0};
   // the kernel runs its J = 4 instantiation when n is a multiple of 4 and the pointers are aligned; flags bit 256 (emulation
-  // only) selects J = 3 there, as an unaligned pointer does (with a K plane when it fits: bit 512 leaves it out)
+  // only) selects J = 3 there, as an unaligned pointer does
   if ((n & 3) == 0 && !(flags & 256)) return band_emulation<4>(Kp, yp, gyp, partials, B, pl, p, flags);
-  if ((n & 3) == 0 && !(flags & 512)) { pl.planes = 4; pl.lds_floats = 4ll * pl.rows_f * pl.w + (long long)kRowTab * pl.rows_f; }
   flags &= 255;
   switch (pl.jl) {
     case 3: return band_emulation<3>(Kp, yp, gyp, partials, B, pl, p, flags);
@@ -270,7 +247,7 @@ int emu_darcy_loss_band(const float* Kp, const float* yp, float* gyp, float* par
 int emu_band_plan(int n, long long lds_floats_max, int* out) {
   band::Plan pl;
   if (!band::choose_plan(n, lds_floats_max, pl)) return 0;
-  out[0] = pl.waves; out[1] = pl.npass; out[2] = pl.nbands; out[3] = pl.rpp; out[4] = (int)pl.lds_floats; out[5] = pl.cap;
+  out[0] = pl.waves; out[1] = pl.npass; out[2] = pl.nbands; out[3] = pl.rpw; out[4] = (int)pl.lds_floats; out[5] = pl.cap;
   return 1;
 }
 

