@@ -859,6 +859,27 @@ def main():
         dt = float(t.max().item())
     means = trainer.epoch_means()
     mark('warm-up + timed steps')
+    # a SHORT timed window (the driver's --steps 20 --warmup 5) starts ~8 ms after the process's first kernels: the GPU reaches
+    # its loaded clocks ~10 steps after any pause (tools/step_series.py: 1.78, 1.75, 1.74, 1.73, 1.69 ... 1.64 ms from step
+    # 11 on, the same ramp after a 20 ms idle mid-run), so steps 6-25 read ~1 % above the rate an epoch of 256 steps runs at.
+    # `value` stays what the contract times; the steady state is reported beside it
+    steady = None
+    if world == 1 and total < 100:
+        n_more = 128
+        for j in range(16):
+            trainer.step(batch(total + j), sched.step(1.0))
+        sync()
+        s0 = time.perf_counter()
+        for j in range(n_more):
+            trainer.step(batch(total + 16 + j), sched.step(1.0))
+        sync()
+        s1 = time.perf_counter()
+        steady = {'ms_per_step': round((s1 - s0) / n_more * 1e3, 4), 'samples_per_s': round(B * n_more / (s1 - s0), 1),
+                  'steps': n_more, 'after_steps': total + 16,
+                  'note': 'same trainer, the steps right behind the timed ones: the timed window of a short run lies inside the '
+                          "GPU's clock ramp (tools/step_series.py, EXPERIMENTS.md round 5)"}
+        trainer.epoch_means()
+        mark('steady-state window')
     ar_us = allreduce_timing(trainer) if world > 1 else None
     host = None
     if not args.graph:                                     # every rank steps (the all-reduce is collective); rank 0 reports
@@ -964,6 +985,8 @@ def main():
         }
         if host is not None:
             out['host_enqueue_ms_per_step'] = host['host_enqueue_ms_per_step']
+        if steady is not None:
+            out['steady_state'] = steady
         if dp1 is not None:
             out['dp1_rccl_ms_per_step'] = dp1['dp1_rccl_ms_per_step']
             out['dp1_rccl'] = dp1

@@ -33,6 +33,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf['traffic'] is None or rf['traffic'] >= 0.99 * rf['algorithmic_bytes_per_launch']
     assert math.isclose(rf['achieved'], rf['algorithmic_bytes_per_launch'] / rf['us_per_launch'] / 1e3, rel_tol=2e-2)
     assert math.isfinite(d['loss_mean_over_run'])
+    # a short window lies inside the GPU's clock ramp: the steady state of the same trainer is reported beside it
+    ss = d['steady_state']
+    assert ss['steps'] == 128 and 0.5 * d['ms_per_step'] < ss['ms_per_step'] < 1.05 * d['ms_per_step']
 
 
 @pytest.mark.gpu
