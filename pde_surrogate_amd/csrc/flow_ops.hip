@@ -225,6 +225,11 @@ __device__ __forceinline__ void block_add_logp(float v, double* acc, int b, int 
   if (tid == 0) atomicAdd(&acc[(long long)rep_of_block(nrep) * rs + b], (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// The coupling network's last layer is a Conv2dZeros: h = (conv + bias) * exp(3 scale) (glow_msc.py:519-531).  With
+// d.gamma = bias and d.beta = scale (NULL: none) the coupling applies that epilogue itself -- `x2` holds the RAW convolution
+// output, is rewritten in place with h (the backward pass reads it), and no PDES_OP_BIAS_SCALE launch stands between
+// the convolution and the coupling; the backward pass turns dL/dh into dL/d(conv) and accumulates {dbias, dscale} into
+// d.bn_grad (slot 2 c + {0, 1} of a replica: the layout of flow_bias_scale_kernel<1>).
 // grid (ceil(HW / 256), B)
 __global__ __launch_bounds__(256) void flow_coupling_kernel(pdes_conv_desc d) {
   __shared__ double red[4];
@@ -232,14 +237,20 @@ __global__ __launch_bounds__(256) void flow_coupling_kernel(pdes_conv_desc d) {
   const int C = d.Cin, n2 = C / 2, n1 = C - n2;
   const bool act = p < HW;
   const float* x = d.x + (size_t)b * d.x_ctot * HW + p;
-  const float* h = d.x2 + (size_t)b * d.x2_ctot * HW + p;
+  float* h = const_cast<float*>(d.x2) + (size_t)b * d.x2_ctot * HW + p;
   float* o = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW + p;
   float ld = 0.f;
   if (act) {
     for (int c = 0; c < n1; ++c) o[(size_t)c * HW] = x[(size_t)c * HW];
     for (int k = 0; k < n2; ++k) {
-      const float shift = h[(size_t)(2 * k) * HW];
-      const float s = sigmoidf_(h[(size_t)(2 * k + 1) * HW] + 2.f);
+      float shift = h[(size_t)(2 * k) * HW], raw = h[(size_t)(2 * k + 1) * HW];
+      if (d.gamma) {
+        shift = (shift + d.gamma[2 * k]) * (d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f);
+        raw = (raw + d.gamma[2 * k + 1]) * (d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f);
+        h[(size_t)(2 * k) * HW] = shift;
+        h[(size_t)(2 * k + 1) * HW] = raw;
+      }
+      const float s = sigmoidf_(raw + 2.f);
       const float v = x[(size_t)(n1 + k) * HW];
       o[(size_t)(n1 + k) * HW] = (d.flags & PDES_FLOW_FORWARD) ? (v + shift) * s : v / s - shift;
       ld += logf(s);
@@ -249,8 +260,10 @@ __global__ __launch_bounds__(256) void flow_coupling_kernel(pdes_conv_desc d) {
 }
 
 __global__ __launch_bounds__(256) void flow_coupling_bwd_kernel(pdes_conv_desc d) {
-  const int HW = d.Hin * d.Win, b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= HW) return;
+  __shared__ float part[2 * 24 * 2][4];          // [h channel][dbias, dscale][wave]   (mix_ok: C <= 48)
+  const int HW = d.Hin * d.Win, b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
+  const bool act = p < HW, fold = d.gamma != nullptr;
+  if (!act && !fold) return;
   const int C = d.Cin, n2 = C / 2, n1 = C - n2;
   const float cst = d.p1 ? d.p1[b] : 0.f;
   const float* x = d.x + (size_t)b * d.x_ctot * HW + p;
@@ -258,23 +271,49 @@ __global__ __launch_bounds__(256) void flow_coupling_bwd_kernel(pdes_conv_desc d
   const float* g = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HW + p;
   float* tx = d.t_in + (size_t)b * d.x_ctot * HW + p;
   float* th = d.t2 + (size_t)b * d.x2_ctot * HW + p;
-  for (int c = 0; c < n1; ++c) {
-    const float v = g[(size_t)c * HW];
-    tx[(size_t)c * HW] = d.t_accumulate ? tx[(size_t)c * HW] + v : v;
-  }
+  if (act)
+    for (int c = 0; c < n1; ++c) {
+      const float v = g[(size_t)c * HW];
+      tx[(size_t)c * HW] = d.t_accumulate ? tx[(size_t)c * HW] + v : v;
+    }
   for (int k = 0; k < n2; ++k) {
-    const float s = sigmoidf_(h[(size_t)(2 * k + 1) * HW] + 2.f);
-    const float gv = g[(size_t)(n1 + k) * HW], v = x[(size_t)(n1 + k) * HW];
-    const float gx = gv / s;
-    tx[(size_t)(n1 + k) * HW] = d.t_accumulate ? tx[(size_t)(n1 + k) * HW] + gx : gx;
-    th[(size_t)(2 * k) * HW] = -gv;
-    th[(size_t)(2 * k + 1) * HW] = (cst - gx * v) * (1.f - s);     // out = v / s - shift, log s; ds/dh = s (1 - s)
+    float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (act) {
+      const float h1 = h[(size_t)(2 * k + 1) * HW];
+      const float s = sigmoidf_(h1 + 2.f);
+      const float gv = g[(size_t)(n1 + k) * HW], v = x[(size_t)(n1 + k) * HW];
+      const float gx = gv / s;
+      tx[(size_t)(n1 + k) * HW] = d.t_accumulate ? tx[(size_t)(n1 + k) * HW] + gx : gx;
+      g0 = -gv;
+      g1 = (cst - gx * v) * (1.f - s);     // out = v / s - shift, log s; ds/dh = s (1 - s)
+      if (fold) {                          // dL/dh -> dL/d(conv) = dL/dh e;  dscale = sum 3 dL/dh h;  dbias = sum dL/d(conv)
+        q0 = 3.f * g0 * h[(size_t)(2 * k) * HW];
+        q1 = 3.f * g1 * h1;
+        g0 *= d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f;
+        g1 *= d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f;
+      }
+      th[(size_t)(2 * k) * HW] = g0;
+      th[(size_t)(2 * k + 1) * HW] = g1;
+    }
+    if (fold) {
+      const float a0 = wave_sum(g0), s0 = wave_sum(q0), a1 = wave_sum(g1), s1 = wave_sum(q1);
+      if ((tid & 63) == 0) {
+        part[(2 * k) * 2 + 0][tid >> 6] = a0; part[(2 * k) * 2 + 1][tid >> 6] = s0;
+        part[(2 * k + 1) * 2 + 0][tid >> 6] = a1; part[(2 * k + 1) * 2 + 1][tid >> 6] = s1;
+      }
+    }
+  }
+  if (!fold) return;
+  __syncthreads();
+  if (tid < 4 * n2) {                             // slot 2 c + {0: dbias, 1: dscale}
+    const double t = ((double)part[tid][0] + (double)part[tid][1]) + ((double)part[tid][2] + (double)part[tid][3]);
+    atomicAdd(&d.bn_grad[(long long)rep_of_block(d.nrep) * d.rep_stride + tid], t);
   }
 }
 
 static bool coupling_ok(const pdes_conv_desc& d) {
-  return flow_common_ok(d) && d.upsample == PDES_OP_COUPLING && d.Cin == d.Cout && d.Cin >= 2 && d.Hin == d.Hout &&
-         d.Win == d.Wout && d.x && d.x2 && d.out && d.x2_ctot >= 2 * (d.Cin / 2);
+  return flow_common_ok(d) && d.upsample == PDES_OP_COUPLING && d.Cin == d.Cout && d.Cin >= 2 && d.Cin <= 48 && d.Hin == d.Hout &&
+         d.Win == d.Wout && d.x && d.x2 && d.out && d.x2_ctot >= 2 * (d.Cin / 2) && (d.gamma || !d.beta);
 }
 
 int flow_coupling_forward(const pdes_conv_desc& d, hipStream_t st) {
@@ -285,7 +324,7 @@ int flow_coupling_forward(const pdes_conv_desc& d, hipStream_t st) {
 }
 
 int flow_coupling_backward(const pdes_conv_desc& d, hipStream_t st) {
-  if (!coupling_ok(d) || !d.g || !d.t_in || !d.t2 || (d.flags & PDES_FLOW_FORWARD)) return PDES_EINVAL;
+  if (!coupling_ok(d) || !d.g || !d.t_in || !d.t2 || (d.flags & PDES_FLOW_FORWARD) || (d.gamma && !d.bn_grad)) return PDES_EINVAL;
   hipLaunchKernelGGL(flow_coupling_bwd_kernel, dim3(cdiv(d.Hin * d.Win, 256), d.B), dim3(256), 0, st, d);
   PDES_LAUNCH_CHECK();
   return PDES_OK;

@@ -33,6 +33,8 @@ FLOW_FORWARD, GAUSS_DETACH_LSD = 1, 2
 MAX_MIX_CHANNELS = 48
 _FUSE_COPY_FINALIZE = True   # PDES_OP_COPY backward applies its channels' finalize on load (False: separate launch; A/B only)
 _MERGE_COPY = True        # torch.cat((y1, cond), 1) as ONE two-source copy descriptor (False: one per source; A/B only)
+_FOLD_ZEROS = True        # the coupling kernels apply the coupling net's Conv2dZeros epilogue (bias, exp(3 scale)) and its
+                          # backward themselves (False: a PDES_OP_BIAS_SCALE launch in between, each way; A/B only)
 
 
 class FlowItem(ctypes.Structure):
@@ -198,8 +200,11 @@ def _coupling_net(specs, bufs, lay, z, nb, hb, n1, n2, cond, cc, r, growth, with
                            conv=f'{cp}.denselayer{k}.conv1', norm=f'{cp}.denselayer{k}.norm1', k=3, pad=1))
     specs.append(_Spec('conv', nb, hb, cn + 3 * growth, 2 * n2, r, conv=cp + '.reduce.conv_zero.conv',
                        norm=cp + '.reduce.norm1', k=3, pad=1))
-    specs.append(_Spec(OP_BIAS_SCALE, hb, hb, 2 * n2, 2 * n2, r, bias=cp + '.reduce.conv_zero.conv.bias',
-                       scale_p=cp + '.reduce.conv_zero.scale'))
+    zeros = dict(bias=cp + '.reduce.conv_zero.conv.bias', scale_p=cp + '.reduce.conv_zero.scale')
+    if _FOLD_ZEROS:
+        return zeros                 # -> the PDES_OP_COUPLING descriptor behind the net
+    specs.append(_Spec(OP_BIAS_SCALE, hb, hb, 2 * n2, 2 * n2, r, **zeros))
+    return {}
 
 
 def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features=48):
@@ -235,16 +240,16 @@ def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features
             first = i == 1 and j == 1
             z = f'z{i}_{j}'
             nb, hb = f'n{i}_{j}', f'h{i}_{j}'
-            _coupling_net(specs, bufs, lay, z, nb, hb, n1, n2, cond, cc, r, growth, True)
+            zeros = _coupling_net(specs, bufs, lay, z, nb, hb, n1, n2, cond, cc, r, growth, True)
             if first:
                 bufs['out'] = [Ci, r]
-                specs.append(_Spec(OP_COUPLING, z, 'out', Ci, Ci, r, h=hb))
+                specs.append(_Spec(OP_COUPLING, z, 'out', Ci, Ci, r, h=hb, **zeros))
             else:
                 ub, zn = f'u{i}_{j}', f'z{i}_{j - 1}'
                 bufs[ub] = [Ci, r]
                 if zn not in bufs:
                     bufs[zn] = [Ci, r]
-                specs.append(_Spec(OP_COUPLING, z, ub, Ci, Ci, r, h=hb))
+                specs.append(_Spec(OP_COUPLING, z, ub, Ci, Ci, r, h=hb, **zeros))
                 specs.append(_Spec(OP_MIX, ub, zn, Ci, Ci, r, index=len(mix)))
                 mix.append((Ci, r, lay + '.norm', lay + '.conv1x1', i, j))
         if i > 1:                                       # Squeeze.reverse (glow_msc.py:629-636, :422-432)
@@ -282,9 +287,9 @@ def _plan_glow_forward(y_channels, enc_blocks, flow_blocks, lu, mix_index, growt
                 specs.append(_Spec(OP_MIX, cur, gb, Ci, Ci, r, index=mix_index[(i, j)], flags=FLOW_FORWARD))
                 cur = gb
             nb, hb, fb = f'n{i}_{j}', f'h{i}_{j}', f'f{i}_{j}'
-            _coupling_net(specs, bufs, lay, cur, nb, hb, n1, n2, cond, cc, r, growth, False)
+            zeros = _coupling_net(specs, bufs, lay, cur, nb, hb, n1, n2, cond, cc, r, growth, False)
             bufs[fb] = [Ci, r]
-            specs.append(_Spec(OP_COUPLING, cur, fb, Ci, Ci, r, h=hb, flags=FLOW_FORWARD))
+            specs.append(_Spec(OP_COUPLING, cur, fb, Ci, Ci, r, h=hb, flags=FLOW_FORWARD, **zeros))
             cur = fb
         if 1 < i < L:                                    # Split.forward (glow_msc.py:561-573)
             p = f'p{i}'
@@ -353,9 +358,9 @@ class _GlowEngine(_EngineBase):
                 n_bn += 2 * s.cin
         aux_off, n_aux = {}, 0
         for i, s in enumerate(specs):
-            if s.kind == OP_BIAS_SCALE:
+            if s.kind == OP_BIAS_SCALE or (s.kind == OP_COUPLING and s.x.get('bias')):
                 aux_off[i] = n_aux
-                n_aux += 2 * s.cout
+                n_aux += 2 * _aux_channels(s)
         mix_off, n_mix = [], 0
         for (c, *_rest) in mixes:
             mix_off.append(n_mix)
@@ -490,6 +495,10 @@ class _GlowEngine(_EngineBase):
                 h = s.x['h']
                 d.x2, d.x2_ctot = self.X[h].data_ptr(), bufs[h][0]
                 d.acc, d.p1 = self._logp_acc, self.glogp.data_ptr()
+                if s.x.get('bias'):                      # the folded Conv2dZeros epilogue of the coupling net
+                    d.gamma = _get_param(net, s.x['bias']).data_ptr()
+                    d.beta = _get_param(net, s.x['scale_p']).data_ptr()
+                    d.bn_grad = a0 + 8 * (base_aux + aux_off[i])
                 if self.has_grad:
                     d.t2 = self.T[h].data_ptr()
                     d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
@@ -532,13 +541,13 @@ class _GlowEngine(_EngineBase):
         self._dummy = torch.zeros(max(s.cout for s in specs), **f32)      # dscale of a bias-only op lands here
         items = []
         for i, s in enumerate(specs):
-            if s.kind != OP_BIAS_SCALE:
+            if i not in aux_off:
                 continue
             it = BnItem()
             it.bn_grad = a0 + 8 * (base_aux + aux_off[i])
             it.dgamma = gv[s.x['bias']].data_ptr()
             it.dbeta = gv[s.x['scale_p']].data_ptr() if s.x['scale_p'] else self._dummy.data_ptr()
-            it.C, it.count = s.cout, 1
+            it.C, it.count = _aux_channels(s), 1
             items.append(it)
         self.n_aux, self.max_aux = len(items), max(it.C for it in items)
         self.aux_table = torch.frombuffer(bytearray(bytes((BnItem * len(items))(*items))), dtype=torch.uint8).to(dev)
@@ -630,6 +639,12 @@ class _GlowEngine(_EngineBase):
         if self.n_mix:
             _lib.check(L.pdes_flow_param_grads(self.flow_table.data_ptr(), self.n_mix, self.glogp.data_ptr(), self.B, self.nrep,
                                                self.rep_stride, st), 'pdes_flow_param_grads')
+
+
+def _aux_channels(s):
+    """channels of the {dbias, dscale} table of a bias/scale op, or of the epilogue folded into a coupling (its 2 n2 shift /
+    scale channels)"""
+    return 2 * (s.cin // 2) if s.kind == OP_COUPLING else s.cout
 
 
 def _get_param(net, path):

@@ -317,6 +317,29 @@ def test_small_map_matrix_core_kernels_against_the_generic_ones(dev, option):
     assert dev_rel[0][0] < 3e-2 and sum(d > 2e-3 for d, _ in dev_rel) <= 16, dev_rel[:10]      # (isolated ReLU flips, see G19)
 
 
+def test_folded_conv2dzeros_epilogue_equals_the_separate_launches(dev, monkeypatch):
+    """the coupling kernels apply the coupling net's Conv2dZeros epilogue (bias, exp(3 scale)) and its backward themselves
+    (glow_msc._FOLD_ZEROS): same y, log p and parameter gradients as with a PDES_OP_BIAS_SCALE launch each way -- the
+    arithmetic per element is identical, only the partition of the {dbias, dscale} sums differs"""
+    from pde_surrogate_amd.models import glow_msc
+    g = golden('G18_cglow_small.npz')
+    x = torch.from_numpy(g['x']).to(dev)
+    res = {}
+    for fold in (True, False):
+        monkeypatch.setattr(glow_msc, '_FOLD_ZEROS', fold)
+        net = _small(g, dev).train()
+        n_bias = sum(1 for s in net._acquire(x).specs if s.kind == glow_msc.OP_BIAS_SCALE)
+        loss, _, _, y, logp = reverse_kl(net, x, _eps(g, dev), float(g['beta']), float(g['weight_bound']))
+        loss.backward()
+        res[fold] = (y.detach().clone(), logp.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}, n_bias)
+    n_layers = sum(g['flow_blocks'])
+    assert res[False][3] - res[True][3] == n_layers            # one launch less per reversible layer, each way
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k, g0 in res[False][2].items():
+        g1 = res[True][2][k]
+        assert float((g1 - g0).norm()) <= 2e-6 * float(g0.norm()) + 1e-9, k
+
+
 def test_reverse_kl_trainer_data_parallel_path_one_rank(dev):
     """the trainer's data-parallel branch (parameter broadcast, flat all-reduce over RCCL, grad_scale = 1 / world) with a
     process group of ONE rank must reproduce the single-process step"""

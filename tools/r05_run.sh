@@ -22,6 +22,8 @@ PY
       tail -12 $OUT/bench.err ;;
     loss) timeout 900 python -m pytest tests/test_loss_gpu.py -m gpu -x -q -p no:cacheprovider > $OUT/gpu_loss.txt 2>&1; echo "loss rc=$?" | tee -a $OUT/status.txt; tail -5 $OUT/gpu_loss.txt ;;
     gensizes) timeout 600 python tools/bench_loss_generic.py 2>&1 | grep -v amdgpu.ids > $OUT/loss_kernel_generic_sizes.log; echo "gensizes rc=$?" | tee -a $OUT/status.txt; cat $OUT/loss_kernel_generic_sizes.log ;;
+    cglow) timeout 900 python -m pytest tests/test_cglow_gpu.py -m gpu -x -q -p no:cacheprovider > $OUT/gpu_cglow.txt 2>&1; echo "cglow rc=$?" | tee -a $OUT/status.txt; tail -5 $OUT/gpu_cglow.txt ;;
+    cglowb) for i in 1 2; do timeout 600 python bench.py --leg cglow --no-cpu-baseline 2> $OUT/cglow_bench.err | tee $OUT/cglow_bench.json | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('ms_per_step','samples_per_s','dispatches_per_step')})"; done ;;
     benchq) timeout 600 python bench.py --no-extras --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; echo "benchq rc=$?" | tee -a $OUT/status.txt; python -c "
 import json,sys; d=json.loads(open('$OUT/bench_quick.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])" ;;
   esac
