@@ -195,7 +195,11 @@ int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* im
                                  (2 n2 channels, n2 = C / 2, n1 = C - n2): out[:n1] = x[:n1]; s = sigmoid(h[2k+1] + 2);
                                  out[n1 + k] = x[n1 + k] / s - h[2k]; acc[b] += sum log s.  PDES_FLOW_FORWARD (:317-334):
                                  out[n1 + k] = (x[n1 + k] + h[2k]) * s.  Backward (z -> y only): t_in = dL/dx (written), t2 = dL/dh,
-                                 p1 = dL/d(logp) per sample (B floats, nullable) */
+                                 p1 = dL/d(logp) per sample (B floats, nullable).  gamma != NULL: x2 holds the RAW output of the
+                                 coupling net's last convolution and this descriptor applies its Conv2dZeros epilogue (:237-252)
+                                 h = (x2 + gamma[c]) * exp(3 beta[c]) (beta = NULL: bias only), rewriting x2 with h; backward:
+                                 t2 = dL/d(raw) = dL/dh exp(3 beta), bn_grad (2 n2, 2) += {dbias, dscale} (the PDES_OP_BIAS_SCALE
+                                 layout) -- no PDES_OP_BIAS_SCALE descriptor between the convolution and the coupling */
 #define PDES_OP_MIX 7         /* InvertibleConv1x1[LU].reverse + ActNorm.reverse (glow_msc.py:390-397): out = (W x - p1) / p0 per pixel,
                                  W = x2 (C, C) row-major, p0 / p1 = ActNorm weight / bias.  PDES_FLOW_FORWARD (:383-388): out = W (p0 x + p1)
                                  (the caller passes the inverse matrix).  Backward: t_in = W^T (g / p0) (written);
