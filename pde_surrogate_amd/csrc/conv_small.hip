@@ -71,26 +71,53 @@ __global__ __launch_bounds__(256 * KG) void conv_small_fwd_kernel(pdes_conv_desc
   float4* cf = reinterpret_cast<float4*>(sm_small);
   float* pl = sm_small + 4 * Cin;
   float* red = pl + Cin * CS;
+  const int ntp = (nt_total + 7) & ~7, nt_base = blockIdx.y * NT;
+  const int ksf = ((Cin + 15) >> 4) * 4;
+  // the weight fragments of this wave group's FIRST k-step: nothing in front of the matrix loop depends on them, so their
+  // round trip runs under the staging of the planes; inside the loop the next k-step's nine fragments are requested
+  // before the current one's MFMAs (a k-step is 9 MFMAs = 0.12 us of matrix time against ~1 us of L2 round trip: without
+  // the prefetch a layer was its 13-22 round trips in a row)
+  float w[9][NT], wn[9][NT];
+  {
+    const float* wp = wm + ((size_t)min(kgrp, ksf - 1) * 9 * ntp + nt_base) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w[t][n] = wp[((size_t)t * ntp + n) * 64];
+  }
   if (d.has_bn)
     for (int c = tid; c < Cin; c += NTH) {
       const BnS k = bn_coef_s(d, c);
       cf[c] = make_float4(k.mean, k.gamma * k.invstd, k.beta, 0.f);
     }
-  for (int i = tid; i < Cin * CS; i += NTH) pl[i] = 0.f;
-  __syncthreads();
+  // the halo of every plane (+ the pad word): the interior is written by the staging loop below, no barrier in between
+  constexpr int NHALO = CS - HWI;
+  for (int i = tid; i < Cin * NHALO; i += NTH) {
+    const int c = i / NHALO, h = i % NHALO;
+    // h: 0 .. PITCH-1 top row, PITCH .. 2 PITCH-1 bottom row, then the two side columns of the WI inner rows, then the pad
+    int off;
+    if (h < PITCH) off = h;
+    else if (h < 2 * PITCH) off = (PITCH - 1) * PITCH + (h - PITCH);
+    else if (h < 2 * PITCH + 2 * WI) { const int r = (h - 2 * PITCH) >> 1; off = (r + 1) * PITCH + ((h & 1) ? PITCH - 1 : 0); }
+    else off = PITCH * PITCH + (h - 2 * PITCH - 2 * WI);
+    pl[c * CS + off] = 0.f;
+  }
+  if (d.has_bn) __syncthreads();               // the coefficients
   const float* xb = d.x + (size_t)b * d.x_ctot * HWI;
-  for (int e = tid; e < Cin * HWI; e += NTH) {
-    const int c = e / HWI, p = e % HWI;
-    float z = xb[e];
+  for (int e = tid; e < Cin * (HWI / 4); e += NTH) {
+    const int c = e / (HWI / 4), p = (e % (HWI / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)c * HWI + p);
+    float z[4] = {v.x, v.y, v.z, v.w};
     if (d.has_bn) {
       const float4 k = cf[c];
-      z = fmaxf(0.f, (z - k.x) * k.y + k.z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[j] = fmaxf(0.f, (z[j] - k.x) * k.y + k.z);
     }
-    pl[c * CS + (p / WI + 1) * PITCH + (p % WI) + 1] = z;
+    float* q = pl + c * CS + (p / WI + 1) * PITCH + (p % WI) + 1;      // (WI is a multiple of 4: the four pixels share a row)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = z[j];
   }
   __syncthreads();
-  const int ntp = (nt_total + 7) & ~7, nt_base = blockIdx.y * NT;
-  const int ksf = ((Cin + 15) >> 4) * 4;
   const int i = lane & 15, kq = lane >> 4;
   // output pixel (oy, ox) reads input (S oy + ky - 1, S ox + kx - 1): with the halo, plane[(S oy + ky) PITCH + S ox + kx]
   const int aoff = (S * (2 * wave + (i >> 3)) + 1) * PITCH + S * (i & 7) + 1;
@@ -100,18 +127,23 @@ __global__ __launch_bounds__(256 * KG) void conv_small_fwd_kernel(pdes_conv_desc
   for (int n = 0; n < NT; ++n) acc[n] = (v4f){0.f, 0.f, 0.f, 0.f};
   for (int ks = kgrp; ks < ksf; ks += KG) {
     const float* ap = pl + min(4 * ks + kq, Cin - 1) * SM_CS + aoff;      // (channels past Cin meet zero weights)
-    const float* wp = wm + ((size_t)ks * 9 * ntp + nt_base) * 64 + lane;
-    float w[9][NT];
+    {
+      const float* wp = wm + ((size_t)min(ks + KG, ksf - 1) * 9 * ntp + nt_base) * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) w[t][n] = wp[((size_t)t * ntp + n) * 64];
+        for (int n = 0; n < NT; ++n) wn[t][n] = wp[((size_t)t * ntp + n) * 64];
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float a = ap[(t / 3 - 1) * SM_PITCH + (t % 3 - 1)];
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[t][n], acc[n], 0, 0, 0);
     }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w[t][n] = wn[t][n];
   }
   if (KG > 1) {                      // the other groups' partial sums: through LDS (the planes are no longer needed)
     __syncthreads();
@@ -168,6 +200,18 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
   float* pl = sm_small;
   float4* cf = reinterpret_cast<float4*>(pl + ((Cout * SM_CS + 3) & ~3));
   float* red = reinterpret_cast<float*>(cf + NT * 16);
+  const int ntp = (nt_total + 7) & ~7;
+  const int ksb = ((Cout + 15) >> 4) * 4;
+  // (the first k-step's weight fragments are requested before anything else, the next k-step's before the current one's
+  //  MFMAs: see the forward kernel)
+  float w[9][NT], wn[9][NT];
+  {
+    const float* wp = wm + (size_t)nt_base * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w[t][n] = wp[((size_t)t * ntp + n) * 64];
+  }
   if (d.has_bn)
     for (int c = tid; c < NT * 16; c += 256) {
       const BnS k = bn_coef_s(d, min(nt_base * 16 + c, d.Cin - 1));
@@ -181,8 +225,6 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
     pl[c * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = gb[e];
   }
   __syncthreads();
-  const int ntp = (nt_total + 7) & ~7;
-  const int ksb = ((Cout + 15) >> 4) * 4;
   const int i = lane & 15, kq = lane >> 4;
   const int aoff = (2 * wave + (i >> 3) + 1) * SM_PITCH + (i & 7) + 1;
   // the epilogue's operands (raw activation, accumulator T) do not depend on the matrix loop: fetch them first
@@ -200,20 +242,23 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
   for (int n = 0; n < NT; ++n) acc[n] = (v4f){0.f, 0.f, 0.f, 0.f};
   for (int ks = 0; ks < ksb; ++ks) {
     const float* ap = pl + min(4 * ks + kq, Cout - 1) * SM_CS + aoff;
-    const float* wp = wm + ((size_t)ks * 9 * ntp + nt_base) * 64 + lane;
-    // all 9 x NT weight fragments of the k-step first (independent loads in flight together), then the MFMAs: with the
-    // load inside the MFMA loop every MFMA waited for its own round trip (54 us per layer instead of ~15)
-    float w[9][NT];
+    {
+      const float* wp = wm + ((size_t)min(ks + 1, ksb - 1) * 9 * ntp + nt_base) * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) w[t][n] = wp[((size_t)t * ntp + n) * 64];
+        for (int n = 0; n < NT; ++n) wn[t][n] = wp[((size_t)t * ntp + n) * 64];
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float a = ap[(t / 3 - 1) * SM_PITCH + (t % 3 - 1)];
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[t][n], acc[n], 0, 0, 0);
     }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w[t][n] = wn[t][n];
   }
   // epilogue: ReLU mask, gamma, T (+)=, dgamma / dbeta, sums of the channels whose T is complete
   const int n = lane & 15;
