@@ -230,6 +230,10 @@ __device__ __forceinline__ void block_add_logp(float v, double* acc, int b, int 
 // output, is rewritten in place with h (the backward pass reads it), and no PDES_OP_BIAS_SCALE launch stands between
 // the convolution and the coupling; the backward pass turns dL/dh into dL/d(conv) and accumulates {dbias, dscale} into
 // d.bn_grad (slot 2 c + {0, 1} of a replica: the layout of flow_bias_scale_kernel<1>).
+// Both kernels walk the channels of ONE pixel per thread: the loads of FLOW_KB channels are issued together, then their
+// arithmetic and stores (a load - compute - store loop per channel was one memory round trip per channel in a row, the
+// stores keeping the compiler from moving the next channel's loads up: 9-14 us per launch on the 12-channel levels).
+constexpr int FLOW_KB = 8;
 // grid (ceil(HW / 256), B)
 __global__ __launch_bounds__(256) void flow_coupling_kernel(pdes_conv_desc d) {
   __shared__ double red[4];
@@ -239,28 +243,49 @@ __global__ __launch_bounds__(256) void flow_coupling_kernel(pdes_conv_desc d) {
   const float* x = d.x + (size_t)b * d.x_ctot * HW + p;
   float* h = const_cast<float*>(d.x2) + (size_t)b * d.x2_ctot * HW + p;
   float* o = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW + p;
+  const bool fwd = (d.flags & PDES_FLOW_FORWARD) != 0;
   float ld = 0.f;
   if (act) {
-    for (int c = 0; c < n1; ++c) o[(size_t)c * HW] = x[(size_t)c * HW];
-    for (int k = 0; k < n2; ++k) {
-      float shift = h[(size_t)(2 * k) * HW], raw = h[(size_t)(2 * k + 1) * HW];
-      if (d.gamma) {
-        shift = (shift + d.gamma[2 * k]) * (d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f);
-        raw = (raw + d.gamma[2 * k + 1]) * (d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f);
-        h[(size_t)(2 * k) * HW] = shift;
-        h[(size_t)(2 * k + 1) * HW] = raw;
+    for (int c0 = 0; c0 < n1; c0 += FLOW_KB) {
+      float v[FLOW_KB];
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j) v[j] = x[(size_t)min(c0 + j, n1 - 1) * HW];
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j)
+        if (c0 + j < n1) o[(size_t)(c0 + j) * HW] = v[j];
+    }
+    for (int k0 = 0; k0 < n2; k0 += FLOW_KB) {
+      float hs[FLOW_KB], hr[FLOW_KB], xv[FLOW_KB];
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j) {
+        const int k = min(k0 + j, n2 - 1);
+        hs[j] = h[(size_t)(2 * k) * HW];
+        hr[j] = h[(size_t)(2 * k + 1) * HW];
+        xv[j] = x[(size_t)(n1 + k) * HW];
       }
-      const float s = sigmoidf_(raw + 2.f);
-      const float v = x[(size_t)(n1 + k) * HW];
-      o[(size_t)(n1 + k) * HW] = (d.flags & PDES_FLOW_FORWARD) ? (v + shift) * s : v / s - shift;
-      ld += logf(s);
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j) {
+        const int k = k0 + j;
+        if (k < n2) {
+          float shift = hs[j], raw = hr[j];
+          if (d.gamma) {
+            shift = (shift + d.gamma[2 * k]) * (d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f);
+            raw = (raw + d.gamma[2 * k + 1]) * (d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f);
+            h[(size_t)(2 * k) * HW] = shift;
+            h[(size_t)(2 * k + 1) * HW] = raw;
+          }
+          const float sg = sigmoidf_(raw + 2.f);
+          o[(size_t)(n1 + k) * HW] = fwd ? (xv[j] + shift) * sg : xv[j] / sg - shift;
+          ld += logf(sg);
+        }
+      }
     }
   }
   if (d.acc) block_add_logp(ld, d.acc, b, d.nrep, d.rep_stride, red);
 }
 
 __global__ __launch_bounds__(256) void flow_coupling_bwd_kernel(pdes_conv_desc d) {
-  __shared__ float part[2 * 24 * 2][4];          // [h channel][dbias, dscale][wave]   (mix_ok: C <= 48)
+  __shared__ float part[2 * 24 * 2][4];          // [h channel][dbias, dscale][wave]   (coupling_ok: C <= 48)
   const int HW = d.Hin * d.Win, b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
   const bool act = p < HW, fold = d.gamma != nullptr;
   if (!act && !fold) return;
@@ -271,35 +296,59 @@ __global__ __launch_bounds__(256) void flow_coupling_bwd_kernel(pdes_conv_desc d
   const float* g = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HW + p;
   float* tx = d.t_in + (size_t)b * d.x_ctot * HW + p;
   float* th = d.t2 + (size_t)b * d.x2_ctot * HW + p;
+  const bool accu = d.t_accumulate != 0;
   if (act)
-    for (int c = 0; c < n1; ++c) {
-      const float v = g[(size_t)c * HW];
-      tx[(size_t)c * HW] = d.t_accumulate ? tx[(size_t)c * HW] + v : v;
-    }
-  for (int k = 0; k < n2; ++k) {
-    float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
-    if (act) {
-      const float h1 = h[(size_t)(2 * k + 1) * HW];
-      const float s = sigmoidf_(h1 + 2.f);
-      const float gv = g[(size_t)(n1 + k) * HW], v = x[(size_t)(n1 + k) * HW];
-      const float gx = gv / s;
-      tx[(size_t)(n1 + k) * HW] = d.t_accumulate ? tx[(size_t)(n1 + k) * HW] + gx : gx;
-      g0 = -gv;
-      g1 = (cst - gx * v) * (1.f - s);     // out = v / s - shift, log s; ds/dh = s (1 - s)
-      if (fold) {                          // dL/dh -> dL/d(conv) = dL/dh e;  dscale = sum 3 dL/dh h;  dbias = sum dL/d(conv)
-        q0 = 3.f * g0 * h[(size_t)(2 * k) * HW];
-        q1 = 3.f * g1 * h1;
-        g0 *= d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f;
-        g1 *= d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f;
+    for (int c0 = 0; c0 < n1; c0 += FLOW_KB) {
+      float v[FLOW_KB];
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j) {
+        const int c = min(c0 + j, n1 - 1);
+        v[j] = g[(size_t)c * HW] + (accu ? tx[(size_t)c * HW] : 0.f);
       }
-      th[(size_t)(2 * k) * HW] = g0;
-      th[(size_t)(2 * k + 1) * HW] = g1;
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j)
+        if (c0 + j < n1) tx[(size_t)(c0 + j) * HW] = v[j];
     }
-    if (fold) {
-      const float a0 = wave_sum(g0), s0 = wave_sum(q0), a1 = wave_sum(g1), s1 = wave_sum(q1);
-      if ((tid & 63) == 0) {
-        part[(2 * k) * 2 + 0][tid >> 6] = a0; part[(2 * k) * 2 + 1][tid >> 6] = s0;
-        part[(2 * k + 1) * 2 + 0][tid >> 6] = a1; part[(2 * k + 1) * 2 + 1][tid >> 6] = s1;
+  for (int k0 = 0; k0 < n2; k0 += FLOW_KB) {
+    float h0[FLOW_KB], h1[FLOW_KB], gv[FLOW_KB], xv[FLOW_KB], told[FLOW_KB];
+#pragma unroll
+    for (int j = 0; j < FLOW_KB; ++j) {
+      const int k = min(k0 + j, n2 - 1);
+      h0[j] = h1[j] = gv[j] = xv[j] = told[j] = 0.f;
+      if (act) {
+        h1[j] = h[(size_t)(2 * k + 1) * HW];
+        if (fold) h0[j] = h[(size_t)(2 * k) * HW];
+        gv[j] = g[(size_t)(n1 + k) * HW];
+        xv[j] = x[(size_t)(n1 + k) * HW];
+        if (accu) told[j] = tx[(size_t)(n1 + k) * HW];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FLOW_KB; ++j) {
+      const int k = k0 + j;
+      if (k >= n2) break;
+      float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
+      if (act) {
+        const float sg = sigmoidf_(h1[j] + 2.f);
+        const float gx = gv[j] / sg;
+        tx[(size_t)(n1 + k) * HW] = told[j] + gx;
+        g0 = -gv[j];
+        g1 = (cst - gx * xv[j]) * (1.f - sg);     // out = v / s - shift, log s; ds/dh = s (1 - s)
+        if (fold) {                               // dL/dh -> dL/d(conv) = dL/dh e;  dscale = sum 3 dL/dh h;  dbias = sum dL/d(conv)
+          q0 = 3.f * g0 * h0[j];
+          q1 = 3.f * g1 * h1[j];
+          g0 *= d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f;
+          g1 *= d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f;
+        }
+        th[(size_t)(2 * k) * HW] = g0;
+        th[(size_t)(2 * k + 1) * HW] = g1;
+      }
+      if (fold) {
+        const float a0 = wave_sum(g0), s0 = wave_sum(q0), a1 = wave_sum(g1), s1 = wave_sum(q1);
+        if ((tid & 63) == 0) {
+          part[(2 * k) * 2 + 0][tid >> 6] = a0; part[(2 * k) * 2 + 1][tid >> 6] = s0;
+          part[(2 * k + 1) * 2 + 0][tid >> 6] = a1; part[(2 * k + 1) * 2 + 1][tid >> 6] = s1;
+        }
       }
     }
   }
