@@ -303,40 +303,53 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct(pdes_conv_desc d, 
 // in LDS; a thread owns 4 consecutive output pixels x 8 channels (32 accumulators), reads per kernel row the 14
 // input values they touch as aligned float4 and the 8 channel weights of a tap as two float4 broadcasts.
 // grid (Hout/4, B), block = 32 pixel groups x Cout/8 channel groups (<= 256 threads).
+//
+// PAIR (round 5): one workgroup = TWO groups of 4 output rows x HALF the channels (grid (Hout/8, 2, B): the same number of
+// workgroups, threads and accumulators).  A half wave is what a (row group, channel group) was before -- 32 pixel groups,
+// the same shuffle tree -- so every fp32 partial sum of the statistics is bit-identical to the unpaired form; the two row
+// groups of a channel (the two halves of a wave) are added in fp64, exactly, in front of ONE atomic instead of two:
+// 12.3 k instead of 24.5 k simultaneous fp64 atomics at the head of every step (15.2 -> 12.2 us stand-alone).  (Summing the
+// eight rows in fp32 instead moved the first BatchNorms' statistics in their last bits and with them which marginal ReLUs
+// flip in the small-batch fixtures: EXPERIMENTS.md round 5.)
+template <bool PAIR>
 __global__ __launch_bounds__(256) void conv_fwd_first7(pdes_conv_desc d) {
-  constexpr int K = 7, RB = 4, XR = 2 * RB + K - 2;               // 13 input rows
+  constexpr int K = 7, RB = PAIR ? 8 : 4, XR = 2 * RB + K - 2;    // 13 (21) input rows
   extern __shared__ __attribute__((aligned(16))) float smq[];
   const int LW = ((d.Win + 2 * 3 + 2 + 3) / 4) * 4;                // bordered row, 16-B pitch (72 for 64 columns)
+  const int CW = PAIR ? d.Cout / 2 : d.Cout, c_lo = PAIR ? (int)blockIdx.y * CW : 0;      // this workgroup's channels
   float* xs = smq;                                                 // [XR][LW]
-  float* wt = smq + XR * LW;                                       // [49][Cout]
-  const int tid = threadIdx.x, b = blockIdx.y, oy0 = blockIdx.x * RB;
-  const int nthr = 32 * (d.Cout / 8);
+  float* wt = smq + XR * LW;                                       // [49][CW]
+  const int tid = threadIdx.x, b = PAIR ? blockIdx.z : blockIdx.y, oy0 = blockIdx.x * RB;
+  const int nthr = (PAIR ? 64 : 32) * (CW / 8);
   const float* xin = d.x + (size_t)b * d.x_ctot * d.Hin * d.Win;
   // staging in two unrolled batches (all global loads of a batch are in flight together)
   {
-    float v[4];
+    constexpr int NX = PAIR ? 6 : 4;                  // XR * LW <= 21 * 72 <= 6 * 256  (13 * 76 < 4 * 256)
+    float v[NX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                     // XR * LW <= 13 * 76 < 4 * 256
+    for (int k = 0; k < NX; ++k) {
       const int i = tid + 256 * k, r = i / LW, q = i % LW;
       const int yy = 2 * oy0 - 3 + r, xx = q - 3;
       const bool ok = i < XR * LW && yy >= 0 && yy < d.Hin && xx >= 0 && xx < d.Win;
       v[k] = ok ? xin[yy * d.Win + xx] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int i = tid + 256 * k; if (i < XR * LW) xs[i] = v[k]; }
+    for (int k = 0; k < NX; ++k) { const int i = tid + 256 * k; if (i < XR * LW) xs[i] = v[k]; }
     float w[13];
+    const float* wsrc = d.w + (size_t)c_lo * 49;      // (Cout, 1, 7, 7): a channel range is one contiguous block
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {                    // 49 * Cout <= 49 * 64 < 13 * 256; coalesced reads
+    for (int k = 0; k < 13; ++k) {                    // 49 * CW <= 49 * 64 < 13 * 256; coalesced reads
       const int i = tid + 256 * k;
-      w[k] = i < 49 * d.Cout ? d.w[i] : 0.f;
+      w[k] = i < 49 * CW ? wsrc[i] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 13; ++k) { const int i = tid + 256 * k; if (i < 49 * d.Cout) wt[(i % 49) * d.Cout + i / 49] = w[k]; }
+    for (int k = 0; k < 13; ++k) { const int i = tid + 256 * k; if (i < 49 * CW) wt[(i % 49) * CW + i / 49] = w[k]; }
   }
   __syncthreads();
   if (tid >= nthr) return;
-  const int pg = tid & 31, cg = tid >> 5;
-  const int row = pg >> 3, ox0 = 4 * (pg & 7);
+  // PAIR: lanes 0-31 of a wave = row group 0, lanes 32-63 = row group 1 of the same channel group
+  const int pg = tid & 31, cg = PAIR ? tid >> 6 : tid >> 5, rg = PAIR ? (tid >> 5) & 1 : 0;
+  const int row = 4 * rg + (pg >> 3), ox0 = 4 * (pg & 7);
   float acc[4][8];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_fwd_first7(pdes_conv_desc d) {
     }
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
-      const float* wp = wt + (ky * K + kx) * d.Cout + 8 * cg;
+      const float* wp = wt + (ky * K + kx) * CW + 8 * cg;
       const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
       const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
@@ -362,8 +375,8 @@ __global__ __launch_bounds__(256) void conv_fwd_first7(pdes_conv_desc d) {
         for (int j = 0; j < 8; ++j) acc[u][j] += xv[2 * u + kx] * wv[j];
     }
   }
-  const int HWo = d.Hout * d.Wout;
-  float* ob = d.out + ((size_t)b * d.out_ctot + d.out_coff + 8 * cg) * HWo + (size_t)(oy0 + row) * d.Wout + ox0;
+  const int HWo = d.Hout * d.Wout, c0 = c_lo + 8 * cg;
+  float* ob = d.out + ((size_t)b * d.out_ctot + d.out_coff + c0) * HWo + (size_t)(oy0 + row) * d.Wout + ox0;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     *reinterpret_cast<float4*>(ob + (size_t)j * HWo) = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
@@ -375,9 +388,11 @@ __global__ __launch_bounds__(256) void conv_fwd_first7(pdes_conv_desc d) {
       float q = (acc[0][j] * acc[0][j] + acc[1][j] * acc[1][j]) + (acc[2][j] * acc[2][j] + acc[3][j] * acc[3][j]);
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 32); q += __shfl_xor(q, o, 32); }
-      if (pg == 0) {
-        atomicAdd(&os[2 * (d.out_coff + 8 * cg + j)], (double)s);
-        atomicAdd(&os[2 * (d.out_coff + 8 * cg + j) + 1], (double)q);
+      double sd = (double)s, qd = (double)q;
+      if (PAIR) { sd += __shfl_xor(sd, 32, 64); qd += __shfl_xor(qd, 32, 64); }      // the other row group: exact in fp64
+      if (pg == 0 && rg == 0) {
+        atomicAdd(&os[2 * (d.out_coff + c0 + j)], sd);
+        atomicAdd(&os[2 * (d.out_coff + c0 + j) + 1], qd);
       }
     }
   }
@@ -529,8 +544,13 @@ int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st) {
   if (rc) return rc;
   if (conv_forward_direct_first7(d)) {
     const int LW = ((d.Win + 2 * 3 + 2 + 3) / 4) * 4;
-    const size_t lds = ((size_t)13 * LW + (size_t)49 * d.Cout) * sizeof(float);
-    hipLaunchKernelGGL(conv_fwd_first7, dim3(d.Hout / 4, d.B), dim3(256), lds, st, d);
+    if (d.Hout % 8 == 0 && d.Cout % 16 == 0) {          // two row groups x half the channels per workgroup: half the atomics
+      const size_t lds = ((size_t)21 * LW + (size_t)49 * (d.Cout / 2)) * sizeof(float);
+      hipLaunchKernelGGL(conv_fwd_first7<true>, dim3(d.Hout / 8, 2, d.B), dim3(256), lds, st, d);
+    } else {
+      const size_t lds = ((size_t)13 * LW + (size_t)49 * d.Cout) * sizeof(float);
+      hipLaunchKernelGGL(conv_fwd_first7<false>, dim3(d.Hout / 4, d.B), dim3(256), lds, st, d);
+    }
     PDES_LAUNCH_CHECK();
     return PDES_OK;
   }
