@@ -318,7 +318,7 @@ class _EngineBase:
         workgroup slots go to the finalize -> data-gradient chain on the main stream first, the weight gradients fill
         what is left"""
         key = self.dev if which == 'a' else (self.dev, which)
-        side = self.net._side_streams.get(key)             # (a per-network override, tools/archive/ab_cumask.py)
+        side = self.net._side_streams.get(key)             # (a per-network override, ab_cumask.py of the earlier rounds (git history))
         if side is None:
             side = _DEVICE_SIDE_STREAMS.get(key)
         if side is None:
@@ -794,7 +794,7 @@ class _HipNet(nn.Module):
         self.wgrad_stream = os.environ.get('PDES_WGRAD_STREAM', '1') != '0'
         # two side streams: the weight gradients of successive layers are independent and each is sized for ~1 wave per
         # SIMD, so two of them fill the chip better beside the data-gradient chain (1.9553 -> 1.9406 ms per step,
-        # same-process A/B, tools/archive/ab_streams.py); PDES_WGRAD_STREAMS=1 selects one
+        # same-process A/B, ab_streams.py of the earlier rounds (git history)); PDES_WGRAD_STREAMS=1 selects one
         self.wgrad_streams = 1 if os.environ.get('PDES_WGRAD_STREAMS', '2') == '1' else 2
 
     # -- flat parameter / gradient storage -------------------------------------------------------

@@ -131,7 +131,7 @@ def test_g19_default_net_from_seeded_initial_values(dev):
     # Every tensor's norm and one random projection.  The bulk agrees to ~1e-5; what remains are ISOLATED ReLU flips
     # (an activation within rounding of zero takes the other branch under a different summation order): one flipped
     # pixel moves one element of a BatchNorm gradient and the weight gradients of the layer that produced the channel
-    # (tools/archive/debug_glow_grads.py: 1 element of 142 differs in the worst tensor).  The reference's own fp32 arithmetic
+    # (debug_glow_grads.py of the earlier rounds (git history): 1 element of 142 differs in the worst tensor).  The reference's own fp32 arithmetic
     # shows the same against fp64: 11 of its 528 tensors are off by 2e-3 .. 7e-3 there.  Hence: all but a few tensors
     # within 2e-3, none beyond 3e-2.
     proj = torch.Generator().manual_seed(14)

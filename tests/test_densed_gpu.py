@@ -328,7 +328,7 @@ def test_g13_bilinear_upsampling(dev):
     norms = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
     # 1e-3 of the reference on every norm and every stored tensor (round 3: ALL 54 BatchNorm gradient tensors are in the
     # fixture besides the layers around the upsampling stages) -- except for the consequences of ONE ReLU flip, which round 3
-    # pinned down on the GPU (tools/archive/debug_g13.py / debug_g13b.py, profiles/r03_g_g13_flip.log; deterministic: 12 identical
+    # pinned down on the GPU (debug_g13.py of the earlier rounds (git history) / debug_g13b.py, profiles/r03_g_g13_flip.log; deterministic: 12 identical
     # runs): at one pixel, channel 51 of DecBlock1's input equals its batch mean to within fp32 rounding; with the fresh
     # BatchNorms (gamma 1, beta 0) EVERY layer of the block thresholds that channel at exactly the mean, so the unit takes the
     # other side of all eight ReLUs at once.  Signature, as measured: (b) the eight DecBlock1 BatchNorm-BIAS gradients differ
