@@ -55,9 +55,10 @@ extern "C" {
  *                                              0: hipEventRecord
  *                           "PDES_FIN_ONLOAD"  1: the backward of the dense blocks' layers (3x3, stride 1, <= 16 output channels) applies
  *                                              the BatchNorm-backward finalize of the layer's output gradient while its data- and
- *                                              weight-gradient kernels stage that operand (no finalize launch for them); 2 (default):
+ *                                              weight-gradient kernels stage that operand (no finalize launch for them); 2:
  *                                              and inside a dense block the fork events ride on the data gradients' completion
- *                                              signals; 0: one pdes_bn_backward_finalize launch per layer
+ *                                              signals; 3 (default): and the first convolution's weight-gradient kernel finalizes
+ *                                              while it stages the gradient planes; 0: one pdes_bn_backward_finalize launch per layer
  *                           "PDES_DG_TILEPIPE" the data gradient of the dense blocks' layers (one chunk of <= 16 output channels) runs
  *                                              M-tile by M-tile -- every tile's epilogue behind its own MFMAs instead of one epilogue at
  *                                              the end -- for layers with at least this many input channels on 32-wide tiles

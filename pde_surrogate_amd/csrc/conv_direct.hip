@@ -408,9 +408,14 @@ __global__ __launch_bounds__(256) void conv_fwd_first7(pdes_conv_desc d) {
 // The row groups of one (channel, ky) are adjacent lanes and are combined with two shuffles.
 // part != nullptr: this image's contribution is STORED to part[b][(co, ci, ky, kx)] (every element has exactly one
 // writer) for the fixed-order split-K reduce -- deterministic; nullptr: fp32 atomics straight into dw.
-template <int COT, int K, int S>
+// GF (pdes_conv_desc.g_fused): `g` still holds the accumulator T of this layer's output buffer; the BatchNorm-backward
+// finalize  dL/dx = invstd (T - mean(T) - xhat mean(T xhat))  is applied while the gradient planes are staged (raw
+// activation = `out`, statistics as in bn_bwd_finalize_kernel) -- the first layer has no data gradient, so nothing else
+// reads its finalized gradient and the finalize launch in front of this kernel disappears from the end of the chain.
+template <int COT, int K, int S, bool GF>
 __global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
+  __shared__ float4 fin_c[COT];                          // GF: {mean, invstd, mean T, mean T xhat} of the workgroup's channels
   constexpr int KK = K * K;
   constexpr int RG = 4;                                 // row groups per (channel, ky)
   constexpr int NX = 4 * S + K - 1;                     // input values touched by 4 consecutive outputs
@@ -423,6 +428,28 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d, f
   // staging: global loads are issued in batches of 4 (x) / 8 (g) float4 per thread before any LDS write, so the
   // workgroup pays the memory latency once per batch instead of once per element
   for (int i = tid; i < d.Cin * LH * LW / 4; i += 256) reinterpret_cast<float4*>(xs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (GF) {
+    // 4 sums x PDES_NREP (<= 16) replicas per channel: one load per lane, 16-lane shuffle reduction (flow_copy_bwd_kernel)
+    static_assert(COT * 64 <= 512, "two rounds of 256 threads");
+    __shared__ double fin_s[COT][4];
+    for (int e = tid; e < COT * 64; e += 256) {
+      const int c = e >> 6, q = (e >> 4) & 3, r = e & 15;
+      const int ch = d.g_coff + min(co0 + c, d.Cout - 1);
+      double v = r < PDES_NREP ? (q < 2 ? d.fin_xstats : d.fin_tstats)[(long long)r * d.rep_stride + 2 * ch + (q & 1)] : 0.0;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+      if (r == 0) fin_s[c][q] = v;
+    }
+    __syncthreads();
+    if (tid < COT) {
+      const double inv_n = 1.0 / ((double)d.B * HWo);
+      const double m = fin_s[tid][0] * inv_n;
+      double var = fin_s[tid][1] * inv_n - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      fin_c[tid] = make_float4((float)m, (float)(1.0 / sqrt(var + (double)d.eps)), (float)(fin_s[tid][2] * inv_n),
+                               (float)(fin_s[tid][3] * inv_n));
+    }
+  }
   __syncthreads();
   const int W4 = d.Win / 4, nx4 = d.Cin * d.Hin * W4;            // Win % 4 == 0 (checked on the host)
   for (int i0 = 0; i0 < nx4; i0 += 4 * 256) {
@@ -445,19 +472,30 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_first(pdes_conv_desc d, f
   }
   const int ng4 = COT * HWo / 4;
   for (int i0 = 0; i0 < ng4; i0 += 8 * 256) {
-    float4 v[8];
+    float4 v[8], xa[GF ? 8 : 1];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = min(i0 + tid + 256 * u, ng4 - 1);
       const int cc = min((4 * i) / HWo, d.Cout - 1 - co0);
-      v[u] = *reinterpret_cast<const float4*>(d.g + ((size_t)b * d.g_ctot + d.g_coff + co0 + cc) * HWo + (4 * i) % HWo);
+      const size_t off = ((size_t)b * d.g_ctot + d.g_coff + co0 + cc) * HWo + (4 * i) % HWo;
+      v[u] = *reinterpret_cast<const float4*>(d.g + off);
+      if (GF) xa[u] = *reinterpret_cast<const float4*>(d.out + off);      // (g_ctot == out_ctot, g_coff == out_coff: checked)
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + tid + 256 * u;
       if (i < ng4) {
         const bool ok = co0 + (4 * i) / HWo < d.Cout;
-        *reinterpret_cast<float4*>(gs + 4 * i) = ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 t = v[u];
+        if (GF) {
+          const float4 k = fin_c[min((4 * i) / HWo, COT - 1)];
+          const float4 x = xa[u];
+          t.x = k.y * (t.x - k.z - (x.x - k.x) * k.y * k.w);
+          t.y = k.y * (t.y - k.z - (x.y - k.x) * k.y * k.w);
+          t.z = k.y * (t.z - k.z - (x.z - k.x) * k.y * k.w);
+          t.w = k.y * (t.w - k.z - (x.w - k.x) * k.y * k.w);
+        }
+        *reinterpret_cast<float4*>(gs + 4 * i) = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   }
@@ -584,6 +622,15 @@ int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st) {
   return PDES_OK;
 }
 
+// does the first-convolution weight-gradient kernel take `d` (the one VALU kernel that can finalize on load)?
+bool conv_backward_weight_first_applies(const pdes_conv_desc& d) {
+  if (!(!d.has_bn && !d.upsample && d.Cin <= 4 && d.ksize == 7 && d.stride == 2 && d.Wout % 4 == 0 && d.Hout % 4 == 0 &&
+        d.Win % 4 == 0))
+    return false;
+  const int LH = d.Hin + 2 * d.pad + 2, LW = ((d.Win + 2 * d.pad + 2 + 4 + 3) / 4) * 4;
+  return ((size_t)d.Cin * LH * LW + (size_t)8 * d.Hout * d.Wout) * sizeof(float) <= 150 * 1024;
+}
+
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st) {
   const int rc = validate(d, 1);
   if (rc) return rc;
@@ -594,11 +641,19 @@ int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st) {
     const size_t lds = ((size_t)d.Cin * LH * LW + (size_t)8 * d.Hout * d.Wout) * sizeof(float);
     if (lds <= 150 * 1024) {
       float* part = first_layer_partials(d) ? d.ws : nullptr;
-      hipLaunchKernelGGL((conv_bwd_weight_first<8, 7, 2>), dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d, part);
+      if (d.g_fused) {
+        if (!d.fin_xstats || !d.fin_tstats || !d.out || d.g_ctot != d.out_ctot || d.g_coff != d.out_coff || d.g_add ||
+            d.nrep != PDES_NREP)
+          return PDES_EINVAL;
+        hipLaunchKernelGGL((conv_bwd_weight_first<8, 7, 2, true>), dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d, part);
+      } else {
+        hipLaunchKernelGGL((conv_bwd_weight_first<8, 7, 2, false>), dim3(d.B, cdiv(d.Cout, 8)), dim3(256), lds, st, d, part);
+      }
       PDES_LAUNCH_CHECK();
       return PDES_OK;
     }
   }
+  if (d.g_fused) return PDES_ENOSUP;                     // (only the first-convolution kernel above finalizes on load)
   int cot;
   switch (d.ksize) { case 1: cot = 16; break; case 3: cot = 8; break; case 5: cot = 4; break; default: cot = 2; }
   const int ncog = cdiv(d.Cout, cot);

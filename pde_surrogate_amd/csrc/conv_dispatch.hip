@@ -10,6 +10,7 @@ namespace pdes {
 int conv_forward_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_data_direct(const pdes_conv_desc& d, hipStream_t st);
 int conv_backward_weight_direct(const pdes_conv_desc& d, hipStream_t st);
+bool conv_backward_weight_first_applies(const pdes_conv_desc& d);
 bool first_layer_partials(const pdes_conv_desc& d);     // conv_direct.hip: the 7x7 first layer writes per-image partials
 bool conv_forward_direct_first7(const pdes_conv_desc& d);               // conv_direct.hip: reads the live weights, no image
 int conv_forward_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry = false);        // PDES_ENOSUP: shape not covered
@@ -27,6 +28,7 @@ int conv_backward_data_up_mfma(const pdes_conv_desc& d, hipStream_t st, bool dry
 int conv_forward_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false);          // 3x3 on 8x8 maps (conv_small.hip)
 int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st);
+bool wgrad_small_applies(const pdes_conv_desc& d);
 int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
 int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int upsample_bilinear_forward(const pdes_conv_desc& d, hipStream_t st);   // PDES_UPSAMPLE_BILINEAR_OP descriptors
@@ -86,6 +88,14 @@ static bool force_direct() { return opt().conv_direct != 0; }
 // (capability queries: nothing is enqueued).  `t` receives the descriptor with g_fused = 1.
 static bool fin_onload(const pdes_conv_desc& d, pdes_conv_desc* t) {
   if (!opt().fin_onload || force_direct() || is_resample_op(d) || !d.fin_tstats || d.g_fused) return false;
+  // the first convolution: no data gradient, its weight-gradient kernel stages the gradient planes itself
+  if (opt().fin_onload >= 3 && !d.has_bn && !d.t_in && !d.g_add && d.nrep == PDES_NREP && d.g_ctot == d.out_ctot && d.g_coff == d.out_coff &&
+      conv_backward_weight_first_applies(d) && !wgrad_small_applies(d) &&
+      conv_backward_weight_mfma(d, nullptr, true) == PDES_ENOSUP) {
+    *t = d;
+    t->g_fused = 1;
+    return true;
+  }
   if (d.ksize != 3 || d.stride != 1 || d.upsample || d.Cout > 16 || !d.has_bn || !d.t_in || d.g_add) return false;
   *t = d;
   t->g_fused = 1;
@@ -127,7 +137,8 @@ extern "C" int pdes_conv_backward_weight(const pdes_context* ctx, const pdes_con
     if (is_resample_op(descs[i])) continue;                          // a resampling op has no weights
     int rc = force_direct() ? PDES_ENOSUP : conv_backward_weight_small(descs[i], st);
     if (rc == PDES_ENOSUP && !force_direct()) rc = conv_backward_weight_mfma(descs[i], st);
-    if (rc == PDES_ENOSUP && descs[i].g_fused) return PDES_EINVAL;      // only the matrix-core kernels finalize on load
+    if (rc == PDES_ENOSUP && descs[i].g_fused && !conv_backward_weight_first_applies(descs[i]))
+      return PDES_EINVAL;                                               // (of the VALU kernels only the first convolution's finalizes on load)
     if (rc == PDES_ENOSUP) {
       // the VALU kernel adds straight into dw.  If the caller planned deferred split-K partials for this layer
       // (pdes_conv_wgrad_plan said yes, e.g. before PDES_CONV_IMPL changed), its reduce must then add zeros

@@ -24,10 +24,11 @@ struct Options {
   int wgrad_wgs = 256;          // PDES_WGRAD_WGS : workgroup target of the split-K weight-gradient plan
   int loss_nt = -1;             // PDES_LOSS_NT   : streaming loads / stores in the loss kernel: -1 = by working-set size, 0, 1
   int fork_signal = 1;          // PDES_FORK_SIGNAL: fork events ride on the finalize kernel's completion signal (0: hipEventRecord)
-  int fin_onload = 2;           // PDES_FIN_ONLOAD : 1: the backward of the dense blocks' 16-output-channel 3x3 layers applies the BatchNorm-
+  int fin_onload = 3;           // PDES_FIN_ONLOAD : 1: the backward of the dense blocks' 16-output-channel 3x3 layers applies the BatchNorm-
                                 //                  backward finalize of the layer's output gradient on operand load (no finalize launch
-                                //                  for them); 2 (default): and the forks inside a dense block ride on the data
-                                //                  gradients' completion signals; 0: one finalize launch per layer
+                                //                  for them); 2: and the forks inside a dense block ride on the data gradients'
+                                //                  completion signals; 3 (default): and the first convolution's weight-gradient kernel
+                                //                  finalizes while it stages the gradient planes; 0: one finalize launch per layer
   int dg_tilepipe16 = 48;       // PDES_DG_TILEPIPE16: the same threshold for the other tile shapes (16-wide maps, half-height tiles)
   int dg_tilepipe = 48;         // PDES_DG_TILEPIPE: the dense blocks' data gradient on 32-wide tiles runs M-tile by M-tile (each tile's
                                 //                  epilogue behind its MFMAs) from this many input channels on; 0: never

@@ -596,8 +596,9 @@ VARIANTS = {   # name -> (option or environment variable, value A, value B): pai
     '1x1_all': ('PDES_MFMA_1X1', '0', '7'),
     '1x1_wgrad': ('PDES_MFMA_1X1', '3', '7'),
     'fork_signal': ('PDES_FORK_SIGNAL', '0', '1'),
-    'fin_onload': ('PDES_FIN_ONLOAD', '0', '2'),             # dense layers: BatchNorm-backward finalize on operand load vs a launch
+    'fin_onload': ('PDES_FIN_ONLOAD', '0', '3'),             # dense layers: BatchNorm-backward finalize on operand load vs a launch
     'fin_onload_signal': ('PDES_FIN_ONLOAD', '1', '2'),      # ... its forks by hipEventRecord vs on the data gradients' completion signals
+    'fin_onload_first': ('PDES_FIN_ONLOAD', '2', '3'),       # ... and the first convolution's weight gradient finalizing on load
     'dg_tilepipe': ('PDES_DG_TILEPIPE', '0', '48'),           # dense data gradients: one epilogue at the end vs tile by tile (same sums, same order)
     'wgrad_hold': ('PDES_WGRAD_HOLD', '0', '5000'),          # the three widest weight gradients released behind their data gradients
 }
