@@ -217,6 +217,12 @@ int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar, float* im
                                  log-stddev, the top latent's `.data`, :524), p1 = dL/d(logp) */
 #define PDES_FLOW_FORWARD 1
 #define PDES_GAUSS_DETACH_LSD 2
+#define PDES_MIX_COUPLED 4    /* PDES_OP_MIX, z -> y only: the affine coupling in front of the invertible 1x1 runs in the same launch.
+                                 x = the COUPLING's input (C channels), h / h_ctot = the coupling net's output (as x2 of
+                                 PDES_OP_COUPLING, gamma / beta / bn_grad = its folded Conv2dZeros epilogue), acc2[b] += sum log s;
+                                 the coupling's output u = (x[:n1], x[n1 + k] / s - h[2k]) is the mix's input and is never
+                                 stored: out = (W u - p1) / p0.  Backward: t_in = dL/dx (written), th = dL/dh (dL/d(raw) with
+                                 gamma), cst = dL/d(logp) per sample, acc as for PDES_OP_MIX with u recomputed from x and h */
 
 typedef struct pdes_conv_desc {
   /* geometry */
@@ -293,6 +299,12 @@ typedef struct pdes_conv_desc {
   /* appended in ABI 21 */
   const float* fin_coef; /* the same table of the OUTPUT buffer (next to fin_xstats), for the finalize of this layer's output
                             channels; NULL: the finalize sums the replicas of x itself */
+  /* appended in ABI 24: PDES_OP_MIX with flags & PDES_MIX_COUPLED (NULL / 0 otherwise) */
+  const float* h;        /* the coupling net's output, (B, h_ctot, H, W); rewritten in place with the Conv2dZeros epilogue if gamma */
+  int h_ctot;
+  float* th;             /* backward: dL/dh (2 n2 channels of h_ctot) */
+  double* acc2;          /* forward: the coupling's log-determinant accumulator (B doubles per replica) */
+  const float* cst;      /* backward: dL/d(logp) per sample (B floats, nullable) */
 } pdes_conv_desc;
 
 /* `descs` is a HOST array; one kernel launch per descriptor, in order.

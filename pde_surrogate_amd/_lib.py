@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpdes_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _c_f = ctypes.c_float
 _c_i = ctypes.c_int

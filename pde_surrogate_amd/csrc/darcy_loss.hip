@@ -592,4 +592,4 @@ extern "C" int pdes_sobel5_grad_adjoint(const float* gh_bar, const float* gv_bar
   return PDES_OK;
 }
 
-extern "C" int pdes_abi_version(void) { return 23; }
+extern "C" int pdes_abi_version(void) { return 24; }

@@ -469,20 +469,217 @@ __global__ __launch_bounds__(PB) void flow_mix_bwd_kernel(pdes_conv_desc d) {
   }
 }
 
+// ---- PDES_MIX_COUPLED: affine coupling + invertible 1x1 (+ ActNorm), z -> y, in ONE launch each way.  Both operators act
+// per pixel: the coupling's output u goes straight into the matrix product's LDS tile and is never stored; the backward
+// pass recomputes it from the coupling's input and h (one sigmoid per channel pair) and runs the coupling's backward on the
+// matrix product's input gradient while that is in registers.  dynamic LDS as for the plain kernels.
+template <int PB>
+__global__ __launch_bounds__(PB) void flow_coupling_mix_kernel(pdes_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float sm_mix[];
+  __shared__ double red[4];
+  const int C = d.Cin, HW = d.Hin * d.Win, b = blockIdx.y, tid = threadIdx.x, p = blockIdx.x * PB + tid;
+  const int n2 = C / 2, n1 = C - n2;
+  float* Ws = sm_mix;
+  float* xs = sm_mix + C * C;
+  for (int i = tid; i < C * C; i += PB) Ws[i] = d.x2[i];
+  const float* x = d.x + (size_t)b * d.x_ctot * HW + p;
+  float* h = const_cast<float*>(d.h) + (size_t)b * d.h_ctot * HW + p;
+  float ld = 0.f;
+  if (p < HW) {
+    for (int c0 = 0; c0 < n1; c0 += FLOW_KB) {
+      float v[FLOW_KB];
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j) v[j] = x[(size_t)min(c0 + j, n1 - 1) * HW];
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j)
+        if (c0 + j < n1) xs[(c0 + j) * (PB + 1) + tid] = v[j];
+    }
+    for (int k0 = 0; k0 < n2; k0 += FLOW_KB) {
+      float hs[FLOW_KB], hr[FLOW_KB], xv[FLOW_KB];
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j) {
+        const int k = min(k0 + j, n2 - 1);
+        hs[j] = h[(size_t)(2 * k) * HW];
+        hr[j] = h[(size_t)(2 * k + 1) * HW];
+        xv[j] = x[(size_t)(n1 + k) * HW];
+      }
+#pragma unroll
+      for (int j = 0; j < FLOW_KB; ++j) {
+        const int k = k0 + j;
+        if (k < n2) {
+          float shift = hs[j], raw = hr[j];
+          if (d.gamma) {
+            shift = (shift + d.gamma[2 * k]) * (d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f);
+            raw = (raw + d.gamma[2 * k + 1]) * (d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f);
+            h[(size_t)(2 * k) * HW] = shift;
+            h[(size_t)(2 * k + 1) * HW] = raw;
+          }
+          const float sg = sigmoidf_(raw + 2.f);
+          xs[(n1 + k) * (PB + 1) + tid] = xv[j] / sg - shift;
+          ld += logf(sg);
+        }
+      }
+    }
+  }
+  if (PB >= 256) {
+    if (d.acc2) block_add_logp(ld, d.acc2, b, d.nrep, d.rep_stride, red);      // (a barrier inside: every thread calls)
+  } else if (d.acc2) {                                                          // one wave per block
+    const float ws = wave_sum(ld);
+    if (tid == 0) atomicAdd(&d.acc2[(long long)rep_of_block(d.nrep) * d.rep_stride + b], (double)ws);
+  }
+  __syncthreads();
+  if (p >= HW) return;
+  float* o = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW + p;
+  for (int oc = 0; oc < C; ++oc) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += Ws[oc * C + c] * xs[c * (PB + 1) + tid];
+    o[(size_t)oc * HW] = (a - d.p1[oc]) / d.p0[oc];
+  }
+}
+
+// dynamic LDS: W [C][C] + xs [C][PB+1] + gs [C][PB+1] + part [2][C][PB/64] + part2 [2 n2][2][PB/64] floats
+template <int PB>
+__global__ __launch_bounds__(PB) void flow_mix_coupling_bwd_kernel(pdes_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float sm_mix[];
+  constexpr int NW = PB / 64;
+  const int C = d.Cin, HW = d.Hin * d.Win, b = blockIdx.y, tid = threadIdx.x, p0 = blockIdx.x * PB;
+  const int n2 = C / 2, n1 = C - n2;
+  float* Ws = sm_mix;
+  float* xs = Ws + C * C;
+  float* gs = xs + C * (PB + 1);
+  float* part = gs + C * (PB + 1);                       // [2][C][NW]
+  float* part2 = part + 2 * C * NW;                      // [2 n2][2][NW]
+  for (int i = tid; i < C * C; i += PB) Ws[i] = d.x2[i];
+  const bool act = p0 + tid < HW, fold = d.gamma != nullptr, accu = d.t_accumulate != 0;
+  const float* x = d.x + (size_t)b * d.x_ctot * HW + p0 + tid;
+  const float* h = d.h + (size_t)b * d.h_ctot * HW + p0 + tid;
+  const float* g = d.g + ((size_t)b * d.g_ctot + d.g_coff) * HW + p0 + tid;
+  const float* y = d.out + ((size_t)b * d.out_ctot + d.out_coff) * HW + p0 + tid;
+  float* tx = d.t_in + (size_t)b * d.x_ctot * HW + p0 + tid;
+  float* th = d.th + (size_t)b * d.h_ctot * HW + p0 + tid;
+  const float cst = d.cst ? d.cst[b] : 0.f;
+  // (1) u, the mix's input, recomputed into xs
+  for (int c0 = 0; c0 < n1; c0 += FLOW_KB) {
+    float v[FLOW_KB];
+#pragma unroll
+    for (int j = 0; j < FLOW_KB; ++j) v[j] = act ? x[(size_t)min(c0 + j, n1 - 1) * HW] : 0.f;
+#pragma unroll
+    for (int j = 0; j < FLOW_KB; ++j)
+      if (c0 + j < n1) xs[(c0 + j) * (PB + 1) + tid] = v[j];
+  }
+  for (int k0 = 0; k0 < n2; k0 += FLOW_KB) {
+    float hs[FLOW_KB], hr[FLOW_KB], xv[FLOW_KB];
+#pragma unroll
+    for (int j = 0; j < FLOW_KB; ++j) {
+      const int k = min(k0 + j, n2 - 1);
+      hs[j] = act ? h[(size_t)(2 * k) * HW] : 0.f;
+      hr[j] = act ? h[(size_t)(2 * k + 1) * HW] : 0.f;
+      xv[j] = act ? x[(size_t)(n1 + k) * HW] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < FLOW_KB; ++j)
+      if (k0 + j < n2) xs[(n1 + k0 + j) * (PB + 1) + tid] = xv[j] / sigmoidf_(hr[j] + 2.f) - hs[j];
+  }
+  // (2) gv = g / weight into gs; the ActNorm's {dweight, dbias} partial sums
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    float gv[8], yv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = min(c0 + j, C - 1);
+      gv[j] = act ? g[(size_t)c * HW] : 0.f;
+      yv[j] = act ? y[(size_t)c * HW] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      if (c >= C) break;
+      const float gq = gv[j] / d.p0[c];
+      gs[c * (PB + 1) + tid] = gq;
+      const float a = wave_sum(-gq * yv[j]), bsum = wave_sum(-gq);
+      if ((tid & 63) == 0) { part[(0 * C + c) * NW + (tid >> 6)] = a; part[(1 * C + c) * NW + (tid >> 6)] = bsum; }
+    }
+  }
+  __syncthreads();
+  // (3) dL/du = W^T gv, and the coupling's backward on it
+  for (int c = 0; c < n1; ++c) {
+    float a = 0.f;
+    for (int oc = 0; oc < C; ++oc) a += Ws[oc * C + c] * gs[oc * (PB + 1) + tid];
+    if (act) tx[(size_t)c * HW] = accu ? tx[(size_t)c * HW] + a : a;
+  }
+  for (int k = 0; k < n2; ++k) {
+    float a = 0.f;
+    for (int oc = 0; oc < C; ++oc) a += Ws[oc * C + n1 + k] * gs[oc * (PB + 1) + tid];
+    float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (act) {
+      const float h0 = h[(size_t)(2 * k) * HW], h1 = h[(size_t)(2 * k + 1) * HW], xv = x[(size_t)(n1 + k) * HW];
+      const float sg = sigmoidf_(h1 + 2.f);
+      const float gx = a / sg;
+      tx[(size_t)(n1 + k) * HW] = accu ? tx[(size_t)(n1 + k) * HW] + gx : gx;
+      g0 = -a;
+      g1 = (cst - gx * xv) * (1.f - sg);
+      if (fold) {
+        q0 = 3.f * g0 * h0;
+        q1 = 3.f * g1 * h1;
+        g0 *= d.beta ? expf(d.beta[2 * k] * 3.f) : 1.f;
+        g1 *= d.beta ? expf(d.beta[2 * k + 1] * 3.f) : 1.f;
+      }
+      th[(size_t)(2 * k) * HW] = g0;
+      th[(size_t)(2 * k + 1) * HW] = g1;
+    }
+    if (fold) {
+      const float a0 = wave_sum(g0), s0 = wave_sum(q0), a1 = wave_sum(g1), s1 = wave_sum(q1);
+      if ((tid & 63) == 0) {
+        float* q = part2 + (size_t)(2 * k) * 2 * NW + (tid >> 6);
+        q[0] = a0; q[NW] = s0; q[2 * NW] = a1; q[3 * NW] = s1;
+      }
+    }
+  }
+  __syncthreads();
+  // (4) parameter gradients: {dweight, dbias, dW} of the mix, {dbias, dscale} of the folded Conv2dZeros epilogue
+  double* acc = d.acc + (long long)rep_of_block(d.nrep) * d.rep_stride;
+  for (int i = tid; i < 2 * C; i += PB) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += part[i * NW + w];
+    atomicAdd(&acc[i], (double)s);
+  }
+  if (fold)
+    for (int i = tid; i < 4 * n2; i += PB) {
+      double s = 0.0;
+      for (int w = 0; w < NW; ++w) s += (double)part2[i * NW + w];
+      atomicAdd(&d.bn_grad[(long long)rep_of_block(d.nrep) * d.rep_stride + i], s);
+    }
+  const int np = min(PB, HW - p0);
+  for (int i = tid; i < C * C; i += PB) {
+    const int oc = i / C, c = i % C;
+    float s = 0.f;
+    for (int q = 0; q < np; ++q) s += gs[oc * (PB + 1) + q] * xs[c * (PB + 1) + q];
+    atomicAdd(&acc[2 * C + i], (double)s);
+  }
+}
+
 static bool mix_ok(const pdes_conv_desc& d) {
-  return flow_common_ok(d) && d.upsample == PDES_OP_MIX && d.Cin == d.Cout && d.Cin <= 48 && d.Hin == d.Hout &&
-         d.Win == d.Wout && d.x && d.x2 && d.out && d.p0 && d.p1;
+  if (!(flow_common_ok(d) && d.upsample == PDES_OP_MIX && d.Cin == d.Cout && d.Cin <= 48 && d.Hin == d.Hout &&
+        d.Win == d.Wout && d.x && d.x2 && d.out && d.p0 && d.p1))
+    return false;
+  if (d.flags & PDES_MIX_COUPLED)
+    return !(d.flags & PDES_FLOW_FORWARD) && d.Cin >= 2 && d.h && d.h_ctot >= 2 * (d.Cin / 2) && (d.gamma || !d.beta);
+  return true;
 }
 
 int flow_mix_forward(const pdes_conv_desc& d, hipStream_t st) {
   if (!mix_ok(d)) return PDES_EINVAL;
   const int C = d.Cin, HW = d.Hin * d.Win;
+  const bool cpl = (d.flags & PDES_MIX_COUPLED) != 0;
   if (C <= 28) {
     constexpr int PB = 256;
-    hipLaunchKernelGGL(flow_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), (C * C + C * (PB + 1)) * sizeof(float), st, d);
+    const size_t lds = (C * C + C * (PB + 1)) * sizeof(float);
+    if (cpl) hipLaunchKernelGGL(flow_coupling_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+    else hipLaunchKernelGGL(flow_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
   } else {
     constexpr int PB = 64;
-    hipLaunchKernelGGL(flow_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), (C * C + C * (PB + 1)) * sizeof(float), st, d);
+    const size_t lds = (C * C + C * (PB + 1)) * sizeof(float);
+    if (cpl) hipLaunchKernelGGL(flow_coupling_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+    else hipLaunchKernelGGL(flow_mix_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
   }
   PDES_LAUNCH_CHECK();
   return PDES_OK;
@@ -490,15 +687,19 @@ int flow_mix_forward(const pdes_conv_desc& d, hipStream_t st) {
 
 int flow_mix_backward(const pdes_conv_desc& d, hipStream_t st) {
   if (!mix_ok(d) || !d.g || !d.t_in || !d.acc || (d.flags & PDES_FLOW_FORWARD)) return PDES_EINVAL;
-  const int C = d.Cin, HW = d.Hin * d.Win;
+  const bool cpl = (d.flags & PDES_MIX_COUPLED) != 0;
+  if (cpl && (!d.th || (d.gamma && !d.bn_grad))) return PDES_EINVAL;
+  const int C = d.Cin, HW = d.Hin * d.Win, n2 = C / 2;
   if (C <= 28) {
     constexpr int PB = 256;
-    const size_t lds = (C * C + 2 * C * (PB + 1) + 2 * C * (PB / 64)) * sizeof(float);
-    hipLaunchKernelGGL(flow_mix_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+    const size_t lds = (C * C + 2 * C * (PB + 1) + 2 * C * (PB / 64) + (cpl ? 4 * n2 * (PB / 64) : 0)) * sizeof(float);
+    if (cpl) hipLaunchKernelGGL(flow_mix_coupling_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+    else hipLaunchKernelGGL(flow_mix_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
   } else {
     constexpr int PB = 64;
-    const size_t lds = (C * C + 2 * C * (PB + 1) + 2 * C * (PB / 64)) * sizeof(float);
-    hipLaunchKernelGGL(flow_mix_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+    const size_t lds = (C * C + 2 * C * (PB + 1) + 2 * C * (PB / 64) + (cpl ? 4 * n2 * (PB / 64) : 0)) * sizeof(float);
+    if (cpl) hipLaunchKernelGGL(flow_mix_coupling_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
+    else hipLaunchKernelGGL(flow_mix_bwd_kernel<PB>, dim3(cdiv(HW, PB), d.B), dim3(PB), lds, st, d);
   }
   PDES_LAUNCH_CHECK();
   return PDES_OK;

@@ -44,6 +44,7 @@ class ConvDesc(ctypes.Structure):
         ('g_add', _P), ('x2', _P), ('x2_ctot', _I), ('t2', _P), ('p0', _P), ('p1', _P), ('acc', _P), ('flags', _I),
         ('wbu_bwd', _P),
         ('coef', _P), ('fin_coef', _P),
+        ('h', _P), ('h_ctot', _I), ('th', _P), ('acc2', _P), ('cst', _P),
     ]
 
 

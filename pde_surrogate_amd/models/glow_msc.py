@@ -29,10 +29,12 @@ _I = ctypes.c_int
 _P = ctypes.c_void_p
 
 OP_COPY, OP_BIAS_SCALE, OP_COUPLING, OP_MIX, OP_UNSQUEEZE, OP_GAUSS = 4, 5, 6, 7, 8, 9       # include/pdes_hip.h
-FLOW_FORWARD, GAUSS_DETACH_LSD = 1, 2
+FLOW_FORWARD, GAUSS_DETACH_LSD, MIX_COUPLED = 1, 2, 4
 MAX_MIX_CHANNELS = 48
 _FUSE_COPY_FINALIZE = True   # PDES_OP_COPY backward applies its channels' finalize on load (False: separate launch; A/B only)
 _MERGE_COPY = True        # torch.cat((y1, cond), 1) as ONE two-source copy descriptor (False: one per source; A/B only)
+_FUSE_COUPLING_MIX = True  # generate(): affine coupling + ActNorm / invertible 1x1 of a reversible layer as ONE descriptor
+                          # (PDES_MIX_COUPLED: the coupling's output is never stored; False: two launches each way; A/B only)
 _FOLD_ZEROS = True        # the coupling kernels apply the coupling net's Conv2dZeros epilogue (bias, exp(3 scale)) and its
                           # backward themselves (False: a PDES_OP_BIAS_SCALE launch in between, each way; A/B only)
 
@@ -246,11 +248,14 @@ def _plan_glow(y_channels, enc_blocks, flow_blocks, lu, growth=16, init_features
                 specs.append(_Spec(OP_COUPLING, z, 'out', Ci, Ci, r, h=hb, **zeros))
             else:
                 ub, zn = f'u{i}_{j}', f'z{i}_{j - 1}'
-                bufs[ub] = [Ci, r]
                 if zn not in bufs:
                     bufs[zn] = [Ci, r]
-                specs.append(_Spec(OP_COUPLING, z, ub, Ci, Ci, r, h=hb, **zeros))
-                specs.append(_Spec(OP_MIX, ub, zn, Ci, Ci, r, index=len(mix)))
+                if _FUSE_COUPLING_MIX:
+                    specs.append(_Spec(OP_MIX, z, zn, Ci, Ci, r, index=len(mix), flags=MIX_COUPLED, h=hb, **zeros))
+                else:
+                    bufs[ub] = [Ci, r]
+                    specs.append(_Spec(OP_COUPLING, z, ub, Ci, Ci, r, h=hb, **zeros))
+                    specs.append(_Spec(OP_MIX, ub, zn, Ci, Ci, r, index=len(mix)))
                 mix.append((Ci, r, lay + '.norm', lay + '.conv1x1', i, j))
         if i > 1:                                       # Squeeze.reverse (glow_msc.py:629-636, :422-432)
             zt = f'z{i - 1}_{flow_blocks[i - 2]}'
@@ -358,7 +363,7 @@ class _GlowEngine(_EngineBase):
                 n_bn += 2 * s.cin
         aux_off, n_aux = {}, 0
         for i, s in enumerate(specs):
-            if s.kind == OP_BIAS_SCALE or (s.kind == OP_COUPLING and s.x.get('bias')):
+            if s.kind == OP_BIAS_SCALE or (s.kind in (OP_COUPLING, OP_MIX) and s.x.get('bias')):
                 aux_off[i] = n_aux
                 n_aux += 2 * _aux_channels(s)
         mix_off, n_mix = [], 0
@@ -509,6 +514,16 @@ class _GlowEngine(_EngineBase):
                 d.p0, d.p1, d.acc = an.weight.data_ptr(), an.bias.data_ptr(), acc
                 if self.has_grad:
                     d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
+                if d.flags & MIX_COUPLED:                  # the affine coupling in front of it, in the same launch
+                    h = s.x['h']
+                    d.h, d.h_ctot = self.X[h].data_ptr(), bufs[h][0]
+                    d.acc2, d.cst = self._logp_acc, self.glogp.data_ptr()
+                    if s.x.get('bias'):
+                        d.gamma = _get_param(net, s.x['bias']).data_ptr()
+                        d.beta = _get_param(net, s.x['scale_p']).data_ptr()
+                        d.bn_grad = a0 + 8 * (base_aux + aux_off[i])
+                    if self.has_grad:
+                        d.th = self.T[h].data_ptr()
             elif s.kind == OP_UNSQUEEZE:
                 if self.has_grad:
                     d.t_in, d.t_accumulate = self.T[s.src].data_ptr(), 0
@@ -644,7 +659,7 @@ class _GlowEngine(_EngineBase):
 def _aux_channels(s):
     """channels of the {dbias, dscale} table of a bias/scale op, or of the epilogue folded into a coupling (its 2 n2 shift /
     scale channels)"""
-    return 2 * (s.cin // 2) if s.kind == OP_COUPLING else s.cout
+    return 2 * (s.cin // 2) if s.kind in (OP_COUPLING, OP_MIX) else s.cout
 
 
 def _get_param(net, path):

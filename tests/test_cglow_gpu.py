@@ -336,8 +336,50 @@ def test_folded_conv2dzeros_epilogue_equals_the_separate_launches(dev, monkeypat
     assert res[False][3] - res[True][3] == n_layers            # one launch less per reversible layer, each way
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for k, g0 in res[False][2].items():
+        if k.endswith('in_conv.bias'):        # (a bias in front of a BatchNorm: its gradient is rounding noise around zero)
+            continue
         g1 = res[True][2][k]
         assert float((g1 - g0).norm()) <= 2e-6 * float(g0.norm()) + 1e-9, k
+
+
+@pytest.mark.parametrize('fixture', ['G18_cglow_small.npz', 'default'])
+def test_coupling_and_invertible_1x1_in_one_launch_equal_two(dev, monkeypatch, fixture):
+    """PDES_MIX_COUPLED (glow_msc._FUSE_COUPLING_MIX): the affine coupling and the ActNorm + invertible 1x1 behind it as one
+    descriptor -- the coupling's output goes straight into the matrix product and is recomputed in the backward pass -- against
+    the two launches each way: same y and log p to the bit (the arithmetic per element is the same), parameter gradients to
+    the partition of the block sums.  Small fixture net (LU) and the default net of train_cglow_reverse_kl.py at batch 32
+    (48 channels on the 8 x 8 level: the 64-pixel workgroups)"""
+    from pde_surrogate_amd.models import glow_msc
+    from pde_surrogate_amd.models.glow_msc import MultiScaleCondGlow
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(glow_msc, '_FUSE_COUPLING_MIX', fuse)
+        if fixture == 'default':
+            torch.manual_seed(5)
+            np.random.seed(5)
+            net = MultiScaleCondGlow(32, 1, 3, [3, 4, 4], [6, 6, 6], LUdecompose=True)
+            perturb_glow(net, torch.Generator().manual_seed(6), 0.4)
+            net = net.to(dev).train()
+            gen = torch.Generator().manual_seed(7)
+            x = torch.exp(0.5 * torch.randn(32, 1, 32, 32, generator=gen)).to(dev)
+            eps = [torch.randn((32,) + s, generator=gen).to(dev) for s in net._z_shapes()]
+            beta, wb = 150.0, 50.0
+        else:
+            g = golden(fixture)
+            net = _small(g, dev).train()
+            x, eps, beta, wb = torch.from_numpy(g['x']).to(dev), _eps(g, dev), float(g['beta']), float(g['weight_bound'])
+        n_desc = len(net._acquire(x).specs)
+        loss, _, _, y, logp = reverse_kl(net, x, eps, beta, wb)
+        loss.backward()
+        res[fuse] = (y.detach().clone(), logp.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}, n_desc)
+    assert res[False][3] > res[True][3]
+    assert torch.equal(res[True][0], res[False][0])
+    np.testing.assert_allclose(res[True][1].cpu().numpy(), res[False][1].cpu().numpy(), rtol=1e-6)      # (log-det sums: block partition)
+    for k, g0 in res[False][2].items():
+        if k.endswith('in_conv.bias'):        # (a bias in front of a BatchNorm: its gradient is rounding noise around zero)
+            continue
+        g1 = res[True][2][k]
+        assert float((g1 - g0).norm()) <= 5e-6 * float(g0.norm()) + 1e-9, (k, float((g1 - g0).norm()), float(g0.norm()))
 
 
 def test_reverse_kl_trainer_data_parallel_path_one_rank(dev):
