@@ -320,7 +320,7 @@ def cglow_timing(dev, steps=60, warm=15, cpu_steps=3):
     out['algorithmic_gflop_per_step'] = {'forward_convolutions': round(fwd / 1e9, 3), 'step_approx_3x': round(3 * fwd / 1e9, 3)}
     out['roofline'] = {'bound': 'mfma', 'peak': 157.3, 'unit': 'TFLOP/s', 'achieved': round(3 * fwd / dt / 1e12, 2),
                        'frac': round(3 * fwd / dt / 157.3e12, 4),
-                       'note': 'whole step against the f32 matrix peak: 402 launches on 8x8 .. 32x32 maps, launch-count bound '
+                       'note': 'whole step against the f32 matrix peak: 384 launches on 8x8 .. 32x32 maps, launch-count bound '
                                '(~12 us per dependent kernel), see profiles/r05_*_cglow_*'}
     if cpu_steps:
         from oracle import glow as oglow

@@ -29,6 +29,7 @@ int conv_forward_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false
 int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st);
 bool wgrad_small_applies(const pdes_conv_desc& d);
+bool wgrad_small_ready(const pdes_conv_desc& d);
 int conv_forward_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);            // 1x1 layers without an LDS tile (conv_mfma_1x1.hip)
 int conv_backward_data_1x1(const pdes_conv_desc& d, hipStream_t st, bool dry = false);
 int upsample_bilinear_forward(const pdes_conv_desc& d, hipStream_t st);   // PDES_UPSAMPLE_BILINEAR_OP descriptors
@@ -99,8 +100,8 @@ static bool fin_onload(const pdes_conv_desc& d, pdes_conv_desc* t) {
   if (d.ksize != 3 || d.stride != 1 || d.upsample || d.Cout > 16 || !d.has_bn || !d.t_in || d.g_add) return false;
   *t = d;
   t->g_fused = 1;
-  return conv_backward_data_small(*t, nullptr, true) == PDES_ENOSUP && conv_backward_data_mfma(*t, nullptr, true) == PDES_OK &&
-         conv_backward_weight_mfma(*t, nullptr, true) == PDES_OK;
+  if (conv_backward_data_small(*t, nullptr, true) == PDES_OK) return wgrad_small_ready(*t);      // the 8 x 8 maps (conv_small.hip)
+  return conv_backward_data_mfma(*t, nullptr, true) == PDES_OK && conv_backward_weight_mfma(*t, nullptr, true) == PDES_OK;
 }
 }  // namespace pdes
 

@@ -88,6 +88,7 @@ __device__ unsigned long long pdes_trace_buf[16];
 static thread_local hipEvent_t tl_stop_event = nullptr;
 void set_dgrad_stop_event(hipEvent_t e) { tl_stop_event = e; }
 bool dgrad_stop_event_pending() { return tl_stop_event != nullptr; }
+hipEvent_t take_dgrad_stop_event() { hipEvent_t e = tl_stop_event; tl_stop_event = nullptr; return e; }       // (conv_small.hip)
 
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 enum { KV_PLAIN = 0, KV_ZEROINS2 = 2 };   // K-operand view: as stored / zero-inserted x2 (stride-2 data gradient)

@@ -14,11 +14,14 @@
 //     a workgroup = (input-channel tile, slice of the batch), each wave one image at a time out of its own LDS
 //     region, the four waves' sums are added in a fixed order and written as one split-K partial (reduced by
 //     pdes_wgrad_reduce_all with every other layer's): deterministic.
+#include <hip/hip_ext.h>
 #include "pdes_common.h"
 #include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 
 namespace pdes {
+
+hipEvent_t take_dgrad_stop_event();       // conv_mfma.hip: the completion signal pdes_backward2 wants on the next data gradient
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -50,8 +53,35 @@ __device__ __forceinline__ BnS bn_coef_s(const pdes_conv_desc& d, int c) {
 bool conv_small_applies(const pdes_conv_desc& d) {
   return opt().mfma_small && !opt().conv_direct && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
          d.Hin == 8 && d.Win == 8 && d.Hout == 8 && d.Wout == 8 && d.Cin <= 352 && d.Cout <= 352 && d.nrep == PDES_NREP &&
-         !d.g_fused;
+         (!d.g_fused || (d.Cout <= 16 && d.fin_xstats && d.fin_tstats && d.out && d.g_ctot == d.out_ctot && d.g_coff == d.out_coff &&
+                         !d.g_add));
 }
+
+// GF (pdes_conv_desc.g_fused, <= 16 output channels): `g` still holds the accumulator T of the layer's output buffer; the
+// data- and weight-gradient kernels apply the BatchNorm-backward finalize  invstd (T - mean T - xhat mean(T xhat))  while they
+// stage the gradient planes (raw activation = `out`): {mean, invstd, mean T, mean T xhat} of the 16 channels, from the
+// replicated fp64 tables -- one load per thread and round, 16-lane shuffle reductions (flow_copy_bwd_kernel's scheme)
+__device__ __forceinline__ void fin_table_small(const pdes_conv_desc& d, float4* fc, double (*sums)[4], int tid, int nthreads) {
+  for (int e = tid; e < 16 * 64; e += nthreads) {
+    const int c = e >> 6, q = (e >> 4) & 3, r = e & 15;
+    const int ch = d.g_coff + min(c, d.Cout - 1);
+    double v = r < PDES_NREP ? (q < 2 ? d.fin_xstats : d.fin_tstats)[(long long)r * d.rep_stride + 2 * ch + (q & 1)] : 0.0;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    if (r == 0) sums[c][q] = v;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const double inv_n = 1.0 / ((double)d.B * 64);
+    const double m = sums[tid][0] * inv_n;
+    double var = sums[tid][1] * inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    fc[tid] = make_float4((float)m, (float)(1.0 / sqrt(var + (double)d.eps)), (float)(sums[tid][2] * inv_n),
+                          (float)(sums[tid][3] * inv_n));
+  }
+}
+__device__ __forceinline__ float fin_apply(const float4 k, float t, float x) { return k.y * (t - k.z - (x - k.x) * k.y * k.w); }
+
 // forward only: also the stride-2 transition onto the 8x8 level (16x16 input planes)
 static bool small_fwd_s2_applies(const pdes_conv_desc& d) {
   return opt().mfma_small && !opt().conv_direct && d.ksize == 3 && d.stride == 2 && d.pad == 1 && !d.upsample && d.has_bn &&
@@ -192,9 +222,11 @@ __global__ __launch_bounds__(256 * KG) void conv_small_fwd_kernel(pdes_conv_desc
 // ------------------------------------------------------------------------------------------------- data gradient
 // grid (B, ceil(input-channel tiles / NT)).  dynamic LDS: planes of g [Cout][SM_CS] + coefficients [NT * 16] float4 +
 // red [4][NT][16][4]
-template <int NT>
+template <int NT, bool GF>
 __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_total) {
   extern __shared__ __attribute__((aligned(16))) float sm_small[];
+  __shared__ float4 fin_c[GF ? 16 : 1];
+  __shared__ double fin_s[GF ? 16 : 1][4];
   const int Cout = d.Cout, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
   const int nt_base = blockIdx.y * NT;
   float* pl = sm_small;
@@ -218,11 +250,15 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
       cf[c] = make_float4(k.mean, k.invstd, k.gamma, k.beta);
     }
   for (int i = tid; i < Cout * SM_CS; i += 256) pl[i] = 0.f;
+  if (GF) fin_table_small(d, fin_c, fin_s, tid, 256);
   __syncthreads();
   const float* gb = d.g + ((size_t)b * d.g_ctot + d.g_coff) * 64;
+  const float* ob = GF ? d.out + ((size_t)b * d.out_ctot + d.out_coff) * 64 : nullptr;
   for (int e = tid; e < Cout * 64; e += 256) {
     const int c = e >> 6, p = e & 63;
-    pl[c * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = gb[e];
+    float z = gb[e];
+    if (GF) z = fin_apply(fin_c[c], z, ob[e]);
+    pl[c * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = z;
   }
   __syncthreads();
   const int i = lane & 15, kq = lane >> 4;
@@ -318,9 +354,11 @@ __global__ __launch_bounds__(256) void conv_small_bwd_kernel(pdes_conv_desc d, c
 // ------------------------------------------------------------------------------------------------- weight gradient
 // grid (ceil(Cin / 16), nsplit), 256 threads.  dynamic LDS: per wave z planes [16][SM_CS] + g planes [NTC * 16][SM_GS];
 // shared: coefficients [16] float4, sums [NTC * 16][16][9]
-template <int NTC>
+template <int NTC, bool GF = false>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(pdes_conv_desc d, float* __restrict__ part, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) float sm_small[];
+  __shared__ float4 fin_c[GF ? 16 : 1];
+  __shared__ double fin_s[GF ? 16 : 1][4];
   constexpr int WREG = 16 * SM_CS + NTC * 16 * SM_GS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ci0 = blockIdx.x * 16, split = blockIdx.y;
@@ -335,6 +373,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(pdes_conv_desc d,
   }
   for (int e = tid; e < NTC * 16 * 16 * 9; e += 256) sums[e] = 0.f;
   for (int e = lane; e < 16 * SM_CS; e += 64) zpl[e] = 0.f;
+  if (GF) fin_table_small(d, fin_c, fin_s, tid, 256);
   __syncthreads();
   v4f acc[9][NTC];
 #pragma unroll
@@ -360,9 +399,15 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(pdes_conv_desc d,
       }
       zpl[cl * SM_CS + ((p >> 3) + 1) * SM_PITCH + (p & 7) + 1] = z;
     }
+    const float* ob = GF ? d.out + ((size_t)(valid ? b : b0) * d.out_ctot + d.out_coff) * 64 : nullptr;
     for (int e = lane; e < NTC * 16 * 64; e += 64) {
       const int co = e >> 6, p = e & 63;
-      gpl[co * SM_GS + p] = (valid && co < d.Cout) ? gb[e] : 0.f;
+      float gvv = 0.f;
+      if (valid && co < d.Cout) {
+        gvv = gb[e];
+        if (GF) gvv = fin_apply(fin_c[co], gvv, ob[e]);
+      }
+      gpl[co * SM_GS + p] = gvv;
     }
     __syncthreads();
 #pragma unroll 2
@@ -443,7 +488,15 @@ int conv_backward_data_small(const pdes_conv_desc& d, hipStream_t st, bool dry) 
   const int nt_total = (d.Cin + 15) / 16;
   constexpr int NT = 4;
   const size_t lds = (size_t)(((d.Cout * SM_CS + 3) & ~3) + NT * 16 * 4 + 4 * NT * 16 * 4) * sizeof(float);
-  hipLaunchKernelGGL(conv_small_bwd_kernel<NT>, dim3(d.B, cdiv(nt_total, NT)), dim3(256), lds, st, d, d.wm_bwd, nt_total);
+  // (the fork of the next layer's weight gradient rides on this launch's completion signal when pdes_backward2 asks for it)
+  hipEvent_t se = take_dgrad_stop_event();
+  const dim3 grid(d.B, cdiv(nt_total, NT));
+  if (d.g_fused && se)
+    hipExtLaunchKernelGGL((conv_small_bwd_kernel<NT, true>), grid, dim3(256), lds, st, nullptr, se, 0, d, d.wm_bwd, nt_total);
+  else if (d.g_fused) hipLaunchKernelGGL((conv_small_bwd_kernel<NT, true>), grid, dim3(256), lds, st, d, d.wm_bwd, nt_total);
+  else if (se)
+    hipExtLaunchKernelGGL((conv_small_bwd_kernel<NT, false>), grid, dim3(256), lds, st, nullptr, se, 0, d, d.wm_bwd, nt_total);
+  else hipLaunchKernelGGL((conv_small_bwd_kernel<NT, false>), grid, dim3(256), lds, st, d, d.wm_bwd, nt_total);
   PDES_LAUNCH_CHECK();
   return PDES_OK;
 }
@@ -457,7 +510,8 @@ int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st) {
   const int ntc = (d.Cout + 15) / 16;
   const size_t lds = (size_t)(64 + ntc * 16 * 16 * 9 + 4 * (16 * SM_CS + ntc * 16 * SM_GS)) * sizeof(float);
   dim3 grid(cdiv(d.Cin, 16), nsplit);
-  if (ntc == 1) hipLaunchKernelGGL(conv_small_wgrad_kernel<1>, grid, dim3(256), lds, st, d, d.ws, nsplit);
+  if (d.g_fused) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, true>), grid, dim3(256), lds, st, d, d.ws, nsplit);      // (<= 16 output channels)
+  else if (ntc == 1) hipLaunchKernelGGL(conv_small_wgrad_kernel<1>, grid, dim3(256), lds, st, d, d.ws, nsplit);
   else if (ntc == 2) hipLaunchKernelGGL(conv_small_wgrad_kernel<2>, grid, dim3(256), lds, st, d, d.ws, nsplit);
   else hipLaunchKernelGGL(conv_small_wgrad_kernel<3>, grid, dim3(256), lds, st, d, d.ws, nsplit);
   PDES_LAUNCH_CHECK();
@@ -469,5 +523,10 @@ int conv_backward_weight_small(const pdes_conv_desc& d, hipStream_t st) {
 }
 
 bool wgrad_small_applies(const pdes_conv_desc& d) { return conv_small_applies(d) && d.Cout <= 48; }
+// would conv_backward_weight_small take `d` as it is (scratch included)?
+bool wgrad_small_ready(const pdes_conv_desc& d) {
+  if (!wgrad_small_applies(d) || !d.ws) return false;
+  return (long long)wgrad_small_splits(d) * d.Cout * d.Cin * 9 * 4 <= d.ws_bytes;
+}
 
 }  // namespace pdes
