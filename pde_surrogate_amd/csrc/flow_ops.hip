@@ -840,22 +840,31 @@ __global__ __launch_bounds__(256) void flow_prepare_kernel(const pdes_flow_item*
   __shared__ double sh_ld;
   __shared__ int sh_piv;
   if (it.lu) {
-    // Bm = (l * l_mask + I) (u * u_mask + diag(exp(log_s) sign_s)),  W = p Bm
+    // Bm = (l * l_mask + I) (u * u_mask + diag(exp(log_s) sign_s)),  W = p Bm.  The three factors are staged in LDS first
+    // (the Gauss-Jordan array is free until the inverse is asked for): with the factors read from global memory inside the
+    // product loops a thread paid one memory round trip per term, 31 us for the launch at the head of every step
+    float* Lf = reinterpret_cast<float*>(&aug[0][0]);
+    float* Uf = Lf + 48 * 48;
+    float* Pf = Uf + 48 * 48;
+    static_assert(sizeof(aug) >= 3 * 48 * 48 * sizeof(float), "staging area");
+    for (int i = tid; i < C * C; i += 256) {
+      const int r = i / C, c = i % C;
+      Lf[i] = c < r ? it.l[i] : (c == r ? 1.f : 0.f);
+      Uf[i] = r < c ? it.u[i] : (r == c ? expf(it.log_s[r]) * it.sign_s[r] : 0.f);
+      Pf[i] = it.p[i];
+    }
+    __syncthreads();
     for (int i = tid; i < C * C; i += 256) {
       const int r = i / C, c = i % C;
       float s = 0.f;
-      for (int k = 0; k < C; ++k) {
-        const float lv = k < r ? it.l[r * C + k] : (k == r ? 1.f : 0.f);
-        const float uv = k < c ? it.u[k * C + c] : (k == c ? expf(it.log_s[k]) * it.sign_s[k] : 0.f);
-        s += lv * uv;
-      }
+      for (int k = 0; k < C; ++k) s += Lf[r * C + k] * Uf[k * C + c];
       Bm[i] = s;
     }
     __syncthreads();
     for (int i = tid; i < C * C; i += 256) {
       const int r = i / C, c = i % C;
       float s = 0.f;
-      for (int k = 0; k < C; ++k) s += it.p[r * C + k] * Bm[k * C + c];
+      for (int k = 0; k < C; ++k) s += Pf[r * C + k] * Bm[k * C + c];
       A[i] = s;
     }
   } else {
@@ -903,12 +912,20 @@ __global__ __launch_bounds__(256) void flow_prepare_kernel(const pdes_flow_item*
       for (int i = tid; i < C * C; i += 256) it.Winv[i] = (float)aug[i / C][C + i % C];
     logdet_w = sh_ld;
   }
+  // log-determinant: the per-channel terms by one thread each (loads in flight together), the sums in the reference's order
+  __shared__ float ld_an[48], ld_ls[48];
+  __syncthreads();
+  if (tid < C) {
+    ld_an[tid] = logf(fabsf(it.an_weight[tid]));
+    ld_ls[tid] = it.lu ? it.log_s[tid] : 0.f;
+  }
+  __syncthreads();
   if (tid == 0) {
     double an = 0.0, ls = 0.0;
-    for (int c = 0; c < C; ++c) an += (double)logf(fabsf(it.an_weight[c]));
+    for (int c = 0; c < C; ++c) an += (double)ld_an[c];
     if (it.lu) {
       float s = 0.f;
-      for (int c = 0; c < C; ++c) s += it.log_s[c];
+      for (int c = 0; c < C; ++c) s += ld_ls[c];
       ls = (double)s;
     } else {
       ls = (double)(float)logdet_w;
@@ -921,14 +938,17 @@ __global__ __launch_bounds__(256) void flow_param_grads_kernel(const pdes_flow_i
                                                                const float* __restrict__ glogp, int B, int nrep, long long rs) {
   const pdes_flow_item it = items[blockIdx.x];
   const int C = it.C, tid = threadIdx.x;
-  __shared__ float dW[48 * 48], M1[48 * 48], Lf[48 * 48], Uf[48 * 48];
+  __shared__ float dW[48 * 48], M1[48 * 48], Lf[48 * 48], Uf[48 * 48], Pf[48 * 48];
   __shared__ float red[4];
   float cb = 0.f;
   if (glogp)
     for (int b = tid; b < B; b += 256) cb += glogp[b];
   cb = wave_sum(cb);
   if ((tid & 63) == 0) red[tid >> 6] = cb;
-  for (int i = tid; i < C * C; i += 256) dW[i] = (float)rep_sum(it.acc, 2 * C + i, nrep, rs);
+  for (int i = tid; i < C * C; i += 256) {
+    dW[i] = (float)rep_sum(it.acc, 2 * C + i, nrep, rs);
+    if (it.lu) Pf[i] = it.p[i];                   // (read from global memory inside the product loop: one round trip per term)
+  }
   __syncthreads();
   const float cB = (red[0] + red[1]) + (red[2] + red[3]);
   const float hw = (float)it.HW;
@@ -945,7 +965,7 @@ __global__ __launch_bounds__(256) void flow_param_grads_kernel(const pdes_flow_i
     Lf[i] = c < r ? it.l[i] : (c == r ? 1.f : 0.f);
     Uf[i] = r < c ? it.u[i] : (r == c ? expf(it.log_s[r]) * it.sign_s[r] : 0.f);
     float s = 0.f;
-    for (int k = 0; k < C; ++k) s += it.p[k * C + r] * dW[k * C + c];       // M1 = P^T dW
+    for (int k = 0; k < C; ++k) s += Pf[k * C + r] * dW[k * C + c];         // M1 = P^T dW
     M1[i] = s;
   }
   __syncthreads();
