@@ -101,6 +101,19 @@ def physical_cores():
     return len(cores) or (os.cpu_count() or 1)
 
 
+def cgroup_cpu_stat():
+    """nr_periods / nr_throttled / throttled_usec of this process's control group (CFS bandwidth control): a non-zero
+    `nr_throttled` over the stepped region means the whole group -- the enqueueing thread included -- stood still"""
+    for p in ('/sys/fs/cgroup/cpu.stat', '/sys/fs/cgroup/cpu/cpu.stat', '/sys/fs/cgroup/cpu,cpuacct/cpu.stat'):
+        try:
+            with open(p) as f:
+                d = dict(line.split() for line in f.read().splitlines())
+            return {k: int(d[k]) for k in ('nr_periods', 'nr_throttled', 'throttled_usec', 'throttled_time') if k in d}
+        except (OSError, ValueError):
+            continue
+    return {}
+
+
 AFFINITY_AT_START = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
 
 
@@ -124,6 +137,10 @@ def cpu_baseline(bs, steps=10, warm=2):
     # oversubscribe them (128 threads on the 64 cores of a node: 1.9 instead of 200 samples/s, 4 minutes of sweep)
     allowed = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else logical
     usable = max(1, min(phys, allowed * phys // max(logical, 1)))
+    from pde_surrogate_amd import parallel as _par
+    quota = _par.cpu_quota()                              # the container's CFS quota (CPUs per period): more threads only get the group throttled
+    if quota is not None:
+        usable = max(1, min(usable, int(quota)))
     cands = sorted({t for t in (4, 8, 16, 32, 64, usable) if 1 <= t <= usable})
     x = torch.from_numpy(grf_kle_fields(bs, seed=7, cache_dir='/tmp'))
     y = torch.randn(bs, 3, 64, 64)
@@ -168,6 +185,7 @@ def cpu_baseline(bs, steps=10, warm=2):
     torch.set_num_threads(t_full)
     return {'value': round(v_full, 2), 'unit': 'samples/s', 'cores': t_full, 'kind': 'port', 'cpu_model': cpu_model(),
             'physical_cores': phys, 'logical_cpus': logical, 'cpus_allowed': allowed, 'physical_cores_usable': usable,
+            'cgroup_cpu_quota': None if quota is None else round(quota, 2),
             'loss_only_samples_per_s': round(v_loss, 1), 'loss_only_threads': t_loss,
             'bs8_samples_per_s': round(v_full8, 2),
             'thread_sweep': {str(t): {'full_step_samples_per_s': sweep[t][0], 'loss_only_samples_per_s': sweep[t][1]}
@@ -344,7 +362,10 @@ def cglow_timing(dev, steps=60, warm=15, cpu_steps=3):
         phys, logical = physical_cores(), os.cpu_count() or 1
         # (8 ... 64 threads: on the 128-core box 16 wins at 0.16 s per step, 64 takes 0.8 s and ALL cores 47 s per step --
         # oversubscription of a workload made of small ops; the sweep stops as soon as a step takes twice the best so far)
-        cands = sorted({t for t in (8, 16, 32, 64) if 1 <= t <= logical})
+        from pde_surrogate_amd import parallel as _par
+        quota = _par.cpu_quota()
+        cap = logical if quota is None else max(1, min(logical, int(quota)))
+        cands = sorted({t for t in (8, 16, 32, 64, cap) if 1 <= t <= cap})
         sweep = {}
         for t in cands:
             torch.set_num_threads(t)
@@ -754,6 +775,11 @@ def main():
             raise SystemExit(f'--global-batch {args.global_batch} is not a multiple of the {world} ranks')
         B = args.global_batch // world
     pins = pin_host(dev, local, world)
+    # BLAS / OpenMP pools within the control group's CPU quota BEFORE the synthetic fields are generated (numpy's 64
+    # OpenBLAS threads spin for ~100 ms behind their last product: on a 16-CPU quota that froze the enqueueing thread for
+    # 20-40 ms inside the timed window of one short run in seven, BENCH_r05's 2.19 ms per step; EXPERIMENTS round 6)
+    from pde_surrogate_amd import parallel as _par
+    host_threads = _par.limit_host_threads(local_world=_par.local_world_size(world))
     torch.manual_seed(1)                                   # identical init on every rank
     with contextlib.redirect_stdout(io.StringIO()):
         model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
@@ -785,18 +811,44 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    # one HIP event behind EVERY step of the process (warm-up and timed): recorded on the stream the step
+    # is enqueued on, read only after the timed region's closing synchronise -- the per-step series in the line shows
+    # whether a short timed window is steady state, a clock ramp or a one-off stall
+    import gc
+    gc_events = []                                         # every collection of the Python GC during the stepped region
+
+    def on_gc(phase, info, _t=[0.0]):
+        if phase == 'start':
+            _t[0] = time.perf_counter()
+        else:
+            gc_events.append({'generation': info['generation'], 'ms': round((time.perf_counter() - _t[0]) * 1e3, 3),
+                              'behind_step': next((j for j in range(total, -1, -1) if step_host[j]), 0)})
+    gc.callbacks.append(on_gc)
+    if os.environ.get('PDES_BENCH_TRACE', '0') == '1':     # diagnosis: host milliseconds of every step by phase
+        trainer.host_prof = {'series': []}
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(total + 1)]
+    step_host = [0.0] * (total + 1)                        # host clock when step i's enqueue returned
+
+    def run_step(i, lr):
+        trainer.step(batch(i), lr)
+        step_ev[i + 1].record()
+        step_host[i + 1] = time.perf_counter()
+
     # warm-up; inside it (auto mode, eager launches) ONE burst of 10 steps is timed behind a device synchronise: how long the
     # host needs to enqueue a step against how long the GPU needs to finish it.  Eight ranks share one host: where the host
     # side comes within 0.8 of the step, the remaining steps replay the forward pass as a hipGraph (bit-identical kernels,
     # ~0.1 ms less host work per step, +0.6 % GPU time on an unconstrained host).  The ranks decide together (MAX).
     probe, i, place_probe = None, 0, None
     can_probe = args.launch_mode == 'auto' and not args.graph and not args.segments and args.warmup >= 16
+    cg0 = cgroup_cpu_stat()
+    step_ev[0].record()
+    step_host[0] = time.perf_counter()
     while i < args.warmup:
         if can_probe and probe is None and i >= min(args.warmup // 2, 24) and args.warmup - i >= 14:
             torch.cuda.synchronize(dev)
             p0 = time.perf_counter()
             for _ in range(10):
-                trainer.step(batch(i), sched.step((i + 1) / total))
+                run_step(i, sched.step((i + 1) / total))
                 i += 1
             p1 = time.perf_counter()
             torch.cuda.synchronize(dev)
@@ -824,12 +876,12 @@ def main():
                 except ValueError:
                     continue
                 for _ in range(2):
-                    trainer.step(batch(i), sched.step((i + 1) / total))
+                    run_step(i, sched.step((i + 1) / total))
                     i += 1
                 sync()
                 q0 = time.perf_counter()
                 for _ in range(18):
-                    trainer.step(batch(i), sched.step((i + 1) / total))
+                    run_step(i, sched.step((i + 1) / total))
                     i += 1
                 torch.cuda.synchronize(dev)
                 t = torch.tensor([time.perf_counter() - q0], device=dev, dtype=torch.float64)
@@ -838,7 +890,7 @@ def main():
             best = min(place_probe, key=place_probe.get)
             trainer.set_bucket_placement(best)
             continue
-        trainer.step(batch(i), sched.step((i + 1) / total))
+        run_step(i, sched.step((i + 1) / total))
         i += 1
     if args.launch_mode == 'forward' and not args.graph and not args.segments:
         trainer.set_launch_mode('forward')
@@ -847,9 +899,15 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
-        trainer.step(batch(i), sched.step((i + 1) / total))
+        run_step(i, sched.step((i + 1) / total))
     sync()
     dt = time.perf_counter() - t0
+    step_ms = [step_ev[j].elapsed_time(step_ev[j + 1]) for j in range(total)]
+    host_ms = [(step_host[j + 1] - step_host[j]) * 1e3 for j in range(total)]
+    gc.callbacks.remove(on_gc)
+    cg1 = cgroup_cpu_stat()
+    throttle = {k: cg1[k] - cg0.get(k, 0) for k in cg1} if cg1 else None
+    host_series, trainer.host_prof = (trainer.host_prof or {}).get('series'), None
     per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
         t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -963,12 +1021,26 @@ def main():
                                      'pipe: layer-level adversarial test of all of these kernels; option PDES_MFMA_B3 = 0 '
                                      'put them back on the f32 pipe)'},
             'loss_mean_over_run': round(means[0], 4),
+            # GPU time of every step of the process: the interval between the HIP events recorded behind consecutive steps on
+            # the launch stream (step W+1's interval contains the barrier + synchronise in front of the timed region), and the
+            # host's enqueue time of the same steps.  Long default runs carry the first and last 40 timed steps.
+            'timed_steps_ms': [round(v, 4) for v in (step_ms[args.warmup:] if args.steps <= 80 else
+                                                     step_ms[args.warmup:args.warmup + 40] + step_ms[-40:])],
+            'warmup_steps_ms': [round(v, 4) for v in (step_ms[:args.warmup] if args.warmup <= 80 else
+                                                      step_ms[:40] + step_ms[args.warmup - 40:args.warmup])],
+            'timed_steps_host_enqueue_ms': [round(v, 4) for v in (host_ms[args.warmup:] if args.steps <= 80 else
+                                                                  host_ms[args.warmup:args.warmup + 40] + host_ms[-40:])],
+            'timed_steps_event_sum_ms': round(sum(step_ms[args.warmup:]), 4),
+            'python_gc_collections_during_steps': [e for e in gc_events if e['generation'] == 2 or e['ms'] > 1.0],
+            'host_phase_series_ms_fwd_loss_bwd': host_series,
             'ranks': torch.distributed.get_world_size() if world > 1 else 1,
             'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 4), 'max': round(max(per_rank_ms), 4),
                                      'all': [round(v, 4) for v in per_rank_ms]},
             'exchange_path': None if world == 1 else ('DirectRccl (ncclAllReduce by pointer)' if trainer._rccl is not None
                                                       else 'torch.distributed.all_reduce'),
             'host_affinity': pins,
+            'host_threads': host_threads,
+            'cgroup_cpu_throttled_during_steps': throttle,
             'allreduce_us_standalone': None if ar_us is None else round(ar_us, 1),
             'host': host,
             'roofline': {'bound': 'hbm', 'kernel': 'darcy_loss_kernel<64,bwd> (fused Sobel+Darcy residual+boundary, fwd+bwd)',

@@ -274,6 +274,87 @@ def pin_rank_to_gpu_numa(device, local_rank=0, local_world=1, group=None):
     return {'pinned': True, 'numa_node': node, 'cpus': _cpulist_str(take), 'n_cpus': len(take), 'threads_moved': n_threads}
 
 
+def cpu_quota(cgroup_root='/sys/fs/cgroup', proc_cgroup='/proc/self/cgroup'):
+    """CPUs' worth of run time per period this process's control group may use (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`; the tightest limit on the path from the process's group to the root), or None
+    when there is no limit.  A container that shows all 256 hardware threads of its host may still own a quota of 16: every
+    thread of the group is frozen for the rest of the 100 ms period once the group's threads have used it up."""
+    rel = ''
+    try:
+        with open(proc_cgroup) as f:
+            for line in f:
+                hid, ctrl, path = line.rstrip('\n').split(':', 2)
+                if ctrl == '' or 'cpu' in ctrl.split(','):
+                    rel = path.lstrip('/')
+                    if ctrl:
+                        break
+    except (OSError, ValueError):
+        pass
+    best = None
+    parts = [p for p in rel.split('/') if p]
+    for depth in range(len(parts), -1, -1):
+        for base in (cgroup_root, os.path.join(cgroup_root, 'cpu'), os.path.join(cgroup_root, 'cpu,cpuacct')):
+            d = os.path.join(base, *parts[:depth])
+            q = None
+            try:
+                with open(os.path.join(d, 'cpu.max')) as f:
+                    a, b = f.read().split()
+                    q = None if a == 'max' else float(a) / float(b)
+            except (OSError, ValueError):
+                try:
+                    with open(os.path.join(d, 'cpu.cfs_quota_us')) as f:
+                        a = float(f.read())
+                    with open(os.path.join(d, 'cpu.cfs_period_us')) as f:
+                        b = float(f.read())
+                    q = a / b if a > 0 and b > 0 else None
+                except (OSError, ValueError):
+                    q = None
+            if q is not None and (best is None or q < best):
+                best = q
+    return best
+
+
+def host_thread_budget(reserve=2, local_world=1):
+    """how many compute threads (BLAS / OpenMP pools) this process can run without starving its own enqueueing thread:
+    min(CPUs it may run on, its share of the control group's CPU quota among the `local_world` ranks of this host) -
+    `reserve`, at least 1"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    q = cpu_quota()
+    if q is not None:
+        n = min(n, int(q / max(local_world, 1)))
+    return max(1, n - reserve)
+
+
+def limit_host_threads(reserve=2, local_world=1):
+    """cap torch's intra-op pool and every BLAS / OpenMP pool threadpoolctl can see at `host_thread_budget`.  Those pools
+    size themselves by the hardware threads they SEE (64 OpenBLAS + 128 OpenMP threads on the 256-thread host of an
+    MI355X node) and keep spinning for ~100 ms behind their last job; in a container with a CPU quota below that (16 CPUs
+    on the boxes this was measured on) the spinning uses the group's quota up, CFS freezes EVERY thread of the group until
+    the 100 ms period ends, and the thread that enqueues the training step stands still for 20-40 ms in the middle of
+    hipLaunchKernel -- one step in a few hundred takes 25 ms instead of 1.6 (round 6: tools/diag/stall_hunt.py, the group's
+    `nr_throttled` counts exactly the runs with such a step).  PDES_HOST_THREADS=0 leaves the pools alone, =N sets N.
+    Returns a dict for the logs; idempotent."""
+    env = os.environ.get('PDES_HOST_THREADS')
+    if env == '0':
+        return {'limited': False, 'why': 'PDES_HOST_THREADS=0'}
+    q = cpu_quota()
+    n = int(env) if env and env.isdigit() else host_thread_budget(reserve, local_world)
+    out = {'limited': True, 'cpu_quota': None if q is None else round(q, 2), 'threads': n, 'torch_threads_before': torch.get_num_threads()}
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    try:
+        import threadpoolctl
+        before = {f"{i['internal_api']}:{i.get('prefix')}": i['num_threads'] for i in threadpoolctl.threadpool_info()}
+        ctl = threadpoolctl.ThreadpoolController()
+        for lib in ctl.lib_controllers:                           # lower, never raise, a pool
+            if lib.num_threads is not None and lib.num_threads > n:
+                lib.set_num_threads(n)
+        out['pools_before'] = before
+    except Exception as e:                                        # noqa: BLE001  (an optimisation must not abort a run)
+        out['threadpoolctl'] = f'{type(e).__name__}: {e}'[:120]
+    return out
+
+
 def set_affinity_all_threads(cpus):
     """sched_setaffinity for every thread of this process (new threads inherit); returns the number of threads moved"""
     n_threads = 0

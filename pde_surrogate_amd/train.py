@@ -104,6 +104,9 @@ class MixedResidualTrainer:
         self.dev = torch.device(device if device is not None else 'cuda:0')
         if self.dev.type != 'cuda':
             raise RuntimeError('MixedResidualTrainer runs on an MI355X only (no CPU fallback)')
+        # the BLAS / OpenMP pools of this process never get more threads than its control group's CPU quota leaves beside
+        # the thread that enqueues the step (parallel.limit_host_threads: spinning pool threads got that thread frozen)
+        self.host_threads = parallel.limit_host_threads(local_world=parallel.local_world_size(1))
         self.wb = float(weight_bound)
         self.nl, self.nb1, self.nb2 = bool(nonlinear), float(beta1), float(beta2)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -284,6 +287,8 @@ class MixedResidualTrainer:
             prof['forward'] = prof.get('forward', 0.0) + (t1 - t0)
             prof['loss'] = prof.get('loss', 0.0) + (t2 - t1)
             prof['backward'] = prof.get('backward', 0.0) + (t3 - t2)
+            if 'series' in prof:                              # per-step phases (bench.py: where a host stall lands)
+                prof['series'].append((round((t1 - t0) * 1e3, 3), round((t2 - t1) * 1e3, 3), round((t3 - t2) * 1e3, 3)))
         return m
 
     def _loss(self, y, st):
@@ -486,6 +491,7 @@ class ReverseKLTrainer:
         self.dev = torch.device(device if device is not None else 'cuda:0')
         if self.dev.type != 'cuda':
             raise RuntimeError('ReverseKLTrainer runs on an MI355X only (no CPU fallback)')
+        self.host_threads = parallel.limit_host_threads(local_world=parallel.local_world_size(1))
         self.wb, self.beta = float(weight_bound), float(beta)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.pg = process_group
