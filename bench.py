@@ -969,17 +969,50 @@ def main():
             dropin = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
     mark('host / dp1 / segment / config-4 / drop-in legs')
     if rank == 0:
-        traffic, traffic_src = None, None
+        # HBM traffic from the PMC counters: the newest profiles/r*_loss_variants_pmc.json (tools/pmc_loss_variants.sh: separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel, FETCH_SIZE doubled per the gfx950 note) -- used ONLY when
+        # the file was measured on the same sources of these kernels as the library loaded now (source fingerprint) and names
+        # the kernel the variant launches; a stale file leaves `traffic` null and says why
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_loss_kernel_pmc.json')))
-        if pmcs:                                             # the latest rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_loss
+        pmc_variants, pmc_src, pmc_why = {}, None, 'no profiles/r*_loss_variants_pmc.json'
+        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_loss_variants_pmc.json')))
+        if pmcs:
             with open(pmcs[-1]) as f:
                 pj = json.load(f)
-            traffic = pj['hbm_bytes_per_launch']
-            traffic_src = f'profiles/{os.path.basename(pmcs[-1])} (B=16384, separate --pmc passes, FETCH_SIZE doubled: gfx950)'
+            if pj.get('source_fingerprint') != bench_loss.source_fingerprint():
+                pmc_why = (f'profiles/{os.path.basename(pmcs[-1])} was measured on other sources of the loss kernels (fingerprint '
+                           f"{pj.get('source_fingerprint')} != {bench_loss.source_fingerprint()}): refused")
+            else:
+                pmc_variants = {v: e for v, e in pj['variants'].items()
+                                if e.get('kernel') == bench_loss.VARIANTS.get(v, (0, 0, None))[2] and 'hbm_bytes_per_launch' in e}
+                pmc_src = (f'profiles/{os.path.basename(pmcs[-1])} (B=16384, separate --pmc passes per kernel, FETCH_SIZE doubled: '
+                           f"gfx950; same kernel sources as this library: fingerprint {pj['source_fingerprint']})")
+        traffic = pmc_variants.get('loss_fwd_bwd', {}).get('hbm_bytes_per_launch')
+        traffic_src = pmc_src if traffic is not None else pmc_why
         us32, gb32 = loss_kernel_timing(dev, B, 200)
         usL, gbL, gbBurst = loss_kernel_timing(dev, 16384, 100, warmup=100, burst=True)
         mark('loss-kernel roofline')
+        # SURVEY 8(d)'s other priced kernels: forward-only loss (the test() path), the nonlinear law, the
+        # stand-alone Sobel pair and its adjoint -- HBM regime (B = 16,384) beside the cache-resident sizes
+        variants = {}
+        for v in bench_loss.VARIANTS:
+            rows = {}
+            for Bv, it, w, label in ((16384, 100, 100, 'hbm regime: working set > 256 MiB Infinity Cache'),
+                                     (256, 200, 20, 'cache-resident'), (B, 200, 20, 'cache-resident / launch-bound (training batch)')):
+                r = bench_loss.time_variant(v, Bv, it, w, dev)
+                rows[str(Bv)] = {'us_per_launch': r['us_per_launch'], 'achieved': r['achieved'], 'frac': r['frac'],
+                                 'algorithmic_bytes_per_launch': r['algorithmic_bytes_per_launch'], 'regime': label}
+            big = rows['16384']
+            e = pmc_variants.get(v, {})
+            variants[v] = {'bound': 'hbm', 'kernel': bench_loss.VARIANTS[v][2], 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
+                           'algorithmic_bytes_per_' + bench_loss.VARIANTS[v][1]: bench_loss.VARIANTS[v][0],
+                           'achieved': big['achieved'], 'frac': big['frac'], 'us_per_launch': big['us_per_launch'], 'batch': 16384,
+                           'traffic': e.get('hbm_bytes_per_launch'),
+                           'traffic_over_algorithmic': None if not e else round(e['traffic_over_algorithmic'], 4),
+                           'by_batch': rows}
+        mark('loss-path roofline variants')
         out = {
             'metric': 'training samples/sec (64x64 GRF-KLE512, bs=%d per GPU)' % B,
             'value': round(GB * args.steps / dt, 1), 'unit': 'samples/s', 'n_gpus': world,
@@ -1055,6 +1088,10 @@ def main():
                                            'frac': round(gb32 / HBM_PEAK_GBPS, 4),
                                            'note': 'cache-resident / launch-bound at the training batch size'}},
         }
+        out['roofline_variants'] = dict(variants, traffic_source=pmc_src if pmc_variants else pmc_why,
+                                        note='HIP events on the launch stream; 16384: 100 launches behind 100 warm-up launches; the '
+                                             'stand-alone Sobel kernels process the 3 output channels of the batch (3 x batch planes '
+                                             'per launch); 32 / 256 are cache-resident and launch-bound, labelled as such')
         if host is not None:
             out['host_enqueue_ms_per_step'] = host['host_enqueue_ms_per_step']
         if steady is not None:

@@ -230,3 +230,55 @@ def test_device_loader_drops_the_last_partial_batch_like_the_reference():
         assert not set(ba.reshape(-1).tolist()) & set(bb.reshape(-1).tolist())
     with pytest.raises(ValueError):
         DeviceLoader(x[:3], batch_size=4, device='cpu')
+
+
+def test_cpu_quota_reads_cgroup_v2_and_v1_and_caps_the_host_thread_pools(tmp_path, monkeypatch):
+    """round 6: a container that shows 256 hardware threads but owns a CFS quota of 16 CPUs froze the enqueueing thread when
+    this process's BLAS pool threads used the quota up (profiles/r06_a_contract_window_host_stalls.txt):
+    parallel.cpu_quota reads the limit, limit_host_threads keeps the pools inside it"""
+    # cgroup v2: /proc/self/cgroup "0::/job", limits on the path from the group to the root, the tightest counts
+    root = tmp_path / 'cg2'
+    (root / 'job').mkdir(parents=True)
+    (root / 'cpu.max').write_text('1600000 100000\n')
+    (root / 'job' / 'cpu.max').write_text('max 100000\n')
+    proc = tmp_path / 'proc2'
+    proc.write_text('0::/job\n')
+    assert parallel.cpu_quota(str(root), str(proc)) == 16.0
+    (root / 'job' / 'cpu.max').write_text('400000 100000\n')
+    assert parallel.cpu_quota(str(root), str(proc)) == 4.0
+    # cgroup v1: cpu controller mounted under <root>/cpu, quota -1 = unlimited
+    root1 = tmp_path / 'cg1'
+    (root1 / 'cpu' / 'box').mkdir(parents=True)
+    (root1 / 'cpu' / 'box' / 'cpu.cfs_quota_us').write_text('-1\n')
+    (root1 / 'cpu' / 'box' / 'cpu.cfs_period_us').write_text('100000\n')
+    proc1 = tmp_path / 'proc1'
+    proc1.write_text('4:memory:/x\n1:cpu,cpuacct:/box\n0::/\n')
+    assert parallel.cpu_quota(str(root1), str(proc1)) is None
+    (root1 / 'cpu' / 'box' / 'cpu.cfs_quota_us').write_text('250000\n')
+    assert parallel.cpu_quota(str(root1), str(proc1)) == 2.5
+    # nothing readable: no limit
+    assert parallel.cpu_quota(str(tmp_path / 'none'), str(tmp_path / 'nofile')) is None
+    # the budget: min(allowed CPUs, the rank's share of the quota) - reserve, never below 1
+    monkeypatch.setattr(parallel, 'cpu_quota', lambda *a: 16.0)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(256)))
+    assert parallel.host_thread_budget(2, 1) == 14 and parallel.host_thread_budget(2, 8) == 1
+    monkeypatch.setattr(parallel, 'cpu_quota', lambda *a: None)
+    assert parallel.host_thread_budget(2, 1) == 254
+    # limit_host_threads lowers (never raises) torch's pool and reports what it did; PDES_HOST_THREADS overrides
+    before = torch.get_num_threads()
+    import threadpoolctl
+    pools = [(lib, lib.num_threads) for lib in threadpoolctl.ThreadpoolController().lib_controllers]
+    try:
+        monkeypatch.setenv('PDES_HOST_THREADS', '0')
+        assert parallel.limit_host_threads() == {'limited': False, 'why': 'PDES_HOST_THREADS=0'}
+        monkeypatch.setenv('PDES_HOST_THREADS', '1')
+        info = parallel.limit_host_threads()
+        assert info['limited'] and info['threads'] == 1 and torch.get_num_threads() == 1
+        monkeypatch.setenv('PDES_HOST_THREADS', '64')
+        parallel.limit_host_threads()
+        assert torch.get_num_threads() == 1                # a cap is never a raise
+    finally:
+        torch.set_num_threads(before)
+        for lib, n in pools:                               # (the rest of the CPU suite keeps its pools)
+            if n:
+                lib.set_num_threads(n)
