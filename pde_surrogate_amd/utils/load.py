@@ -61,6 +61,17 @@ def load_data(hdf5_file, ndata, batch_size, only_input=True, return_stats=False)
     return data_loader, stats
 
 
+def reference_epoch_order(n):
+    """the permutation of `n` samples the reference's `DataLoader(TensorDataset(...), shuffle=True)` (utils/load.py:34-35)
+    uses for its NEXT epoch, drawn exactly as torch draws it -- through a real DataLoader over the indices, so whatever the
+    installed torch takes from the GLOBAL generator when an iterator is created (the iterator's base seed, the
+    RandomSampler's seed) is taken here too, in the same order.  With the reference's seed and creation order (Parser:
+    manual_seed -> DenseED -> loaders) a run of this build therefore sees the reference's minibatches, epoch by epoch
+    (tests/golden/G25: the permutations of the reference's own run)."""
+    loader = DataLoader(range(n), batch_size=n, shuffle=True, collate_fn=lambda b: b)
+    return torch.tensor(next(iter(loader)), dtype=torch.int64)
+
+
 class DeviceLoader:
     """Device-resident replacement for DataLoader(shuffle=True, drop_last=True): the whole dataset
     lives in HBM (4096 x 16 KiB = 64 MiB), a minibatch is one index_select.  With world_size > 1 every
@@ -68,7 +79,7 @@ class DeviceLoader:
     that is identical on all ranks (same generator seed).  Like the reference's loader (utils/load.py:34-35 there:
     drop_last=True) samples beyond the last full global batch of an epoch's permutation are dropped."""
 
-    def __init__(self, *tensors, batch_size, device, shuffle=True, seed=0, rank=0, world_size=1):
+    def __init__(self, *tensors, batch_size, device, shuffle=True, seed=0, rank=0, world_size=1, order='own'):
         self.tensors = [t.to(device) for t in tensors]
         self.n = self.tensors[0].shape[0]
         self.batch_size, self.rank, self.world = batch_size, rank, world_size
@@ -76,6 +87,11 @@ class DeviceLoader:
         if self.n < self.global_batch:
             raise ValueError(f'{self.n} samples are fewer than one global batch of {self.global_batch}')
         self.shuffle = shuffle
+        # order='reference': every epoch's permutation comes from torch's global generator the way the reference's
+        # DataLoader draws it (reference_epoch_order); 'own': from a generator of this loader seeded with `seed`
+        if order not in ('own', 'reference'):
+            raise ValueError("DeviceLoader order: 'own' or 'reference'")
+        self.order = order
         self.gen = torch.Generator(device='cpu').manual_seed(seed)
         self.device = device
 
@@ -83,7 +99,12 @@ class DeviceLoader:
         return self.n // self.global_batch
 
     def __iter__(self):
-        perm = torch.randperm(self.n, generator=self.gen) if self.shuffle else torch.arange(self.n)
+        if not self.shuffle:
+            perm = torch.arange(self.n)
+        elif self.order == 'reference':
+            perm = reference_epoch_order(self.n)
+        else:
+            perm = torch.randperm(self.n, generator=self.gen)
         perm = perm.to(self.device)
         for i in range(len(self)):
             lo = i * self.global_batch + self.rank * self.batch_size

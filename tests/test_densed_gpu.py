@@ -96,6 +96,11 @@ def _default_net(dev):
     return net.to(dev).train()
 
 
+# bounds of the drift assertions at the end of the G23 test (today's count minus two; twice-and-a-bit the reference's own floor)
+G23_MEDIAN_OVER_FLOOR_MAX = 2.2
+G23_WITHIN_1E3_MIN = 22
+
+
 def test_g23_channelized_batch_against_the_reference(dev):
     """BASELINE configs[3]: the default DenseED on CHANNELIZED fields -- two-valued, sharp interfaces,
     the input family SURVEY section 7 flags for E[x^2] - E[x]^2 cancellation in the first BatchNorms and for ReLU flips -- at
@@ -134,8 +139,20 @@ def test_g23_channelized_batch_against_the_reference(dev):
     e64 = sorted(((rel_l2(grads[k[7:]], g[k]), floor[k[7:]], k[7:]) for k in g.files if k.startswith('grad64/')), reverse=True)
     print('G23 worst vs the reference (err, reference floor):', [(f'{e:.2e}', f'{f:.2e}', k) for e, f, k in errs[:6]])
     print('G23 worst vs fp64:', [(f'{e:.2e}', f'{f:.2e}', k) for e, f, k in e64[:6]])
-    print('G23 tensors within 1e-3 of the reference: %d of %d; median error %.2e' %
-          (sum(e < 1e-3 for e, _, _ in errs), len(errs), float(np.median([e for e, _, _ in errs]))))
+    n_close, med = sum(e < 1e-3 for e, _, _ in errs), float(np.median([e for e, _, _ in errs]))
+    print('G23 tensors within 1e-3 of the reference: %d of %d; median error %.2e' % (n_close, len(errs), med))
+    #  what is printed is asserted, so that a slow drift cannot hide under the per-tensor bounds.  The
+    # yardstick is the REFERENCE's own rounding error on this input (fp32 against the fp64 oracle, stored per tensor: median
+    # 0.90e-3 over the 82 tensors, 53 of them within 1e-3): two fp32 pipelines that are each that far from the exact
+    # gradient sit ~1.4-2x that from each other.  Round 6 on the MI355X: median 1.70e-3 against the reference, 24 tensors
+    # within 1e-3 of it
+    floor_med = float(np.median(g['ref_fp32_vs_fp64_floor']))
+    med64 = float(np.median([e for e, _, _ in e64]))
+    floor_med64 = float(np.median([f for _, f, _ in e64]))
+    print('G23 medians: vs reference %.2e (reference floor %.2e), vs fp64 over the 71 tensors %.2e (reference floor there %.2e)'
+          % (med, floor_med, med64, floor_med64))
+    assert med <= G23_MEDIAN_OVER_FLOOR_MAX * floor_med and n_close >= G23_WITHIN_1E3_MIN, (med, floor_med, n_close)
+    assert med64 <= G23_MEDIAN_OVER_FLOOR_MAX * floor_med64, (med64, floor_med64)
     for e, f, k in errs:
         assert e < 1e-3 + 2.0 * f, (k, e, f)
     assert len(e64) == 71
@@ -149,12 +166,19 @@ def test_g11_headline_batch_every_gradient_tensor(dev):
     matrix-core kernels -- the tile shapes / split-K plans / wave-group variants are chosen by batch size"""
     from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
     g = golden('G11_densed_default_b32.npz')
+    g24 = golden('G24_densed_default_b32_outputs.npz')      # round 6: the reference's output on this batch, every sample
     net = _default_net(dev)
     x = torch.from_numpy(g['x']).to(dev)
     y = net(x)
     yc = y.detach().cpu().numpy()
-    assert rel_l2(yc[0], g['y0']) < 1e-5
-    np.testing.assert_allclose(yc[:, :, ::8, ::8], g['y_slice'], rtol=1e-3, atol=1e-4)
+    # the whole headline batch at the output tolerance (rel-L2 1e-5): first and last sample, the slices over all 32, and
+    # every sample's norm and per-channel mean (VERDICT r5 item 3: the slice used to be held to rtol 1e-3 only)
+    assert rel_l2(yc[0], g['y0']) < 1e-5 and rel_l2(yc[31], g24['y_last']) < 1e-5
+    assert rel_l2(yc[:, :, ::8, ::8], g['y_slice']) < 1e-5 and rel_l2(yc[:, :, ::4, ::4], g24['y_slice4']) < 1e-5
+    for b in range(32):
+        assert rel_l2(yc[b, :, ::4, ::4], g24['y_slice4'][b]) < 1e-5, b
+    np.testing.assert_allclose(np.sqrt((yc.astype(np.float64) ** 2).sum(axis=(1, 2, 3))), g24['y_norms'], rtol=1e-5)
+    np.testing.assert_allclose(yc.astype(np.float64).mean(axis=(2, 3)), g24['y_channel_means'], rtol=1e-4, atol=1e-5)
     loss, l_pde, l_dir, l_neu = darcy_mixed_residual_loss(x, y, 10.0)
     ref = g['terms']
     np.testing.assert_allclose([float(loss.detach()), float(l_pde), float(l_dir), float(l_neu)],

@@ -390,3 +390,26 @@ def test_g22_oracle_above_the_training_batch(B):
         assert abs((gr * fixed_projection(gr.shape, i)).sum() - g[t + 'grad_proj'][i]) < tol * g[t + 'grad_norms'][i] * np.sqrt(gr.size / 2), k
         if t + 'grad/' + k in g.files:
             assert rel_l2(gr, g[t + 'grad/' + k]) < tol, k
+
+
+def test_g25_config1_first_steps_of_the_references_own_run():
+    """BASELINE configs[0] (`--ntrain 512 --batch-size 8`, the reference's script run unmodified by tools/gen_golden.py
+    round6): the oracle on the reference's first minibatches (its DataLoader's recorded permutation) reproduces the
+    reference's per-step losses -- step 1 at 1e-5, then within the chaos of an fp32 Adam trajectory (see G7)"""
+    g = golden('G25_config1_cli_run.npz')
+    x = g['k_u16_over_256'].astype(np.float32) / 256.0
+    assert x.shape == (576, 1, 64, 64) and g['step_losses'].shape == (128,)
+    torch.manual_seed(1)
+    sd = codec.densed_init(1, 3, [6, 8, 6], 16, 48)
+    tr = train.CpuTrainer(sd, [6, 8, 6], lr=1e-3, lr_div=2.0, lr_pct=0.3)
+    perm = g['train_perms'][0]
+    for step in range(1, 4):
+        idx = perm[(step - 1) * 8:step * 8]
+        loss, lr, _ = tr.step(torch.from_numpy(x[:512][idx]), step / 128)
+        tol = {1: 1e-5, 2: 1e-3}.get(step, 0.15)
+        assert abs(loss - g['step_losses'][step - 1]) <= tol * abs(g['step_losses'][step - 1]), (step, loss)
+    # the logged per-epoch training loss is the mean of the step losses (train_codec_mixed_residual.py:240-242)
+    np.testing.assert_allclose(g['loss_train'], g['step_losses'].reshape(2, 64).mean(1), rtol=1e-12)
+    # and the test-set metrics of the fixture follow from its own arrays (load.py:28-30)
+    y = g['y_test_i16_over_1024'].astype(np.float32) / 1024.0
+    np.testing.assert_allclose(train.y_variation(y), g['y_variation'], rtol=1e-5)

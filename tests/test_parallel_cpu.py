@@ -282,3 +282,32 @@ def test_cpu_quota_reads_cgroup_v2_and_v1_and_caps_the_host_thread_pools(tmp_pat
         for lib, n in pools:                               # (the rest of the CPU suite keeps its pools)
             if n:
                 lib.set_num_threads(n)
+
+
+def test_reference_epoch_order_draws_the_reference_dataloaders_permutations():
+    """round 6: with the reference's seed and creation order (Parser: manual_seed(1) -> DenseED -> loaders) the permutations
+    DeviceLoader(order='reference') draws are the ones the reference's own DataLoaders drew in its run of BASELINE
+    configs[0] (tests/golden/G25: train epoch 1, test epoch 1, train epoch 2, test epoch 2 -- recorded from
+    /root/reference's script by tools/gen_golden.py round6)"""
+    import contextlib
+    import io
+    import numpy as np
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.utils.load import DeviceLoader, reference_epoch_order
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'G25_config1_cli_run.npz'))
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)       # consumes the generator like the reference's
+    for e in range(2):
+        assert np.array_equal(reference_epoch_order(512).numpy(), g['train_perms'][e])
+        assert np.array_equal(reference_epoch_order(64).numpy(), g['test_perms'][e])
+    # through the loader: batches = consecutive slices of that permutation
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
+    x = torch.arange(512, dtype=torch.float32).reshape(512, 1)
+    dl = DeviceLoader(x, batch_size=8, device='cpu', order='reference')
+    seen = torch.cat([b[0].reshape(-1) for b in dl]).long().numpy()
+    assert np.array_equal(seen, g['train_perms'][0])
+    with pytest.raises(ValueError):
+        DeviceLoader(x, batch_size=8, device='cpu', order='sorted')

@@ -13,6 +13,7 @@ whether the local torch reproduces it).
     python tools/gen_golden.py round3     # only G21 (any field size; correct=False through the loss functions)
     python tools/gen_golden.py round4     # only W_seeded (seeded initial parameters) and G22 (DenseED at B = 64 / 128 / 256)
     python tools/gen_golden.py round5     # only G23 (BASELINE configs[3]: the default DenseED on channelized fields, B = 32)
+    python tools/gen_golden.py round6     # only G24 (G11's outputs, every sample) and G25 (configs[0] end to end through the reference's script)
 """
 import hashlib
 import io
@@ -423,6 +424,111 @@ def gen_round5():
                                                           names[int(floor.argmax())]))
     np.savez_compressed(os.path.join(OUT, 'G23_densed_channelized_b32.npz'), **g)
     print('G23_densed_channelized_b32.npz', os.path.getsize(os.path.join(OUT, 'G23_densed_channelized_b32.npz')))
+
+
+def gen_round6():
+    """round 6.
+    G24: per-sample output norms, the last sample and the per-channel means of the reference's output on G11's batch (the
+         fixture held sample 0 and a slice): the test asserts 1e-5 on first / last / slice / every sample's norm.
+    G25: BASELINE configs[0] END TO END: the reference's own script, unmodified (runpy; h5py replaced by an in-memory module
+         holding the arrays -- h5py is not installed here), `--data grf_kle512 --ntrain 512 --batch-size 8 --epochs 2` (+ a
+         64-sample test set) on the CPU: the loss of every one of its 128 steps, the permutations its DataLoaders drew, the
+         four per-epoch log files, the final first-layer weights.  The dataset is stored quantised (K = uint16 / 256, targets =
+         int16 / 1024: exact in fp32, so every machine feeds the same bits)."""
+    import runpy
+    import shutil
+    import tempfile
+    import types
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    # ---- G24
+    g11 = np.load(os.path.join(OUT, 'G11_densed_default_b32.npz'))
+    torch.manual_seed(1)
+    net = quiet(DenseED, 1, 3, 64, [6, 8, 6], 16, 48)
+    net.train()
+    yo = net(torch.from_numpy(g11['x'])).detach().numpy()
+    assert np.array_equal(yo[0], g11['y0']), 'the reference no longer reproduces G11 bit for bit on this machine'
+    np.savez_compressed(os.path.join(OUT, 'G24_densed_default_b32_outputs.npz'), y_last=yo[-1],
+                        y_norms=np.sqrt((yo.astype(np.float64) ** 2).sum(axis=(1, 2, 3))),
+                        y_channel_means=yo.astype(np.float64).mean(axis=(2, 3)), y_slice4=yo[:, :, ::4, ::4])
+    # ---- G25
+    ntrain, ntest = 512, 64
+    K = grf_kle_fields(ntrain + ntest, seed=25, cache_dir='/tmp')
+    kq = np.clip(np.rint(K * 256.0), 1, 65535).astype(np.uint16)
+    x_all = kq.astype(np.float32) / 256.0
+    rng = np.random.default_rng(2025)
+    jj = (np.arange(64) + 0.5) / 64
+
+    def smooth(a):
+        for ax in (-1, -2):
+            a = (np.roll(a, 1, ax) + 2 * a + np.roll(a, -1, ax)) / 4
+        return a
+    u = (1.0 - jj)[None, None, None, :] + 0.05 * smooth(smooth(rng.standard_normal((ntest, 1, 64, 64))))
+    s1 = x_all[ntrain:] * (1.0 + 0.1 * smooth(rng.standard_normal((ntest, 1, 64, 64))))
+    s2 = 0.3 * smooth(smooth(rng.standard_normal((ntest, 1, 64, 64))))
+    yq = np.clip(np.rint(np.concatenate([u, s1, s2], 1) * 1024.0), -32768, 32767).astype(np.int16)
+    y_test = yq.astype(np.float32) / 1024.0
+    files = {'kle512_lhs10000_train.hdf5': {'input': x_all[:ntrain]},
+             'kle512_lhs1000_val.hdf5': {'input': x_all[ntrain:], 'output': y_test}}
+
+    class _File(dict):
+        def __init__(self, path, mode='r'):
+            super().__init__(files[os.path.basename(path)])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+    shim = types.ModuleType('h5py')
+    shim.File = _File
+    sys.modules['h5py'] = shim
+    step_losses, perms = [], []
+    item0, randperm0 = torch.Tensor.item, torch.randperm
+
+    def item(self):
+        v = item0(self)
+        if self.grad_fn is not None and self.dim() == 0:        # `loss.item()` of the training loop (:240); test() runs under no_grad
+            step_losses.append(v)
+        return v
+
+    def randperm(n, *a, **k):
+        r = randperm0(n, *a, **k)
+        if k.get('generator') is not None:
+            perms.append((int(n), r.numpy().copy()))
+        return r
+    tmp = tempfile.mkdtemp(prefix='g25_')
+    argv0, cwd0 = sys.argv, os.getcwd()
+    torch.Tensor.item, torch.randperm = item, randperm
+    try:
+        sys.argv = ['train_codec_mixed_residual.py', '--data', 'grf_kle512', '--ntrain', str(ntrain), '--ntest', str(ntest),
+                    '--batch-size', '8', '--test-batch-size', '64', '--epochs', '2', '--exp-dir', tmp, '--data-dir', tmp,
+                    '--plot-freq', '1000', '--ckpt-freq', '1000', '--cuda', '0']
+        os.chdir(tmp)
+        torch.set_num_threads(8)
+        ns = runpy.run_path(os.path.join(REF, 'train_codec_mixed_residual.py'), run_name='__main__')
+    finally:
+        torch.Tensor.item, torch.randperm = item0, randperm0
+        sys.argv = argv0
+        os.chdir(cwd0)
+        del sys.modules['h5py']
+    args = ns['args']
+    logs = {m: np.loadtxt(os.path.join(args.train_dir, m + '.txt')) for m in ('loss_train', 'loss_test', 'nrmse_test', 'r2_test')}
+    model = ns['model']
+    assert len(step_losses) == 128, len(step_losses)
+    # (a RandomSampler run to exhaustion draws a second, unused permutation from its local generator -- the
+    #  `[: num_samples % n]` tail of its __iter__: every other recorded permutation is an epoch's order)
+    train_perms = np.stack([p for n, p in perms if n == ntrain][0:4:2])
+    test_perms = np.stack([p for n, p in perms if n == ntest][0:4:2])
+    assert len([1 for n, _ in perms if n == ntrain]) == 4 and len([1 for n, _ in perms if n == ntest]) >= 4
+    np.savez_compressed(os.path.join(OUT, 'G25_config1_cli_run.npz'), k_u16_over_256=kq, y_test_i16_over_1024=yq,
+                        argv=np.array(sys.argv if False else ['--data', 'grf_kle512', '--ntrain', '512', '--ntest', '64', '--batch-size', '8',
+                                                              '--test-batch-size', '64', '--epochs', '2', '--seed', '1']),
+                        step_losses=np.array(step_losses, np.float64), train_perms=train_perms, test_perms=test_perms,
+                        final_In_conv=model.features.In_conv.weight.detach().numpy(),
+                        final_running_mean=model.features.LastTransUp.norm3.running_mean.numpy(),
+                        y_variation=ns['y_test_variation'], **logs)
+    print('G25: step losses', step_losses[:4], '...', step_losses[-2:], '| logs', {k: v.tolist() for k, v in logs.items()})
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def gen_dropout():
@@ -854,6 +960,9 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'round4':  # only W_seeded (initial parameters) and G22 (B = 64 / 128 / 256)
         torch.set_num_threads(8)
         gen_round4()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round6':  # only G24 (G11's outputs in full) and G25 (configs[0] through the reference's script)
+        torch.set_num_threads(8)
+        gen_round6()
     elif len(sys.argv) > 1 and sys.argv[1] == 'round5':  # only G23 (default DenseED on channelized fields, B = 32)
         torch.set_num_threads(8)
         gen_round5()

@@ -77,9 +77,9 @@ def main(argv=None):
     y_test_variation = y_variation(y_test)
     say(f'Test output variation per channel: {y_test_variation}')
     train_loader = DeviceLoader(torch.from_numpy(x_train), torch.from_numpy(y_train), batch_size=args.batch_size,
-                                device=device, seed=args.seed, rank=rank, world_size=world)
+                                device=device, seed=args.seed, rank=rank, world_size=world, order='reference')
     test_loader = DeviceLoader(torch.from_numpy(x_test), torch.from_numpy(y_test), batch_size=args.test_batch_size,
-                               device=device, shuffle=False)
+                               device=device, shuffle=True, order='reference')   # (the reference's load_data shuffles both)
     say(f'# out pixels: {y_test[0].size}')
 
     scheduler = OneCycleScheduler(lr_max=args.lr, div_factor=args.lr_div, pct_start=args.lr_pct)

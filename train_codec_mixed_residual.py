@@ -204,10 +204,13 @@ def main(argv=None):
     have_targets = y_test is not None
     y_test_variation = y_variation(y_test) if have_targets else np.full(3, np.nan)
     say(f'Test output variation per channel: {y_test_variation}')
+    # both loaders shuffle like the reference's (utils/load.py:34-35 there: load_data builds train AND test loader with
+    # shuffle=True) and draw every epoch's permutation from torch's global generator the way its DataLoader does: with the
+    # reference's seed this run trains on the reference's minibatches, in its order (tests/golden/G25)
     train_loader = DeviceLoader(torch.from_numpy(x_train), batch_size=args.batch_size, device=device,
-                                seed=args.seed, rank=rank, world_size=world)
+                                seed=args.seed, rank=rank, world_size=world, order='reference')
     test_tensors = [torch.from_numpy(x_test)] + ([torch.from_numpy(y_test)] if have_targets else [])
-    test_loader = DeviceLoader(*test_tensors, batch_size=args.test_batch_size, device=device, shuffle=False)
+    test_loader = DeviceLoader(*test_tensors, batch_size=args.test_batch_size, device=device, shuffle=True, order='reference')
 
     scheduler = OneCycleScheduler(lr_max=args.lr, div_factor=args.lr_div, pct_start=args.lr_pct)
     sobel_filter = SobelFilter(args.imsize, correct=True, device=device)
