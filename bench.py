@@ -592,7 +592,7 @@ def config4_timing(dev, B, ntrain=4096, steps=128, warm=32):
             'loss_mean_over_timed_steps': round(means[0], 4)}
 
 
-def dropin_timing(dev, data, perm, B, steps=100, warm=20):
+def dropin_timing(dev, data, perm, B, steps=100, warm=20, optim_module=None):
     """the reference's loop body VERBATIM (train_codec_mixed_residual.py:224-240) on the drop-in modules: `model(input)` through
     autograd, the three loss functions of models/darcy.py, `loss.backward()`, `torch.optim.Adam`, the per-step
     `loss.item()` -- what a maintainer of the reference gets by changing only the imports, beside the
@@ -608,7 +608,8 @@ def dropin_timing(dev, data, perm, B, steps=100, warm=20):
     torch.manual_seed(1)
     with contextlib.redirect_stdout(io.StringIO()):
         model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48).to(dev)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    optim = optim_module or torch.optim        # the reference: `import torch.optim as optim` ... `optim.Adam(...)` (:151-152)
+    optimizer = optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
     scheduler = OneCycleScheduler(lr_max=1e-3, div_factor=2.0, pct_start=0.3)
     sobel_filter = SobelFilter(64, correct=True, device=dev)
     weight_bound, n, total = 10.0, data.shape[0], warm + steps
@@ -659,9 +660,9 @@ def dropin_timing(dev, data, perm, B, steps=100, warm=20):
             'ms_per_step': round(dt / steps * 1e3, 4), 'ms_per_step_without_loss_item': round(dt_nosync * 1e3, 4),
             'steps': steps, 'warmup': warm, 'loss_mean_over_timed_steps': round(item / steps, 4),
             'loss_kernel_launches_per_step': 2,
+            'optimizer': f'{type(optimizer).__module__}.Adam', 'optimizer_fused': optimizer.param_groups[0].get('fused'),
             'note': 'one forward-only + one backward launch of the fused loss kernel per step (the three functions share one '
-                    'autograd node; upstream gradients reach the kernel through device memory: no host sync in backward); '
-                    'torch.optim.Adam is torch\'s (multi-tensor) optimiser over 82 parameter views of the flat buffer'}
+                    'autograd node; upstream gradients reach the kernel through device memory: no host sync in backward)'}
 
 
 def allreduce_timing(trainer, iters=50):
@@ -964,7 +965,14 @@ def main():
         except Exception as e:
             c4 = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
         try:
+            # (a) torch.optim untouched: a plain torch.optim.Adam over the HIP network's parameters takes its fused=True
+            #     implementation (global step pre-hook of this build); (b) `from pde_surrogate_amd import optim` in place of
+            #     `import torch.optim as optim`: the step is one launch of the flat Adam kernel
             dropin = dropin_timing(dev, data, perm, B, steps=min(args.steps, 100))
+            from pde_surrogate_amd import optim as _poptim
+            d2 = dropin_timing(dev, data, perm, B, steps=min(args.steps, 100), optim_module=_poptim)
+            dropin['with_optim_import_redirected'] = {k: d2[k] for k in ('samples_per_s', 'ms_per_step', 'ms_per_step_without_loss_item',
+                                                                          'optimizer', 'loss_mean_over_timed_steps')}
         except Exception as e:
             dropin = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
     mark('host / dp1 / segment / config-4 / drop-in legs')

@@ -49,6 +49,16 @@ __device__ __forceinline__ LossParams loss_params_weighted(LossParams p) {
 }
 #endif
 
+// w * x; SAFE: an exactly zero weight SKIPS the term -- a backward pass that reaches only some of the four loss terms
+// (conv_boundary_condition alone, say) launches the kernel with zero weights for the others, and 0 * inf / 0 * NaN of a
+// residual that term never looked at must not poison the gradient of the terms it did.  `w` is uniform.  The
+// select costs the specialised kernel 1.3 % (2.3 % nonlinear) at B = 16,384, so only the instantiations behind
+// pdes_darcy_loss_dw (weights in device memory: the autograd path) carry it; the any-size kernels use the plain product.
+#ifdef __HIPCC__
+template <bool SAFE>
+__device__ __forceinline__ float wmul(float w, float x) { return (SAFE && w == 0.f) ? 0.f : w * x; }
+#endif
+
 namespace gen {
 
 constexpr int kNonlinear = 1, kNoTB = 2, kUncorrected = 4;    // = PDES_LOSS_* of include/pdes_hip.h

@@ -179,7 +179,7 @@ struct Geo {
 // ------------------------------------------------------------------------------------------
 // NOTB: conv_continuity_constraint(use_tb=False), darcy.py:224 -- rows 0 and N-1 are left out of the continuity
 // residual (its mean is then over (N-2) N pixels per image: the host scales a_cont accordingly)
-template <int N, bool BWD, bool NONLIN, bool NOTB = false>
+template <int N, bool BWD, bool NONLIN, bool NOTB = false, bool SAFE = false>
 __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? PDES_LOSS_WPS : 1)) void darcy_loss_kernel(const float* __restrict__ Kp,
                                                                 const float* __restrict__ yp,
                                                                 float* __restrict__ gyp,
@@ -255,16 +255,16 @@ __global__ __launch_bounds__(Geo<N>::NT, (N == 64 ? PDES_LOSS_WPS : 1)) void dar
       sum_cont += c * c;
       if (tb) sum_neu += s2_own.v[i] * s2_own.v[i];
       if (BWD) {
-        R1[k].v[i] = p.a_const * r1 * q1;
-        R2[k].v[i] = p.a_const * r2 * q2 + (tb ? p.b_neu * s2_own.v[i] : 0.f);
-        P1[k].v[i] = p.a_const * K * r1;
-        P2[k].v[i] = p.a_const * K * r2;
-        CC[k].v[i] = p.a_cont * c;
+        R1[k].v[i] = wmul<SAFE>(p.a_const, r1 * q1);            // (SAFE: an exactly zero weight skips its term, darcy_generic.h)
+        R2[k].v[i] = wmul<SAFE>(p.a_const, r2 * q2) + (tb ? wmul<SAFE>(p.b_neu, s2_own.v[i]) : 0.f);
+        P1[k].v[i] = wmul<SAFE>(p.a_const, K * r1);
+        P2[k].v[i] = wmul<SAFE>(p.a_const, K * r2);
+        CC[k].v[i] = wmul<SAFE>(p.a_cont, c);
       }
     }
     float db = 0.f;
-    if (first) { const float e = u_own.v[0] - 1.f; sum_dir += e * e; db = p.b_dir * e; }
-    if (last) { const float e = u_own.v[3]; sum_dir += e * e; db = p.b_dir * e; }
+    if (first) { const float e = u_own.v[0] - 1.f; sum_dir += e * e; db = wmul<SAFE>(p.b_dir, e); }
+    if (last) { const float e = u_own.v[3]; sum_dir += e * e; db = wmul<SAFE>(p.b_dir, e); }
     dub[k] = db;
   }
 
@@ -451,7 +451,10 @@ static int launch_loss(const float* K, const float* y, float* gy, float* partial
     else hipLaunchKernelGGL((darcy_loss_kernel<N, false, false, true>), grid, block, 0, st, K, y, gy, partials, p);
     return 0;
   }
-  if (gy) {
+  if (gy && p.wdev) {   // weights in device memory (pdes_darcy_loss_dw, the autograd path): a zero weight skips its term
+    if (nonlinear) hipLaunchKernelGGL((darcy_loss_kernel<N, true, true, false, true>), grid, block, 0, st, K, y, gy, partials, p);
+    else hipLaunchKernelGGL((darcy_loss_kernel<N, true, false, false, true>), grid, block, 0, st, K, y, gy, partials, p);
+  } else if (gy) {
     if (nonlinear) hipLaunchKernelGGL((darcy_loss_kernel<N, true, true>), grid, block, 0, st, K, y, gy, partials, p);
     else hipLaunchKernelGGL((darcy_loss_kernel<N, true, false>), grid, block, 0, st, K, y, gy, partials, p);
   } else {

@@ -20,7 +20,10 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from .. import optim as _optim
 from ..utils.misc import module_size  # noqa: F401  (the reference's codec.py:14-21)
+
+_optim.install_auto_fused_hook()      # a plain torch.optim.Adam over a HIP network's parameters takes its fused implementation
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -842,6 +845,10 @@ class _HipNet(nn.Module):
                 m.num_batches_tracked.data = m.num_batches_tracked.data.to(device)
         self._flat, self._gscratch, self._gscratch_views = flat, gflat, views
         self._params = [p for _, p in named]
+        import weakref
+        me = weakref.ref(self)
+        for p in self._params:                  # pde_surrogate_amd.optim finds the flat buffers through its parameters
+            p._pdes_owner = me
         # packed weight copies (zero padded once; the pack kernel rewrites the live part every forward)
         self._packed, items, mx = {}, [], 0
         self._identity = {}
@@ -1079,6 +1086,14 @@ class _HipNet(nn.Module):
             eng = self._new_engine(key)
         pool.append(eng)
         return eng
+
+    def zero_grad(self, set_to_none=True):
+        """nn.Module.zero_grad; the default (gradients to None) without the per-parameter checks of the generic loop --
+        0.11 -> 0.03 ms of host time per step of the drop-in loop body (train_codec_mixed_residual.py:225 there)"""
+        if not set_to_none or getattr(self, '_flat', None) is None:
+            return super().zero_grad(set_to_none)
+        for p in self._params:
+            p.grad = None
 
     def forward(self, x):
         _lib.require_cuda(x)

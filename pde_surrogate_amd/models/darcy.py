@@ -155,14 +155,35 @@ _last_lock = threading.Lock()
 
 
 class _Shared:
-    __slots__ = ('out_ref', 'out_version', 'k_ptr', 'k_version', 'nonlinear', 'betas', 'use_tb', 'correct', 'terms', 'node')
+    # `terms` is a STRONG reference, and has to be: in `constitutive(...) + continuity(...)` the slices die with the sum, and
+    # the boundary call two lines later must still find the 4-vector.  It keeps K, y and the graph above `output` alive until
+    # the pair's backward runs, the next pair replaces it, or `forget_shared_loss()` is called (one entry per thread;
+    # INTEGRATION.md section 1).
+    __slots__ = ('out_ref', 'out_version', 'k_ptr', 'k_version', 'nonlinear', 'betas', 'use_tb', 'correct', 'terms', 'node_ref')
+
+
+def forget_shared_loss():
+    """drop the remembered (input, output) pair of the calling thread -- e.g. after an evaluation loop that ran with grad
+    mode on and never called backward (the entry would otherwise hold that last graph until the next loss call)"""
+    with _last_lock:
+        _last.pop(threading.get_ident(), None)
+
+
+def _share_node(output):
+    """one shared node only where it cannot change what autograd allows.  For a LEAF `output` the reference's three loss
+    functions build three independent graphs, and `.backward()` on each of them in turn is legal without retain_graph: there
+    every call gets its own node.  For a network's output (a non-leaf) separate backward calls without retain_graph fail in
+    the reference as well (the network's own graph is freed by the first), so sharing the loss node costs nothing.
+    PDES_SHARE_LOSS_NODE=0 turns the sharing off altogether."""
+    import os
+    return output.grad_fn is not None and os.environ.get('PDES_SHARE_LOSS_NODE', '1') != '0'
 
 
 def _forget(ctx):
     """the backward of a remembered pair has run (on whichever thread): drop it"""
     with _last_lock:
         for tid, e in list(_last.items()):
-            if e.node is ctx:
+            if e.node_ref() is ctx or e.node_ref() is None:
                 del _last[tid]
 
 
@@ -170,23 +191,28 @@ def _terms(input, output, need, nonlinear=False, beta1=0.0, beta2=0.0, use_tb=Tr
     """the four terms of `output` (and `input`, for the constitutive term) as ONE differentiable 4-vector.
     need: which of its settings this caller depends on -- 'const' (K, law, correct), 'cont' (use_tb, correct), 'bound'"""
     tid = threading.get_ident()
-    e = _last.get(tid)
-    if e is not None and e.out_ref() is output and e.out_version == output._version and \
-            e.terms.requires_grad == (torch.is_grad_enabled() and output.requires_grad):
+    share = _share_node(output) or not (torch.is_grad_enabled() and output.requires_grad)   # (no graph: nothing to share but the launch)
+    e = _last.get(tid) if share else None
+    terms = e.terms if e is not None else None
+    if terms is not None and e.out_ref() is output and e.out_version == output._version and \
+            terms.requires_grad == (torch.is_grad_enabled() and output.requires_grad):
         if need == 'bound':
-            return e.terms
+            return terms
         if need == 'cont' and e.use_tb == use_tb and e.correct == correct:
-            return e.terms
+            return terms
         if need == 'const' and e.k_ptr is not None and input is not None and e.k_ptr == input.data_ptr() and \
                 e.k_version == input._version and e.nonlinear == nonlinear and e.betas == (beta1, beta2) and e.correct == correct:
-            return e.terms
+            return terms
     t = _Terms.apply(input, output, nonlinear, beta1, beta2, use_tb, correct)
+    if not share:
+        return t
     e = _Shared()
     e.out_ref, e.out_version = weakref.ref(output), output._version
     e.k_ptr, e.k_version = (input.data_ptr(), input._version) if input is not None else (None, None)
     e.nonlinear, e.betas, e.use_tb, e.correct = nonlinear, (beta1, beta2), use_tb, correct
     e.terms = t
-    e.node = t.grad_fn          # (the ctx handed to _Terms.backward IS this node: `_forget` compares identities)
+    # (the ctx handed to _Terms.backward IS the node t.grad_fn: `_forget` compares identities)
+    e.node_ref = weakref.ref(t.grad_fn) if t.grad_fn is not None else (lambda: None)
     with _last_lock:
         if len(_last) > 64:     # threads that came and went
             _last.clear()

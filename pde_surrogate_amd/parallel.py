@@ -97,6 +97,69 @@ class DirectRccl:
             pass
 
 
+class CollectiveWatchdog:
+    """A collective that never completes (a peer died, a rank took another branch) blocks its stream for ever; the host keeps
+    enqueueing until the queue is full and then hangs inside a HIP call no exception can leave.  This daemon thread turns that
+    into an error: `arm(what, done)` registers a collective just enqueued with a callable that is True once it has completed
+    (an event's `query`); one still outstanding after `timeout` seconds is reported -- rank, host, what, how long -- through
+    `on_timeout(message)`, by default a line on stderr and `os._exit(13)` so that the launcher tears the job down.
+    PDES_DP_TIMEOUT_S sets the timeout (default 30 s; 0 disables the watchdog)."""
+
+    def __init__(self, rank=0, world=1, timeout=None, on_timeout=None, poll=0.5):
+        import collections
+        import threading
+        self.rank, self.world = rank, world
+        self.timeout = float(os.environ.get('PDES_DP_TIMEOUT_S', '30')) if timeout is None else float(timeout)
+        self.on_timeout = on_timeout or self._die
+        self.poll = poll
+        self._pending = collections.deque()
+        self._lock = threading.Lock()
+        self._stop = threading.Event()
+        self.fired = None
+        self._thread = None
+        if self.timeout > 0:
+            self._thread = threading.Thread(target=self._run, name='pdes-collective-watchdog', daemon=True)
+            self._thread.start()
+
+    def arm(self, what, done):
+        if self._thread is not None:
+            import time
+            with self._lock:
+                self._pending.append((time.monotonic(), what, done))
+                while len(self._pending) > 64:                   # (completed long ago: the oldest entries are checked first)
+                    self._pending.popleft()
+
+    @staticmethod
+    def _die(message):
+        sys.stderr.write(message + '\n')
+        sys.stderr.flush()
+        os._exit(13)
+
+    def _run(self):
+        import time
+        while not self._stop.wait(self.poll):
+            with self._lock:
+                while self._pending and self._safe(self._pending[0][2]):
+                    self._pending.popleft()
+                head = self._pending[0] if self._pending else None
+            if head is not None and time.monotonic() - head[0] > self.timeout:
+                self.fired = (f'[pde_surrogate_amd] rank {self.rank} of {self.world} on {socket.gethostname()}: {head[1]} has not '
+                              f'completed {time.monotonic() - head[0]:.0f} s after it was enqueued (PDES_DP_TIMEOUT_S = {self.timeout:g}): a '
+                              'peer rank is gone or did not enter the collective; aborting this rank')
+                self.on_timeout(self.fired)
+                return
+
+    @staticmethod
+    def _safe(done):
+        try:
+            return bool(done())
+        except Exception:                                         # noqa: BLE001  (a failed query is not a completion)
+            return False
+
+    def close(self):
+        self._stop.set()
+
+
 def make_direct_rccl(group, device):
     """a DirectRccl over `group` for the per-step gradient exchange, or None (-> torch.distributed.all_reduce): when the
     backend is not nccl, when PDES_DP_DIRECT=0, or when ANY rank failed to build or probe its communicator -- the ranks
@@ -255,7 +318,9 @@ def pin_rank_to_gpu_numa(device, local_rank=0, local_world=1, group=None):
         return {'pinned': False, 'why': 'no GPU'}
     node, cpus = gpu_numa_cpus(device)               # (never raises: every rank reaches the collective below)
     nodes, lists = [node] * max(local_world, 1), [cpus] * max(local_world, 1)
-    if local_world > 1 and dist.is_available() and dist.is_initialized():
+    # (gated on the GROUP's size, which every rank agrees on -- not on this host's rank count: on a heterogeneous multi-node
+    #  launch a host with a single rank must still enter the collective the others enter)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         host = socket.gethostname()
         got = [None] * dist.get_world_size(group)
         dist.all_gather_object(got, (host, local_rank, node, cpus), group=group)

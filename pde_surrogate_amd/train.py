@@ -184,10 +184,15 @@ class MixedResidualTrainer:
             # choice over gloo, and the fallback when the direct communicator cannot be made; PDES_DP_DIRECT=0 selects
             # it) costs the host ~0.3 ms per call.
             self._rccl = parallel.make_direct_rccl(process_group, self.dev)
+            # a gradient exchange that does not complete within PDES_DP_TIMEOUT_S (30 s) becomes a clear error naming the rank
+            self._watchdog = parallel.CollectiveWatchdog(torch.distributed.get_rank(process_group), self.world)
 
     def close(self):
         """release what the trainer holds outside torch's allocator: the direct RCCL communicator (idempotent)"""
         r, self._rccl = getattr(self, '_rccl', None), None
+        w, self._watchdog = getattr(self, '_watchdog', None), None
+        if w is not None:
+            w.close()
         if r is not None:
             r.close()
 
@@ -343,6 +348,11 @@ class MixedResidualTrainer:
         self.n_accum += 1
         if self._hook is not None:                            # data parallel (a group of ONE rank still runs the path)
             self._exchange_rest()
+            wd = getattr(self, '_watchdog', None)
+            if wd is not None and wd.timeout > 0:             # one event behind the step's last collective (main stream)
+                ev = torch.cuda.Event()
+                ev.record()
+                wd.arm(f'the gradient all-reduce of training step {self.step_count}', ev.query)
         if self.use_graph:
             rc = self._L.pdes_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
                                         self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), 1.0 / self.world,

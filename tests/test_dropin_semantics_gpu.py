@@ -335,3 +335,126 @@ def test_data_parallel_two_ranks_equals_mean_of_shard_gradients(dev, cfg):
     assert rel_l2(p0.numpy(), want.numpy()) < 1e-4
     # the logged loss of a rank is the mean over ITS shards
     assert out[0][1][0] != out[1][1][0]
+
+
+def test_optim_adam_takes_one_launch_and_equals_torch_adam(dev, monkeypatch):
+    """round 6: `from pde_surrogate_amd import optim` in place of `import torch.optim as optim` --
+    optim.Adam over a HIP network's parameters is ONE launch of the flat kernel per step and leaves the parameters, the
+    moments and the state_dict torch.optim.Adam leaves (weight decay included); a gradient that is no longer the backward's
+    own view (clipping by assignment), a second parameter group or a foreign model run torch's implementation; a state_dict
+    round trip in the middle of a run changes nothing; a step between a forward and its backward is still refused."""
+    from pde_surrogate_amd import _lib, optim
+    x = torch.exp(0.3 * torch.randn(4, 1, 64, 64, device=dev))
+    calls = []
+    L = _lib.lib()
+    real = L.pdes_adam_step_host
+
+    class _Spy:
+        def __getattr__(self, k):
+            if k == 'pdes_adam_step_host':
+                def f(*a):
+                    calls.append(a[7])
+                    return real(*a)
+                return f
+            return getattr(L, k)
+    monkeypatch.setattr(_lib, 'lib', lambda: _Spy())
+    def shadow_of(net, **kw):
+        """torch.optim.Adam over CLONES of the network's parameters, fed the network's own gradients each step: the two
+        optimisers see identical inputs (two networks trained side by side drift apart chaotically, see G7)"""
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in net.parameters()]
+        return ps, torch.optim.Adam(ps, foreach=True, **kw)
+
+    def feed(net, ps):
+        for p, q in zip(net.parameters(), ps):
+            q.grad = p.grad.detach().clone()
+
+    def same(net, ps, tol=3e-5):      # (BatchNorm biases start at zero: the whole value is the update; the flat kernel vs foreach: 7e-6)
+        for (k, p), q in zip(net.named_parameters(), ps):
+            assert rel_l2(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < tol, k
+    for wd in (0.0, 1e-2):
+        a = _small(dev)
+        oa = optim.Adam(a.parameters(), lr=1e-3, weight_decay=wd)
+        ps, ob = shadow_of(a, lr=1e-3, weight_decay=wd)
+        del calls[:]
+        for step in range(4):
+            a.zero_grad()
+            _loss(x, a(x)).backward()
+            feed(a, ps)
+            for opt in (oa, ob):
+                for gp in opt.param_groups:
+                    gp['lr'] = 1e-3 * (1 + step)
+            if step == 2:                                            # a state_dict round trip in the middle of the run
+                oa.load_state_dict(oa.state_dict())
+            oa.step()
+            ob.step()
+            same(a, ps)
+        assert calls == [a._flat.numel()] * 4, calls                 # four steps = four launches over the whole flat buffer
+        sa, sb = oa.state_dict(), ob.state_dict()
+        assert sa['param_groups'][0]['params'] == sb['param_groups'][0]['params'] and len(sa['state']) == len(sb['state'])
+        for i in sb['state']:
+            assert float(sa['state'][i]['step']) == float(sb['state'][i]['step']) == 4.0
+            assert rel_l2(sa['state'][i]['exp_avg'].cpu().numpy(), sb['state'][i]['exp_avg'].cpu().numpy()) < 5e-5
+            assert rel_l2(sa['state'][i]['exp_avg_sq'].cpu().numpy(), sb['state'][i]['exp_avg_sq'].cpu().numpy()) < 5e-5
+    # a replaced gradient: torch's path, same numbers as torch
+    del calls[:]
+    a.zero_grad()
+    _loss(x, a(x)).backward()
+    p0 = next(a.parameters())
+    p0.grad = p0.grad.clamp(-1e-3, 1e-3)
+    feed(a, ps)
+    oa.step()
+    ob.step()
+    assert calls == []
+    same(a, ps)
+    assert float(oa.state_dict()['state'][0]['step']) == 5.0
+    # ... and back on the flat path with the next clean backward
+    a.zero_grad()
+    _loss(x, a(x)).backward()
+    oa.step()
+    assert calls == [a._flat.numel()] and float(oa.state_dict()['state'][3]['step']) == 6.0
+    # a step between a forward and its backward is an error, as with torch's in-place update
+    y = a(x)
+    oa.step()
+    with pytest.raises(RuntimeError, match='modified in place'):
+        _loss(x, y).backward()
+    # a foreign model: plain torch.optim.Adam behaviour
+    lin = torch.nn.Linear(4, 4).to(dev)
+    ol = optim.Adam(lin.parameters(), lr=1e-2)
+    lin(torch.randn(2, 4, device=dev)).sum().backward()
+    del calls[:]
+    ol.step()
+    assert calls == [] and float(ol.state_dict()['state'][0]['step']) == 1.0
+
+
+def test_plain_torch_adam_over_a_hip_network_defaults_to_its_fused_implementation(dev, monkeypatch):
+    """the reference's own line `optim.Adam(model.parameters(), ...)` with torch.optim untouched: a global optimiser step
+    pre-hook (installed when models/codec.py is imported) picks `fused=True` before the first step -- 1.8 -> 0.27 ms of host
+    time per step on the default net -- unless the user chose foreach / fused, or PDES_ADAM_AUTO_FUSED=0; zero_grad() of
+    the network sets every gradient to None"""
+    x = torch.exp(0.3 * torch.randn(4, 1, 64, 64, device=dev))
+
+    def one_step(**kw):
+        net = _small(dev)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, **kw)
+        net.zero_grad()
+        _loss(x, net(x)).backward()
+        assert all(p.grad is not None for p in net.parameters())
+        opt.step()
+        net.zero_grad()
+        assert all(p.grad is None for p in net.parameters())
+        return opt.param_groups[0]['fused'], opt.param_groups[0]['foreach'], net
+    fused, foreach, n1 = one_step()
+    assert fused is True and foreach is None
+    assert one_step(foreach=True)[:2] == (None, True)
+    assert one_step(fused=False)[:2] == (False, None)
+    monkeypatch.setenv('PDES_ADAM_AUTO_FUSED', '0')
+    fused, foreach, n2 = one_step()
+    assert fused is None
+    for (k, pa), (_, pb) in zip(n1.named_parameters(), n2.named_parameters()):        # the same update either way
+        assert rel_l2(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 2e-6, k
+    lin = torch.nn.Linear(4, 4).to(dev)                                                 # other models are left alone
+    monkeypatch.delenv('PDES_ADAM_AUTO_FUSED')
+    ol = torch.optim.Adam(lin.parameters())
+    lin(torch.randn(2, 4, device=dev)).sum().backward()
+    ol.step()
+    assert ol.param_groups[0]['fused'] is None

@@ -127,7 +127,8 @@ def test_dropin_loss_functions_share_one_launch_and_never_sync(dev, monkeypatch)
     monkeypatch.setattr(darcy, 'darcy_loss_launch', counting)
     Kn, yn, K, y0 = _fields(4, 64, 11, dev)
     sob = SobelFilter(64, correct=True, device=dev)
-    y = y0.clone().requires_grad_(True)
+    yl = y0.clone().requires_grad_(True)
+    y = yl * 1.0                      # a network's output is a NON-LEAF: that is where the three functions share one node
     loss_pde = darcy.conv_constitutive_constraint(K, y, sob) + darcy.conv_continuity_constraint(y, sob)
     ld, ln = darcy.conv_boundary_condition(y)
     loss = loss_pde + (ld + ln) * 10.0
@@ -143,7 +144,38 @@ def test_dropin_loss_functions_share_one_launch_and_never_sync(dev, monkeypatch)
     ref_terms, ref_grad = real(K, y0, (1.0, 1.0, 10.0, 10.0), True)
     np.testing.assert_allclose(float(loss), float(ref_terms[0]), rtol=1e-6)
     np.testing.assert_allclose(float(fused), float(ref_terms[0]), rtol=1e-6)
+    assert rel_l2(yl.grad.cpu().numpy(), ref_grad.cpu().numpy()) < 1e-6
+    # for a LEAF output the reference's functions build independent graphs -- `.backward()` on each loss in
+    # turn is legal without retain_graph and accumulates; here every call then gets its own node (3 + 3 launches)
+    del calls[:]
+    y = y0.clone().requires_grad_(True)
+    la, lb = darcy.conv_constitutive_constraint(K, y, sob), darcy.conv_continuity_constraint(y, sob)
+    ld, ln = darcy.conv_boundary_condition(y)
+    la.backward()
+    lb.backward()
+    ((ld + ln) * 10.0).backward()
+    assert [c[0] for c in calls] == ['fwd', 'fwd', 'fwd', 'bwd', 'bwd', 'bwd']
     assert rel_l2(y.grad.cpu().numpy(), ref_grad.cpu().numpy()) < 1e-6
+    # the one remembered pair per thread can be dropped by hand (an evaluation loop with grad mode on)
+    import gc
+    import weakref
+    y = yl * 1.0
+    lc = darcy.conv_constitutive_constraint(K, y, sob)
+    base = weakref.ref(lc._base)
+    del lc
+    darcy.forget_shared_loss()
+    gc.collect()
+    assert base() is None
+    # a backward pass that reaches only the boundary terms must not be poisoned by a non-finite value in a
+    # term it never asked for (zero weight x inf): sigma1 = inf at one pixel, gradient of the boundary loss alone
+    del calls[:]
+    ybad = y0.clone()
+    ybad[0, 1, 20, 20] = float('inf')
+    ybl = ybad.clone().requires_grad_(True)
+    ld, ln = darcy.conv_boundary_condition(ybl * 1.0)
+    (ld + ln).backward()
+    _, gb = real(K, y0, (0.0, 0.0, 1.0, 1.0), True)          # the boundary terms do not look at sigma1: the clean field's gradient
+    assert torch.isfinite(ybl.grad).all() and rel_l2(ybl.grad.cpu().numpy(), gb.cpu().numpy()) < 1e-6
     # the remembered pair was dropped by its backward; whatever is remembered next must never be served stale
     del calls[:]
     y = y0.clone().requires_grad_(True)

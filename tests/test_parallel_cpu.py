@@ -311,3 +311,105 @@ def test_reference_epoch_order_draws_the_reference_dataloaders_permutations():
     assert np.array_equal(seen, g['train_perms'][0])
     with pytest.raises(ValueError):
         DeviceLoader(x, batch_size=8, device='cpu', order='sorted')
+
+
+def _worker8(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    r, _, w = parallel.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    B, GB, ntrain, n = 32, 256, 8192, 740091                       # configs[2]: global batch 256 = 8 x 32, the default net's buffer
+    perm = torch.randperm(ntrain, generator=torch.Generator().manual_seed(1))
+    mine = [parallel.shard_indices(perm, step, B, rank, world) for step in range(3)]
+    # the flat gradient buffer in the two buckets of the trainer: bucket A = the tail (convolution weights from TransUp1
+    # on), bucket B = the head.  'wgrad' / 'wgrad_b': A first (from a weight-gradient stream), then B; 'main': one exchange
+    off = 288_651
+    g_local = torch.sin(torch.arange(n, dtype=torch.float32) * (rank + 1) * 1e-3)
+    expect = sum(torch.sin(torch.arange(n, dtype=torch.float32) * (q + 1) * 1e-3) for q in range(world))
+    results = {}
+    for place in ('wgrad', 'wgrad_b', 'main'):
+        g = g_local.clone()
+        if place == 'main':
+            dist.all_reduce(g)
+        else:
+            dist.all_reduce(g[off:])
+            dist.all_reduce(g[:off])
+        results[place] = g
+    assert torch.equal(results['wgrad'], results['wgrad_b'])
+    assert torch.allclose(results['wgrad'], results['main'], rtol=0, atol=1e-5) and torch.allclose(results['main'], expect, atol=1e-5)
+    # Adam with grad_scale = 1 / world on every rank: identical parameters everywhere
+    torch.manual_seed(1)
+    p = torch.randn(n)
+    parallel.adam_reference_(p, results['wgrad'], torch.zeros(n), torch.zeros(n), 1, 1e-3, grad_scale=1.0 / world)
+    digest = float(p.double().sum()), float(p[::997].double().abs().sum())
+    # NUMA placement of eight ranks over two sockets with SMT pairs
+    n0, n1 = parallel._parse_cpulist('0-63,128-191'), parallel._parse_cpulist('64-127,192-255')
+    nodes, lists = [0, 0, 0, 0, 1, 1, 1, 1], [n0] * 4 + [n1] * 4
+    groups = [[c, c + 128] for c in (range(64) if rank < 4 else range(64, 128))]
+    plan = parallel.plan_affinity(rank, nodes, lists, set(range(256)), groups)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, ([m.tolist() for m in mine], digest, plan, parallel.host_thread_budget(2, parallel.local_world_size(world))))
+    # a collective that never completes on ONE rank: the watchdog names that rank
+    if rank == 5:
+        msgs = []
+        wd = parallel.CollectiveWatchdog(rank, world, timeout=0.3, on_timeout=msgs.append, poll=0.05)
+        wd.arm('the gradient all-reduce of training step 7', lambda: False)
+        import time
+        t0 = time.monotonic()
+        while not msgs and time.monotonic() - t0 < 5:
+            time.sleep(0.05)
+        wd.close()
+        out['watchdog'] = msgs[0] if msgs else None
+    if rank == 0:
+        out['gathered'] = gathered
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world8_gloo():
+    """the 8-rank job of BASELINE configs[2] on the CPU: eight processes over gloo -- the shards of
+    every global batch of 256 partition it, the two-bucket exchange equals the single one in every placement and the exact
+    sum over the ranks, Adam leaves identical parameters on all ranks, the eight NUMA plans are disjoint halves of the two
+    sockets by physical core, and a collective that hangs on one rank is reported by that rank's watchdog"""
+    world, port = 8, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker8, args=(world, port, out), nprocs=world, join=True)
+    got = out['gathered']
+    perm = torch.randperm(8192, generator=torch.Generator().manual_seed(1))
+    for step in range(3):
+        batch = [i for r in range(8) for i in got[r][0][step]]
+        assert batch == perm[step * 256:(step + 1) * 256].tolist()                # contiguous slices, rank order, no overlap
+        assert all(len(got[r][0][step]) == 32 for r in range(8))
+    assert len({got[r][1] for r in range(8)}) == 1                                 # identical parameters after the step
+    plans = [got[r][2] for r in range(8)]
+    assert all(len(p_) == 32 for p_ in plans) and len({c for p_ in plans for c in p_}) == 256
+    assert all({c % 128 for c in plans[a]}.isdisjoint({c % 128 for c in plans[b]}) for a in range(8) for b in range(a + 1, 8))
+    assert len({got[r][3] for r in range(8)}) == 1 and got[0][3] >= 1              # every rank: the same pool budget
+    msg = out['watchdog']
+    assert msg is not None and 'rank 5 of 8' in msg and 'training step 7' in msg and 'PDES_DP_TIMEOUT_S' in msg
+
+
+def test_bench_rendezvous_world8_global_batch_256_offsets_of_every_rank():
+    """`bench.py --gpus 8 --rendezvous-only --global-batch 256` under the driver's launch contract with EIGHT ranks (gloo
+    here): per-rank batch 32, and the offsets of every rank into the shared permutation for the first three global steps"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE='8', LOCAL_WORLD_SIZE='8', OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--rendezvous-only',
+                                       '--global-batch', '256'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line['ranks'] == 8 and line['world_size'] == 8 and line['backend'] == 'gloo'
+    assert line['scaling'] == 'strong' and line['global_batch'] == 256 and line['per_rank_batch'] == 32
+    assert line['first_offsets'] == [[i * 256 + r * 32 for i in range(3)] for r in range(8)]
+    assert len(line['host_affinity']) == 8
+    assert all('rendezvous' not in o[0] for o in outs[1:])

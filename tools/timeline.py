@@ -7,7 +7,7 @@ import sqlite3
 import sys
 
 
-def main(path, nlast=0):
+def main(path, nlast=0, marker='adam', first=False):
     c = sqlite3.connect(path)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
     kd = [t for t in tabs if 'kernel_dispatch' in t and 'rocpd_kernel_dispatch' in t]
@@ -17,8 +17,11 @@ def main(path, nlast=0):
     else:
         raise SystemExit('no kernels view; tables: %s' % tabs)
     # a step = (after the previous adam launch) .. adam launch; take the last complete one
-    idx = [i for i, r in enumerate(rows) if 'adam' in r[0]]
-    if len(idx) >= 2:
+    # (marker: a substring of the kernel that ENDS a step -- or, with `first`, BEGINS one: the drop-in loop's batch gather)
+    idx = [i for i, r in enumerate(rows) if marker in r[0]]
+    if first and len(idx) >= 3:
+        rows = rows[idx[-3]: idx[-2]]
+    elif len(idx) >= 2:
         rows = rows[idx[-2] + 1: idx[-1] + 1]
     t0 = rows[0][1]
     last_end = {}
@@ -45,4 +48,5 @@ def main(path, nlast=0):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 400)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 400, sys.argv[3] if len(sys.argv) > 3 else 'adam',
+         len(sys.argv) > 4 and sys.argv[4] == 'first')
