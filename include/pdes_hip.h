@@ -39,7 +39,7 @@ extern "C" {
  * arguments; these select among equivalent kernels and exist for A/B measurements and cross-checks).
  *   pdes_context_create   n_events order-only events are created on the CURRENT device (pdes_backward with a
  *                         second stream needs n_layers + 1); returns hipError_t > 0 on failure.
- *   pdes_context_set_option  value = decimal string (NULL = default); PDES_ENOSUP: unknown key.  The twelve keys
+ *   pdes_context_set_option  value = decimal string (NULL = default); PDES_ENOSUP: unknown key.  The thirteen keys
  *                         (csrc/pdes_options.h; each selects between EQUIVALENT kernels, for cross-checks and re-tuning):
  *                           "PDES_CONV_IMPL"   "direct": the generic VALU kernels for every convolution | "auto"
  *                           "PDES_MFMA_B3"     bit mask of the bf16 x3 split kernels, default 31 (0: the exact-f32 pipe everywhere):
@@ -64,6 +64,9 @@ extern "C" {
  *                                              the end -- for layers with at least this many input channels on 32-wide tiles
  *                                              (default 48: all of them); 0: never.  "PDES_DG_TILEPIPE16": the same for the other
  *                                              tile shapes (16-wide maps; default 48)
+ *                           "PDES_MFMA_MT2"    1 (default): the forward of a 16-output-channel 3x3 layer whose grid of 4-row tiles
+ *                                              would leave half the CUs without a workgroup (16x16 maps at batch 32) runs on tiles of
+ *                                              2 rows x 16 pixels | 0: 4-row tiles
  *                           "PDES_WGRAD_HOLD"  pdes_backward with a second stream: the weight gradient of a layer of at least this
  *                                              many MFLOP (2 B Hout Wout Cout Cin k^2 / 1e6) is released behind the layer's data
  *                                              gradient instead of beside it; 0: never

@@ -110,7 +110,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   const int ntp = (nt_total + 7) & ~7;       // N-tiles of the packed weight image (zero padded)
   constexpr int KK = KS * KS;
   constexpr int KSW = 4 / WAVES_K;          // k-steps of a chunk handled by one wave
-  static_assert(WAVES_K == 1 || MT >= 4, "K-split waves each own MT/4 M-tiles at the end");
+  static_assert(WAVES_K == 1 || MT >= 2, "K-split waves: MT/4 M-tiles per wave at the end (MT = 2: one tile each for two waves)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // ids inside the wave group
@@ -547,7 +547,7 @@ void conv_mfma_kernel(pdes_conv_desc d, const float* __restrict__ wm, int nt_tot
   TR(4);
   // ---- combine the K-split partial sums: wave w ends up owning M-tiles [w*MT/4, (w+1)*MT/4)
   constexpr int NWV = 4 * NG;                                        // K-split waves of the workgroup
-  constexpr int NOWN = (WAVES_K == 4) ? ((MT >= NWV) ? NWV : 4) : 1;   // waves that own output M-tiles afterwards
+  constexpr int NOWN = (WAVES_K == 4) ? ((MT >= NWV) ? NWV : (MT >= 4 ? 4 : MT)) : 1;   // waves that own output M-tiles afterwards
   constexpr int MT_OWN = (WAVES_K == 4) ? MT / NOWN : MT;
   const int mt0 = (WAVES_K == 4) ? MT_OWN * gwave : 0;
   const bool owner = WAVES_K != 4 || gwave < NOWN;
@@ -732,6 +732,10 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
   if (nt_total == 1) {
     wk = 4; ntw = 1;
     if (tiles8 < 256 && mt4_ok) mt = 4;
+    // round 6: the forward of the 16x16 dense layers at batch 32 is 128 workgroups of MT = 4 on 256 CUs -- tiles of 2 rows x
+    // 16 pixels put a workgroup on every CU and halve its serial chain of MFMAs (18 per wave and chunk; the two halo rows
+    // are staged twice as often: out of L2).  PDES_MFMA_MT2=0 keeps MT = 4.
+    if (!bwd && KS == 3 && S == 1 && mt == 4 && twg == 1 && tiles8 * 2 < 256 && H % 2 == 0 && nchunk >= 3 && opt().mfma_mt2) mt = 2;
   } else {
     wk = 1;
     const bool ntw2_ok = KS != 5 && kpad > 16 && nt_total > 4;
@@ -822,6 +826,7 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
       PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 2)
       PDES_TRY(2, 4, 4, 1) PDES_TRY(2, 4, 1, 1) PDES_TRY(2, 4, 1, 2)
       PDES_TRY(1, 4, 4, 1) PDES_TRY(1, 4, 1, 1) PDES_TRY(1, 4, 1, 2)
+      if constexpr (KS == 3 && MODE == MODE_FWD) { PDES_TRY(1, 2, 4, 1) }
     }
   } else {
     PDES_TRY(2, 8, 1, 1) PDES_TRY(2, 8, 1, 2) PDES_TRY(1, 8, 1, 1) PDES_TRY(1, 8, 1, 2)

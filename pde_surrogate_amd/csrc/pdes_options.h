@@ -2,7 +2,7 @@
 // Nothing in the library reads the environment on its own: pdes_context_load_env() does, once, when the caller
 // asks for it; every other read goes through opt(), which resolves to the options of the context the running
 // entry point was called with (or to the compiled-in defaults for a NULL context).
-// Twelve options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
+// Thirteen options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
 // parts; the A/B measurements that settled the defaults, and the knobs that went with them, are in EXPERIMENTS.md.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,6 +32,8 @@ struct Options {
   int dg_tilepipe16 = 48;       // PDES_DG_TILEPIPE16: the same threshold for the other tile shapes (16-wide maps, half-height tiles)
   int dg_tilepipe = 48;         // PDES_DG_TILEPIPE: the dense blocks' data gradient on 32-wide tiles runs M-tile by M-tile (each tile's
                                 //                  epilogue behind its MFMAs) from this many input channels on; 0: never
+  int mfma_mt2 = 1;             // PDES_MFMA_MT2   : the forward of K-split (16-output-channel) layers whose MT = 4 grid leaves half the CUs
+                                //                  empty (16x16 maps at batch 32) runs on tiles of 2 rows x 16 pixels (round 6); 0: MT = 4
   int wgrad_hold = 0;           // PDES_WGRAD_HOLD : pdes_backward releases the weight gradient of a layer with >= this many MFLOP
                                 //                  (2 B Hout Wout Cout Cin k^2 / 1e6) behind the layer's DATA gradient instead of beside
                                 //                  it (0: never): two kernels that each fill the chip gain nothing from running together
