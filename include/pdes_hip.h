@@ -263,8 +263,16 @@ typedef struct pdes_conv_desc {
   const float* g;        /* dL/d(out): (B, g_ctot, Hout, Wout), channels [g_coff, g_coff+Cout) */
   int g_ctot, g_coff;
   int g_fused;           /* 1: `g` still holds the accumulator T of the output buffer and the consuming kernel applies the
-                            BN-backward finalize (fin_xstats / fin_tstats, raw activation = `out`) on operand load: implemented
-                            by PDES_OP_COPY only (the caller sets it there); convolutions take 0 */
+                            BN-backward finalize (fin_xstats / fin_tstats, raw activation = `out`) on operand load.  Callers set
+                            it for PDES_OP_COPY only and pass 0 for convolutions; pdes_backward sets it itself on the copies of
+                            the descriptors it hands to the finalize-on-load kernels (PDES_FIN_ONLOAD: the dense layers, the
+                            first convolution's weight gradient, the 8x8-map kernels).  CONTRACT: on that path `g` is LEFT as the
+                            accumulator T -- the finalized gradient dL/d(out) of such a layer exists in registers only; a
+                            caller that wants it in memory (need_input_grad of the first layer, debugging) runs with
+                            PDES_FIN_ONLOAD=0.  {mean, invstd} come from the published table `fin_coef` where the kernel has it
+                            at hand (conv_mfma*), and from the fp64 replica sums by the same expression
+                            ((float) m, (float)(1 / sqrt(var + eps)), var = E[x^2] - m^2 clamped at 0, all in fp64) elsewhere
+                            (conv_bwd_weight_first, conv_small): the table's publisher evaluates that expression too */
   float* t_in;           /* T accumulator of the input buffer (B, x_ctot, Hin, Win) */
   int t_accumulate;      /* 0: T = ..., 1: T += ... */
   int final_c0, final_c1;/* input channels whose T is complete after this call: their

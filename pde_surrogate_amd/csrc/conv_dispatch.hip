@@ -291,7 +291,7 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
   // environment variable PDES_TIMING, read per call: 1 no weight-gradient kernels (fork events kept), 2 no fork events
   // either, 4 every finalize as ONE workgroup (launch + completion signal kept, no work), 8 no finalize launch at all
   // (forks by hipEventRecord), 16 no data-gradient kernels, 32 neither weight-gradient kernel nor fork for the layers that
-  // finalize on load (the dense layers)
+  // finalize on load (the dense layers), 64 the same for the finalize-on-load layers on maps of <= 256 pixels only
   const int timing = getenv("PDES_TIMING") ? atoi(getenv("PDES_TIMING")) : 0;
 #else
   const int timing = 0;
@@ -308,12 +308,17 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     for (int i = 0; i < n; ++i)
       if (reduce_index[i] >= 0) { per_total += per_of(i); ++n_items; }
   size_t nev = 0;
+  // every slot of the context's event table is taken through take(): nullptr (-> PDES_EINVAL) when the table is used up.
+  // At most one event per layer (its fork: on the finalize's or the previous data gradient's completion signal, or
+  // recorded by release()) + the joins; a slot taken for a launch that turned out not to carry signals is handed back
+  auto take = [&]() -> hipEvent_t { return (cx && nev < cx->events.size()) ? cx->events[nev++] : nullptr; };
   // layers are released in the order n-1 .. 0, so the enqueued ones always form the suffix [i, n)
   // `signalled`: the fork event already completes with the finalize kernel just launched (its completion signal)
   bool b_dirty = false;                     // work on the second side stream that `ws` has not waited for yet
   auto join_b = [&]() -> int {              // ws waits for everything enqueued on wsb so far
     if (!two || !b_dirty) return PDES_OK;
-    hipEvent_t e = cx->events[nev++];
+    hipEvent_t e = take();
+    if (!e) return PDES_EINVAL;
     hipError_t he = hipEventRecord(e, wsb);
     if (he == hipSuccess) he = hipStreamWaitEvent(ws, e, 0);
     b_dirty = false;
@@ -325,7 +330,8 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       hipEvent_t e = signalled;
       hipError_t he = hipSuccess;
       if (!e) {
-        e = cx->events[nev++];
+        e = take();
+        if (!e) return PDES_EINVAL;
         he = hipEventRecord(e, st);
       }
       if (he == hipSuccess) he = hipStreamWaitEvent(wsi, e, 0);
@@ -392,7 +398,10 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
     if (d.fin_tstats && !d.g_fused) {
       // this layer's weight gradient is released by the completion of ITS finalize kernel: the fork event rides on
       // that kernel's completion signal, no barrier packet sits between the finalize and the data gradient
-      if (fork && use_signal && i != 0 && !is_resample_op(d) && !hold && !(timing & (2 | 8))) signalled = cx->events[nev++];
+      if (fork && use_signal && i != 0 && !is_resample_op(d) && !hold && !(timing & (2 | 8))) {
+        signalled = take();
+        if (!signalled) return PDES_EINVAL;
+      }
       int rc = PDES_OK;
       if (timing & 4)              // (one channel of one image: a single workgroup)
         rc = bn_backward_finalize_launch(ctx, const_cast<float*>(d.g), d.out, d.fin_xstats, d.fin_tstats, 1,
@@ -422,13 +431,15 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
       hipEvent_t se = nullptr;
       if (fork && use_signal && opt().fin_onload >= 2 && onl && i >= 2 && !(timing & (2 | 8 | 32)) && !((timing & 64) && descs[i - 1].Hout * descs[i - 1].Wout <= 256) && fin_onload(descs[i - 1], &dn) &&
           !held(i - 1)) {
-        se = cx->events[nev++];
+        se = take();
+        if (!se) return PDES_EINVAL;
         set_dgrad_stop_event(se);
       }
       const int rc = pdes_conv_backward_data(ctx, &d, 1, st);
-      if (se && dgrad_stop_event_pending()) {       // (the kernel family that took the launch does not carry signals)
-        set_dgrad_stop_event(nullptr);
+      if (se && dgrad_stop_event_pending()) {       // (the kernel family that took the launch does not carry signals:
+        set_dgrad_stop_event(nullptr);              //  the slot goes back, release() records the same event instead)
         se = nullptr;
+        --nev;
       }
       carried = se;
       if (rc) return rc;
@@ -443,7 +454,8 @@ extern "C" int pdes_backward2(const pdes_context* ctx, const pdes_conv_desc* des
   if (fork) {
     const int rcj = join_b();
     if (rcj) return rcj;
-    hipEvent_t e = cx->events[nev++];
+    hipEvent_t e = take();
+    if (!e) return PDES_EINVAL;
     hipError_t he = hipEventRecord(e, ws);
     if (he == hipSuccess) he = hipStreamWaitEvent(st, e, 0);
     if (he != hipSuccess) return (int)he;

@@ -330,9 +330,26 @@ def test_data_parallel_two_ranks_equals_mean_of_shard_gradients(dev, cfg):
         for r in range(2):                                              # both "ranks" apply the same averaged step
             parallel.adam_reference_(trs[r].flat, gsum, ms[r], vs[r], step + 1, 1e-3, grad_scale=0.5)
     want = torch.cat([p.detach().reshape(-1) for p in nets[0].parameters()]).cpu()
-    # (Adam's first steps are ~lr * sign(g): entries whose averaged gradient is rounding noise may differ in sign
-    #  between the kernel and the torch restatement of Adam, hence 1e-4 on the parameters and not 1e-6)
-    assert rel_l2(p0.numpy(), want.numpy()) < 1e-4
+    # Adam's first steps are ~lr * sign(g): an entry whose averaged gradient is rounding noise may take the other sign
+    # between the kernel and the torch restatement of Adam, and then sits 2 lr away.  Measured: 2.563e-05 (default net) in
+    # every one of ~20 runs of round 6 but one, a full-suite run that read 1.75e-4 and could not be reproduced (alone, behind
+    # every earlier test file, in suite order; the step's gradients are bitwise reproducible in-process:
+    # tools/diag/determinism_stress.py, experiments/round6.md section 8).  A wrong shard, a wrong BatchNorm scope or a missed
+    # bucket moves EVERY entry by ~lr per step (rel-L2 ~1e-1): the bound is 5e-4 on the norm, and at most 1 % of the
+    # entries may sit further than a tenth of one Adam step from the emulation.
+    e_par = rel_l2(p0.numpy(), want.numpy())
+    far = float(((p0 - want).abs() > 1e-4).float().mean())
+    print('data-parallel parameters vs mean-of-shard-gradients emulation (%s): rel-L2 %.3e, entries further than 0.1 lr: %.2e'
+          % (cfg, e_par, far))
+    if e_par >= 1e-4:                                                   # say where, should the odd run come back
+        names = [k for k, _ in nets[0].named_parameters()]
+        off, worst = 0, []
+        for k, q in zip(names, nets[0].parameters()):
+            a, b = p0[off:off + q.numel()], want[off:off + q.numel()]
+            worst.append((float((a - b).norm() / b.norm().clamp_min(1e-30)), k))
+            off += q.numel()
+        print('  per-tensor rel-L2, worst five:', sorted(worst, reverse=True)[:5])
+    assert e_par < 5e-4 and far < 0.01
     # the logged loss of a rank is the mean over ITS shards
     assert out[0][1][0] != out[1][1][0]
 
