@@ -23,7 +23,7 @@ def sources():
 
 
 def headers():
-    return glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(os.path.dirname(HERE), 'include', '*.h'))
+    return glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + glob.glob(os.path.join(os.path.dirname(HERE), 'include', '*.h'))
 
 
 def needs_build():

@@ -736,6 +736,8 @@ static int launch_mfma(const pdes_conv_desc& d, const float* wm, int W, int H, h
     // 16 pixels put a workgroup on every CU and halve its serial chain of MFMAs (18 per wave and chunk; the two halo rows
     // are staged twice as often: out of L2).  PDES_MFMA_MT2=0 keeps MT = 4.
     if (!bwd && KS == 3 && S == 1 && mt == 4 && twg == 1 && tiles8 * 2 < 256 && H % 2 == 0 && nchunk >= 3 && opt().mfma_mt2) mt = 2;
+    // (round 6, measured and removed: the 32-wide maps' forward -- exactly one MT = 8 workgroup per CU at batch 32 -- on tiles of
+    //  2 rows x 32 pixels: 188 -> 207 us over the twelve layers, step +1.1 %; experiments/round6.md)
   } else {
     wk = 1;
     const bool ntw2_ok = KS != 5 && kpad > 16 && nt_total > 4;

@@ -80,6 +80,29 @@ inline bool make_plan(int n, int waves, int npass, int nbands, Plan& p) {
   return true;
 }
 
+// The same plan as a compile-time constant (round 6: instantiations of the kernel with the geometry folded in for the common
+// sizes -- every n, spr, w, rpw, plane offset and band boundary becomes an immediate).  The launcher uses such an instantiation
+// only when plan_equal() says that choose_plan picked exactly this plan at run time.
+constexpr Plan fixed_plan(int n, int waves, int npass, int nbands) {
+  Plan p{};
+  const int spr = (n + 3) >> 2;
+  p.n = n; p.spr = spr; p.jl = (n - 1) & 3; p.w = 4 * spr;
+  p.waves = waves; p.npass = npass; p.rpw = 64 * waves / spr; p.cap = p.rpw * npass;
+  p.nbands = nbands;
+  const int own_max = (n + nbands - 1) / nbands;
+  p.own_base = n / nbands; p.own_rem = n % nbands;
+  p.inv_spr = 65536 / spr + 1;
+  p.seam = (waves > 1 && 64 % spr != 0) ? 1 : 0;
+  p.rows_f = own_max + 4 < n ? own_max + 4 : n;
+  p.lds_floats = 3ll * p.rows_f * p.w + (long long)kRowTab * p.rows_f;
+  return p;
+}
+inline bool plan_equal(const Plan& a, const Plan& b) {
+  return a.n == b.n && a.spr == b.spr && a.jl == b.jl && a.rpw == b.rpw && a.w == b.w && a.waves == b.waves &&
+         a.npass == b.npass && a.cap == b.cap && a.nbands == b.nbands && a.rows_f == b.rows_f && a.own_base == b.own_base &&
+         a.own_rem == b.own_rem && a.inv_spr == b.inv_spr && a.seam == b.seam && a.lds_floats == b.lds_floats;
+}
+
 // waves in {1, 2, 4, 8} (workgroups of 3, 5, 6, 7 waves load the four SIMDs of a CU unevenly: measured 10-45 % slower at the
 // same slot use), passes in {1, 2}: the most strip slots doing own work.  Ties (measured, EXPERIMENTS.md round 5): two
 // passes before one (half the bands, half the halo rows: 5-12 %), then 4 waves, 2, 8, 1 (2-4 %).  False: size not served.

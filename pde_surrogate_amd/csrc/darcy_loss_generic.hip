@@ -22,6 +22,7 @@
 #include "pdes_common.h"
 #include "darcy_generic.h"
 #include "darcy_band.h"
+#include "pdes_options.h"
 #include "../../include/pdes_hip.h"
 
 namespace pdes {
@@ -187,156 +188,24 @@ template <bool BWD, int NPASS, int J, bool SEAM>
 __global__ __launch_bounds__(512, 4) void darcy_loss_band_kernel(const float* __restrict__ Kp, const float* __restrict__ yp,
                                                               float* __restrict__ gyp, float* __restrict__ partials,
                                                               LossParams p_in, band::Plan pl, int flags) {
-  using namespace band;
-  const LossParams p = BWD ? loss_params_weighted(p_in) : p_in;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ float red[8 * 4];
-  __shared__ __attribute__((aligned(16))) float seam[SEAM ? NPASS * 8 * 16 : 4];
-  const int bi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
-  constexpr bool A = J == 4;
-  constexpr int jl = WidthClass<J>::jl;
-  const int n = pl.n, w = pl.w;
-  const size_t nn = (size_t)n * n;
-  const float fn = (float)n;
-  const bool correct = !(flags & kUncorrected);
-  const BandGeo g = band_geo(pl, bi);
-  LaneConst c = lane_const(pl, tid, correct, false);
-  const float* Kb = Kp + (size_t)b * nn;
-  const float* yb = yp + (size_t)b * 3 * nn;
-  float* gb = BWD ? gyp + (size_t)b * 3 * nn : nullptr;
-  const int plane = pl.rows_f * w, rows_f = g.fr1 - g.fr0;
-  float* tab = lds + 3 * plane;                              // the row table (darcy_band.h), read after the first barrier
-  if (tid < rows_f) rowtab_build(tab, g.fr0 + tid, n, correct, g.fr0, g.fr1, w);
+#include "darcy_band_kernel_body.inc"
+}
 
-  int row[NPASS];
-#pragma unroll
-  for (int k = 0; k < NPASS; ++k) row[k] = slot_row(pl, g, k, c);
-  const int scol = strip_col<J>(pl, c);
-  // the conductivities of this lane's strips: requested first, used after the staging
-  V4 kk[NPASS];
-#pragma unroll
-  for (int k = 0; k < NPASS; ++k) {
-    const bool ok = c.active && row[k] < g.sr1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kk[k].v[j] = 0.f;
-    if (ok) kk[k] = gld4<A>(Kb + (size_t)row[k] * n + scol, p.nt);
-  }
-  {
-    // the three fields on rows fr0 .. fr1, strip by strip (w = 4 spr: strip i of the range is float4 i of a plane).  The
-    // loads of ALL planes are issued before the first LDS store: bytes in flight are what the staging phase runs on
-    const int per = rows_f * pl.spr;
-    const float inv_s = 1.0f / (float)pl.spr;
-#pragma unroll 1
-    for (int base = tid; base < per; base += 2 * nthreads) {
-      V4 v[3][2];
-      bool lastf[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = base + u * nthreads;
-        int off = 4 * i;
-        lastf[u] = false;
-        if (!A) {
-          const int rr = (int)(((float)i + 0.5f) * inv_s);          // i / spr (exact: i < 2^15, spr <= 64)
-          const int cs = i - rr * pl.spr;
-          lastf[u] = cs == pl.spr - 1;
-          off = rr * n + ((jl < 3 && lastf[u]) ? n - 4 : 4 * cs);
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          if (i < per) v[q][u] = gld4<A>(yb + q * nn + (size_t)g.fr0 * n + off, p.nt);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = base + u * nthreads;
-        if (i < per) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            V4 x = v[q][u];
-            if (!A && jl < 3) {
-              LaneConst cl;
-              cl.last = lastf[u];
-              x = last_strip_shift<J>(x, cl);
-            }
-            st4(lds + q * plane + 4 * i, x.v);
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NPASS; ++k)
-    if (!A && jl < 3) kk[k] = last_strip_shift<J>(kk[k], c);
-  __syncthreads();
-
-  const BPlane U{lds, g.fr0, g.fr1, w}, X1{lds + plane, g.fr0, g.fr1, w}, X2{lds + 2 * plane, g.fr0, g.fr1, w};
-  float sums[4] = {0.f, 0.f, 0.f, 0.f};
-  StripOut so[NPASS];
-  int sq = -64;
-  // Phase B.  The vertical half of a pass reads the field planes, the horizontal half works on registers: behind a barrier
-  // in the middle of the LAST pass (with seams every pass has one there) no wave reads the fields any more, and the
-  // sources of the passes before go into the planes at once instead of waiting in registers through the last pass
-#pragma unroll
-  for (int k = 0; k < NPASS; ++k) {
-    const int r = row[k], rc = r < g.sr1 ? r : g.sr1 - 1;
-    const bool ok = c.active && r < g.sr1, own = ok && r >= g.r0 && r < g.r1;
-    const FwdVert f = fwd_vert<J>(U, X1, X2, rowtab_read<false>(tab, rc, c.cs, g.fr0, w), c);
-    if (SEAM) seam_publish<J>(seam + (k * 8 + wave) * 16, lane, f.us, f.ud, f.as, f.bd);
-    if (SEAM || k == NPASS - 1) __syncthreads();
-    if (SEAM) sq = seam_source(k, lane, wave, pl.waves);
-    if (BWD && k == NPASS - 1) {
-#pragma unroll
-      for (int kp = 0; kp < NPASS - 1; ++kp)
-        if (c.active && row[kp] < g.sr1) {
-          float* q = lds + (row[kp] - g.fr0) * w + 4 * c.cs;
-          st4(q, so[kp].p1.v); st4(q + plane, so[kp].p2.v); st4(q + 2 * plane, so[kp].cc.v);
-        }
-    }
-    so[k] = fwd_finish<J>(f, halo_of<J, SEAM>(f.us, lane, seam, sq), halo_of<J, SEAM>(f.ud, lane, seam, sq + 2),
-                          halo_of<J, SEAM>(f.as, lane, seam, sq + 4), halo_of<J, SEAM>(f.bd, lane, seam, sq + 6), kk[k], rc, n, c, p,
-                          flags, fn, own, sums);
-    if (BWD && k == NPASS - 1 && ok) {
-      float* q = lds + (r - g.fr0) * w + 4 * c.cs;
-      st4(q, so[k].p1.v); st4(q + plane, so[k].p2.v); st4(q + 2 * plane, so[k].cc.v);
-    }
-  }
-  {
-    const float t0 = wave_sum(sums[0]), t1 = wave_sum(sums[1]), t2 = wave_sum(sums[2]), t3 = wave_sum(sums[3]);
-    if (lane == 0) { red[wave * 4 + 0] = t0; red[wave * 4 + 1] = t1; red[wave * 4 + 2] = t2; red[wave * 4 + 3] = t3; }
-  }
-  __syncthreads();                     // the sources and the waves' sums are in LDS (and the seam words have been read)
-  if (tid < 4) {
-    float t = 0.f;
-    for (int wv = 0; wv < pl.waves; ++wv) t += red[wv * 4 + tid];           // fixed order: deterministic
-    partials[((size_t)b * pl.nbands + bi) * 4 + tid] = t;
-  }
-  if (!BWD) return;
-  lane_const_adj(pl, c, correct);
-  const BPlane G1{lds, g.fr0, g.fr1, w}, G2{lds + plane, g.fr0, g.fr1, w}, GC{lds + 2 * plane, g.fr0, g.fr1, w};
-#pragma unroll
-  for (int k = 0; k < NPASS; ++k) {
-    const int r = row[k], rc = r < g.r0 ? g.r0 : (r < g.r1 ? r : g.r1 - 1);
-    const bool own = c.active && r >= g.r0 && r < g.r1;
-    V4 du, d1, d2;
-    {
-      const AdjVert a = adj_vert<J>(G1, G2, GC, rowtab_read<true>(tab, rc, c.cs, g.fr0, w), c);
-      if (SEAM) {
-        seam_publish<J>(seam + (k * 8 + wave) * 16, lane, a.p1s, a.p2d, a.ccs, a.ccd);
-        __syncthreads();
-        sq = seam_source(k, lane, wave, pl.waves);
-      }
-      adj_finish<J>(a, halo_of<J, SEAM>(a.p1s, lane, seam, sq), halo_of<J, SEAM>(a.p2d, lane, seam, sq + 2),
-                    halo_of<J, SEAM>(a.ccs, lane, seam, sq + 4), halo_of<J, SEAM>(a.ccd, lane, seam, sq + 6), so[k], c, fn, du, d1, d2);
-    }
-    if (own) {
-      float* o = gb + (size_t)r * n + 4 * c.cs;
-      if (jl == 3 || !c.last) {
-        gst4<A>(o, du, p.nt); gst4<A>(o + nn, d1, p.nt); gst4<A>(o + 2 * nn, d2, p.nt);
-      } else {
-#pragma unroll
-        for (int j = 0; j <= jl; ++j) { o[j] = du.v[j]; o[nn + j] = d1.v[j]; o[2 * nn + j] = d2.v[j]; }
-      }
-    }
-  }
+// Round 6: the same body with the geometry of ONE field size and the default loss flags as compile-time
+// constants.  ALIGNED = the aligned width class (n a multiple of 4 behind 16-byte aligned pointers: checked by the launcher).
+// OCC: waves per SIMD the register budget is sized for (4 = 128 registers; the two-pass instantiations WITH seams need 3 = 168 to
+// stay out of scratch, which costs this kernel more than the fourth wave brings).
+template <bool BWD, int N, int WAVES, int NPASS, int NBANDS, bool ALIGNED, int OCC>
+__global__ __launch_bounds__(64 * WAVES, OCC) void darcy_loss_band_fixed_kernel(const float* __restrict__ Kp,
+                                                                            const float* __restrict__ yp,
+                                                                            float* __restrict__ gyp,
+                                                                            float* __restrict__ partials, LossParams p_in) {
+  constexpr band::Plan pl = band::fixed_plan(N, WAVES, NPASS, NBANDS);
+  constexpr int J = ALIGNED ? 4 : ((N - 1) & 3);
+  constexpr bool SEAM = pl.seam != 0;
+  constexpr int flags = 0;
+  static_assert(!ALIGNED || (N & 3) == 0, "the aligned width class needs a multiple of 4");
+#include "darcy_band_kernel_body.inc"
 }
 
 
@@ -410,6 +279,32 @@ int launch_loss_generic(const float* K, const float* y, float* gy, float* partia
     const bool a16 = (n & 3) == 0 && aligned16(K) && aligned16(y) && (!gy || aligned16(gy));
     const dim3 grid(pl.nbands, B), block(64 * pl.waves);
     const size_t shmem = (size_t)pl.lds_floats * sizeof(float);
+    // the common sizes with the reference's default loss (flags 0): geometry folded into the instantiation (round 6)
+    if ((flags & (gen::kNonlinear | gen::kNoTB | gen::kUncorrected)) == 0 && opt().band_fixed) {       // (PDES_BAND_FIXED=0: the run-time plan, for cross-checks)
+#define PDES_BAND_FIXED(N_, W_, NP_, NB_, A_, OCC_)                                                                      \
+      if (n == N_ && a16 == A_ && band::plan_equal(pl, band::fixed_plan(N_, W_, NP_, NB_))) {                                \
+        if (gy) hipLaunchKernelGGL((darcy_loss_band_fixed_kernel<true, N_, W_, NP_, NB_, A_, OCC_>), grid, block, shmem, st, K, y, gy, partials, p); \
+        else hipLaunchKernelGGL((darcy_loss_band_fixed_kernel<false, N_, W_, NP_, NB_, A_, 4>), grid, block, shmem, st, K, y, gy, partials, p);   \
+        return PDES_OK;                                                                                                     \
+      }
+      PDES_BAND_FIXED(48, 2, 2, 3, true, 3)
+      PDES_BAND_FIXED(65, 4, 1, 5, false, 4)
+      PDES_BAND_FIXED(66, 4, 2, 3, false, 4)
+      PDES_BAND_FIXED(96, 4, 2, 6, true, 3)
+      PDES_BAND_FIXED(128, 4, 2, 10, true, 4)
+      PDES_BAND_FIXED(256, 8, 2, 19, true, 4)
+      PDES_BAND_FIXED(100, 4, 2, 6, true, 3)
+      PDES_BAND_FIXED(129, 8, 2, 5, false, 4)
+      PDES_BAND_FIXED(130, 8, 2, 5, false, 4)
+      PDES_BAND_FIXED(131, 8, 2, 5, false, 4)
+      PDES_BAND_FIXED(200, 8, 2, 12, true, 4)
+      PDES_BAND_FIXED(100, 4, 2, 6, true, 3)
+      PDES_BAND_FIXED(129, 8, 2, 5, false, 4)
+      PDES_BAND_FIXED(130, 8, 2, 5, false, 4)
+      PDES_BAND_FIXED(131, 8, 2, 5, false, 4)
+      PDES_BAND_FIXED(200, 8, 2, 12, true, 4)
+#undef PDES_BAND_FIXED
+    }
 #define PDES_BAND_LAUNCH(BWD_, NP_, J_, S_) \
     hipLaunchKernelGGL((darcy_loss_band_kernel<BWD_, NP_, J_, S_>), grid, block, shmem, st, K, y, gy, partials, p, pl, flags)
 #define PDES_BAND_LAUNCH_S(BWD_, NP_, J_) \

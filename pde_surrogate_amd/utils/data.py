@@ -23,7 +23,7 @@ def kle_basis(imsize=64, n_kle=512, ell=0.25, cache_dir=None):
         return _KLE_CACHE[key]
     path = None
     if cache_dir:
-        path = os.path.join(cache_dir, f'kle_{imsize}_{n_kle}_{ell}.npy')
+        path = os.path.join(cache_dir, f'kle_v2_{imsize}_{n_kle}_{ell}.npy')
         if os.path.exists(path):
             _KLE_CACHE[key] = np.load(path)
             return _KLE_CACHE[key]
@@ -32,14 +32,32 @@ def kle_basis(imsize=64, n_kle=512, ell=0.25, cache_dir=None):
     pts = np.stack([xx.ravel(), yy.ravel()], 1)
     d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
     cov = np.exp(-d / ell)
+    # The covariance has the square's symmetries: many eigenvalues come in PAIRS, and LAPACK's basis of such a plane (like
+    # every eigenvector's sign) changes with the BLAS thread count.  Round 6: the fields -- and with them every number a
+    # test or bench run prints -- depended on which process wrote the cache file first, one with a capped or an uncapped
+    # pool.  The decomposition therefore runs on ONE thread (7 s for 512 of 4,096 pairs, once per box: cached), and the
+    # component of largest magnitude of every eigenvector is made positive.
     try:
-        from scipy.linalg import eigh
-        n = cov.shape[0]
-        lam, phi = eigh(cov, subset_by_index=[n - n_kle, n - 1])
+        import scipy.linalg                      # (loaded BEFORE the limiter is built: it only sees libraries already mapped)
     except Exception:  # pragma: no cover
-        lam, phi = np.linalg.eigh(cov)
-        lam, phi = lam[-n_kle:], phi[:, -n_kle:]
+        pass
+    try:
+        from threadpoolctl import threadpool_limits
+        one_thread = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        import contextlib
+        one_thread = contextlib.nullcontext()
+    with one_thread:
+        try:
+            from scipy.linalg import eigh
+            n = cov.shape[0]
+            lam, phi = eigh(cov, subset_by_index=[n - n_kle, n - 1])
+        except Exception:  # pragma: no cover
+            lam, phi = np.linalg.eigh(cov)
+            lam, phi = lam[-n_kle:], phi[:, -n_kle:]
     lam, phi = lam[::-1], phi[:, ::-1]
+    pivot = np.abs(phi).argmax(axis=0)
+    phi = phi * np.sign(phi[pivot, np.arange(phi.shape[1])])[None, :]
     basis = (phi * np.sqrt(np.maximum(lam, 0.0))[None, :]).T.copy()
     _KLE_CACHE[key] = basis
     if path:
