@@ -331,12 +331,11 @@ def test_data_parallel_two_ranks_equals_mean_of_shard_gradients(dev, cfg):
             parallel.adam_reference_(trs[r].flat, gsum, ms[r], vs[r], step + 1, 1e-3, grad_scale=0.5)
     want = torch.cat([p.detach().reshape(-1) for p in nets[0].parameters()]).cpu()
     # Adam's first steps are ~lr * sign(g): an entry whose averaged gradient is rounding noise may take the other sign
-    # between the kernel and the torch restatement of Adam, and then sits 2 lr away.  Measured: 2.563e-05 (default net) in
-    # every one of ~20 runs of round 6 but one, a full-suite run that read 1.75e-4 and could not be reproduced (alone, behind
-    # every earlier test file, in suite order; the step's gradients are bitwise reproducible in-process:
-    # tools/diag/determinism_stress.py, experiments/round6.md section 8).  A wrong shard, a wrong BatchNorm scope or a missed
-    # bucket moves EVERY entry by ~lr per step (rel-L2 ~1e-1): the bound is 5e-4 on the norm, and at most 1 % of the
-    # entries may sit further than a tenth of one Adam step from the emulation.
+    # between the kernel and the torch restatement of Adam, and then sits 2 lr away -- how many do depends on the DATA:
+    # 2.6e-5 / 1.75e-4 / 7.7e-5 (default net) on three sets of GRF fields (round 6: the generator's eigenbasis depended on
+    # the BLAS thread count of whichever process wrote the cache first, experiments/round6.md entry 10; now canonical).
+    # A wrong shard, a wrong BatchNorm scope or a missed bucket moves EVERY entry by ~lr per step (rel-L2 ~1e-1): the
+    # bound is 5e-4 on the norm, and at most 1 % of the entries may sit further than a tenth of one Adam step away.
     e_par = rel_l2(p0.numpy(), want.numpy())
     far = float(((p0 - want).abs() > 1e-4).float().mean())
     print('data-parallel parameters vs mean-of-shard-gradients emulation (%s): rel-L2 %.3e, entries further than 0.1 lr: %.2e'

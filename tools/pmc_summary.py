@@ -67,15 +67,14 @@ def collect(path):
     ns = {}
     exec(src[src.index('PLANE ='):src.index('def make_launch')], ns)
     rows = [json.loads(l) for l in open(path) if l.startswith('{')]
-    import hashlib
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for f in ('darcy_loss.hip', 'darcy_loss_generic.hip', 'darcy_generic.h', 'darcy_band.h', 'pdes_common.h'):
-        h.update(open(os.path.join(root, 'pde_surrogate_amd', 'csrc', f), 'rb').read())
+    # the fingerprint of the measured kernels' sources: the SAME function bench.py checks the file with (bench_loss.py; its
+    # file list, not a copy of it)
+    fp_ns = {'os': os, '__file__': os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bench_loss.py')}
+    exec(src[src.index('def source_fingerprint'):src.index("if __name__ == '__main__'")], fp_ns)
     out = {'method': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace and rocprofv3 --pmc WRITE_SIZE --kernel-trace in separate passes, one '
                      'process per variant and counter (python tools/bench_loss.py pmc <variant>: 12 dispatches at B = 16384); KiB per '
                      'dispatch, mean over the dispatches; FETCH_SIZE doubled per the gfx950 correction for 16-byte-per-lane coalesced '
-                     'reads (MI355X_MICROARCH.md)', 'batch': 16384, 'source_fingerprint': h.hexdigest()[:16], 'variants': {}}
+                     'reads (MI355X_MICROARCH.md)', 'batch': 16384, 'source_fingerprint': fp_ns['source_fingerprint'](), 'variants': {}}
     by = defaultdict(dict)
     for r in rows:
         by[r['variant']][r['counter']] = r
