@@ -635,11 +635,32 @@ def dropin_timing(dev, data, perm, B, steps=100, warm=20, optim_module=None):
         body(i)
     torch.cuda.synchronize(dev)
     loss_train = 0.
+    cg0 = cgroup_cpu_stat()
+    import gc
+    # (round 6: a generation-2 collection of the Python GC -- 100-110 ms over this process's heap -- landed inside this leg's
+    #  timed loop in two of three runs and moved its mean from 1.97 to 3.0 ms per step.  Collected now, survivors frozen: the
+    #  loop's own garbage is young.  Collections of >= 1 ms inside the loop are still reported.)
+    gc.collect()
+    gc.freeze()
+    gc_events = []                                      # collections of the Python GC inside the timed loop
+
+    def on_gc(phase, info, _t=[0.0]):
+        if phase == 'start':
+            _t[0] = time.perf_counter()
+        else:
+            gc_events.append({'generation': info['generation'], 'ms': round((time.perf_counter() - _t[0]) * 1e3, 2)})
+    gc.callbacks.append(on_gc)
     t0 = time.perf_counter()
+    marks = [t0]
     for i in range(warm, total):
         body(i)
+        marks.append(time.perf_counter())               # (the body ends in loss.item(): every step is synchronised anyway)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    per_step = sorted(b - a for a, b in zip(marks, marks[1:]))
+    gc.callbacks.remove(on_gc)
+    cg1 = cgroup_cpu_stat()
+    throttle = {k: cg1[k] - cg0.get(k, 0) for k in cg1} if cg1 else None
     # the same loop without the reference's per-step host read of the loss (what that synchronisation costs)
     t1 = time.perf_counter()
     item, k = loss_train, min(steps, 50)
@@ -658,9 +679,15 @@ def dropin_timing(dev, data, perm, B, steps=100, warm=20, optim_module=None):
     return {'loop': 'reference loop body verbatim: model(input) -> constitutive + continuity + boundary loss functions -> '
                     'loss.backward() -> torch.optim.Adam.step() -> loss.item()', 'samples_per_s': round(B * steps / dt, 1),
             'ms_per_step': round(dt / steps * 1e3, 4), 'ms_per_step_without_loss_item': round(dt_nosync * 1e3, 4),
+            # (median / slowest single step of the timed loop: one host stall of tens of ms moves the mean of 100 steps by 10-50 %)
+            'ms_per_step_median': round(per_step[len(per_step) // 2] * 1e3, 4), 'ms_slowest_step': round(per_step[-1] * 1e3, 2),
+            'cgroup_cpu_throttled_during_steps': throttle, 'python_gc_collections_during_steps': [e for e in gc_events if e['ms'] >= 1.0],
             'steps': steps, 'warmup': warm, 'loss_mean_over_timed_steps': round(item / steps, 4),
             'loss_kernel_launches_per_step': 2,
             'optimizer': f'{type(optimizer).__module__}.Adam', 'optimizer_fused': optimizer.param_groups[0].get('fused'),
+            # (a plain torch.optim.Adam over a HIP network becomes pde_surrogate_amd.optim.Adam at its first step: global step
+            #  pre-hook, PDES_ADAM_AUTO_FUSED; True = the steps ran as one launch of the flat kernel)
+            'optimizer_flat_kernel': getattr(optimizer, '_flat_state', None) is not None,
             'note': 'one forward-only + one backward launch of the fused loss kernel per step (the three functions share one '
                     'autograd node; upstream gradients reach the kernel through device memory: no host sync in backward)'}
 
@@ -816,6 +843,9 @@ def main():
     # is enqueued on, read only after the timed region's closing synchronise -- the per-step series in the line shows
     # whether a short timed window is steady state, a clock ramp or a one-off stall
     import gc
+    gc.collect()                                           # (the heap built up by data generation and construction is collected and
+    gc.freeze()                                            #  frozen BEFORE the first step: no GPU work, no step -- a full collection
+    #                                                         is ~100 ms in this process, three times the driver's 20-step window)
     gc_events = []                                         # every collection of the Python GC during the stepped region
 
     def on_gc(phase, info, _t=[0.0]):
@@ -965,9 +995,10 @@ def main():
         except Exception as e:
             c4 = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
         try:
-            # (a) torch.optim untouched: a plain torch.optim.Adam over the HIP network's parameters takes its fused=True
-            #     implementation (global step pre-hook of this build); (b) `from pde_surrogate_amd import optim` in place of
-            #     `import torch.optim as optim`: the step is one launch of the flat Adam kernel
+            # (a) torch.optim untouched: a plain torch.optim.Adam over the HIP network's parameters is retargeted to the flat
+            #     kernel at its first step (global step pre-hook of this build; round 6 first selected fused=True there);
+            #     (b) `from pde_surrogate_amd import optim` in place of `import torch.optim as optim`: the same class from
+            #     the start
             dropin = dropin_timing(dev, data, perm, B, steps=min(args.steps, 100))
             from pde_surrogate_amd import optim as _poptim
             d2 = dropin_timing(dev, data, perm, B, steps=min(args.steps, 100), optim_module=_poptim)

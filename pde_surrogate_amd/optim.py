@@ -11,9 +11,9 @@ Two ways in, both without touching the loop body:
   * `from pde_surrogate_amd import optim` in place of `import torch.optim as optim` (the same import
     redirection as for the model / loss modules): `optim.Adam` below -- a subclass of `torch.optim.Adam` that takes the flat
     path whenever it can prove it applies and is torch's own optimiser otherwise (any parameter list, any option);
-  * nothing at all: importing `pde_surrogate_amd.models.codec` registers a global optimiser step pre-hook that switches a
-    plain `torch.optim.Adam` over exactly one such network's parameters to its `fused=True` implementation before its first
-    step (an option of the same class the user could have passed; PDES_ADAM_AUTO_FUSED=0 leaves it alone).
+  * nothing at all: importing `pde_surrogate_amd.models.codec` registers a global optimiser step pre-hook that turns a
+    plain `torch.optim.Adam` over exactly one such network's parameters, at its first step, into the subclass below
+    (PDES_ADAM_AUTO_FUSED=1: only selects `fused=True` of the same class; =0 leaves it alone).
 
 Everything else of `torch.optim` is re-exported unchanged.
 """
@@ -140,18 +140,31 @@ _hook_handle = None
 
 def _auto_fused_hook(optimizer, args, kwargs):
     """global step pre-hook: a plain torch.optim.Adam over exactly one HIP network's parameters, about to take its FIRST
-    step with neither `foreach` nor `fused` chosen -> `fused=True` (0.27 ms of host time per step instead of 1.8)"""
+    step with neither `foreach` nor `fused` chosen.  PDES_ADAM_AUTO_FUSED (read here, per optimiser):
+      2 (default)  the object becomes a `pde_surrogate_amd.optim.Adam` (the subclass above: same state, same state_dict, still
+                   an instance of torch.optim.Adam).  THIS step is already dispatched to torch's implementation and runs it
+                   once; every later step is one launch of the flat kernel while the gradients are the backward's own views,
+                   torch's implementation otherwise -- exactly what `import pde_surrogate_amd.optim as optim` gives
+      1            `fused=True` of the same class (0.27 ms of host time per step instead of 1.8; round 6's first form)
+      0            nothing"""
     if type(optimizer) is not _TorchAdam or getattr(optimizer, '_pdes_checked', False):
         return None
     optimizer._pdes_checked = True
-    if os.environ.get('PDES_ADAM_AUTO_FUSED', '1') == '0' or len(optimizer.param_groups) != 1:
+    mode = os.environ.get('PDES_ADAM_AUTO_FUSED', '2')
+    if mode == '0' or len(optimizer.param_groups) != 1:
         return None
     g = optimizer.param_groups[0]
     if g.get('foreach') is not None or g.get('fused') is not None or g.get('capturable') or g.get('differentiable'):
         return None
     if optimizer.state or _owner(g['params']) is None:       # (already stepped: its state is in the foreach layout)
         return None
-    g['fused'] = True
+    if mode == '1' or g.get('amsgrad') or g.get('maximize'):
+        g['fused'] = True
+        return None
+    optimizer.__class__ = Adam
+    optimizer._flat_net, optimizer._flat_tries, optimizer._flat_state = None, 0, None
+    optimizer._hyper = (ctypes.c_float * 8)()
+    optimizer._patch_step_function()             # (torch wraps `step` of an optimiser's CLASS at construction: do it for ours)
     return None
 
 

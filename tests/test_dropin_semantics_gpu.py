@@ -444,30 +444,61 @@ def test_optim_adam_takes_one_launch_and_equals_torch_adam(dev, monkeypatch):
 
 def test_plain_torch_adam_over_a_hip_network_defaults_to_its_fused_implementation(dev, monkeypatch):
     """the reference's own line `optim.Adam(model.parameters(), ...)` with torch.optim untouched: a global optimiser step
-    pre-hook (installed when models/codec.py is imported) picks `fused=True` before the first step -- 1.8 -> 0.27 ms of host
-    time per step on the default net -- unless the user chose foreach / fused, or PDES_ADAM_AUTO_FUSED=0; zero_grad() of
-    the network sets every gradient to None"""
+    pre-hook (installed when models/codec.py is imported) turns the optimiser into pde_surrogate_amd.optim.Adam at its first
+    step (default: every later step is ONE launch of the flat kernel), or picks `fused=True` (PDES_ADAM_AUTO_FUSED=1) --
+    unless the user chose foreach / fused, or PDES_ADAM_AUTO_FUSED=0; the same update in all three; zero_grad() of the network
+    sets every gradient to None"""
+    from pde_surrogate_amd import _lib, optim
     x = torch.exp(0.3 * torch.randn(4, 1, 64, 64, device=dev))
+    calls = []
+    L = _lib.lib()
+    real = L.pdes_adam_step_host
 
-    def one_step(**kw):
+    class _Spy:
+        def __getattr__(self, k):
+            if k == 'pdes_adam_step_host':
+                def f(*a):
+                    calls.append(a[7])
+                    return real(*a)
+                return f
+            return getattr(L, k)
+    monkeypatch.setattr(_lib, 'lib', lambda: _Spy())
+
+    def steps(n=3, **kw):
+        torch.manual_seed(3)
         net = _small(dev)
         opt = torch.optim.Adam(net.parameters(), lr=1e-3, **kw)
-        net.zero_grad()
-        _loss(x, net(x)).backward()
-        assert all(p.grad is not None for p in net.parameters())
-        opt.step()
-        net.zero_grad()
-        assert all(p.grad is None for p in net.parameters())
-        return opt.param_groups[0]['fused'], opt.param_groups[0]['foreach'], net
-    fused, foreach, n1 = one_step()
-    assert fused is True and foreach is None
-    assert one_step(foreach=True)[:2] == (None, True)
-    assert one_step(fused=False)[:2] == (False, None)
+        del calls[:]
+        for _ in range(n):
+            net.zero_grad()
+            _loss(x, net(x)).backward()
+            assert all(p.grad is not None for p in net.parameters())
+            opt.step()
+            net.zero_grad()
+            assert all(p.grad is None for p in net.parameters())
+        return opt, net, list(calls)
+    opt, n2, c = steps()                                              # default: the flat kernel from the second step on
+    assert type(opt) is optim.Adam and isinstance(opt, torch.optim.Adam)
+    assert opt.param_groups[0]['fused'] is None and c == [n2._flat.numel()] * 2
+    assert float(opt.state_dict()['state'][0]['step']) == 3.0
+    sd = opt.state_dict()
+    fresh = torch.optim.Adam(n2.parameters(), lr=1e-3)                # its state_dict loads into a plain torch.optim.Adam
+    fresh.load_state_dict(sd)
+    opt, _, c = steps(foreach=True)
+    assert type(opt) is torch.optim.Adam and (opt.param_groups[0]['fused'], opt.param_groups[0]['foreach']) == (None, True) and c == []
+    opt, _, c = steps(fused=False)
+    assert type(opt) is torch.optim.Adam and opt.param_groups[0]['fused'] is False and c == []
+    monkeypatch.setenv('PDES_ADAM_AUTO_FUSED', '1')
+    opt, n1, c = steps()
+    assert type(opt) is torch.optim.Adam and opt.param_groups[0]['fused'] is True and c == []
     monkeypatch.setenv('PDES_ADAM_AUTO_FUSED', '0')
-    fused, foreach, n2 = one_step()
-    assert fused is None
-    for (k, pa), (_, pb) in zip(n1.named_parameters(), n2.named_parameters()):        # the same update either way
-        assert rel_l2(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 2e-6, k
+    opt, n0, c = steps()
+    assert type(opt) is torch.optim.Adam and opt.param_groups[0]['fused'] is None and c == []
+    for (k, pa), (_, pb), (_, pc) in zip(n0.named_parameters(), n1.named_parameters(), n2.named_parameters()):
+        # (three Adam steps from the same seed: foreach vs fused vs one foreach + two flat steps; BatchNorm biases start at
+        #  zero, the whole value is the update)
+        assert rel_l2(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 1e-4, k
+        assert rel_l2(pc.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 1e-4, k
     lin = torch.nn.Linear(4, 4).to(dev)                                                 # other models are left alone
     monkeypatch.delenv('PDES_ADAM_AUTO_FUSED')
     ol = torch.optim.Adam(lin.parameters())
