@@ -18,15 +18,17 @@ D=$(db $OUT/bench)
 python $ROOT/tools/rocprof_summary.py $D > $OUT/kernel_stats.csv
 python $ROOT/tools/timeline.py $D > $OUT/step_timeline.txt
 python $ROOT/tools/rocprof_summary.py $D --by-grid darcy_loss > $OUT/loss_kernel_by_batch.csv
-python $ROOT/tools/rocprof_summary.py $D --per-launch darcy_loss 8388608 > $OUT/loss_kernel_per_launch.csv
+python $ROOT/tools/rocprof_summary.py $D --per-launch "darcy_loss_kernel<64, true, false, false, false>" 8388608 > $OUT/loss_kernel_per_launch.csv
 python - $OUT/loss_kernel_per_launch.csv > $OUT/loss_kernel_sustained.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-last = rows[-100:]                      # bench.py: 1 + 3 burst + 100 warm-up launches, then the 100 timed ones
+# bench.py's `roofline`: 1 + 3 burst + 100 warm-up launches, then the 100 HIP-event timed ones = dispatches 104 .. 203 of the
+# linear fwd+bwd kernel at B = 16384 (round 6: `roofline_variants` launches the same kernel 200 more times later in the run)
+last = rows[104:204]
 d = [float(r['duration_us']) for r in last]
 avg = sum(d) / len(d)
 b = 114688 * 16384
-print(f'# darcy_loss_kernel<64,true,false>, B = 16384: the LAST 100 of {len(rows)} dispatches of `bench.py` (the HIP-event timed ones, after 100+ back-to-back warm-up launches)')
+print(f'# darcy_loss_kernel<64, true, false, false, false>, B = 16384: dispatches 104 .. 203 of {len(rows)} of `bench.py` (the HIP-event timed launches of `roofline`, behind 100+ back-to-back warm-up launches)')
 print(f'# avg_us,{avg:.3f},min_us,{min(d):.3f},max_us,{max(d):.3f},algorithmic_bytes,{b},GBps,{b / avg / 1e3:.1f},frac_of_8TBps,{b / avg / 1e3 / 8000:.4f}')
 print('launch,start_us,duration_us')
 for r in last:
