@@ -125,9 +125,10 @@ def unpin_host():
         parallel.set_affinity_all_threads(AFFINITY_AT_START)
 
 
-def cpu_baseline(bs, steps=10, warm=2):
+def cpu_baseline(bs, steps=40, warm=2):
     """the CPU oracle (port of the reference's PyTorch-CPU path) on this box's host cores (2 warm-up +
-    >= 10 timed full steps at bs = 32, plus the loss-only forward + backward rate, and bs = 8 for config 1).  The rates
+    >= 10 timed full steps at bs = 32 -- 40: ~8 s at the ~160 samples/s of this box, the whole leg 10-15 s of CPU work --
+    plus the loss-only forward + backward rate, and bs = 8 for config 1).  The rates
     are the BEST over a sweep of torch.set_num_threads (a 128-thread box runs this small workload fastest on a
     fraction of its cores: VERDICT r2 weak #9); the thread count that wins is reported next to the physical-core count"""
     from oracle import codec as oc, darcy as od, train as ot
@@ -180,7 +181,7 @@ def cpu_baseline(bs, steps=10, warm=2):
     x8 = x[:8].contiguous()
     v_full8 = full_rate(trainer(), x8, 5, 2)
     torch.set_num_threads(t_loss)
-    n_loss = 50
+    n_loss = 200
     v_loss = loss_rate(n_loss)
     torch.set_num_threads(t_full)
     return {'value': round(v_full, 2), 'unit': 'samples/s', 'cores': t_full, 'kind': 'port', 'cpu_model': cpu_model(),
