@@ -67,6 +67,8 @@ extern "C" {
  *                           "PDES_MFMA_MT2"    1 (default): the forward of a 16-output-channel 3x3 layer whose grid of 4-row tiles
  *                                              would leave half the CUs without a workgroup (16x16 maps at batch 32) runs on tiles of
  *                                              2 rows x 16 pixels | 0: 4-row tiles
+ *                           "PDES_XCD_MAP"     1 (default): kernels whose workgroups re-read each other's halo rows remap blockIdx so that
+ *                                              one XCD (its own L2) takes whole images | 0: blockIdx as launched (A/B, cross-checks)
  *                           "PDES_BAND_FIXED"  1 (default): the any-size loss kernel (row bands, 8 <= n <= 256) runs the instantiation with
  *                                              compile-time geometry where one exists for the field size and the flags are 0
  *                                              (48, 65, 66, 96, 100, 128, 129, 130, 131, 200, 256) | 0: always the run-time plan (cross-checks)

@@ -24,7 +24,7 @@ static const Knob kKnobs[] = {
     {"PDES_FORK_SIGNAL", &Options::fork_signal}, {"PDES_WGRAD_HOLD", &Options::wgrad_hold},
     {"PDES_FIN_ONLOAD", &Options::fin_onload}, {"PDES_DG_TILEPIPE", &Options::dg_tilepipe},
     {"PDES_DG_TILEPIPE16", &Options::dg_tilepipe16}, {"PDES_MFMA_MT2", &Options::mfma_mt2},
-    {"PDES_BAND_FIXED", &Options::band_fixed},
+    {"PDES_BAND_FIXED", &Options::band_fixed}, {"PDES_XCD_MAP", &Options::xcd_map},
 };
 
 static int set_knob(Options& o, const char* key, const char* value) {

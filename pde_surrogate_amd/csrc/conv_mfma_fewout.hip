@@ -35,13 +35,23 @@ struct FewGeo {
 };
 
 template <int NMT, int R>
-__global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d) {
+__global__ __launch_bounds__(256) void conv5_fewout_fwd_kernel(pdes_conv_desc d, int xcd_map) {
   using G = FewGeo<NMT, R>;
   constexpr int W = G::W;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y, oy0 = blockIdx.x * R;
+  // Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: with (row block, image) =
+  // blockIdx, the row blocks of ONE image -- which re-read each other's halo rows: (R + 4) / R = 3 x the input at R = 2 -- sit
+  // on 8 different L2s and every re-read goes to the Infinity Cache (100 MB per launch for the 49 -> 3 layer: the kernel
+  // ran at that bandwidth, not at its matrix time).  Remapped so that an XCD takes whole images (round 6).
+  int b = blockIdx.y, rb = blockIdx.x;
+  if (xcd_map && (gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, j = lin >> 3;
+    b = xcd + 8 * (j / (int)gridDim.x);
+    rb = j % (int)gridDim.x;
+  }
+  const int oy0 = rb * R;
   const int H = d.Hin, HW = H * W;
   const int kpad = (d.Cin + 15) & ~15, nchunk = kpad / 16, ksteps = kpad / 4;
   float4* cf4 = reinterpret_cast<float4*>(smem);            // [kpad] {mean, gamma*invstd, beta, -}
@@ -204,7 +214,7 @@ int conv_forward_fewout(const pdes_conv_desc& d, hipStream_t st, bool dry) {    
     size_t fl = (size_t)16 * G::CS;                                                                   \
     const size_t red = (size_t)4 * 16 * NMT_ * 17;                                                     \
     if (red > fl) fl = red;                                                                           \
-    hipLaunchKernelGGL((conv5_fewout_fwd_kernel<NMT_, R_>), grid, block, (4 * (size_t)kpad + fl) * sizeof(float), st, d); \
+    hipLaunchKernelGGL((conv5_fewout_fwd_kernel<NMT_, R_>), grid, block, (4 * (size_t)kpad + fl) * sizeof(float), st, d, opt().xcd_map); \
   } while (0)
   if (R == 4) {
     if (d.Win == 64) PDES_FEW_LAUNCH(5, 4);

@@ -2,7 +2,7 @@
 // Nothing in the library reads the environment on its own: pdes_context_load_env() does, once, when the caller
 // asks for it; every other read goes through opt(), which resolves to the options of the context the running
 // entry point was called with (or to the compiled-in defaults for a NULL context).
-// Fourteen options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
+// Fifteen options: each selects between equivalent kernels for cross-checks (the GPU tests) or re-tuning on other
 // parts; the A/B measurements that settled the defaults, and the knobs that went with them, are in EXPERIMENTS.md.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,6 +34,8 @@ struct Options {
                                 //                  epilogue behind its MFMAs) from this many input channels on; 0: never
   int mfma_mt2 = 1;             // PDES_MFMA_MT2   : the forward of K-split (16-output-channel) layers whose MT = 4 grid leaves half the CUs
                                 //                  empty (16x16 maps at batch 32) runs on tiles of 2 rows x 16 pixels (round 6); 0: MT = 4
+  int xcd_map = 1;              // PDES_XCD_MAP    : halo-tiled kernels map their workgroups so that an XCD (own L2) takes whole images
+                                //                  instead of every eighth tile of every image (round 6); 0: blockIdx as launched
   int band_fixed = 1;           // PDES_BAND_FIXED : the any-size loss kernel's instantiations with compile-time geometry for the common
                                 //                  sizes (48, 65, 66, 96, 100, 128 .. 131, 200, 256; round 6); 0: always the run-time plan (cross-checks)
   int wgrad_hold = 0;           // PDES_WGRAD_HOLD : pdes_backward releases the weight gradient of a layer with >= this many MFLOP
