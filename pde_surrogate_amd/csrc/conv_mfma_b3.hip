@@ -68,15 +68,28 @@ __device__ __forceinline__ BnB bn_coef_b3(const pdes_conv_desc& d, int c, bool p
 // grid: (tiles of the map, B, ceil(N-tiles / 8)); dynamic LDS: [kpad32] float4 coefficients (forward) + 2 buffers
 template <int TWG, int MTP, int MODE, bool APIPE = false>
 __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pdes_conv_desc d, const unsigned short* __restrict__ wb,
-                                                          int nt_total, int tail_on) {
+                                                          int nt_total, int tail_on_x) {
+  const int tail_on = tail_on_x & 1;                     // (bit 1: XCD-aware workgroup order, below)
   using G = B3Geo<TWG, MTP>;
   constexpr int MT = G::MT, NT_W = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b3[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y;
+  // (image, tile, N-tile group) of this workgroup.  As launched -- blockIdx = (tile, image, group) -- the tiles of one image,
+  // which re-read each other's halo rows, go to eight different XCDs (workgroups are dealt round-robin by linear id, each XCD
+  // has its own L2), and the N-tile groups, which re-read the WHOLE operand tile, run a full grid plane apart.  With bit 1 of
+  // the last argument (PDES_XCD_MAP) an XCD takes whole images, and on it the groups of a tile run back to back, then the
+  // next tile of the same image: the re-reads hit L2 instead of the Infinity Cache (round 6).
+  int b = blockIdx.y, tile_id = blockIdx.x, zg = blockIdx.z;
+  if ((tail_on_x & 2) && (gridDim.y & 7) == 0) {
+    const int gx = gridDim.x, gz = gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + (int)gridDim.y * blockIdx.z), j = lin >> 3;
+    zg = j % gz;
+    tile_id = (j / gz) % gx;
+    b = (lin & 7) + 8 * (j / (gz * gx));
+  }
   const int ntp = (nt_total + 7) & ~7;
-  const int nt_base = (blockIdx.z * 4 + wave) * NT_W;
+  const int nt_base = (zg * 4 + wave) * NT_W;
 
   constexpr bool UPB = MODE == B3_UPBWD;
   constexpr int NTAP = UPB ? 4 : 9;
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(256, MTP == 4 ? 2 : 1) void conv_mfma_b3_kernel(pde
   if (tail)
     for (int i = tid; i < 4 * G::FCS; i += 256) ftile[i] = 0.f;      // channels >= rtail stay zero (their weights are zero, 0 * NaN is not)
   const int tiles_x = W / G::TW;
-  const int oy0 = (blockIdx.x / tiles_x) * G::TH, ox0 = (blockIdx.x % tiles_x) * G::TW;
+  const int oy0 = (tile_id / tiles_x) * G::TH, ox0 = (tile_id % tiles_x) * G::TW;
 
   if (MODE == B3_FWD) {
     for (int c = tid; c < kpad; c += 256) {
@@ -491,7 +504,7 @@ static int launch_b3(const pdes_conv_desc& d, const unsigned short* wb, hipStrea
   do {                                                                                                        \
     using GL = B3Geo<TWG_, MT_>;                                                                              \
     const size_t lds = cf + 2 * (size_t)GL::BUF * 2 + 4 * (size_t)GL::FCS * sizeof(float);                    \
-    const int tail_on = (opt().b3_tail && d.w) ? 1 : 0;                                                       \
+    const int tail_on = ((opt().b3_tail && d.w) ? 1 : 0) | (opt().xcd_map ? 2 : 0);                                                     \
     if (MT_ == 4)       /* A-operand fragments of the next (tap, M-tile) read before this one's MFMAs */     \
       hipLaunchKernelGGL((conv_mfma_b3_kernel<TWG_, MT_, MODE, true>), grid, block, lds, st, d, wb, nt_total, tail_on);  \
     else                                                                                                      \
