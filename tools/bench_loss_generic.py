@@ -40,8 +40,8 @@ CASES = [(64, 16384, 0, 'specialised 64x64'), (64, 16384, 16, 'row bands 64x64')
          (65, 16384, 0, "row bands 65x65"), (65, 16384, 8, "tiles 65x65"), (66, 16384, 0, "row bands 66x66"), (96, 7168, 0, "row bands 96x96"),
          (128, 4096, 0, 'row bands 128x128'), (128, 4096, 8, 'tiles 128x128'),
          (48, 28672, 0, 'row bands 48x48'), (48, 28672, 8, 'tiles 48x48'),
-         (100, 6554, 0, 'row bands 100x100'), (129, 3938, 0, 'row bands 129x129'), (130, 3878, 0, 'row bands 130x130'),
-         (131, 3819, 0, 'row bands 131x131'), (200, 1638, 0, 'row bands 200x200'),
+         (100, 6552, 0, 'row bands 100x100'), (129, 3936, 0, 'row bands 129x129'), (130, 3872, 0, 'row bands 130x130'),
+         (131, 3816, 0, 'row bands 131x131'), (200, 1640, 0, 'row bands 200x200'),
          (256, 1024, 0, 'row bands 256x256'), (256, 1024, 8, 'tiles 256x256'),
          (32, 65536, 0, 'specialised 32x32'), (32, 65536, 16, 'row bands 32x32'),
          (64, 32, 16, 'row bands 64x64 at the training batch'), (64, 32, 0, 'specialised 64x64 at the training batch'),
