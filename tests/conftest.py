@@ -111,3 +111,19 @@ def option():
     for k in touched:
         _lib.set_option(k, None)
         _lib._overrides.pop(k, None)
+
+
+@pytest.fixture(autouse=True)
+def _seed_every_test(request):
+    """Every test starts from RNG streams that depend on ITS name only (round 6: inputs drawn from the global torch / numpy
+    generators made a test's numbers depend on which tests ran before it -- with Adam's m / sqrt(v) behind them, enough to
+    cross a bound in one suite order and not in another).  Tests that seed themselves are unaffected."""
+    import zlib
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff
+    np.random.seed(seed)
+    try:
+        import torch
+        torch.manual_seed(seed)
+    except ImportError:      # pragma: no cover
+        pass
+    yield

@@ -449,6 +449,7 @@ def test_plain_torch_adam_over_a_hip_network_defaults_to_its_fused_implementatio
     unless the user chose foreach / fused, or PDES_ADAM_AUTO_FUSED=0; the same update in all three; zero_grad() of the network
     sets every gradient to None"""
     from pde_surrogate_amd import _lib, optim
+    torch.manual_seed(11)
     x = torch.exp(0.3 * torch.randn(4, 1, 64, 64, device=dev))
     calls = []
     L = _lib.lib()
@@ -494,11 +495,15 @@ def test_plain_torch_adam_over_a_hip_network_defaults_to_its_fused_implementatio
     monkeypatch.setenv('PDES_ADAM_AUTO_FUSED', '0')
     opt, n0, c = steps()
     assert type(opt) is torch.optim.Adam and opt.param_groups[0]['fused'] is None and c == []
+    # Three Adam steps from the same seed: foreach vs fused vs one foreach + two flat steps.  A sanity band only -- this small
+    # net's 8- / 16-channel layers run on the VALU kernels, whose weight gradients are fp32 atomics (not bit-reproducible from
+    # run to run), and three steps of m / sqrt(v) turn rounding-level gradient differences into ~1e-3 of a BatchNorm bias that
+    # starts at zero (measured 3.4e-4).  The equality of the flat kernel with torch's Adam ON IDENTICAL GRADIENTS is
+    # test_optim_adam_takes_one_launch_and_equals_torch_adam above.
     for (k, pa), (_, pb), (_, pc) in zip(n0.named_parameters(), n1.named_parameters(), n2.named_parameters()):
-        # (three Adam steps from the same seed: foreach vs fused vs one foreach + two flat steps; BatchNorm biases start at
-        #  zero, the whole value is the update)
-        assert rel_l2(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 1e-4, k
-        assert rel_l2(pc.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 1e-4, k
+        assert torch.isfinite(pc).all(), k
+        assert rel_l2(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 5e-3, k
+        assert rel_l2(pc.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 5e-3, k
     lin = torch.nn.Linear(4, 4).to(dev)                                                 # other models are left alone
     monkeypatch.delenv('PDES_ADAM_AUTO_FUSED')
     ol = torch.optim.Adam(lin.parameters())
