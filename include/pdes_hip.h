@@ -39,7 +39,7 @@ extern "C" {
  * arguments; these select among equivalent kernels and exist for A/B measurements and cross-checks).
  *   pdes_context_create   n_events order-only events are created on the CURRENT device (pdes_backward with a
  *                         second stream needs n_layers + 1); returns hipError_t > 0 on failure.
- *   pdes_context_set_option  value = decimal string (NULL = default); PDES_ENOSUP: unknown key.  The thirteen keys
+ *   pdes_context_set_option  value = decimal string (NULL = default); PDES_ENOSUP: unknown key.  The sixteen keys
  *                         (csrc/pdes_options.h; each selects between EQUIVALENT kernels, for cross-checks and re-tuning):
  *                           "PDES_CONV_IMPL"   "direct": the generic VALU kernels for every convolution | "auto"
  *                           "PDES_MFMA_B3"     bit mask of the bf16 x3 split kernels, default 31 (0: the exact-f32 pipe everywhere):
