@@ -714,6 +714,27 @@ def test_run_to_run_determinism(dev):
         assert differing == [], differing
 
 
+def test_xcd_aware_workgroup_order_changes_no_bit(dev, option):
+    """round 6: PDES_XCD_MAP only changes WHICH workgroup computes which (image, tile, N-tile group) of the wide-layer and
+    5x5 kernels (an XCD takes whole images): output, loss and every parameter gradient of the default net at the headline
+    batch are bitwise the same with the order as launched"""
+    from pde_surrogate_amd.models.darcy import darcy_mixed_residual_loss
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    net = _default_net(dev)
+    x = torch.from_numpy(grf_kle_fields(32, n_kle=64, seed=5, cache_dir='/tmp')).to(dev)
+    runs = {}
+    for v in (1, 0):
+        option('PDES_XCD_MAP', v)
+        net.zero_grad()
+        y = net(x)
+        loss = darcy_mixed_residual_loss(x, y, 10.0)[0]
+        loss.backward()
+        runs[v] = (y.detach().clone(), float(loss.detach()), {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert torch.equal(runs[1][0], runs[0][0]) and runs[1][1] == runs[0][1]
+    differing = [k for k in runs[0][2] if not torch.equal(runs[1][2][k], runs[0][2][k])]
+    assert differing == [], differing
+
+
 def test_coefficient_table_holds_the_batch_statistics_of_every_consumed_channel(dev):
     """pdes_conv_desc.coef: after a training-mode forward every channel a BatchNorm'd consumer read has its {mean, invstd}
     published behind the statistics arena -- the values of torch's batch statistics of the raw activation buffers -- and the
