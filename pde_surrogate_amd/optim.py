@@ -161,10 +161,16 @@ def _auto_fused_hook(optimizer, args, kwargs):
     if mode == '1' or g.get('amsgrad') or g.get('maximize'):
         g['fused'] = True
         return None
-    optimizer.__class__ = Adam
-    optimizer._flat_net, optimizer._flat_tries, optimizer._flat_state = None, 0, None
-    optimizer._hyper = (ctypes.c_float * 8)()
-    optimizer._patch_step_function()             # (torch wraps `step` of an optimiser's CLASS at construction: do it for ours)
+    try:
+        optimizer.__class__ = Adam
+        optimizer._flat_net, optimizer._flat_tries, optimizer._flat_state = None, 0, None
+        optimizer._hyper = (ctypes.c_float * 8)()
+        patch = getattr(optimizer, '_patch_step_function', None)
+        if patch is not None:                    # (torch wraps `step` of an optimiser's CLASS at construction: do it for ours;
+            patch()                              #  without it the subclass's step simply runs unwrapped -- no hooks, same update)
+    except Exception:                            # never let an acceleration break the user's optimiser: back to the plain class
+        optimizer.__class__ = _TorchAdam
+        g['fused'] = True
     return None
 
 
