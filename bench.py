@@ -553,6 +553,52 @@ def segments_timing(dev, data, perm, B, steps=100):
             'segments': [list(s_) for s_ in pr.segments]}
 
 
+def eval_path_timing(dev, n_val=512, bs=64, passes=8):
+    """SURVEY 8(f) rank 1, the reference's `test()` (train_codec_mixed_residual.py:166-206): eval-mode forward of the default
+    DenseED at its test batch size (64), the forward-only loss kernel, the NRMSE / R^2 accumulators on the device -- one host
+    read per pass over the validation set.  Samples/s over `passes` passes of `n_val` fields (synthetic inputs and targets)."""
+    import contextlib
+    import io
+    import numpy as np
+    from pde_surrogate_amd.metrics import TestMetrics
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.models.darcy import darcy_loss_launch
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48).to(dev)
+    x = torch.from_numpy(grf_kle_fields(n_val, cache_dir='/tmp')).to(dev)
+    y = torch.randn(n_val, 3, 64, 64, device=dev)
+    model.train()
+    with torch.no_grad():                      # running statistics from one training-mode forward, as after an epoch
+        model(x[:bs])
+    model.eval()
+    metrics = TestMetrics(3, dev)
+    acc = torch.zeros(5, device=dev, dtype=torch.float64)
+
+    def one_pass():
+        metrics.reset()
+        acc.zero_()
+        with torch.no_grad():
+            for lo in range(0, n_val, bs):
+                out = model(x[lo:lo + bs])
+                terms, _ = darcy_loss_launch(x[lo:lo + bs], out, (1.0, 1.0, 10.0, 10.0), False)
+                acc.add_(terms)
+                metrics.update(out, y[lo:lo + bs])
+        return float(acc[0]), metrics.result(np.ones(3))
+    one_pass()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        loss, (rel, r2) = one_pass()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {'workload': f'test() of the reference: eval forward + forward-only loss + NRMSE / R^2, default DenseED, bs {bs}, '
+                        f'{n_val} validation fields, {passes} passes (one host read per pass)',
+            'samples_per_s': round(n_val * passes / dt, 1), 'ms_per_batch': round(dt / (passes * (n_val // bs)) * 1e3, 4),
+            'finite': bool(np.isfinite(loss) and np.all(np.isfinite(rel)))}
+
+
 def config4_timing(dev, B, ntrain=4096, steps=128, warm=32):
     """configs[3] of BASELINE.json: channelized (two-valued, sharp-interface) 64 x 64 fields, ntrain 4096, bs 32, the default
     DenseED from scratch on the fused step -- the same kernels as the headline (they are data independent), on the input
@@ -989,12 +1035,16 @@ def main():
             seg = segments_timing(dev, data, perm, B)
         except Exception as e:
             seg = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
-    c4, dropin = None, None
+    c4, dropin, evalp = None, None, None
     if world == 1 and not args.no_extras and not args.graph:
         try:
             c4 = config4_timing(dev, B, steps=min(args.steps, 128))
         except Exception as e:
             c4 = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
+        try:
+            evalp = eval_path_timing(dev)
+        except Exception as e:
+            evalp = {'samples_per_s': None, 'error': f'{type(e).__name__}: {e}'[:300]}
         try:
             # (a) torch.optim untouched: a plain torch.optim.Adam over the HIP network's parameters is retargeted to the flat
             #     kernel at its first step (global step pre-hook of this build; round 6 first selected fused=True there);
@@ -1143,6 +1193,8 @@ def main():
             out['segment_graphs'] = seg
         if c4 is not None:
             out['config4_channelized'] = c4
+        if evalp is not None:
+            out['eval_path'] = evalp
         if dropin is not None:
             out['dropin'] = dropin
         if world == 1 and not args.no_extras:
