@@ -599,6 +599,35 @@ def eval_path_timing(dev, n_val=512, bs=64, passes=8):
             'finite': bool(np.isfinite(loss) and np.all(np.isfinite(rel)))}
 
 
+def max_likelihood_timing(dev, B, steps=100, warm=20):
+    """SURVEY 8(f) rank 1, train_codec_max_likelihood.py:197-211: the data-driven loop body (the same DenseED, F.mse_loss against
+    simulation targets) as the fused step with the MSE launch in place of the Darcy loss (MaxLikelihoodTrainer)"""
+    import contextlib
+    import io
+    from pde_surrogate_amd.models.codec import DenseED
+    from pde_surrogate_amd.train import MaxLikelihoodTrainer
+    from pde_surrogate_amd.utils.data import grf_kle_fields
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DenseED(1, 3, 64, [6, 8, 6], growth_rate=16, init_features=48)
+    tr = MaxLikelihoodTrainer(model, B, 64, lr=1e-3, device=dev)
+    x = torch.from_numpy(grf_kle_fields(8 * B, cache_dir='/tmp')).to(dev)
+    y = torch.randn(8 * B, 3, 64, 64, device=dev)
+    for i in range(warm):
+        tr.step(x[(i % 8) * B:(i % 8 + 1) * B], y[(i % 8) * B:(i % 8 + 1) * B], 1e-3)
+    tr.epoch_means()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(x[(i % 8) * B:(i % 8 + 1) * B], y[(i % 8) * B:(i % 8 + 1) * B], 1e-3)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    m = tr.epoch_means()
+    return {'workload': f'train_codec_max_likelihood.py loop body: default DenseED, bs {B}, MSE against (synthetic) targets, fused step',
+            'samples_per_s': round(B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 4), 'steps': steps,
+            'mse_mean_over_timed_steps': float(m[0]) if len(m) else None}
+
+
 def config4_timing(dev, B, ntrain=4096, steps=128, warm=32):
     """configs[3] of BASELINE.json: channelized (two-valued, sharp-interface) 64 x 64 fields, ntrain 4096, bs 32, the default
     DenseED from scratch on the fused step -- the same kernels as the headline (they are data independent), on the input
@@ -1035,7 +1064,7 @@ def main():
             seg = segments_timing(dev, data, perm, B)
         except Exception as e:
             seg = {'ms_per_step': None, 'error': f'{type(e).__name__}: {e}'[:300]}
-    c4, dropin, evalp = None, None, None
+    c4, dropin, evalp, mlk = None, None, None, None
     if world == 1 and not args.no_extras and not args.graph:
         try:
             c4 = config4_timing(dev, B, steps=min(args.steps, 128))
@@ -1045,6 +1074,10 @@ def main():
             evalp = eval_path_timing(dev)
         except Exception as e:
             evalp = {'samples_per_s': None, 'error': f'{type(e).__name__}: {e}'[:300]}
+        try:
+            mlk = max_likelihood_timing(dev, B, steps=min(args.steps, 100))
+        except Exception as e:
+            mlk = {'samples_per_s': None, 'error': f'{type(e).__name__}: {e}'[:300]}
         try:
             # (a) torch.optim untouched: a plain torch.optim.Adam over the HIP network's parameters is retargeted to the flat
             #     kernel at its first step (global step pre-hook of this build; round 6 first selected fused=True there);
@@ -1195,6 +1228,8 @@ def main():
             out['config4_channelized'] = c4
         if evalp is not None:
             out['eval_path'] = evalp
+        if mlk is not None:
+            out['max_likelihood'] = mlk
         if dropin is not None:
             out['dropin'] = dropin
         if world == 1 and not args.no_extras:
